@@ -1,0 +1,246 @@
+"""Generate the golden vectors under tests/golden/ from the REFERENCE itself.
+
+Runs only in the authoring container (needs /root/reference).  It imports the
+reference's `Code/models/unet.py` by path (with a stub for the absent
+`torchsummaryX`), loads the deterministic synthetic parameters of
+`ammcnet_aaai2021_amd.synthetic`, runs the reference modules on deterministic
+inputs and stores inputs' recipe + expected outputs as small .npz files.
+Nothing of the reference's source is stored: only numbers.
+
+    python tests/golden/make_golden.py
+"""
+from __future__ import annotations
+
+import importlib.util
+import json
+import os
+import pickle
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/Code"
+
+from ammcnet_aaai2021_amd import synthetic as S  # noqa: E402
+
+warnings.filterwarnings("ignore")
+
+
+def load_ref_unet():
+    sys.modules["torchsummaryX"] = types.SimpleNamespace(summary=lambda *a, **k: None)
+    spec = importlib.util.spec_from_file_location("ref_unet", f"{REF}/models/unet.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def sub(t: torch.Tensor, step: int) -> np.ndarray:
+    """strided spatial subsample of an NCHW tensor"""
+    return t.detach()[..., ::step, ::step].contiguous().numpy()
+
+
+def moments(t: torch.Tensor) -> np.ndarray:
+    t = t.detach().double()
+    dims = [0, 2, 3]
+    return np.stack([t.mean(dims).numpy(), t.var(dims, unbiased=False).numpy()]).astype(np.float64)
+
+
+def hook_outputs(net, names):
+    got, handles = {}, []
+    mods = dict(net.named_modules())
+    for n in names:
+        def fn(_m, _i, o, n=n):
+            got[n] = o
+        handles.append(mods[n].register_forward_hook(fn))
+    return got, handles
+
+
+STAGES = ["rgb.inc", "rgb.down1", "rgb.down2", "rgb.down3", "rgb.vq_down3", "rgb.vq_down3.quan.quantize",
+          "op.inc", "op.down1", "op.down2", "op.down3", "op.vq_down3", "op.vq_down3.quan.quantize", "bridge",
+          "rgb.up1", "rgb.up2", "rgb.up3", "op.up1", "op.up2", "op.up3"]
+
+
+def twostream_eval(ref, hw, batch, n_embed, name, full):
+    cfg = dict(in_channel=(12, 6), out_channel=(3, 2), embed_dim=64, n_embed=n_embed, k=2)
+    sd = S.make_twostream_state(**cfg)
+    net = ref.get_twostream(cfg["in_channel"], cfg["out_channel"], 64, n_embed, 2)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    rgb_x, op_x, rgb_t, op_t = S.make_clips(batch, hw, hw, tag=name)
+    got, handles = hook_outputs(net, STAGES)
+    with torch.no_grad():
+        rgb, op, (rd, od), (rq, oq) = net(rgb_x, op_x)
+    for h in handles:
+        h.remove()
+    out = {"rgb_diff": rd.numpy(), "op_diff": od.numpy(),
+           "rgb_q": rq.numpy(), "op_q": oq.numpy(),
+           "rgb_moments": moments(rgb), "op_moments": moments(op)}
+    step = 1 if full else 4
+    out["rgb"] = sub(rgb, step)
+    out["op"] = sub(op, step)
+    out["out_step"] = np.int64(step)
+    # per-sample PSNR of the rgb prediction vs the synthetic target (utils.py:130-148 arithmetic)
+    n = rgb.shape[1] * rgb.shape[2] * rgb.shape[3]
+    sq = ((rgb_t + 1) / 2 - (rgb + 1) / 2) ** 2
+    out["rgb_psnr"] = (10 * torch.log10(1.0 / (sq.sum([1, 2, 3]) / n))).numpy()
+    for st in STAGES:
+        o = got[st]
+        if st == "bridge":
+            bs = max(1, o[0].shape[-1] // 16)
+            out["st.rgb.bridge"], out["st.op.bridge"] = sub(o[0], bs), sub(o[1], bs)
+            out["mo.rgb.bridge"], out["mo.op.bridge"] = moments(o[0]), moments(o[1])
+        elif st.endswith("quantize"):
+            out[f"st.{st}"] = o[0].numpy() if full else o[0][:, ::2, ::2].contiguous().numpy()
+        elif st.endswith("vq_down3"):
+            out[f"st.{st}"] = sub(o[0], max(1, o[0].shape[-1] // 16))
+            out[f"mo.{st}"] = moments(o[0])
+        else:
+            out[f"st.{st}"] = sub(o, max(1, o.shape[-1] // 16))    # <=16x16 samples per channel
+            out[f"mo.{st}"] = moments(o)
+    out["cfg"] = np.array(json.dumps(dict(hw=hw, batch=batch, tag=name, **cfg)))
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    print(name, {k: getattr(v, "shape", None) for k, v in list(out.items())[:8]})
+
+
+def twostream_train(ref, hw, batch, name):
+    cfg = dict(in_channel=(12, 6), out_channel=(3, 2), embed_dim=64, n_embed=256, k=2)
+    sd = S.make_twostream_state(**cfg)
+    net = ref.get_twostream(cfg["in_channel"], cfg["out_channel"], 64, 256, 2)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    rgb_x, op_x, rgb_t, op_t = S.make_clips(batch, hw, hw, tag=name)
+    rgb, op, (rd, od), _ = net(rgb_x, op_x)
+    # G-only objective: L2-norm intensity (losses_utils.py:124-129) on both
+    # streams + the two commit terms; all lambdas 1.
+    loss = torch.norm(rgb - rgb_t, p=2, dim=1).mean() + torch.norm(op - op_t, p=2, dim=1).mean() + (rd + od).sum()
+    loss.backward()
+    out = {"loss": loss.detach().numpy(), "rgb": rgb.detach().numpy(), "op": op.detach().numpy(),
+           "rgb_diff": rd.detach().numpy(), "op_diff": od.detach().numpy()}
+    for k, p in net.named_parameters():
+        g = p.grad.detach()
+        out[f"gn.{k}"] = np.float64(g.double().norm().item())
+        out[f"gs.{k}"] = g.flatten()[:: max(1, g.numel() // 64)][:64].contiguous().numpy()
+    params = dict(net.named_parameters())
+    for k, v in net.state_dict().items():
+        if k in params:
+            continue
+        if v.numel() <= 64 * 256:
+            out[f"buf.{k}"] = v.numpy()
+    out["cfg"] = np.array(json.dumps(dict(hw=hw, batch=batch, tag=name, **cfg)))
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    print(name, float(loss))
+
+
+def unet_eval(ref, hw, batch, name):
+    sd = S.make_unet_state(12, 3)
+    net = ref.get_unet(12, 3)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    x = S.make_clips(batch, hw, hw, tag=name)[0]
+    with torch.no_grad():
+        y = net(x)
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), y=y.numpy(), moments=moments(y),
+                        cfg=np.array(json.dumps(dict(hw=hw, batch=batch, tag=name))))
+    print(name, y.shape)
+
+
+def quantize_cases(ref, name="quantize_cases"):
+    """`Quantize_topk` alone: shipped shape, cfg2 (2000 slots), cfg5-like (512-d, 8192 slots),
+    a deliberate near-tie case, and one training step (EMA buffers)."""
+    out = {}
+    cases = {"m256": (64, 256, 2, (2, 8, 8)), "m2000": (64, 2000, 2, (1, 8, 8)),
+             "d512m8192": (512, 8192, 2, (1, 4, 4)), "k3": (64, 256, 3, (1, 4, 8))}
+    for cname, (d, m, k, bhw) in cases.items():
+        q = ref.Quantize_topk(d, m, k=k)
+        embed = S.hashed_normal(f"{name}:{cname}:embed", (d, m), 0.9)
+        q.embed.copy_(embed)
+        q.eval()
+        x = S.hashed_normal(f"{name}:{cname}:x", (*bhw, d), 0.8)
+        with torch.no_grad():
+            qk, diff, q1 = q(x)
+        out[f"{cname}.qk"], out[f"{cname}.diff"], out[f"{cname}.q1"] = qk.numpy(), diff.numpy(), q1.numpy()
+        out[f"{cname}.cfg"] = np.array(json.dumps(dict(d=d, m=m, k=k, bhw=bhw)))
+    # near tie: x exactly halfway between two slots along one axis (+ tiny offset)
+    d, m, k = 64, 256, 2
+    q = ref.Quantize_topk(d, m, k=k)
+    embed = S.hashed_normal(f"{name}:tie:embed", (d, m), 0.9)
+    q.embed.copy_(embed)
+    q.eval()
+    e = embed.t()
+    x = (0.5 * (e[0:32] + e[32:64]) + 1e-3 * (e[0:32] - e[32:64])).reshape(1, 4, 8, d)
+    with torch.no_grad():
+        qk, diff, q1 = q(x)
+    out["tie.qk"], out["tie.diff"], out["tie.x"] = qk.numpy(), diff.numpy(), x.numpy()
+    # training step: EMA update of the buffers
+    q = ref.Quantize_topk(64, 256, k=2)
+    q.embed.copy_(S.hashed_normal(f"{name}:ema:embed", (64, 256), 0.9))
+    q.cluster_size.copy_(S.hashed_uniform(f"{name}:ema:cs", (256,), 0.5, 4.0))
+    q.embed_avg.copy_(S.hashed_normal(f"{name}:ema:ea", (64, 256), 1.5))
+    q.train()
+    x = S.hashed_normal(f"{name}:ema:x", (2, 8, 8, 64), 0.8).requires_grad_(True)
+    qk, diff, q1 = q(x)
+    diff.backward()
+    out["ema.qk"], out["ema.diff"] = qk.detach().numpy(), diff.detach().numpy()
+    out["ema.embed"], out["ema.cluster_size"], out["ema.embed_avg"] = \
+        q.embed.numpy(), q.cluster_size.numpy(), q.embed_avg.numpy()
+    out["ema.dx"] = x.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    print(name, len(out))
+
+
+def shipped_record_structure(name="shipped_records_ped2"):
+    """Structure of the authors' own per-frame score pickle for ped2
+    (ammcnet_os/model_result_save/ped2/...): video lengths and the run lengths of
+    constant commit score (pins: one commit scalar per batch of 16 clips, first 4
+    frames back-filled; test_helper.py:414-473)."""
+    p = f"{REF}/ammcnet_os/model_result_save/ped2/img_pred_fea_comm_rgb_auc/save_pickle/ped2"
+    with open(p, "rb") as fp:
+        d = pickle.load(fp)
+    vids = []
+    for psnr, comm in zip(d["rgb_img_pred_records"], d["rgb_fea_comm_records"]):
+        comm = np.asarray(comm)
+        runs, start = [], 0
+        for i in range(1, len(comm) + 1):
+            if i == len(comm) or comm[i] != comm[start]:
+                runs.append(i - start)
+                start = i
+        vids.append({"frames": int(len(comm)), "commit_runs": runs,
+                     "psnr_head_equal": bool(np.all(np.asarray(psnr)[:4] == np.asarray(psnr)[4]))})
+    with open(os.path.join(HERE, f"{name}.json"), "w") as fp:
+        json.dump({"keys": sorted(d.keys()), "dataset": d["dataset"], "videos": vids}, fp, indent=1)
+    print(name, [v["frames"] for v in vids])
+
+
+def param_counts(ref, name="param_counts"):
+    net = ref.get_twostream((12, 6), (3, 2), 64, 256, 2)
+    one = ref.get_unet_vq_topk_res(12, 3, 64, 256, 2)
+    plain = ref.get_unet(12, 3)
+    with open(os.path.join(HERE, f"{name}.json"), "w") as fp:
+        json.dump({"twostream": sum(p.numel() for p in net.parameters()),
+                   "unetmem_v7_rgb": sum(p.numel() for p in one.parameters()),
+                   "unet_12_3": sum(p.numel() for p in plain.parameters()),
+                   "twostream_state_entries": len(net.state_dict()),
+                   "twostream_state_keys": list(net.state_dict().keys())}, fp, indent=0)
+
+
+def main():
+    torch.set_num_threads(8)
+    ref = load_ref_unet()
+    param_counts(ref)
+    shipped_record_structure()
+    quantize_cases(ref)
+    unet_eval(ref, 64, 2, "unet_64_b2_eval")
+    twostream_eval(ref, 64, 2, 256, "twostream_64_b2_eval", full=True)
+    twostream_eval(ref, 64, 2, 2000, "twostream_64_b2_m2000_eval", full=True)
+    twostream_eval(ref, 256, 2, 256, "twostream_256_b2_eval", full=False)
+    twostream_train(ref, 64, 2, "twostream_64_b2_train")
+
+
+if __name__ == "__main__":
+    main()
