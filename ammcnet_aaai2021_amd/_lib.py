@@ -1,0 +1,88 @@
+"""ctypes binding of libammc_hip.so (the C ABI declared in include/ammc_hip.h).
+
+The HIP library is the product: if it is missing or fails to load this module
+raises - there is no CPU or ATen fallback anywhere in the package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libammc_hip.so")
+ABI_VERSION = 1
+
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+
+_p = C.c_void_p
+_i32 = C.c_int32
+_i64 = C.c_int64
+_f32 = C.c_float
+
+
+class AmmcConvDesc(C.Structure):
+    """mirror of `struct AmmcConvDesc` (include/ammc_hip.h)"""
+    _fields_ = [
+        ("x", _p), ("w", _p), ("y", _p), ("scale", _p), ("shift", _p), ("res", _p),
+        ("batch", _i32), ("height", _i32), ("width", _i32),
+        ("cin", _i32), ("ntaps", _i32), ("n", _i32), ("up", _i32), ("cgroup", _i32),
+        ("act", _i32), ("reserved", _i32),
+        ("x_bs", _i64), ("x_rs", _i64), ("x_ps", _i64),
+        ("y_bs", _i64), ("y_rs", _i64), ("y_ps", _i64),
+        ("r_bs", _i64), ("r_rs", _i64), ("r_ps", _i64),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/ammc_hip.h declares
+SIGNATURES = {
+    "ammc_abi_version": (C.c_int, []),
+    "ammc_build_info": (C.c_char_p, []),
+    "ammc_error_string": (C.c_char_p, [C.c_int]),
+    "ammc_conv_gemm_f32": (C.c_int, [C.POINTER(AmmcConvDesc), _p]),
+    "ammc_pack_outc_weight_f32": (C.c_int, [_p, _i32, _i32, _p, _p]),
+    "ammc_conv3x3_out_tanh_f32": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p]),
+    "ammc_maxpool2x2_f32": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _p]),
+    "ammc_nchw_to_nhwc_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _i64, _i64, _i64, _i32, _p]),
+    "ammc_nhwc_to_nchw_f32": (C.c_int, [_p, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _p, _p]),
+    "ammc_zero_halo_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p]),
+    "ammc_pack_conv_weight_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
+    "ammc_pack_convt_weight_f32": (C.c_int, [_p, _i32, _i32, _p, _p]),
+    "ammc_bn_fold_f32": (C.c_int, [_p, _p, _p, _p, _f32, _i32, _p, _p, _p]),
+    "ammc_pack_codebook_f32": (C.c_int, [_p, _i32, _i32, _p, _p, _p]),
+    "ammc_memory_topk_blocks": (C.c_int, [_i32]),
+    "ammc_memory_topk_fwd_f32": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
+    "ammc_sum_partials_f32": (C.c_int, [_p, _i32, _f32, _p, _p]),
+}
+
+_lib = None
+
+
+class AmmcHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """dlopen libammc_hip.so and type every entry point.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AmmcHipError(
+            f"{LIB_PATH} is missing: build it with `python -m ammcnet_aaai2021_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.ammc_abi_version()
+    if got != ABI_VERSION:
+        raise AmmcHipError(f"libammc_hip ABI {got} != binding ABI {ABI_VERSION}: rebuild the library")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().ammc_error_string(rc).decode()
+        raise AmmcHipError(f"libammc_hip {what} failed: {msg} (code {rc})")

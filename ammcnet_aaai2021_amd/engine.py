@@ -1,0 +1,458 @@
+"""Launch plans for the HIP path: which kernel runs on which buffer, in what order.
+
+An engine belongs to one model (`UNet`, `UNetMem_v7` or `twostream`).  It keeps
+  * the pre-packed weights (K-major conv filters, folded eval-BatchNorm, the
+    slot-major codebook copy) - rebuilt when a parameter/buffer changes;
+  * one workspace per input shape: every activation of the network as a
+    halo-padded NHWC fp32 buffer in HBM, allocated once (halo zeroed once:
+    kernels only ever write interiors);
+  * one launch plan per input shape: the fully resolved argument lists of every
+    C-ABI call, so a forward is a flat loop of ctypes calls on the current HIP
+    stream (and can be captured into a hipGraph, `capture()`).
+
+Layout decisions: the skip tensor of each encoder level and
+the ConvTranspose output of the matching decoder level are channel slices of
+ONE concat buffer, so torch.cat (reference unet.py:57) costs nothing; max-pool
+reads the skip slice in place.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_RELU, AmmcConvDesc
+
+BN_EPS = 1e-5
+
+
+def _ptr(t: torch.Tensor, elem_off: int = 0) -> int:
+    return t.data_ptr() + 4 * elem_off
+
+
+class Act:
+    """A [B, H, W, C] activation: a channel slice of an NHWC buffer with `halo` zero pixels."""
+
+    def __init__(self, buf: torch.Tensor, B: int, H: int, W: int, c: int, c_off: int = 0, halo: int = 1):
+        self.buf, self.B, self.H, self.W, self.c, self.c_off, self.halo = buf, B, H, W, c, c_off, halo
+        self.c_total = buf.shape[-1]
+        self.ps = self.c_total
+        self.rs = (W + 2 * halo) * self.ps
+        self.bs = (H + 2 * halo) * self.rs
+
+    @property
+    def strides(self) -> Tuple[int, int, int]:
+        return self.bs, self.rs, self.ps
+
+    def tap0(self) -> int:
+        """address of window tap (0,0) of pixel (0,0): the halo corner"""
+        assert self.halo == 1
+        return _ptr(self.buf, self.c_off)
+
+    def pix0(self) -> int:
+        """address of pixel (0,0) itself"""
+        return _ptr(self.buf, self.halo * (self.rs + self.ps) + self.c_off)
+
+    def slice(self, c_off: int, c: int) -> "Act":
+        return Act(self.buf, self.B, self.H, self.W, c, self.c_off + c_off, self.halo)
+
+    def interior(self) -> torch.Tensor:
+        """NHWC view [B,H,W,c] (for tests / debugging)"""
+        h = self.halo
+        return self.buf[:, h:h + self.H, h:h + self.W, self.c_off:self.c_off + self.c]
+
+
+def _kpad(k: int) -> int:
+    return (k + 31) // 32 * 32
+
+
+def _cin_pad(c: int) -> int:
+    p = 4
+    while p < c:
+        p *= 2
+    return p
+
+
+class Plan:
+    """A flat list of resolved C-ABI calls."""
+
+    def __init__(self):
+        self.calls: List[Tuple] = []
+        self.meta: List[dict] = []
+        self.keep: List = []
+
+    def add(self, fn, *args, name: str = "", flops: float = 0.0, nbytes: float = 0.0, kernel: str = ""):
+        self.calls.append((fn, args, name))
+        self.meta.append(dict(name=name, flops=flops, bytes=nbytes, kernel=kernel))
+
+    def run(self, stream: int):
+        for fn, args, name in self.calls:
+            rc = fn(*args, stream)
+            if rc != 0:
+                _lib.check(rc, name or fn.__name__)
+
+    def run_timed(self, stream: int):
+        """Same launches, each bracketed by HIP events on the launch stream.
+        Returns [(meta, milliseconds)]; used by bench.py for the roofline figures."""
+        evs = []
+        for fn, args, name in self.calls:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args, stream)
+            e1.record()
+            if rc != 0:
+                _lib.check(rc, name or fn.__name__)
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        return [(m, e0.elapsed_time(e1)) for m, (e0, e1) in zip(self.meta, evs)]
+
+
+class _Packer:
+    """weight pre-packing through the C ABI"""
+
+    def __init__(self, device):
+        self.lib = _lib.load()
+        self.device = device
+
+    def stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def conv(self, w: torch.Tensor, ksize: int) -> Tuple[torch.Tensor, int]:
+        cout, cin = w.shape[0], w.shape[1]
+        cin_p = _cin_pad(cin) if ksize == 3 else _kpad(cin)
+        out = torch.empty((cout, _kpad(ksize * ksize * cin_p)), device=self.device, dtype=torch.float32)
+        w = w.detach().contiguous()
+        _lib.check(self.lib.ammc_pack_conv_weight_f32(_ptr(w), cout, cin, ksize, cin_p, _ptr(out), self.stream()),
+                   "pack_conv_weight")
+        return out, cin_p
+
+    def convt(self, w: torch.Tensor) -> torch.Tensor:
+        cin, co = w.shape[0], w.shape[1]
+        out = torch.empty((4 * co, cin), device=self.device, dtype=torch.float32)
+        w = w.detach().contiguous()
+        _lib.check(self.lib.ammc_pack_convt_weight_f32(_ptr(w), cin, co, _ptr(out), self.stream()), "pack_convt")
+        return out
+
+    def outc(self, w: torch.Tensor) -> torch.Tensor:
+        cout, cin = w.shape[0], w.shape[1]
+        out = torch.empty((9, cin, 4), device=self.device, dtype=torch.float32)
+        w = w.detach().contiguous()
+        _lib.check(self.lib.ammc_pack_outc_weight_f32(_ptr(w), cout, cin, _ptr(out), self.stream()), "pack_outc")
+        return out
+
+    def bn(self, bn: torch.nn.BatchNorm2d) -> Tuple[torch.Tensor, torch.Tensor]:
+        c = bn.num_features
+        scale = torch.empty(c, device=self.device, dtype=torch.float32)
+        shift = torch.empty(c, device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.ammc_bn_fold_f32(_ptr(bn.weight.detach()), _ptr(bn.bias.detach()),
+                                             _ptr(bn.running_mean), _ptr(bn.running_var), float(bn.eps), c,
+                                             _ptr(scale), _ptr(shift), self.stream()), "bn_fold")
+        return scale, shift
+
+    def codebook(self, embed: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        d, m = embed.shape
+        e_md = torch.empty((m, d), device=self.device, dtype=torch.float32)
+        enorm = torch.empty(m, device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.ammc_pack_codebook_f32(_ptr(embed), d, m, _ptr(e_md), _ptr(enorm), self.stream()),
+                   "pack_codebook")
+        return e_md, enorm
+
+
+class _DoubleConvPack:
+    def __init__(self, pk: _Packer, dc):
+        seq = dc.conv
+        self.w0, self.cin_p = pk.conv(seq[0].weight, 3)
+        self.cin = seq[0].weight.shape[1]
+        self.s0, self.b0 = pk.bn(seq[1])
+        self.w1, _ = pk.conv(seq[3].weight, 3)
+        self.s1, self.b1 = pk.bn(seq[4])
+        self.cout = seq[0].weight.shape[0]
+
+
+class _StreamPack:
+    """packed parameters of one U-Net stream (`UNet` / `UNetMem_v7`)"""
+
+    def __init__(self, pk: _Packer, net):
+        self.inc = _DoubleConvPack(pk, net.inc.conv)
+        self.down = [_DoubleConvPack(pk, d.mpconv[1]) for d in (net.down1, net.down2, net.down3)]
+        self.up = []
+        for u in (net.up1, net.up2, net.up3):
+            self.up.append((pk.convt(u.up.weight), u.up.bias.detach(), _DoubleConvPack(pk, u.conv)))
+        self.outc_w = pk.outc(net.outc.weight)
+        self.outc_b = net.outc.bias.detach()
+        self.cout = net.outc.weight.shape[0]
+        self.cin = net.inc.conv.conv[0].weight.shape[1]
+        self.vq = None
+        if hasattr(net, "vq_down3"):
+            q = net.vq_down3.quan
+            enc_w, _ = pk.conv(q.enc.weight, 1)
+            dec_w, _ = pk.conv(q.dec.weight, 1)
+            e_md, enorm = pk.codebook(q.quantize.embed)
+            self.vq = dict(enc_w=enc_w, enc_b=q.enc.bias.detach(), dec_w=dec_w, dec_b=q.dec.bias.detach(),
+                           embed=q.quantize.embed, e_md=e_md, enorm=enorm, d=q.quantize.dim,
+                           m=q.quantize.n_embed, k=q.quantize.k)
+
+
+class _Builder:
+    """appends resolved kernel calls to a Plan"""
+
+    def __init__(self, plan: Plan, device):
+        self.plan = plan
+        self.lib = _lib.load()
+        self.device = device
+
+    def buf(self, *shape) -> torch.Tensor:
+        # zeros once: kernels write interiors only, so the halo stays zero forever
+        t = torch.zeros(shape, device=self.device, dtype=torch.float32)
+        self.plan.keep.append(t)
+        return t
+
+    def act(self, B, H, W, c, halo=1) -> Act:
+        return Act(self.buf(B, H + 2 * halo, W + 2 * halo, c), B, H, W, c, 0, halo)
+
+    def conv(self, x: Act, w: torch.Tensor, y: Act, *, ntaps: int, cin: int, n: int, scale=None, shift=None,
+             act=ACT_NONE, res: Optional[Act] = None, up: int = 1, cgroup: Optional[int] = None, name="conv",
+             cin_true: Optional[int] = None):
+        d = AmmcConvDesc()
+        d.x = x.tap0() if ntaps == 9 else x.pix0()
+        d.w = _ptr(w)
+        d.y = y.pix0()
+        d.scale = _ptr(scale) if scale is not None else None
+        d.shift = _ptr(shift) if shift is not None else None
+        d.res = res.pix0() if res is not None else None
+        d.batch, d.height, d.width = x.B, x.H, x.W
+        d.cin, d.ntaps, d.n, d.up = cin, ntaps, n, up
+        d.cgroup = cgroup if cgroup is not None else n
+        d.act = act
+        d.x_bs, d.x_rs, d.x_ps = x.strides
+        d.y_bs, d.y_rs, d.y_ps = y.strides
+        if res is not None:
+            d.r_bs, d.r_rs, d.r_ps = res.strides
+        self.plan.keep.append(d)
+        self.plan.keep.extend(t for t in (w, scale, shift) if t is not None)
+        # algorithmic work of this launch: 2*M*N*K with the TRUE channel count;
+        # bytes = input read once + output written once (+ residual read), weights excluded
+        m_pix = x.B * x.H * x.W
+        ct = cin_true if cin_true is not None else cin
+        flops = 2.0 * m_pix * n * ntaps * ct
+        nbytes = 4.0 * m_pix * (ct + n + (n if res is not None else 0))
+        tile = "128x128" if n % 128 == 0 else "128x64"
+        self.plan.add(self.lib.ammc_conv_gemm_f32, C.byref(d), name=name, flops=flops, nbytes=nbytes,
+                      kernel=f"conv_gemm_f32<{tile}>")
+
+    def double_conv(self, x: Act, p: _DoubleConvPack, mid: Act, y: Act, res: Optional[Act] = None, name="dc"):
+        self.conv(x, p.w0, mid, ntaps=9, cin=p.cin_p, n=p.cout, scale=p.s0, shift=p.b0, act=ACT_RELU,
+                  name=f"{name}.conv0", cin_true=p.cin)
+        self.conv(mid, p.w1, y, ntaps=9, cin=p.cout, n=p.cout, scale=p.s1, shift=p.b1, act=ACT_RELU, res=res,
+                  name=f"{name}.conv1")
+
+    def maxpool(self, x: Act, y: Act, name="pool"):
+        self.plan.add(self.lib.ammc_maxpool2x2_f32, x.pix0(), *x.strides, y.pix0(), *y.strides,
+                      y.B, y.H, y.W, y.c, name=name, nbytes=4.0 * 5 * y.B * y.H * y.W * y.c, kernel="maxpool2x2")
+
+    def convt(self, x: Act, w: torch.Tensor, bias: torch.Tensor, y: Act, name="convt"):
+        co = w.shape[0] // 4
+        # bias per GEMM column: the same [co] vector for each of the 4 (dy,dx) groups
+        b4 = bias.repeat(4).contiguous()
+        self.plan.keep.append(b4)
+        self.conv(x, w, y, ntaps=1, cin=w.shape[1], n=4 * co, shift=b4, up=2, cgroup=co, name=name)
+
+
+class StreamGraph:
+    """buffers + plan fragments of one U-Net stream at one input shape"""
+
+    def __init__(self, bld: _Builder, sp: _StreamPack, B: int, H: int, W: int):
+        if H % 8 or W % 8:
+            raise ValueError(f"frame size {H}x{W} must be divisible by 8 (three 2x2 poolings)")
+        self.sp, self.B, self.H, self.W = sp, B, H, W
+        self.bld = bld
+        chans = (64, 128, 256, 512)
+        self.x_in = bld.act(B, H, W, sp.inc.cin_p)
+        # concat buffers of the three decoder levels; first half = the encoder's skip tensor
+        self.cat = [bld.act(B, H >> i, W >> i, 2 * chans[i]) for i in range(3)]
+        self.skip = [self.cat[i].slice(0, chans[i]) for i in range(3)]
+        self.x4 = bld.act(B, H >> 3, W >> 3, 512)
+        self.bottom = self.x4          # what the decoder consumes (replaced by vq / bridge outputs)
+
+    def encode(self):
+        bld, sp = self.bld, self.sp
+        B, H, W = self.B, self.H, self.W
+        chans = (64, 128, 256, 512)
+        mid = bld.act(B, H, W, 64)
+        bld.double_conv(self.x_in, sp.inc, mid, self.skip[0], name="inc")
+        for i in range(3):
+            h, w = H >> (i + 1), W >> (i + 1)
+            pooled = bld.act(B, h, w, chans[i])
+            bld.maxpool(self.skip[i], pooled, name=f"down{i + 1}.pool")
+            mid = bld.act(B, h, w, chans[i + 1])
+            out = self.skip[i + 1] if i < 2 else self.x4
+            bld.double_conv(pooled, sp.down[i], mid, out, name=f"down{i + 1}")
+
+    def memory(self):
+        """enc 1x1 -> fused distance/top-k/gather -> dec 1x1 + residual  (unet.py:318-331, 379-387)"""
+        bld, v = self.bld, self.sp.vq
+        B, h, w = self.B, self.H >> 3, self.W >> 3
+        n, d, m, k = B * h * w, v["d"], v["m"], v["k"]
+        lib = bld.lib
+        self.z = bld.act(B, h, w, d, halo=0)
+        bld.conv(self.x4, v["enc_w"], self.z, ntaps=1, cin=512, n=d, shift=v["enc_b"], name="vq.enc")
+        self.idx = torch.zeros((n, k), device=bld.device, dtype=torch.int32)
+        self.qk = bld.act(B, h, w, k * d, halo=0)
+        self.q_one = bld.buf(B, h, w, d)
+        nblk = lib.ammc_memory_topk_blocks(n)
+        self.diff_part = bld.buf(nblk)
+        self.diff = bld.buf(1)
+        bld.plan.keep.extend([self.idx, v["embed"], v["e_md"], v["enorm"]])
+        bld.plan.add(lib.ammc_memory_topk_fwd_f32, _ptr(self.z.buf), _ptr(v["embed"]), _ptr(v["e_md"]),
+                     _ptr(v["enorm"]), n, d, m, k, self.idx.data_ptr(), _ptr(self.qk.buf), _ptr(self.q_one),
+                     _ptr(self.diff_part), name="vq.memory_topk", flops=2.0 * n * d * m,
+                     nbytes=4.0 * (n * d + d * m + n * k * d + n * k + n * d), kernel="memory_topk")
+        bld.plan.add(lib.ammc_sum_partials_f32, _ptr(self.diff_part), nblk, 1.0 / float(n * d), _ptr(self.diff),
+                     name="vq.diff")
+        self.x4q = bld.act(B, h, w, 512)
+        bld.conv(self.qk, v["dec_w"], self.x4q, ntaps=1, cin=k * d, n=512, shift=v["dec_b"], res=self.x4,
+                 name="vq.dec")
+        self.bottom = self.x4q
+
+    def decode(self):
+        bld, sp = self.bld, self.sp
+        B, H, W = self.B, self.H, self.W
+        chans = (64, 128, 256, 512)
+        y = self.bottom
+        for j, lvl in enumerate((2, 1, 0)):            # up1 -> level 2 (H/4), up2 -> level 1, up3 -> level 0
+            wt, bias, dc = sp.up[j]
+            c = chans[lvl]
+            bld.convt(y, wt, bias, self.cat[lvl].slice(c, c), name=f"up{j + 1}.up")
+            h, w = H >> lvl, W >> lvl
+            mid = bld.act(B, h, w, c)
+            out = bld.act(B, h, w, c)
+            bld.double_conv(self.cat[lvl], dc, mid, out, name=f"up{j + 1}")
+            y = out
+        self.u3 = y
+
+
+class EvalEngine:
+    """eval-mode forward of `UNet`, `UNetMem_v7` or `twostream` on the HIP kernels"""
+
+    def __init__(self, module, kind: str):
+        self.module = module
+        self.kind = kind                      # "unet" | "unetmem" | "twostream"
+        self.lib = _lib.load()
+        self._packs = None
+        self._pack_version = None
+        self._plans: Dict[Tuple, dict] = {}
+
+    # ---- parameters ---------------------------------------------------------------
+    def _version(self):
+        v = 0
+        for t in self.module.parameters():
+            v += t._version
+        for t in self.module.buffers():
+            v += t._version
+        first = next(self.module.parameters())
+        return (v, first.device, first.data_ptr())
+
+    def _ensure_packs(self, device):
+        ver = self._version()
+        if self._packs is not None and ver == self._pack_version:
+            return
+        pk = _Packer(device)
+        m = self.module
+        if self.kind == "twostream":
+            self._packs = dict(rgb=_StreamPack(pk, m.rgb), op=_StreamPack(pk, m.op),
+                               o2f=_DoubleConvPack(pk, m.bridge.O2F), f2o=_DoubleConvPack(pk, m.bridge.F20))
+        else:
+            self._packs = dict(net=_StreamPack(pk, m))
+        self._pack_version = ver
+        self._plans.clear()               # plans hold pointers to the old packs
+
+    # ---- plans ----------------------------------------------------------------------
+    def _build(self, B, H, W, device) -> dict:
+        plan = Plan()
+        bld = _Builder(plan, device)
+        st = {}
+        if self.kind == "twostream":
+            r = StreamGraph(bld, self._packs["rgb"], B, H, W)
+            o = StreamGraph(bld, self._packs["op"], B, H, W)
+            r.encode()
+            r.memory()
+            o.encode()
+            o.memory()
+            h, w = H >> 3, W >> 3
+            # AMFT bridge: x = zx + O2F(zy); y = zy + F20(zx)   (unet.py:962-965)
+            mid = bld.act(B, h, w, 512)
+            xb = bld.act(B, h, w, 512)
+            bld.double_conv(o.x4q, self._packs["o2f"], mid, xb, res=r.x4q, name="bridge.O2F")
+            mid2 = bld.act(B, h, w, 512)
+            yb = bld.act(B, h, w, 512)
+            bld.double_conv(r.x4q, self._packs["f2o"], mid2, yb, res=o.x4q, name="bridge.F20")
+            r.bottom, o.bottom = xb, yb
+            r.decode()
+            o.decode()
+            st = dict(streams=[r, o], bridge=(xb, yb))
+        else:
+            s = StreamGraph(bld, self._packs["net"], B, H, W)
+            s.encode()
+            if self.kind == "unetmem":
+                s.memory()
+            s.decode()
+            st = dict(streams=[s])
+        st["plan"] = plan
+        return st
+
+    def _get(self, B, H, W, device) -> dict:
+        self._ensure_packs(device)
+        key = (B, H, W, device)
+        st = self._plans.get(key)
+        if st is None:
+            st = self._build(B, H, W, device)
+            self._plans[key] = st
+        return st
+
+    def bottleneck_views(self):
+        """NCHW views of the rgb bottleneck before / after the memory block (the reference's
+        `quant_befor` / `quant_after`, unet.py:986,988).  Views of the workspace: valid until the
+        next forward of the same shape."""
+        s = self._last["streams"][0]
+        return (s.x4.interior().permute(0, 3, 1, 2), s.x4q.interior().permute(0, 3, 1, 2))
+
+    # ---- forward ----------------------------------------------------------------------
+    def forward(self, *inputs: torch.Tensor):
+        x0 = inputs[0]
+        if not x0.is_cuda:
+            raise _lib.AmmcHipError("the HIP path needs CUDA/HIP tensors (module and inputs on the GPU); "
+                                    "there is no CPU fallback")
+        B, _, H, W = x0.shape
+        st = self._get(B, H, W, x0.device)
+        stream = torch.cuda.current_stream(x0.device).cuda_stream
+        lib = self.lib
+        streams: List[StreamGraph] = st["streams"]
+        outs = []
+        keep = []
+        for s, x in zip(streams, inputs):
+            if x.shape[1] != s.sp.cin or x.shape[0] != B or x.shape[2] != H or x.shape[3] != W:
+                raise ValueError(f"input shape {tuple(x.shape)} does not match the model ({s.sp.cin} channels)")
+            x = x.detach()
+            if x.dtype != torch.float32 or not x.is_contiguous():
+                x = x.float().contiguous()
+            keep.append(x)
+            _lib.check(lib.ammc_nchw_to_nhwc_f32(_ptr(x), B, s.sp.cin, H, W, s.x_in.pix0(), *s.x_in.strides,
+                                                 s.sp.inc.cin_p, stream), "nchw_to_nhwc")
+        st["plan"].run(stream)
+        for s in streams:
+            y = torch.empty((B, s.sp.cout, H, W), device=x0.device, dtype=torch.float32)
+            _lib.check(lib.ammc_conv3x3_out_tanh_f32(s.u3.tap0(), *s.u3.strides, _ptr(s.sp.outc_w),
+                                                     _ptr(s.sp.outc_b), B, H, W, 64, s.sp.cout, _ptr(y), stream),
+                       "outc_tanh")
+            outs.append(y)
+        self._last = st
+        if self.kind == "unet":
+            return outs[0]
+        diffs = tuple(s.diff.clone() for s in streams)
+        qs = tuple(s.q_one.clone() for s in streams)
+        if self.kind == "unetmem":
+            return outs[0], diffs[0], qs[0]
+        return outs[0], outs[1], diffs, qs

@@ -1,0 +1,214 @@
+"""Host-side mirror of the reference's model interface for the hot path.
+
+Same class names, constructor arguments, attribute names, `forward` signatures,
+return values and `state_dict` layout as the live classes of the reference's
+`Code/models/unet.py` (double_conv :8-20, inconv :23-30, down :33-41, up :44-59,
+UNet :61-83, Quantize_topk :267-316, enc_quan_dec_topk :318-331,
+enc_quan_dec_res_topk :379-387, UNetMem_v7 :908-937, bridge :956-965,
+twostream :967-1007, get_unet :1130, get_unet_vq_topk_res :1213, get_twostream
+:1241), so a checkpoint of the reference loads with `load_state_dict(strict=True)`
+and `Code/main/run_test` / `run_train` can use these classes unchanged.
+
+What differs is everything underneath: the torch.nn leaf modules here only
+HOLD parameters.  `forward` never calls ATen convolution / batch-norm / topk:
+it hands raw device pointers to the gfx950 kernels of libammc_hip.so through
+the launch plans in `engine.py`.  If the library is missing, or the tensors are
+not on the GPU, forward raises; there is no fallback.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .engine import EvalEngine
+
+
+def _no_training(mod):
+    if mod.training:
+        raise NotImplementedError(
+            f"{type(mod).__name__}: the training-mode HIP path (batch-stat BatchNorm, EMA codebook update, "
+            "backward kernels) is not built yet; call .eval() - there is no ATen fallback")
+
+
+class double_conv(nn.Module):
+    """[conv3x3 (pad 1, no bias) -> BatchNorm2d -> ReLU] x 2; BN + ReLU live in the conv epilogue."""
+
+    def __init__(self, in_ch, out_ch):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Conv2d(in_ch, out_ch, 3, padding=1, bias=False),
+                                  nn.BatchNorm2d(out_ch),
+                                  nn.ReLU(inplace=True),
+                                  nn.Conv2d(out_ch, out_ch, 3, padding=1, bias=False),
+                                  nn.BatchNorm2d(out_ch),
+                                  nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        _no_training(self)
+        return ops.double_conv_eval(self, x)
+
+
+class inconv(nn.Module):
+    def __init__(self, in_ch, out_ch):
+        super().__init__()
+        self.conv = double_conv(in_ch, out_ch)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class down(nn.Module):
+    def __init__(self, in_ch, out_ch):
+        super().__init__()
+        self.mpconv = nn.Sequential(nn.MaxPool2d(2), double_conv(in_ch, out_ch))
+
+    def forward(self, x):
+        _no_training(self)
+        return ops.double_conv_eval(self.mpconv[1], x, pool_first=True)
+
+
+class up(nn.Module):
+    def __init__(self, in_ch, out_ch):
+        super().__init__()
+        self.up = nn.ConvTranspose2d(in_ch, in_ch // 2, 2, stride=2)
+        self.conv = double_conv(in_ch, out_ch)
+
+    def forward(self, x1, x2):
+        _no_training(self)
+        return ops.up_eval(self, x1, x2)
+
+
+class UNet(nn.Module):
+    def __init__(self, input_channels, output_channel=3):
+        super().__init__()
+        self.inc = inconv(input_channels, 64)
+        self.down1 = down(64, 128)
+        self.down2 = down(128, 256)
+        self.down3 = down(256, 512)
+        self.up1 = up(512, 256)
+        self.up2 = up(256, 128)
+        self.up3 = up(128, 64)
+        self.outc = nn.Conv2d(64, output_channel, kernel_size=3, padding=1)
+        self._engine = None
+
+    def forward(self, x):
+        _no_training(self)
+        if self._engine is None:
+            object.__setattr__(self, "_engine", EvalEngine(self, "unet"))
+        return self._engine.forward(x)
+
+
+class Quantize_topk(nn.Module):
+    """memory module: L2 distance to every slot, k nearest slots concatenated, commit distance"""
+
+    def __init__(self, dim, n_embed, decay=0.99, eps=1e-5, k=1):
+        super().__init__()
+        self.dim = dim
+        self.n_embed = n_embed
+        self.decay = decay
+        self.eps = eps
+        self.k = k
+        embed = torch.randn(dim, n_embed)
+        self.register_buffer("embed", embed)
+        self.register_buffer("cluster_size", torch.zeros(n_embed))
+        self.register_buffer("embed_avg", embed.clone())
+
+    def forward(self, input):
+        _no_training(self)
+        return ops.quantize_topk_eval(self, input)
+
+    def embed_code(self, embed_id):
+        return ops.embed_rows(self.embed, embed_id)
+
+
+class enc_quan_dec_topk(nn.Module):
+    def __init__(self, in_c, embed_dim, n_embed, k=1):
+        super().__init__()
+        self.enc = nn.Conv2d(in_c, embed_dim, 1)
+        self.quantize = Quantize_topk(dim=embed_dim, n_embed=n_embed, k=k)
+        self.dec = nn.Conv2d(embed_dim * k, in_c, 1)
+
+    def forward(self, x):
+        _no_training(self)
+        return ops.vq_block_eval(self, x, residual=False)
+
+
+class enc_quan_dec_res_topk(nn.Module):
+    def __init__(self, in_c, embed_dim, n_embed, k=1):
+        super().__init__()
+        self.quan = enc_quan_dec_topk(in_c, embed_dim, n_embed, k=k)
+
+    def forward(self, x):
+        _no_training(self)
+        return ops.vq_block_eval(self.quan, x, residual=True)
+
+
+class UNetMem_v7(nn.Module):
+    def __init__(self, input_channels=3, output_channel=3, embed_dim=64, n_embed=512, k=1,
+                 layer_nums=4, features_root=64):
+        super().__init__()
+        self.inc = inconv(input_channels, 64)
+        self.down1 = down(64, 128)
+        self.down2 = down(128, 256)
+        self.down3 = down(256, 512)
+        self.up1 = up(512, 256)
+        self.up2 = up(256, 128)
+        self.up3 = up(128, 64)
+        self.outc = nn.Conv2d(64, output_channel, kernel_size=3, padding=1)
+        self.vq_down3 = enc_quan_dec_res_topk(512, embed_dim, n_embed, k=k)
+        self._engine = None
+
+    def forward(self, x):
+        _no_training(self)
+        if self._engine is None:
+            object.__setattr__(self, "_engine", EvalEngine(self, "unetmem"))
+        return self._engine.forward(x)
+
+
+class bridge(nn.Module):
+    """AMFT: x = zx + O2F(zy), y = zy + F20(zx); the adds are conv epilogues"""
+
+    def __init__(self, in_c=64):
+        super().__init__()
+        self.O2F = double_conv(in_c, in_c)
+        self.F20 = double_conv(in_c, in_c)
+
+    def forward(self, zx, zy):
+        _no_training(self)
+        return (ops.double_conv_eval(self.O2F, zy, residual=zx),
+                ops.double_conv_eval(self.F20, zx, residual=zy))
+
+
+class twostream(nn.Module):
+    def __init__(self, rgb_in_c, rgb_out_c, op_in_c, op_out_c, embed_dim=64, n_embed=512, k=1,
+                 layer_nums=4, features_root=64):
+        super().__init__()
+        self.rgb = UNetMem_v7(rgb_in_c, rgb_out_c, embed_dim, n_embed, k, layer_nums, features_root)
+        self.op = UNetMem_v7(op_in_c, op_out_c, embed_dim, n_embed, k, layer_nums, features_root)
+        self.bridge = bridge(in_c=512)
+        self._engine = None
+
+    def forward(self, rgb_x, op_x):
+        _no_training(self)
+        if self._engine is None:
+            object.__setattr__(self, "_engine", EvalEngine(self, "twostream"))
+        out = self._engine.forward(rgb_x, op_x)
+        # reference side effects (unet.py:986, 988): attributes nobody reads; kept as NCHW views on request
+        self.quant_befor, self.quant_after = self._engine.bottleneck_views()
+        return out
+
+
+def get_unet(in_channel, out_channel, embed_dim=0, n_embed=0, k=0):
+    return UNet(in_channel, out_channel)
+
+
+def get_unet_vq_topk_res(in_channel, out_channel, embed_dim=64, n_embed=512, k=1):
+    return UNetMem_v7(in_channel, out_channel, embed_dim, n_embed, k)
+
+
+def get_twostream(in_channel, out_channel, embed_dim, n_embed, k, layer_nums=4, features_root=64):
+    rgb_in_c, op_in_c = in_channel
+    rgb_out_c, op_out_c = out_channel
+    return twostream(rgb_in_c=rgb_in_c, rgb_out_c=rgb_out_c, op_in_c=op_in_c, op_out_c=op_out_c,
+                     embed_dim=embed_dim, n_embed=n_embed, k=k, layer_nums=layer_nums,
+                     features_root=features_root)

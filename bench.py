@@ -1,0 +1,180 @@
+"""Benchmark of the hot path: frames/s of `twostream.forward` on synthetic 256x256 clips.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): Ped2-shaped dual-stream network with a 2000-slot memory
+(embed_dim 64, k 2), inference, batch 16 per GPU, inputs resident in HBM.  One "step" = one
+forward over one batch.  N > 1 = N independent replicas on disjoint clips (the reference has
+no multi-GPU semantics; inference shards by whole batches and needs no collective), so
+`scaling` is "weak" and `value` is the sum over ranks.
+
+Besides the contract fields the JSON line carries
+  roofline      algorithmic FLOPs of the dominant kernel (conv_gemm_f32<128x128>) per launch divided
+                by its average launch duration (HIP events on the launch stream), against
+                the fp32 MFMA peak of MI355X (157.3 TFLOP/s)
+  cpu_baseline  the CPU oracle (oracle/ammc_oracle.py, "port") timed on this host on a
+                bounded sample of the same workload (rank 0, N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--batch", type=int, default=16, help="clips per GPU per step")
+    p.add_argument("--n-embed", type=int, default=2000)
+    p.add_argument("--size", type=int, default=256)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample-batch", type=int, default=2)
+    p.add_argument("--cpu-iters", type=int, default=3)
+    return p.parse_args()
+
+
+def cpu_baseline(args):
+    """the CPU restatement of the same forward on a bounded sample (kind "port")"""
+    from ammcnet_aaai2021_amd import synthetic as S
+    from oracle import ammc_oracle as O
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    sd = S.make_twostream_state(n_embed=args.n_embed)
+    b = args.cpu_sample_batch
+    rgb_x, op_x, _, _ = S.make_clips(b, args.size, args.size, tag="bench")
+    times = []
+    with torch.no_grad():
+        O.twostream_forward(sd, rgb_x, op_x, 2)                     # warm-up
+        for _ in range(args.cpu_iters):
+            t0 = time.perf_counter()
+            O.twostream_forward(sd, rgb_x, op_x, 2)
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(b / med, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{args.cpu_iters} timed forwards (median) of batch {b} at {args.size}x{args.size}, "
+                      f"n_embed {args.n_embed}, torch CPU fp32, {threads} threads"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import ammcnet_aaai2021_amd as A
+    from ammcnet_aaai2021_amd import synthetic as S
+
+    sd = S.make_twostream_state(n_embed=args.n_embed)
+    net = A.get_twostream((12, 6), (3, 2), 64, args.n_embed, 2)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    # each rank works on its own clips (weak scaling: per-GPU work fixed)
+    rgb_x, op_x, _, _ = S.make_clips(args.batch, args.size, args.size, tag=f"bench{rank}")
+    rgb_x, op_x = rgb_x.to(dev), op_x.to(dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = net(rgb_x, op_x)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = net(rgb_x, op_x)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    assert bool(torch.isfinite(out[0]).all())
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel, measured live with HIP events --------------
+    roof = None
+    per_kernel = {}
+    if rank == 0:
+        st = net._engine._last
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        agg = {}
+        reps = 3
+        for _ in range(reps):
+            for meta, ms in st["plan"].run_timed(stream):
+                a = agg.setdefault(meta["kernel"] or meta["name"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+                a["ms"] += ms
+                a["flops"] += meta["flops"]
+                a["bytes"] += meta["bytes"]
+                a["launches"] += 1
+        total_ms = sum(a["ms"] for a in agg.values()) / reps
+        for kname, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+            per_kernel[kname] = dict(launches_per_step=a["launches"] // reps, avg_us=round(1e3 * a["ms"] / a["launches"], 2),
+                                     share=round(a["ms"] / reps / total_ms, 4),
+                                     tflops=round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 2) if a["flops"] else None,
+                                     gbs=round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1) if a["bytes"] else None)
+        dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
+        a = dom[1]
+        achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
+        roof = {"kernel": dom[0], "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "flops_per_launch": a["flops"] / a["launches"], "avg_launch_us": round(1e3 * a["ms"] / a["launches"], 2),
+                "launches_per_step": a["launches"] // reps}
+
+    if rank == 0:
+        from oracle.ammc_oracle import fwd_flops_per_clip
+        frames = args.batch * args.steps * world
+        value = frames / elapsed
+        flops_clip = fwd_flops_per_clip(args.size, args.size, n_embed=args.n_embed)
+        line = {
+            "metric": "frames/sec, 256x256x4 dual-stream clips (twostream forward, inference)",
+            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Ped2 full dual-stream + 2000-slot memory module, batch=16, inference "
+                                   "(BASELINE.json configs[1])",
+                       "batch_per_gpu": args.batch, "frame": f"{args.size}x{args.size}", "n_embed": args.n_embed,
+                       "embed_dim": 64, "k": 2, "parallelism": f"replicas x{world} (no collective)",
+                       "gflop_per_frame": round(flops_clip / 1e9, 2)},
+            "whole_path_tflops": round(value * flops_clip / 1e12 / world, 2),
+            "whole_path_frac_of_f32_mfma_peak": round(value * flops_clip / 1e12 / world / PEAK_F32_MFMA_TFLOPS, 4),
+            "roofline": roof,
+            "kernels": per_kernel,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,144 @@
+/*
+ * ammc_hip.h - C ABI of libammc_hip.so: the MI355X (gfx950) kernels behind the
+ * appearance-motion memory-consistency network's forward()/backward().
+ *
+ * The reference (NjuHaoZhang/AMMCNet_AAAI2021) has no native code: its hot
+ * path is `twostream.forward` (Code/models/unet.py:981-1007) executed by
+ * torch.nn modules on cuDNN/ATen.  Every entry below replaces the ATen/cuDNN
+ * call(s) named in its comment; the Python host
+ * (ammcnet_aaai2021_amd/unet.py) keeps the reference's nn.Module interface and
+ * state_dict layout and binds these symbols with ctypes.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; device pointers unless stated;
+ *   - every entry takes the hipStream_t to launch on (as void*), launches
+ *     asynchronously, allocates nothing and never synchronises;
+ *   - return 0 on success, a negative AMMC_E* code on bad arguments, or the
+ *     positive hipError_t of a failed launch; never abort();
+ *   - activations inside the path are fp32 NHWC ("pixel-major"); tensors that
+ *     feed a 3x3 convolution carry a one-pixel zero halo:
+ *     [B][H+2][W+2][C].  Strides below are in ELEMENTS.
+ */
+#ifndef AMMC_HIP_H
+#define AMMC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMMC_OK 0
+#define AMMC_EINVAL (-1)   /* bad shape / alignment / null pointer   */
+#define AMMC_EUNSUP (-2)   /* shape not supported by any kernel tile */
+
+#define AMMC_ACT_NONE 0
+#define AMMC_ACT_RELU 1
+#define AMMC_ACT_TANH 2
+
+/* library / device identification ---------------------------------------- */
+int ammc_abi_version(void);                    /* bumps on any signature change */
+const char* ammc_build_info(void);             /* "gfx950 ..." */
+const char* ammc_error_string(int code);
+
+/*
+ * Implicit-GEMM convolution on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32):
+ *   y[m, n] = act( scale[n] * sum_k A[m, k] * Wp[n, k] + shift[n] ) + res[m, n]
+ * m runs over the B*H*W pixels, k = tap*Cin + c over `ntaps` (1 or 9) window
+ * taps and Cin channels; A is gathered on the fly from the NHWC input.
+ *
+ * Replaces, by mode:
+ *   ntaps=9            nn.Conv2d(3x3, pad 1, bias=False) + BatchNorm2d(eval) + ReLU
+ *                      (unet.py:11-16, `double_conv`), the AMFT residual add
+ *                      (unet.py:962-965) through `res`
+ *   ntaps=1            nn.Conv2d 1x1 + bias, `enc`/`dec` (unet.py:321-330) and
+ *                      `out += x` (unet.py:386) through `res`
+ *   ntaps=1, up=2      nn.ConvTranspose2d(C, C/2, 2, stride 2) + bias (unet.py:47,51):
+ *                      N = 4*cgroup columns, column n = (dy*2+dx)*cgroup + co is
+ *                      scattered to pixel (2y+dy, 2x+dx); writing into a channel
+ *                      slice of the concat buffer replaces torch.cat (unet.py:57)
+ */
+typedef struct AmmcConvDesc {
+  const float* x;        /* input, offset to tap (0,0) of pixel (0,0,0), channel 0        */
+  const float* w;        /* packed weights [N][Kpad], Kpad = roundup(ntaps*Cin, 32)       */
+  float* y;              /* output, offset to pixel (0,0,0) (+halo) and channel offset     */
+  const float* scale;    /* [N] or NULL (=1)                                              */
+  const float* shift;    /* [N] or NULL (=0)                                              */
+  const float* res;      /* residual added after the activation, or NULL                  */
+  int32_t batch, height, width;        /* pixel space of m                               */
+  int32_t cin;           /* channels per tap: power of two >= 4                           */
+  int32_t ntaps;         /* 9 (3x3, pad 1 via the halo) or 1                              */
+  int32_t n;             /* GEMM N: multiple of 64                                        */
+  int32_t up;            /* 1, or 2 for the ConvTranspose scatter                         */
+  int32_t cgroup;        /* channels per (dy,dx) group when up=2 (multiple of 32); else n */
+  int32_t act;           /* AMMC_ACT_*                                                    */
+  int32_t reserved;
+  int64_t x_bs, x_rs, x_ps;            /* input batch / row / pixel strides              */
+  int64_t y_bs, y_rs, y_ps;            /* output strides (of the OUTPUT resolution)      */
+  int64_t r_bs, r_rs, r_ps;            /* residual strides                               */
+} AmmcConvDesc;
+
+int ammc_conv_gemm_f32(const AmmcConvDesc* desc, void* stream);
+
+/* 3x3 conv with 1..4 output channels + bias + tanh, NCHW output:
+ * `outc` followed by torch.tanh (unet.py:920, 998-1007).  x is halo-padded NHWC
+ * (offset to tap (0,0) of pixel (0,0,0)); w_packed comes from ammc_pack_outc_weight_f32
+ * (OIHW [cout][cin][3][3] -> [9][cin][4]). */
+int ammc_pack_outc_weight_f32(const float* w_oihw, int32_t cout, int32_t cin, float* out, void* stream);
+int ammc_conv3x3_out_tanh_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps,
+                              const float* w_packed, const float* bias,
+                              int32_t batch, int32_t height, int32_t width,
+                              int32_t cin, int32_t cout, float* y_nchw, void* stream);
+
+/* nn.MaxPool2d(2) (unet.py:36) on NHWC; input strides explicit (the skip tensor lives in
+ * the concat buffer), output strides explicit (halo-padded). h,w are OUTPUT sizes. */
+int ammc_maxpool2x2_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps,
+                        float* y, int64_t y_bs, int64_t y_rs, int64_t y_ps,
+                        int32_t batch, int32_t h, int32_t w, int32_t c, void* stream);
+
+/* module-boundary layout change: NCHW fp32 [B,C,H,W] -> NHWC with explicit strides
+ * (y points at pixel (0,0), i.e. inside the halo; channels c..cp-1 are written as zero,
+ * cp % 4 == 0).  Writing into a channel slice of a wider buffer is allowed. */
+int ammc_nchw_to_nhwc_f32(const float* x, int32_t batch, int32_t c, int32_t h, int32_t w,
+                          float* y, int64_t y_bs, int64_t y_rs, int64_t y_ps, int32_t cp, void* stream);
+/* NHWC (strided) -> NCHW, for tensors handed back across the module boundary */
+int ammc_nhwc_to_nchw_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps,
+                          int32_t batch, int32_t c, int32_t h, int32_t w, float* y, void* stream);
+/* zero the one-pixel border of a [B][H+2][W+2][C] buffer */
+int ammc_zero_halo_f32(float* y, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream);
+
+/* weight pre-packing (run once per load_state_dict / optimizer step) ------ */
+/* OIHW [cout][cin][kh][kw] (kh=kw=3 or 1) -> [cout][Kpad], k = (r*kw+s)*cin_p + c */
+int ammc_pack_conv_weight_f32(const float* w_oihw, int32_t cout, int32_t cin, int32_t ksize,
+                              int32_t cin_p, float* out, void* stream);
+/* ConvTranspose2d IOHW [cin][co][2][2] -> [4*co][cin], row (dy*2+dx)*co + c_out */
+int ammc_pack_convt_weight_f32(const float* w_iohw, int32_t cin, int32_t co, float* out, void* stream);
+/* eval-mode BatchNorm2d folded to y = scale*x + shift (unet.py:12,15) */
+int ammc_bn_fold_f32(const float* gamma, const float* beta, const float* mean, const float* var,
+                     float eps, int32_t c, float* scale, float* shift, void* stream);
+/* codebook [D][M] -> slot-major [M][D] plus |E_m|^2 (unet.py:287, 315-316) */
+int ammc_pack_codebook_f32(const float* embed_dm, int32_t d, int32_t m, float* embed_md,
+                           float* enorm, void* stream);
+
+/*
+ * Memory addressing, forward (`Quantize_topk.forward`, unet.py:282-297, 310-313):
+ * squared-L2 distance of each of n feature vectors x[n][d] to the m slots,
+ * the k nearest slots (nearest first), their rows gathered and concatenated
+ * into q_topk[n][k*d], q_one[n][d] = x + (E[i1]-x), and per-block partial
+ * sums of (E[i1]-x)^2 written to diff_partial[ammc_memory_topk_blocks(n)].
+ * embed_dm is the module's own buffer [d][m]; embed_md / enorm come from
+ * ammc_pack_codebook_f32.  d in {64,128,192,256}, k <= 4, q_one may be NULL.
+ * The n x m distance matrix never reaches HBM.
+ */
+int ammc_memory_topk_blocks(int32_t n);
+int ammc_memory_topk_fwd_f32(const float* x, const float* embed_dm, const float* embed_md,
+                             const float* enorm, int32_t n, int32_t d, int32_t m, int32_t k,
+                             int32_t* idx_topk, float* q_topk, float* q_one,
+                             float* diff_partial, void* stream);
+/* diff = sum(partials) / count, fixed order (deterministic) */
+int ammc_sum_partials_f32(const float* partial, int32_t nparts, float inv_count, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMMC_HIP_H */
