@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libammc_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 
@@ -26,10 +26,11 @@ class AmmcConvDesc(C.Structure):
         ("x", _p), ("w", _p), ("y", _p), ("scale", _p), ("shift", _p), ("res", _p),
         ("batch", _i32), ("height", _i32), ("width", _i32),
         ("cin", _i32), ("ntaps", _i32), ("n", _i32), ("up", _i32), ("cgroup", _i32),
-        ("act", _i32), ("reserved", _i32),
+        ("act", _i32), ("n_store", _i32),
         ("x_bs", _i64), ("x_rs", _i64), ("x_ps", _i64),
         ("y_bs", _i64), ("y_rs", _i64), ("y_ps", _i64),
         ("r_bs", _i64), ("r_rs", _i64), ("r_ps", _i64),
+        ("y_cs", _i64),
     ]
 
 

@@ -179,6 +179,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(ConvArgs a) {
     const float sc = d.scale ? d.scale[ncol] : 1.f;
     const float sh = d.shift ? d.shift[ncol] : 0.f;
     int co = ncol;
+    const int nstore = d.n_store > 0 ? d.n_store : d.n;
+    const int64_t ycs = d.y_cs > 0 ? d.y_cs : 1;
     int goff = 0;
     if (d.up == 2) {
       const int g = ncol / d.cgroup;
@@ -191,12 +193,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(ConvArgs a) {
       for (int r = 0; r < 16; ++r) {
         const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const int o = tab_out[row];
-        if (o >= 0) {
+        if (o >= 0 && co < nstore) {
           float v = acc[i][j][r] * sc + sh;
           if (d.act == AMMC_ACT_RELU) v = v > 0.f ? v : 0.f;
           else if (d.act == AMMC_ACT_TANH) v = tanhf(v);
           if (d.res) v += d.res[tab_res[row] + co];
-          d.y[o + goff + co] = v;
+          d.y[o + goff + (int64_t)co * ycs] = v;
         }
       }
     }
@@ -234,7 +236,8 @@ extern "C" int ammc_conv_gemm_f32(const AmmcConvDesc* desc, void* stream) {
   if (d.ntaps != 9 && d.ntaps != 1) return AMMC_EINVAL;
   if (d.ntaps == 9 && (d.cin < 4 || (d.cin & (d.cin - 1)))) return AMMC_EUNSUP;   // power of two
   if (d.ntaps == 1 && (d.cin <= 0 || d.cin % 32)) return AMMC_EUNSUP;
-  if (d.n <= 0 || (d.n % 64)) return AMMC_EUNSUP;
+  if (d.n <= 0 || (d.n != 32 && (d.n % 64))) return AMMC_EUNSUP;
+  if (d.n_store < 0 || d.n_store > d.n || d.y_cs < 0) return AMMC_EINVAL;
   if (d.up != 1 && d.up != 2) return AMMC_EINVAL;
   if (d.up == 2 && (d.cgroup <= 0 || d.cgroup % 32 || d.n != 4 * d.cgroup)) return AMMC_EINVAL;
   if (((uintptr_t)d.x | (uintptr_t)d.w) & 15) return AMMC_EINVAL;   // 16-B DMA pieces
@@ -254,6 +257,7 @@ extern "C" int ammc_conv_gemm_f32(const AmmcConvDesc* desc, void* stream) {
   a.cin_log2 = ammc_ilog2(d.cin);
   a.n_tiles = 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (d.n == 32) return launch<4, 1, 1, 1>(a, s);        // 128 x 32,  waves 4x1 of 32x32 (small-N layers)
   if (d.n % 128 == 0) return launch<2, 2, 2, 2>(a, s);   // 128 x 128, waves 2x2 of 64x64
   return launch<4, 1, 1, 2>(a, s);                        // 128 x 64,  waves 4x1 of 32x64
 }

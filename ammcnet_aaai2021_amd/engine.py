@@ -23,7 +23,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_RELU, AmmcConvDesc
+from ._lib import ACT_NONE, ACT_RELU, ACT_TANH, AmmcConvDesc
 
 BN_EPS = 1e-5
 
@@ -181,9 +181,13 @@ class _StreamPack:
         self.up = []
         for u in (net.up1, net.up2, net.up3):
             self.up.append((pk.convt(u.up.weight), u.up.bias.detach(), _DoubleConvPack(pk, u.conv)))
-        self.outc_w = pk.outc(net.outc.weight)
-        self.outc_b = net.outc.bias.detach()
+        # `outc` rides in a 32-column MFMA tile: pad the 2-3 filters (and the bias) to 32 rows
         self.cout = net.outc.weight.shape[0]
+        w32 = torch.zeros((32,) + tuple(net.outc.weight.shape[1:]), device=pk.device, dtype=torch.float32)
+        w32[:self.cout].copy_(net.outc.weight.detach())
+        self.outc_w, _ = pk.conv(w32, 3)
+        self.outc_b = torch.zeros(32, device=pk.device, dtype=torch.float32)
+        self.outc_b[:self.cout].copy_(net.outc.bias.detach())
         self.cin = net.inc.conv.conv[0].weight.shape[1]
         self.vq = None
         if hasattr(net, "vq_down3"):
@@ -239,9 +243,21 @@ class _Builder:
         ct = cin_true if cin_true is not None else cin
         flops = 2.0 * m_pix * n * ntaps * ct
         nbytes = 4.0 * m_pix * (ct + n + (n if res is not None else 0))
-        tile = "128x128" if n % 128 == 0 else "128x64"
+        tile = "128x32" if n == 32 else "128x128" if n % 128 == 0 else "128x64"
         self.plan.add(self.lib.ammc_conv_gemm_f32, C.byref(d), name=name, flops=flops, nbytes=nbytes,
                       kernel=f"conv_gemm_f32<{tile}>")
+        return d
+
+    def outc_desc(self, x: Act, w: torch.Tensor, bias32: torch.Tensor, cout: int) -> AmmcConvDesc:
+        """`outc` + tanh with an NCHW store; the output pointer is patched per call (fresh tensor)"""
+        d = AmmcConvDesc()
+        d.x, d.w, d.shift = x.tap0(), _ptr(w), _ptr(bias32)
+        d.batch, d.height, d.width = x.B, x.H, x.W
+        d.cin, d.ntaps, d.n, d.up, d.cgroup, d.act, d.n_store = x.c, 9, 32, 1, 32, ACT_TANH, cout
+        d.x_bs, d.x_rs, d.x_ps = x.strides
+        d.y_bs, d.y_rs, d.y_ps, d.y_cs = cout * x.H * x.W, x.W, 1, x.H * x.W
+        self.plan.keep.extend([d, w, bias32])
+        return d
 
     def double_conv(self, x: Act, p: _DoubleConvPack, mid: Act, y: Act, res: Optional[Act] = None, name="dc"):
         self.conv(x, p.w0, mid, ntaps=9, cin=p.cin_p, n=p.cout, scale=p.s0, shift=p.b0, act=ACT_RELU,
@@ -332,6 +348,7 @@ class StreamGraph:
             bld.double_conv(self.cat[lvl], dc, mid, out, name=f"up{j + 1}")
             y = out
         self.u3 = y
+        self.outc = bld.outc_desc(y, sp.outc_w, sp.outc_b, sp.cout)
 
 
 class EvalEngine:
@@ -344,6 +361,8 @@ class EvalEngine:
         self._packs = None
         self._pack_version = None
         self._plans: Dict[Tuple, dict] = {}
+        self._timed = False          # bench.py: bracket every launch with HIP events
+        self.timings = []
 
     # ---- parameters ---------------------------------------------------------------
     def _version(self):
@@ -432,6 +451,20 @@ class EvalEngine:
         streams: List[StreamGraph] = st["streams"]
         outs = []
         keep = []
+        timed = self._timed
+        recs = []
+
+        def launch(fn, args, meta):
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            rc = fn(*args, stream)
+            if timed:
+                e1.record()
+                recs.append((meta, e0, e1))
+            if rc != 0:
+                _lib.check(rc, meta["name"])
+
         for s, x in zip(streams, inputs):
             if x.shape[1] != s.sp.cin or x.shape[0] != B or x.shape[2] != H or x.shape[3] != W:
                 raise ValueError(f"input shape {tuple(x.shape)} does not match the model ({s.sp.cin} channels)")
@@ -439,15 +472,26 @@ class EvalEngine:
             if x.dtype != torch.float32 or not x.is_contiguous():
                 x = x.float().contiguous()
             keep.append(x)
-            _lib.check(lib.ammc_nchw_to_nhwc_f32(_ptr(x), B, s.sp.cin, H, W, s.x_in.pix0(), *s.x_in.strides,
-                                                 s.sp.inc.cin_p, stream), "nchw_to_nhwc")
-        st["plan"].run(stream)
+            launch(lib.ammc_nchw_to_nhwc_f32, (_ptr(x), B, s.sp.cin, H, W, s.x_in.pix0(), *s.x_in.strides,
+                                               s.sp.inc.cin_p),
+                   dict(name="nchw_to_nhwc", kernel="nchw_to_nhwc", flops=0.0,
+                        bytes=4.0 * B * H * W * (s.sp.cin + s.sp.inc.cin_p)))
+        if timed:
+            plan = st["plan"]
+            for (fn, args, _), meta in zip(plan.calls, plan.meta):
+                launch(fn, args, meta)
+        else:
+            st["plan"].run(stream)
         for s in streams:
             y = torch.empty((B, s.sp.cout, H, W), device=x0.device, dtype=torch.float32)
-            _lib.check(lib.ammc_conv3x3_out_tanh_f32(s.u3.tap0(), *s.u3.strides, _ptr(s.sp.outc_w),
-                                                     _ptr(s.sp.outc_b), B, H, W, 64, s.sp.cout, _ptr(y), stream),
-                       "outc_tanh")
+            s.outc.y = _ptr(y)
+            launch(lib.ammc_conv_gemm_f32, (C.byref(s.outc),),
+                   dict(name="outc_tanh", kernel="conv_gemm_f32<128x32>", flops=2.0 * B * H * W * 9 * 64 * s.sp.cout,
+                        bytes=4.0 * B * H * W * (64 + s.sp.cout)))
             outs.append(y)
+        if timed:
+            torch.cuda.synchronize()
+            self.timings = [(m, e0.elapsed_time(e1)) for m, e0, e1 in recs]
         self._last = st
         if self.kind == "unet":
             return outs[0]

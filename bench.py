@@ -42,8 +42,8 @@ def parse():
     p.add_argument("--n-embed", type=int, default=2000)
     p.add_argument("--size", type=int, default=256)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-sample-batch", type=int, default=2)
-    p.add_argument("--cpu-iters", type=int, default=3)
+    p.add_argument("--cpu-sample-batch", type=int, default=4)
+    p.add_argument("--cpu-iters", type=int, default=10)
     return p.parse_args()
 
 
@@ -51,14 +51,25 @@ def cpu_baseline(args):
     """the CPU restatement of the same forward on a bounded sample (kind "port")"""
     from ammcnet_aaai2021_amd import synthetic as S
     from oracle import ammc_oracle as O
-    threads = os.cpu_count() or 1
-    torch.set_num_threads(threads)
     sd = S.make_twostream_state(n_embed=args.n_embed)
     b = args.cpu_sample_batch
     rgb_x, op_x, _, _ = S.make_clips(b, args.size, args.size, tag="bench")
-    times = []
+    ncpu = os.cpu_count() or 1
+    # ATen's CPU convolutions stop scaling (and then collapse) well before 256 threads on the
+    # GPU box's 2x64-core host: take the best of a few thread counts, one forward each
+    best = None
     with torch.no_grad():
-        O.twostream_forward(sd, rgb_x, op_x, 2)                     # warm-up
+        for th in sorted({min(t, ncpu) for t in (8, 16, 32)}):
+            torch.set_num_threads(th)
+            O.twostream_forward(sd, rgb_x, op_x, 2)                 # warm-up at this thread count
+            t0 = time.perf_counter()
+            O.twostream_forward(sd, rgb_x, op_x, 2)
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[1]:
+                best = (th, dt)
+        threads = best[0]
+        torch.set_num_threads(threads)
+        times = []
         for _ in range(args.cpu_iters):
             t0 = time.perf_counter()
             O.twostream_forward(sd, rgb_x, op_x, 2)
@@ -67,7 +78,8 @@ def cpu_baseline(args):
     med = times[len(times) // 2]
     return {"value": round(b / med, 4), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"{args.cpu_iters} timed forwards (median) of batch {b} at {args.size}x{args.size}, "
-                      f"n_embed {args.n_embed}, torch CPU fp32, {threads} threads"}
+                      f"n_embed {args.n_embed}, torch CPU fp32, best of 8/16/32 threads = {threads} "
+                      f"(host has {ncpu} logical CPUs)"}
 
 
 def main():
@@ -123,17 +135,20 @@ def main():
     roof = None
     per_kernel = {}
     if rank == 0:
-        st = net._engine._last
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        eng = net._engine
         agg = {}
         reps = 3
+        eng._timed = True
         for _ in range(reps):
-            for meta, ms in st["plan"].run_timed(stream):
+            with torch.no_grad():
+                net(rgb_x, op_x)
+            for meta, ms in eng.timings:
                 a = agg.setdefault(meta["kernel"] or meta["name"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
                 a["ms"] += ms
                 a["flops"] += meta["flops"]
                 a["bytes"] += meta["bytes"]
                 a["launches"] += 1
+        eng._timed = False
         total_ms = sum(a["ms"] for a in agg.values()) / reps
         for kname, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
             per_kernel[kname] = dict(launches_per_step=a["launches"] // reps, avg_us=round(1e3 * a["ms"] / a["launches"], 2),

@@ -53,6 +53,10 @@ const char* ammc_error_string(int code);
  *                      (unet.py:962-965) through `res`
  *   ntaps=1            nn.Conv2d 1x1 + bias, `enc`/`dec` (unet.py:321-330) and
  *                      `out += x` (unet.py:386) through `res`
+ *   ntaps=9, n=32, n_store=cout, act=TANH, NCHW strides
+ *                      `outc` + torch.tanh (unet.py:920, 998-1007): the 2-3 output channels
+ *                      ride in a 32-wide MFMA column tile (the VALU form, kept below as
+ *                      ammc_conv3x3_out_tanh_f32, is L1-line-bound and 7x slower)
  *   ntaps=1, up=2      nn.ConvTranspose2d(C, C/2, 2, stride 2) + bias (unet.py:47,51):
  *                      N = 4*cgroup columns, column n = (dy*2+dx)*cgroup + co is
  *                      scattered to pixel (2y+dy, 2x+dx); writing into a channel
@@ -68,14 +72,15 @@ typedef struct AmmcConvDesc {
   int32_t batch, height, width;        /* pixel space of m                               */
   int32_t cin;           /* channels per tap: power of two >= 4                           */
   int32_t ntaps;         /* 9 (3x3, pad 1 via the halo) or 1                              */
-  int32_t n;             /* GEMM N: multiple of 64                                        */
+  int32_t n;             /* GEMM N: 32, or a multiple of 64                               */
   int32_t up;            /* 1, or 2 for the ConvTranspose scatter                         */
   int32_t cgroup;        /* channels per (dy,dx) group when up=2 (multiple of 32); else n */
   int32_t act;           /* AMMC_ACT_*                                                    */
-  int32_t reserved;
+  int32_t n_store;       /* columns actually stored (0 = all n); lets a small-N layer pad N to 32 */
   int64_t x_bs, x_rs, x_ps;            /* input batch / row / pixel strides              */
   int64_t y_bs, y_rs, y_ps;            /* output strides (of the OUTPUT resolution)      */
   int64_t r_bs, r_rs, r_ps;            /* residual strides                               */
+  int64_t y_cs;          /* output channel stride: 0/1 = NHWC; H*W (with y_ps=1, y_rs=W) = NCHW    */
 } AmmcConvDesc;
 
 int ammc_conv_gemm_f32(const AmmcConvDesc* desc, void* stream);
