@@ -158,8 +158,15 @@ def main():
         dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
         a = dom[1]
         achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
+        # HBM-side bytes per launch cannot be read live: they come from the committed PMC passes
+        # (tools/profile_bench.sh -> profiles/rNN_pmc_traffic.json) of this same command
+        traffic = None
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1:]:
+            with open(path) as fp:
+                traffic = json.load(fp)["kernels"].get(dom[0], {}).get("traffic_bytes_per_launch")
         roof = {"kernel": dom[0], "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                 "flops_per_launch": a["flops"] / a["launches"], "avg_launch_us": round(1e3 * a["ms"] / a["launches"], 2),
                 "launches_per_step": a["launches"] // reps}
 
