@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libammc_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 4
 
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 
@@ -30,9 +30,21 @@ class AmmcConvDesc(C.Structure):
         ("x_bs", _i64), ("x_rs", _i64), ("x_ps", _i64),
         ("y_bs", _i64), ("y_rs", _i64), ("y_ps", _i64),
         ("r_bs", _i64), ("r_rs", _i64), ("r_ps", _i64),
-        ("y_cs", _i64),
+        ("y_cs", _i64), ("x_step", _i32), ("reserved2", _i32),
     ]
 
+
+class AmmcWgradDesc(C.Structure):
+    """mirror of `struct AmmcWgradDesc` (include/ammc_hip.h)"""
+    _fields_ = [
+        ("g", _p), ("a", _p), ("dw", _p), ("zeros", _p),
+        ("batch", _i32), ("height", _i32), ("width", _i32), ("n", _i32), ("cin", _i32), ("ntaps", _i32),
+        ("a_step", _i32), ("reserved", _i32),
+        ("g_bs", _i64), ("g_rs", _i64), ("g_ps", _i64), ("a_bs", _i64), ("a_rs", _i64), ("a_ps", _i64),
+    ]
+
+
+_s3 = [_i64, _i64, _i64]
 
 # name -> (restype, argtypes); every symbol include/ammc_hip.h declares
 SIGNATURES = {
@@ -53,6 +65,23 @@ SIGNATURES = {
     "ammc_memory_topk_blocks": (C.c_int, [_i32]),
     "ammc_memory_topk_fwd_f32": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
     "ammc_sum_partials_f32": (C.c_int, [_p, _i32, _f32, _p, _p]),
+    "ammc_conv_wgrad_f32": (C.c_int, [C.POINTER(AmmcWgradDesc), _p]),
+    "ammc_unpack_conv_wgrad_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
+    "ammc_unpack_convt_wgrad_f32": (C.c_int, [_p, _i32, _i32, _p, _p]),
+    "ammc_pack_conv_dgrad_weight_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
+    "ammc_transpose_pad_f32": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
+    "ammc_chan_reduce_blocks": (C.c_int, [_i32]),
+    "ammc_bn_stats_f32": (C.c_int, [_p] + _s3 + [_i32, _i32, _i32, _i32, _p, _p]),
+    "ammc_bn_finalize_f32": (C.c_int, [_p, _i32, _i32, _f32, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _p]),
+    "ammc_scale_shift_act_f32": (C.c_int, [_p] + _s3 + [_p, _p, _p] + _s3 + [_p] + _s3 + [_i32] * 5 + [_p]),
+    "ammc_bn_bwd_reduce_f32": (C.c_int, [_p] + _s3 + [_p] + _s3 + [_p, _p, _p, _p] + [_i32] * 5 + [_p, _p]),
+    "ammc_bn_bwd_apply_f32": (C.c_int, [_p] + _s3 + [_p] + _s3 + [_p, _p, _p, _p, _p, _i32, _p] + _s3 + [_i32] * 4 + [_p]),
+    "ammc_chan_sum_f32": (C.c_int, [_p] + _s3 + [_i32, _i32, _i32, _i32, _p, _p]),
+    "ammc_reduce_partials_f32": (C.c_int, [_p, _i32, _i32, _f32, _p, _p]),
+    "ammc_maxpool2x2_bwd_f32": (C.c_int, [_p] + _s3 + [_p] + _s3 + [_p] + _s3 + [_p] + _s3 + [_i32] * 4 + [_p]),
+    "ammc_tanh_bwd_nhwc_f32": (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _p] + _s3 + [_i32, _p]),
+    "ammc_commit_bwd_f32": (C.c_int, [_p, _p, _p, _i32, _p, _p, _p, _i32, _i32, _p]),
+    "ammc_codebook_ema_f32": (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _p, _p, _p, _p]),
 }
 
 _lib = None

@@ -49,6 +49,10 @@ __device__ __forceinline__ void issue_chunk(const AmmcConvDesc& d, int cin_log2,
     const int r = (tap * 11) >> 5;               // tap / 3 for tap in [0, 8]
     const int s = tap - 3 * r;
     toff = (int64_t)r * d.x_rs + (int64_t)s * d.x_ps + (k & (d.cin - 1));
+  } else if (d.ntaps == 4) {                    // 2x2 window on a 2x-resolution input (ConvTranspose dgrad)
+    int tap = k >> cin_log2;
+    tap = tap < 3 ? tap : 3;
+    toff = (int64_t)(tap >> 1) * d.x_rs + (int64_t)(tap & 1) * d.x_ps + (k & (d.cin - 1));
   } else {
     toff = k;
   }
@@ -91,6 +95,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(ConvArgs a) {
   // piece p = j*256 + tid  ->  tile row j*32 + (tid >> 3), physical slot tid & 7;
   // the logical slot it must fetch is (tid & 7) ^ ((row >> 1) & 7) = (tid&7) ^ ((tid>>4)&7).
   const int sl = (tid & 7) ^ ((tid >> 4) & 7);
+  const int xstep = d.x_step > 1 ? d.x_step : 1;
   const float* a_src[AJ];
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(ConvArgs a) {
     const int t = m / W;
     const int y = t % H;
     const int b = t / H;
-    a_src[j] = d.x + ((int64_t)b * d.x_bs + (int64_t)y * d.x_rs + (int64_t)x * d.x_ps);
+    a_src[j] = d.x + ((int64_t)b * d.x_bs + (int64_t)(y * xstep) * d.x_rs + (int64_t)(x * xstep) * d.x_ps);
   }
   const float* b_src[BJ];
 #pragma unroll
@@ -233,8 +238,9 @@ extern "C" int ammc_conv_gemm_f32(const AmmcConvDesc* desc, void* stream) {
   if (!desc || !desc->x || !desc->w || !desc->y) return AMMC_EINVAL;
   const AmmcConvDesc& d = *desc;
   if (d.batch <= 0 || d.height <= 0 || d.width <= 0) return AMMC_EINVAL;
-  if (d.ntaps != 9 && d.ntaps != 1) return AMMC_EINVAL;
-  if (d.ntaps == 9 && (d.cin < 4 || (d.cin & (d.cin - 1)))) return AMMC_EUNSUP;   // power of two
+  if (d.ntaps != 9 && d.ntaps != 1 && d.ntaps != 4) return AMMC_EINVAL;
+  if (d.ntaps != 1 && (d.cin < 4 || (d.cin & (d.cin - 1)))) return AMMC_EUNSUP;   // power of two
+  if (d.x_step < 0 || d.x_step > 2) return AMMC_EINVAL;
   if (d.ntaps == 1 && (d.cin <= 0 || d.cin % 32)) return AMMC_EUNSUP;
   if (d.n <= 0 || (d.n != 32 && (d.n % 64))) return AMMC_EUNSUP;
   if (d.n_store < 0 || d.n_store > d.n || d.y_cs < 0) return AMMC_EINVAL;

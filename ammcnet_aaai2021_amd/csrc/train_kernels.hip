@@ -1,0 +1,511 @@
+// Training-mode pieces of the path that are not contractions: batch-statistics BatchNorm
+// (forward statistics / apply, backward reductions / apply), max-pool and tanh backward, the
+// commit-loss gradient, the EMA codebook update, per-channel bias-gradient sums and the
+// filter re-layouts for the input-gradient convolutions.  All are streaming kernels over
+// NHWC tensors with explicit strides (16 B per lane); their roofline is HBM.
+//
+// Reference semantics (Code/models/unet.py): nn.BatchNorm2d in training mode (:12,15: biased
+// variance to normalise, unbiased for the running estimate, momentum 0.1), nn.MaxPool2d(2)
+// (:36), torch.tanh (:1007), `diff` (:310), EMA update (:298-309).
+#include "ammc_common.h"
+
+namespace ammc_impl {
+
+struct Tensor3 {          // NHWC view: element offset of pixel (b, y, x), channel 0
+  int64_t bs, rs, ps;
+};
+
+__device__ __forceinline__ int64_t pix_off(int m, int H, int W, const Tensor3& t) {
+  const int x = m % W;
+  const int q = m / W;
+  const int y = q % H;
+  const int b = q / H;
+  return (int64_t)b * t.bs + (int64_t)y * t.rs + (int64_t)x * t.ps;
+}
+
+constexpr int RED_PIX = 2048;      // pixels per workgroup in the per-channel reductions
+
+// ---- per-channel reductions ---------------------------------------------------------
+// MODE 0: sum(x), sum(x^2)                         (BN forward statistics)
+// MODE 1: sum(g), sum(g * xhat), g = dy * [pre>0]  (BN backward), xhat = (c - mean) * invstd
+// MODE 2: sum(x)                                   (bias gradients)
+// Layout: thread = (channel group of 4, pixel lane); partial[block][q][C].
+template <int MODE>
+__global__ __launch_bounds__(256) void chan_reduce_kernel(
+    const float* __restrict__ x, Tensor3 xt, const float* __restrict__ dy, Tensor3 dt,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, int relu, int M, int H, int W, int C, float* __restrict__ partial) {
+  __shared__ f32x4 red[2][256];
+  const int C4 = C >> 2;
+  const int tx = threadIdx.x % C4;
+  const int ty = threadIdx.x / C4;
+  const int PY = 256 / C4;
+  const int m0 = blockIdx.x * RED_PIX;
+  const int m1 = min(m0 + RED_PIX, M);
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 mu, is, ga, be;
+  if (MODE == 1 && ty < PY) {
+    mu = *reinterpret_cast<const f32x4*>(mean + tx * 4);
+    is = *reinterpret_cast<const f32x4*>(invstd + tx * 4);
+    ga = *reinterpret_cast<const f32x4*>(gamma + tx * 4);
+    be = *reinterpret_cast<const f32x4*>(beta + tx * 4);
+  }
+  if (ty < PY) {
+    for (int m = m0 + ty; m < m1; m += PY) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + pix_off(m, H, W, xt) + tx * 4);
+      if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s0[i] += v[i]; s1[i] += v[i] * v[i]; }
+      } else if (MODE == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s0[i] += v[i];
+      } else {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dy + pix_off(m, H, W, dt) + tx * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float xh = (v[i] - mu[i]) * is[i];
+          const float pre = v[i] * ga[i] + be[i];      // ga = folded scale, be = folded shift: the forward's expression
+          const float gi = (!relu || pre > 0.f) ? g[i] : 0.f;
+          s0[i] += gi;
+          s1[i] += gi * xh;
+        }
+      }
+    }
+  }
+  red[0][threadIdx.x] = s0;
+  red[1][threadIdx.x] = s1;
+  __syncthreads();
+  if (ty == 0) {
+    for (int j = 1; j < PY; ++j) {
+      const f32x4 a0 = red[0][j * C4 + tx], a1 = red[1][j * C4 + tx];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { s0[i] += a0[i]; s1[i] += a1[i]; }
+    }
+    float* p = partial + (int64_t)blockIdx.x * (MODE == 2 ? 1 : 2) * C;
+    *reinterpret_cast<f32x4*>(p + tx * 4) = s0;
+    if (MODE != 2) *reinterpret_cast<f32x4*>(p + C + tx * 4) = s1;
+  }
+}
+
+// partial[nblk][Q][C] -> out[Q][C], double accumulation, fixed order (deterministic)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nblk, int QC,
+                                                              float scale, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= QC) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)partial[(int64_t)b * QC + i];
+  out[i] = (float)(s * (double)scale);
+}
+
+// BN training finalize: batch mean / biased var -> invstd, folded scale/shift; running stats.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    const float* __restrict__ partial, int nblk, int C, float count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
+    float* __restrict__ running_var, float* __restrict__ mean, float* __restrict__ invstd,
+    float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, ss = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s += (double)partial[(int64_t)b * 2 * C + c];
+    ss += (double)partial[(int64_t)b * 2 * C + C + c];
+  }
+  const double mu = s / count;
+  double var = ss / count - mu * mu;
+  var = var > 0.0 ? var : 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  mean[c] = (float)mu;
+  invstd[c] = is;
+  const float sc = gamma[c] * is;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mu * sc;
+  const double unbiased = count > 1.f ? var * (double)count / ((double)count - 1.0) : var;
+  running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+  running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+}
+
+// y = act(x * scale + shift) + res        (interior pixels only: halos stay zero)
+__global__ __launch_bounds__(256) void scale_shift_act_kernel(
+    const float* __restrict__ x, Tensor3 xt, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ res, Tensor3 rt, float* __restrict__ y, Tensor3 yt, int relu, int M, int H, int W,
+    int C4) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (int64_t)M * C4) return;
+  const int c4 = (int)(gid % C4);
+  const int m = (int)(gid / C4);
+  const f32x4 v = *reinterpret_cast<const f32x4*>(x + pix_off(m, H, W, xt) + c4 * 4);
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
+  f32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float t = v[i] * sc[i] + sh[i];
+    if (relu) t = t > 0.f ? t : 0.f;
+    o[i] = t;
+  }
+  if (res) {
+    const f32x4 r = *reinterpret_cast<const f32x4*>(res + pix_off(m, H, W, rt) + c4 * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] += r[i];
+  }
+  *reinterpret_cast<f32x4*>(y + pix_off(m, H, W, yt) + c4 * 4) = o;
+}
+
+// dc = gamma * invstd * (g - sum_g / M - xhat * sum_gx / M),  g = dy * [pre > 0]
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const float* __restrict__ c, Tensor3 ct, const float* __restrict__ dy, Tensor3 dt,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ sums /* [2][C]: dbeta, dgamma */, float inv_count,
+    int relu, float* __restrict__ dc, Tensor3 ot, int M, int H, int W, int C4) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (int64_t)M * C4) return;
+  const int c4 = (int)(gid % C4);
+  const int m = (int)(gid / C4);
+  const int C = C4 * 4;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(c + pix_off(m, H, W, ct) + c4 * 4);
+  const f32x4 g = *reinterpret_cast<const f32x4*>(dy + pix_off(m, H, W, dt) + c4 * 4);
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4);
+  const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c4 * 4);
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c4 * 4);
+  const f32x4 be = *reinterpret_cast<const f32x4*>(beta + c4 * 4);
+  const f32x4 sg = *reinterpret_cast<const f32x4*>(sums + c4 * 4);
+  const f32x4 sgx = *reinterpret_cast<const f32x4*>(sums + C + c4 * 4);
+  f32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float xh = (v[i] - mu[i]) * is[i];
+    const float pre = v[i] * ga[i] + be[i];             // ga = folded scale (gamma*invstd), be = folded shift
+    const float gi = (!relu || pre > 0.f) ? g[i] : 0.f;
+    o[i] = ga[i] * (gi - sg[i] * inv_count - xh * sgx[i] * inv_count);
+  }
+  *reinterpret_cast<f32x4*>(dc + pix_off(m, H, W, ot) + c4 * 4) = o;
+}
+
+// MaxPool2d(2) backward (+ the gradient that reaches the same tensor through the skip path):
+// dx[2y+i][2x+j] = add[2y+i][2x+j] + (first max position in row-major window order ? dp[y][x] : 0)
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(
+    const float* __restrict__ x, Tensor3 xt, const float* __restrict__ dp, Tensor3 pt,
+    const float* __restrict__ add, Tensor3 at, float* __restrict__ dx, Tensor3 ot, int M, int h, int w, int C4) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (int64_t)M * C4) return;
+  const int c4 = (int)(gid % C4);
+  const int m = (int)(gid / C4);
+  const int xx = m % w, q = m / w, yy = q % h, b = q / h;
+  const float* s = x + (int64_t)b * xt.bs + (int64_t)(2 * yy) * xt.rs + (int64_t)(2 * xx) * xt.ps + c4 * 4;
+  const f32x4 g = *reinterpret_cast<const f32x4*>(dp + (int64_t)b * pt.bs + (int64_t)yy * pt.rs + (int64_t)xx * pt.ps + c4 * 4);
+  f32x4 v[4];
+  v[0] = *reinterpret_cast<const f32x4*>(s);
+  v[1] = *reinterpret_cast<const f32x4*>(s + xt.ps);
+  v[2] = *reinterpret_cast<const f32x4*>(s + xt.rs);
+  v[3] = *reinterpret_cast<const f32x4*>(s + xt.rs + xt.ps);
+  f32x4 o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int arg = 0;
+    float best = v[0][i];
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+      if (v[j][i] > best) { best = v[j][i]; arg = j; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j][i] = (j == arg) ? g[i] : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t po = (int64_t)(j >> 1);
+    const int64_t qo = (int64_t)(j & 1);
+    if (add) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(add + (int64_t)b * at.bs + (2 * yy + po) * at.rs + (2 * xx + qo) * at.ps + c4 * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[j][i] += a[i];
+    }
+    *reinterpret_cast<f32x4*>(dx + (int64_t)b * ot.bs + (2 * yy + po) * ot.rs + (2 * xx + qo) * ot.ps + c4 * 4) = o[j];
+  }
+}
+
+// d(pre-tanh) = dout * (1 - out^2), NCHW -> NHWC (channels >= C written as zero up to Cp)
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                       int B, int C, int H, int W, float* __restrict__ y, Tensor3 yt,
+                                                       int Cp4) {
+  const int64_t total = (int64_t)B * Cp4 * H * W;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int xw = (int)(gid % W);
+  int64_t t = gid / W;
+  const int yh = (int)(t % H);
+  t /= H;
+  const int g = (int)(t % Cp4);
+  const int b = (int)(t / Cp4);
+  f32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = g * 4 + i;
+    float r = 0.f;
+    if (c < C) {
+      const int64_t o = (((int64_t)b * C + c) * H + yh) * W + xw;
+      const float ov = out[o];
+      r = dout[o] * (1.f - ov * ov);
+    }
+    v[i] = r;
+  }
+  *reinterpret_cast<f32x4*>(y + (int64_t)b * yt.bs + (int64_t)yh * yt.rs + (int64_t)xw * yt.ps + g * 4) = v;
+}
+
+// dz = ddiff * 2 (z - E[idx0]) / (N*D)  (+ dq)       (autograd of unet.py:310-311)
+__global__ __launch_bounds__(256) void commit_bwd_kernel(const float* __restrict__ z, const float* __restrict__ e_md,
+                                                         const int* __restrict__ idx, int k,
+                                                         const float* __restrict__ ddiff, float coef,
+                                                         const float* __restrict__ dq, float* __restrict__ dz,
+                                                         int N, int D4) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (int64_t)N * D4) return;
+  const int d4 = (int)(gid % D4);
+  const int n = (int)(gid / D4);
+  const int s = idx[(int64_t)n * k];
+  const f32x4 zv = *reinterpret_cast<const f32x4*>(z + (int64_t)n * D4 * 4 + d4 * 4);
+  const f32x4 ev = *reinterpret_cast<const f32x4*>(e_md + (int64_t)s * D4 * 4 + d4 * 4);
+  const float g = (ddiff ? ddiff[0] : 0.f) * coef;
+  f32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = g * (zv[i] - ev[i]);
+  if (dq) {
+    const f32x4 q = *reinterpret_cast<const f32x4*>(dq + (int64_t)n * D4 * 4 + d4 * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] += q[i];
+  }
+  *reinterpret_cast<f32x4*>(dz + (int64_t)n * D4 * 4 + d4 * 4) = o;
+}
+
+// EMA codebook update, step 1: one workgroup per slot, thread = feature.  Rows are visited in
+// index order, so the sums are deterministic (no atomics).
+__global__ __launch_bounds__(256) void ema_accumulate_kernel(const float* __restrict__ x, const int* __restrict__ idx,
+                                                             int k, int N, int D, int M, float decay, float omd,
+                                                             float* __restrict__ cluster_size,
+                                                             float* __restrict__ embed_avg /* [D][M] */) {
+  const int slot = blockIdx.x;
+  __shared__ int hits[256];
+  __shared__ int wcount[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float sum = 0.f;
+  int count = 0;
+  for (int base = 0; base < N; base += 256) {
+    const int n = base + threadIdx.x;
+    const bool hit = n < N && idx[(int64_t)n * k] == slot;
+    // ordered compaction (row order is kept, so the float sums are deterministic)
+    const unsigned long long bal = __ballot(hit);
+    if (lane == 0) wcount[wave] = __popcll(bal);
+    __syncthreads();
+    int off = 0, nh = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w < wave) off += wcount[w];
+      nh += wcount[w];
+    }
+    if (hit) hits[off + __popcll(bal & ((1ull << lane) - 1ull))] = n;
+    __syncthreads();
+    count += nh;
+    for (int d = threadIdx.x; d < D; d += 256)
+      for (int i = 0; i < nh; ++i) sum += x[(int64_t)hits[i] * D + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) cluster_size[slot] = decay * cluster_size[slot] + omd * (float)count;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    // note: with D > 256 the loop above accumulates several features into one `sum`; guarded on the host (D <= 256)
+    embed_avg[(int64_t)d * M + slot] = decay * embed_avg[(int64_t)d * M + slot] + omd * sum;
+  }
+}
+
+// step 2: n = sum(cluster_size); embed = embed_avg / ((cs + eps) / (n + M eps) * n)
+__global__ __launch_bounds__(256) void ema_normalize_kernel(const float* __restrict__ cluster_size,
+                                                            const float* __restrict__ embed_avg, int D, int M,
+                                                            float eps, float* __restrict__ embed) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < M; i += 256) s += cluster_size[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float n = red[0];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)D * M; i += (int64_t)gridDim.x * 256) {
+    const int slot = (int)(i % M);
+    const float smoothed = (cluster_size[slot] + eps) / (n + M * eps) * n;
+    embed[i] = embed_avg[i] / smoothed;
+  }
+}
+
+// OIHW [cout][cin][3][3] -> input-gradient filter [cin][Kpad], k = (r*3+s)*cout_p + n,
+// value W[n][c][2-r][2-s]   (transposed and flipped)
+__global__ __launch_bounds__(256) void pack_conv_dgrad_weight_kernel(const float* __restrict__ w, int cout, int cin,
+                                                                     int cout_p, int kpad, int rows,
+                                                                     float* __restrict__ out) {
+  const int64_t total = (int64_t)rows * kpad;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int k = (int)(gid % kpad);
+  const int c = (int)(gid / kpad);
+  const int tap = k / cout_p, n = k % cout_p;
+  float v = 0.f;
+  if (tap < 9 && n < cout && c < cin) v = w[((int64_t)n * cin + c) * 9 + (8 - tap)];
+  out[gid] = v;
+}
+
+// [rows][cols] -> [cols][rows_p] zero padded (1x1 conv input-gradient filter)
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ w, int rows, int cols,
+                                                            int rows_p, float* __restrict__ out) {
+  const int64_t total = (int64_t)cols * rows_p;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int r = (int)(gid % rows_p);
+  const int c = (int)(gid / rows_p);
+  out[gid] = r < rows ? w[(int64_t)r * cols + c] : 0.f;
+}
+
+inline unsigned nblk(int64_t total) { return (unsigned)((total + 255) / 256); }
+
+}  // namespace ammc_impl
+using namespace ammc_impl;
+
+extern "C" {
+
+int ammc_chan_reduce_blocks(int32_t pixels) { return pixels <= 0 ? 0 : (pixels + RED_PIX - 1) / RED_PIX; }
+
+static int check_nhwc(const void* p, int b, int h, int w, int c) {
+  if (!p || b <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3) || c > 1024) return AMMC_EINVAL;
+  return AMMC_OK;
+}
+
+int ammc_bn_stats_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, int32_t batch, int32_t h, int32_t w,
+                      int32_t c, float* partial, void* stream) {
+  if (check_nhwc(x, batch, h, w, c) || !partial) return AMMC_EINVAL;
+  const int M = batch * h * w;
+  Tensor3 xt{x_bs, x_rs, x_ps}, none{0, 0, 0};
+  hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(ammc_chan_reduce_blocks(M)), dim3(256), 0, (hipStream_t)stream,
+                     x, xt, nullptr, none, nullptr, nullptr, nullptr, nullptr, 0, M, h, w, c, partial);
+  return ammc_launch_status();
+}
+
+int ammc_bn_finalize_f32(const float* partial, int32_t nblocks, int32_t c, float count, const float* gamma,
+                         const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                         float* mean, float* invstd, float* scale, float* shift, void* stream) {
+  if (!partial || !gamma || !beta || !running_mean || !running_var || !mean || !invstd || !scale || !shift ||
+      nblocks <= 0 || c <= 0 || count <= 0.f) return AMMC_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(nblk(c)), dim3(256), 0, (hipStream_t)stream, partial, nblocks, c,
+                     count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+  return ammc_launch_status();
+}
+
+int ammc_scale_shift_act_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, const float* scale,
+                             const float* shift, const float* res, int64_t r_bs, int64_t r_rs, int64_t r_ps,
+                             float* y, int64_t y_bs, int64_t y_rs, int64_t y_ps, int32_t relu, int32_t batch,
+                             int32_t h, int32_t w, int32_t c, void* stream) {
+  if (check_nhwc(x, batch, h, w, c) || !scale || !shift || !y) return AMMC_EINVAL;
+  const int M = batch * h * w;
+  Tensor3 xt{x_bs, x_rs, x_ps}, rt{r_bs, r_rs, r_ps}, yt{y_bs, y_rs, y_ps};
+  hipLaunchKernelGGL(scale_shift_act_kernel, dim3(nblk((int64_t)M * (c >> 2))), dim3(256), 0, (hipStream_t)stream,
+                     x, xt, scale, shift, res, rt, y, yt, relu, M, h, w, c >> 2);
+  return ammc_launch_status();
+}
+
+int ammc_bn_bwd_reduce_f32(const float* c_raw, int64_t c_bs, int64_t c_rs, int64_t c_ps, const float* dy,
+                           int64_t d_bs, int64_t d_rs, int64_t d_ps, const float* mean, const float* invstd,
+                           const float* gamma, const float* beta, int32_t relu, int32_t batch, int32_t h, int32_t w,
+                           int32_t c, float* partial, void* stream) {
+  if (check_nhwc(c_raw, batch, h, w, c) || !dy || !mean || !invstd || !gamma || !beta || !partial) return AMMC_EINVAL;
+  const int M = batch * h * w;
+  Tensor3 ct{c_bs, c_rs, c_ps}, dt{d_bs, d_rs, d_ps};
+  hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(ammc_chan_reduce_blocks(M)), dim3(256), 0, (hipStream_t)stream,
+                     c_raw, ct, dy, dt, mean, invstd, gamma, beta, relu, M, h, w, c, partial);
+  return ammc_launch_status();
+}
+
+int ammc_bn_bwd_apply_f32(const float* c_raw, int64_t c_bs, int64_t c_rs, int64_t c_ps, const float* dy,
+                          int64_t d_bs, int64_t d_rs, int64_t d_ps, const float* mean, const float* invstd,
+                          const float* gamma, const float* beta, const float* sums, int32_t relu, float* dc,
+                          int64_t o_bs, int64_t o_rs, int64_t o_ps, int32_t batch, int32_t h, int32_t w, int32_t c,
+                          void* stream) {
+  if (check_nhwc(c_raw, batch, h, w, c) || !dy || !mean || !invstd || !gamma || !beta || !sums || !dc) return AMMC_EINVAL;
+  const int M = batch * h * w;
+  Tensor3 ct{c_bs, c_rs, c_ps}, dt{d_bs, d_rs, d_ps}, ot{o_bs, o_rs, o_ps};
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk((int64_t)M * (c >> 2))), dim3(256), 0, (hipStream_t)stream,
+                     c_raw, ct, dy, dt, mean, invstd, gamma, beta, sums, 1.f / (float)M, relu, dc, ot, M, h, w, c >> 2);
+  return ammc_launch_status();
+}
+
+int ammc_chan_sum_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, int32_t batch, int32_t h, int32_t w,
+                      int32_t c, float* partial, void* stream) {
+  if (check_nhwc(x, batch, h, w, c) || !partial) return AMMC_EINVAL;
+  const int M = batch * h * w;
+  Tensor3 xt{x_bs, x_rs, x_ps}, none{0, 0, 0};
+  hipLaunchKernelGGL(chan_reduce_kernel<2>, dim3(ammc_chan_reduce_blocks(M)), dim3(256), 0, (hipStream_t)stream,
+                     x, xt, nullptr, none, nullptr, nullptr, nullptr, nullptr, 0, M, h, w, c, partial);
+  return ammc_launch_status();
+}
+
+int ammc_reduce_partials_f32(const float* partial, int32_t nblocks, int32_t qc, float scale, float* out, void* stream) {
+  if (!partial || !out || nblocks <= 0 || qc <= 0) return AMMC_EINVAL;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(nblk(qc)), dim3(256), 0, (hipStream_t)stream, partial, nblocks, qc,
+                     scale, out);
+  return ammc_launch_status();
+}
+
+int ammc_maxpool2x2_bwd_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, const float* dp, int64_t p_bs,
+                            int64_t p_rs, int64_t p_ps, const float* add, int64_t a_bs, int64_t a_rs, int64_t a_ps,
+                            float* dx, int64_t o_bs, int64_t o_rs, int64_t o_ps, int32_t batch, int32_t h, int32_t w,
+                            int32_t c, void* stream) {
+  if (!x || !dp || !dx || batch <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3)) return AMMC_EINVAL;
+  const int M = batch * h * w;
+  Tensor3 xt{x_bs, x_rs, x_ps}, pt{p_bs, p_rs, p_ps}, at{a_bs, a_rs, a_ps}, ot{o_bs, o_rs, o_ps};
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblk((int64_t)M * (c >> 2))), dim3(256), 0, (hipStream_t)stream, x, xt,
+                     dp, pt, add, at, dx, ot, M, h, w, c >> 2);
+  return ammc_launch_status();
+}
+
+int ammc_tanh_bwd_nhwc_f32(const float* dout_nchw, const float* out_nchw, int32_t batch, int32_t c, int32_t h,
+                           int32_t w, float* y, int64_t y_bs, int64_t y_rs, int64_t y_ps, int32_t cp, void* stream) {
+  if (!dout_nchw || !out_nchw || !y || batch <= 0 || c <= 0 || h <= 0 || w <= 0 || cp < c || (cp & 3)) return AMMC_EINVAL;
+  Tensor3 yt{y_bs, y_rs, y_ps};
+  const int64_t total = (int64_t)batch * (cp >> 2) * h * w;
+  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, dout_nchw, out_nchw, batch,
+                     c, h, w, y, yt, cp >> 2);
+  return ammc_launch_status();
+}
+
+int ammc_commit_bwd_f32(const float* z, const float* embed_md, const int32_t* idx_topk, int32_t k,
+                        const float* ddiff, const float* dq, float* dz, int32_t n, int32_t d, void* stream) {
+  if (!z || !embed_md || !idx_topk || !dz || n <= 0 || d <= 0 || (d & 3) || k <= 0) return AMMC_EINVAL;
+  hipLaunchKernelGGL(commit_bwd_kernel, dim3(nblk((int64_t)n * (d >> 2))), dim3(256), 0, (hipStream_t)stream, z,
+                     embed_md, idx_topk, k, ddiff, 2.f / ((float)n * (float)d), dq, dz, n, d >> 2);
+  return ammc_launch_status();
+}
+
+int ammc_codebook_ema_f32(const float* x, const int32_t* idx_topk, int32_t k, int32_t n, int32_t d, int32_t m,
+                          float decay, float one_minus_decay, float eps, float* cluster_size, float* embed_avg,
+                          float* embed, void* stream) {
+  if (!x || !idx_topk || !cluster_size || !embed_avg || !embed || n <= 0 || d <= 0 || m <= 0 || k <= 0) return AMMC_EINVAL;
+  if (d > 256) return AMMC_EUNSUP;
+  hipLaunchKernelGGL(ema_accumulate_kernel, dim3(m), dim3(256), 0, (hipStream_t)stream, x, idx_topk, k, n, d, m, decay,
+                     one_minus_decay, cluster_size, embed_avg);
+  hipLaunchKernelGGL(ema_normalize_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, cluster_size, embed_avg, d, m,
+                     eps, embed);
+  return ammc_launch_status();
+}
+
+int ammc_pack_conv_dgrad_weight_f32(const float* w_oihw, int32_t cout, int32_t cin, int32_t cout_p, int32_t rows,
+                                    float* out, void* stream) {
+  if (!w_oihw || !out || cout <= 0 || cin <= 0 || cout_p < cout || rows < cin) return AMMC_EINVAL;
+  const int kpad = ((9 * cout_p + 31) / 32) * 32;
+  hipLaunchKernelGGL(pack_conv_dgrad_weight_kernel, dim3(nblk((int64_t)rows * kpad)), dim3(256), 0,
+                     (hipStream_t)stream, w_oihw, cout, cin, cout_p, kpad, rows, out);
+  return ammc_launch_status();
+}
+
+int ammc_transpose_pad_f32(const float* w, int32_t rows, int32_t cols, int32_t rows_p, float* out, void* stream) {
+  if (!w || !out || rows <= 0 || cols <= 0 || rows_p < rows) return AMMC_EINVAL;
+  hipLaunchKernelGGL(transpose_pad_kernel, dim3(nblk((int64_t)cols * rows_p)), dim3(256), 0, (hipStream_t)stream, w,
+                     rows, cols, rows_p, out);
+  return ammc_launch_status();
+}
+
+}  // extern "C"

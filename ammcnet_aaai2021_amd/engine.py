@@ -372,7 +372,8 @@ class EvalEngine:
         for t in self.module.buffers():
             v += t._version
         first = next(self.module.parameters())
-        return (v, first.device, first.data_ptr())
+        # _param_epoch: bumped by the training engine, which updates buffers through raw pointers
+        return (v, first.device, first.data_ptr(), getattr(self.module, "_param_epoch", 0))
 
     def _ensure_packs(self, device):
         ver = self._version()

@@ -1,0 +1,515 @@
+"""Training-mode forward and backward of the path on the HIP kernels.
+
+`TrainEngine.forward` runs the network in `.train()` semantics (batch-statistics BatchNorm
+with running-stat update, EMA codebook update, reference unet.py:298-309) and keeps what the
+backward needs in a per-shape workspace; `TrainEngine.backward` is the hand-scheduled reverse
+pass (the reference gets it from torch.autograd): input-gradient convolutions run through
+`ammc_conv_gemm_f32` with flipped/transposed filters, weight gradients through
+`ammc_conv_wgrad_f32`, everything else through the streaming kernels of train_kernels.hip.
+`HipPathFunction` surfaces the pair as ONE torch.autograd.Function whose inputs are the clips
+and all parameters, so optimizers / DDP / RCCL all-reduce see ordinary `.grad` tensors.
+
+Gradient flow facts this file relies on: the memory read is a lookup into a
+buffer, so the only gradient reaching `enc` is the commit term; `dec` gets ordinary GEMM
+gradients; the vq residual passes the gradient through unchanged.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_TANH, AmmcConvDesc, AmmcWgradDesc
+from .engine import Act, _cin_pad, _kpad, _ptr
+
+BN_MOMENTUM = 0.1
+CHANS = (64, 128, 256, 512)
+
+
+class _WS:
+    """workspace allocator: zero-initialised once (kernels only write interiors)"""
+
+    def __init__(self, device):
+        self.device = device
+        self.lib = _lib.load()
+        self.bytes = 0
+
+    def buf(self, *shape, dtype=torch.float32) -> torch.Tensor:
+        t = torch.zeros(shape, device=self.device, dtype=dtype)
+        self.bytes += t.numel() * t.element_size()
+        return t
+
+    def act(self, B, H, W, c, halo=1) -> Act:
+        return Act(self.buf(B, H + 2 * halo, W + 2 * halo, c), B, H, W, c, 0, halo)
+
+
+def _stream(dev) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _chk(rc, what):
+    if rc != 0:
+        _lib.check(rc, what)
+
+
+class _Ops:
+    """immediate-mode launches of the C ABI on the current stream"""
+
+    def __init__(self, ws: _WS):
+        self.ws, self.lib, self.dev = ws, ws.lib, ws.device
+        self.zeros = ws.buf(1024)
+
+    @property
+    def s(self):
+        return _stream(self.dev)
+
+    def conv(self, x: Act, w: torch.Tensor, y: Act, *, ntaps, cin, n, scale=None, shift=None, act=ACT_NONE,
+             res: Optional[Act] = None, up=1, cgroup=None, x_step=1, what="conv"):
+        d = AmmcConvDesc()
+        d.x = x.tap0() if ntaps == 9 else x.pix0()
+        d.w, d.y = _ptr(w), y.pix0()
+        d.scale = _ptr(scale) if scale is not None else None
+        d.shift = _ptr(shift) if shift is not None else None
+        d.res = res.pix0() if res is not None else None
+        d.batch, d.height, d.width = y.B // 1, (y.H // up), (y.W // up)
+        d.cin, d.ntaps, d.n, d.up, d.act, d.x_step = cin, ntaps, n, up, act, x_step
+        d.cgroup = cgroup if cgroup is not None else n
+        d.x_bs, d.x_rs, d.x_ps = x.strides
+        d.y_bs, d.y_rs, d.y_ps = y.strides
+        if res is not None:
+            d.r_bs, d.r_rs, d.r_ps = res.strides
+        _chk(self.lib.ammc_conv_gemm_f32(C.byref(d), self.s), what)
+
+    def wgrad(self, g: Act, a: Act, dw: torch.Tensor, *, n, cin, ntaps, a_step=1, what="wgrad"):
+        dw.zero_()
+        d = AmmcWgradDesc()
+        d.g = g.pix0()
+        d.a = a.tap0() if ntaps == 9 else a.pix0()
+        d.dw, d.zeros = _ptr(dw), _ptr(self.zeros)
+        d.batch, d.height, d.width = g.B, g.H, g.W
+        d.n, d.cin, d.ntaps, d.a_step = n, cin, ntaps, a_step
+        d.g_bs, d.g_rs, d.g_ps = g.strides
+        d.a_bs, d.a_rs, d.a_ps = a.strides
+        _chk(self.lib.ammc_conv_wgrad_f32(C.byref(d), self.s), what)
+
+    def chan_sum(self, x: Act, c: int, scratch: torch.Tensor) -> torch.Tensor:
+        """per-channel sum over pixels of the first c channels of x (bias gradient)"""
+        nb = self.lib.ammc_chan_reduce_blocks(x.B * x.H * x.W)
+        _chk(self.lib.ammc_chan_sum_f32(x.pix0(), *x.strides, x.B, x.H, x.W, c, _ptr(scratch), self.s), "chan_sum")
+        out = torch.empty(c, device=self.dev, dtype=torch.float32)
+        _chk(self.lib.ammc_reduce_partials_f32(_ptr(scratch), nb, c, 1.0, _ptr(out), self.s), "reduce_partials")
+        return out
+
+
+class _ConvBN:
+    """conv3x3 (no bias) + BatchNorm2d (batch statistics) + ReLU [+ residual]"""
+
+    def __init__(self, ops: _Ops, conv, bn, x: Act, y: Act, res: Optional[Act], name: str):
+        ws = ops.ws
+        self.ops, self.conv, self.bn, self.x, self.y, self.res, self.name = ops, conv, bn, x, y, res, name
+        self.cout, self.cin = conv.weight.shape[0], conv.weight.shape[1]
+        self.cin_p = _cin_pad(self.cin)
+        assert x.c == self.cin_p or x.c == self.cin, (name, x.c, self.cin_p)
+        self.kpad = _kpad(9 * self.cin_p)
+        self.wp = ws.buf(self.cout, self.kpad)                       # forward filter, packed
+        self.craw = ws.act(x.B, x.H, x.W, self.cout)                 # raw conv output (saved for backward)
+        self.mean, self.invstd = ws.buf(self.cout), ws.buf(self.cout)
+        self.scale, self.shift = ws.buf(self.cout), ws.buf(self.cout)
+        self.nblk = ops.lib.ammc_chan_reduce_blocks(x.B * x.H * x.W)
+        self.partial = ws.buf(self.nblk, 2, self.cout)
+        # backward
+        self.dc = ws.act(x.B, x.H, x.W, self.cout)
+        self.dwp = ws.buf(self.cout, self.kpad)
+        self.rows = max(64, (self.cin + 63) // 64 * 64) if self.cin >= 32 else 0   # dgrad filter rows
+        self.wdp = ws.buf(self.rows, _kpad(9 * self.cout)) if self.rows else None
+
+    def forward(self):
+        o, lib, s = self.ops, self.ops.lib, self.ops.s
+        w = self.conv.weight.detach()
+        _chk(lib.ammc_pack_conv_weight_f32(_ptr(w), self.cout, self.cin, 3, self.cin_p, _ptr(self.wp), s), "pack")
+        o.conv(self.x, self.wp, self.craw, ntaps=9, cin=self.cin_p, n=self.cout, what=self.name)
+        c = self.craw
+        _chk(lib.ammc_bn_stats_f32(c.pix0(), *c.strides, c.B, c.H, c.W, self.cout, _ptr(self.partial), s), "bn_stats")
+        bn = self.bn
+        _chk(lib.ammc_bn_finalize_f32(_ptr(self.partial), self.nblk, self.cout, float(c.B * c.H * c.W),
+                                      _ptr(bn.weight.detach()), _ptr(bn.bias.detach()), float(bn.eps),
+                                      float(bn.momentum if bn.momentum is not None else BN_MOMENTUM),
+                                      _ptr(bn.running_mean), _ptr(bn.running_var), _ptr(self.mean),
+                                      _ptr(self.invstd), _ptr(self.scale), _ptr(self.shift), s), "bn_finalize")
+        bn.num_batches_tracked += 1
+        r = self.res
+        _chk(lib.ammc_scale_shift_act_f32(c.pix0(), *c.strides, _ptr(self.scale), _ptr(self.shift),
+                                          r.pix0() if r is not None else None, *(r.strides if r is not None else (0, 0, 0)),
+                                          self.y.pix0(), *self.y.strides, 1, c.B, c.H, c.W, self.cout, s), "bn_apply")
+
+    def backward(self, dy: Act, da: Optional[Act], da_res: Optional[Act], grads: Dict):
+        """dy: gradient w.r.t. this unit's output.  Writes da = dgrad (+ da_res) if asked;
+        stores the parameter gradients in `grads`."""
+        o, lib, s = self.ops, self.ops.lib, self.ops.s
+        c = self.craw
+        _chk(lib.ammc_bn_bwd_reduce_f32(c.pix0(), *c.strides, dy.pix0(), *dy.strides, _ptr(self.mean), _ptr(self.invstd),
+                                        _ptr(self.scale), _ptr(self.shift), 1, c.B, c.H, c.W, self.cout,
+                                        _ptr(self.partial), s), "bn_bwd_reduce")
+        sums = torch.empty(2 * self.cout, device=o.dev, dtype=torch.float32)
+        _chk(lib.ammc_reduce_partials_f32(_ptr(self.partial), self.nblk, 2 * self.cout, 1.0, _ptr(sums), s), "reduce")
+        grads[self.bn.bias] = sums[:self.cout]
+        grads[self.bn.weight] = sums[self.cout:]
+        _chk(lib.ammc_bn_bwd_apply_f32(c.pix0(), *c.strides, dy.pix0(), *dy.strides, _ptr(self.mean), _ptr(self.invstd),
+                                       _ptr(self.scale), _ptr(self.shift), _ptr(sums), 1, self.dc.pix0(),
+                                       *self.dc.strides, c.B, c.H, c.W, self.cout, s), "bn_bwd_apply")
+        o.wgrad(self.dc, self.x, self.dwp, n=self.cout, cin=self.cin_p, ntaps=9, what=self.name + ".wgrad")
+        dw = torch.empty_like(self.conv.weight)
+        _chk(lib.ammc_unpack_conv_wgrad_f32(_ptr(self.dwp), self.cout, self.cin, 3, self.cin_p, _ptr(dw), s), "unpack")
+        grads[self.conv.weight] = dw
+        if da is not None:
+            w = self.conv.weight.detach()
+            _chk(lib.ammc_pack_conv_dgrad_weight_f32(_ptr(w), self.cout, self.cin, self.cout, self.rows,
+                                                     _ptr(self.wdp), s), "pack_dgrad")
+            o.conv(self.dc, self.wdp, da, ntaps=9, cin=self.cout, n=self.rows, res=da_res, what=self.name + ".dgrad")
+
+
+class _DoubleConv:
+    def __init__(self, ops: _Ops, dc, x: Act, y: Act, res: Optional[Act], name: str):
+        seq = dc.conv
+        self.mid = ops.ws.act(x.B, x.H, x.W, seq[0].weight.shape[0])
+        self.u0 = _ConvBN(ops, seq[0], seq[1], x, self.mid, None, name + ".conv0")
+        self.u1 = _ConvBN(ops, seq[3], seq[4], self.mid, y, res, name + ".conv1")
+        self.dmid = ops.ws.act(x.B, x.H, x.W, seq[0].weight.shape[0])
+
+    def forward(self):
+        self.u0.forward()
+        self.u1.forward()
+
+    def backward(self, dy: Act, da: Optional[Act], da_res: Optional[Act], grads):
+        self.u1.backward(dy, self.dmid, None, grads)
+        self.u0.backward(self.dmid, da, da_res, grads)
+
+
+class _Stream:
+    """one U-Net stream (`UNet` / `UNetMem_v7`) in training mode"""
+
+    def __init__(self, ops: _Ops, net, B, H, W, has_vq: bool):
+        if H % 8 or W % 8:
+            raise ValueError(f"frame size {H}x{W} must be divisible by 8")
+        ws, lib = ops.ws, ops.lib
+        self.ops, self.net, self.B, self.H, self.W, self.has_vq = ops, net, B, H, W, has_vq
+        self.cin = net.inc.conv.conv[0].weight.shape[1]
+        self.cout = net.outc.weight.shape[0]
+        self.x_in = ws.act(B, H, W, _cin_pad(self.cin))
+        self.cat = [ws.act(B, H >> i, W >> i, 2 * CHANS[i]) for i in range(3)]
+        self.skip = [self.cat[i].slice(0, CHANS[i]) for i in range(3)]
+        self.x4 = ws.act(B, H >> 3, W >> 3, 512)
+        self.inc = _DoubleConv(ops, net.inc.conv, self.x_in, self.skip[0], None, "inc")
+        self.pooled, self.down = [], []
+        for i, d in enumerate((net.down1, net.down2, net.down3)):
+            p = ws.act(B, H >> (i + 1), W >> (i + 1), CHANS[i])
+            out = self.skip[i + 1] if i < 2 else self.x4
+            self.pooled.append(p)
+            self.down.append(_DoubleConv(ops, d.mpconv[1], p, out, None, f"down{i + 1}"))
+        h, w = H >> 3, W >> 3
+        self.bottom = self.x4
+        if has_vq:
+            q = net.vq_down3.quan
+            self.q = q
+            self.d, self.m, self.k = q.quantize.dim, q.quantize.n_embed, q.quantize.k
+            n = B * h * w
+            self.n = n
+            self.z = ws.act(B, h, w, self.d, halo=0)
+            self.qk = ws.act(B, h, w, self.k * self.d, halo=0)
+            self.q_one = ws.buf(B, h, w, self.d)
+            self.idx = ws.buf(n, self.k, dtype=torch.int32)
+            self.nblk_q = lib.ammc_memory_topk_blocks(n)
+            self.diff_part = ws.buf(self.nblk_q)
+            self.e_md, self.enorm = ws.buf(self.m, self.d), ws.buf(self.m)
+            self.enc_wp = ws.buf(self.d, 512)
+            self.dec_wp = ws.buf(512, _kpad(self.k * self.d))
+            self.x4q = ws.act(B, h, w, 512)
+            self.bottom = self.x4q
+            self.dz = ws.act(B, h, w, self.d, halo=0)
+            self.enc_dwp = ws.buf(max(self.d, 32), 512)
+            self.dec_dwp = ws.buf(512, _kpad(self.k * self.d))
+            self.enc_wT = ws.buf(512, _kpad(self.d))
+            self.dx4 = ws.act(B, h, w, 512)
+        # decoder (inputs are set by the owner: `bottom` may be replaced by the bridge output)
+        self.up_mods = (net.up1, net.up2, net.up3)
+        self.up_dc: List[_DoubleConv] = []
+        self.up_out: List[Act] = []
+        self.up_wp, self.up_b4, self.up_dwp, self.up_wT = [], [], [], []
+        for j, lvl in enumerate((2, 1, 0)):
+            c = CHANS[lvl]
+            out = ws.act(B, H >> lvl, W >> lvl, c)
+            self.up_out.append(out)
+            self.up_dc.append(_DoubleConv(ops, self.up_mods[j].conv, self.cat[lvl], out, None, f"up{j + 1}"))
+            self.up_wp.append(ws.buf(4 * c, 2 * c))
+            self.up_b4.append(ws.buf(4 * c))
+            self.up_dwp.append(ws.buf(2 * c, 4 * c))
+            self.up_wT.append(ws.buf(2 * c, 4 * c))
+        self.u3 = self.up_out[2]
+        self.outc_wp = ws.buf(32, 576)
+        self.outc_b = ws.buf(32)
+        self.w32 = ws.buf(32, 64, 3, 3)
+        # backward buffers
+        self.dpre = ws.act(B, H, W, 32)
+        self.du = [ws.act(B, H >> lvl, W >> lvl, CHANS[lvl]) for lvl in (2, 1, 0)]      # grads of up outputs
+        self.dcat = [ws.act(B, H >> i, W >> i, 2 * CHANS[i]) for i in range(3)]
+        self.dbottom = ws.act(B, h, w, 512)
+        self.dskip_tot = [ws.act(B, H >> i, W >> i, CHANS[i]) for i in range(3)]
+        self.dpooled = [ws.act(B, H >> (i + 1), W >> (i + 1), CHANS[i]) for i in range(3)]
+        self.outc_dwp = ws.buf(32, 576)
+        self.outc_wdp = ws.buf(64, _kpad(9 * 32))
+        self.scratch = ws.buf(lib.ammc_chan_reduce_blocks(B * H * W) * 512 + 1024)
+
+    # ---- forward pieces -------------------------------------------------------------
+    def encode(self, x: torch.Tensor):
+        o, lib, s = self.ops, self.ops.lib, self.ops.s
+        _chk(lib.ammc_nchw_to_nhwc_f32(_ptr(x), self.B, self.cin, self.H, self.W, self.x_in.pix0(),
+                                       *self.x_in.strides, self.x_in.c, s), "nchw_to_nhwc")
+        self.inc.forward()
+        for i in range(3):
+            p, sk = self.pooled[i], self.skip[i]
+            _chk(lib.ammc_maxpool2x2_f32(sk.pix0(), *sk.strides, p.pix0(), *p.strides, p.B, p.H, p.W, p.c, s), "pool")
+            self.down[i].forward()
+
+    def memory(self):
+        o, lib, s, q = self.ops, self.ops.lib, self.ops.s, self.q
+        qz = q.quantize
+        _chk(lib.ammc_pack_conv_weight_f32(_ptr(q.enc.weight.detach()), self.d, 512, 1, 512, _ptr(self.enc_wp), s), "pack")
+        _chk(lib.ammc_pack_conv_weight_f32(_ptr(q.dec.weight.detach()), 512, self.k * self.d, 1, _kpad(self.k * self.d),
+                                           _ptr(self.dec_wp), s), "pack")
+        _chk(lib.ammc_pack_codebook_f32(_ptr(qz.embed), self.d, self.m, _ptr(self.e_md), _ptr(self.enorm), s), "codebook")
+        o.conv(self.x4, self.enc_wp, self.z, ntaps=1, cin=512, n=self.d, shift=q.enc.bias.detach(), what="vq.enc")
+        _chk(lib.ammc_memory_topk_fwd_f32(_ptr(self.z.buf), _ptr(qz.embed), _ptr(self.e_md), _ptr(self.enorm), self.n,
+                                          self.d, self.m, self.k, self.idx.data_ptr(), _ptr(self.qk.buf),
+                                          _ptr(self.q_one), _ptr(self.diff_part), s), "memory_topk")
+        diff = torch.empty(1, device=o.dev, dtype=torch.float32)
+        _chk(lib.ammc_sum_partials_f32(_ptr(self.diff_part), self.nblk_q, 1.0 / float(self.n * self.d), _ptr(diff), s),
+             "diff")
+        # EMA update AFTER the lookups (they use the pre-update codebook, unet.py:291-309); e_md keeps the
+        # pre-update rows, which is what the backward's commit gradient needs
+        _chk(lib.ammc_codebook_ema_f32(_ptr(self.z.buf), self.idx.data_ptr(), self.k, self.n, self.d, self.m,
+                                       float(qz.decay), float(1 - qz.decay), float(qz.eps), _ptr(qz.cluster_size),
+                                       _ptr(qz.embed_avg), _ptr(qz.embed), s), "codebook_ema")
+        o.conv(self.qk, self.dec_wp, self.x4q, ntaps=1, cin=self.k * self.d, n=512, shift=q.dec.bias.detach(),
+               res=self.x4, what="vq.dec")
+        return diff, self.q_one.clone()
+
+    def decode(self, bottom: Act):
+        o, lib, s = self.ops, self.ops.lib, self.ops.s
+        self.dec_in = bottom
+        y = bottom
+        for j, lvl in enumerate((2, 1, 0)):
+            c = CHANS[lvl]
+            m = self.up_mods[j]
+            _chk(lib.ammc_pack_convt_weight_f32(_ptr(m.up.weight.detach()), 2 * c, c, _ptr(self.up_wp[j]), s), "pack")
+            self.up_b4[j].copy_(m.up.bias.detach().repeat(4))
+            o.conv(y, self.up_wp[j], self.cat[lvl].slice(c, c), ntaps=1, cin=2 * c, n=4 * c, shift=self.up_b4[j], up=2,
+                   cgroup=c, what=f"up{j + 1}.up")
+            self.up_dc[j].forward()
+            y = self.up_out[j]
+        net = self.net
+        self.w32.zero_()
+        self.w32[:self.cout].copy_(net.outc.weight.detach())
+        _chk(lib.ammc_pack_conv_weight_f32(_ptr(self.w32), 32, 64, 3, 64, _ptr(self.outc_wp), s), "pack")
+        self.outc_b.zero_()
+        self.outc_b[:self.cout].copy_(net.outc.bias.detach())
+        out = torch.empty((self.B, self.cout, self.H, self.W), device=o.dev, dtype=torch.float32)
+        d = AmmcConvDesc()
+        u3 = self.u3
+        d.x, d.w, d.shift, d.y = u3.tap0(), _ptr(self.outc_wp), _ptr(self.outc_b), _ptr(out)
+        d.batch, d.height, d.width = self.B, self.H, self.W
+        d.cin, d.ntaps, d.n, d.up, d.cgroup, d.act, d.n_store = 64, 9, 32, 1, 32, ACT_TANH, self.cout
+        d.x_bs, d.x_rs, d.x_ps = u3.strides
+        d.y_bs, d.y_rs, d.y_ps, d.y_cs = self.cout * self.H * self.W, self.W, 1, self.H * self.W
+        _chk(lib.ammc_conv_gemm_f32(C.byref(d), s), "outc")
+        self.out = out
+        return out
+
+    # ---- backward pieces ------------------------------------------------------------
+    def decode_backward(self, dout: torch.Tensor, grads) -> Act:
+        """from d(tanh output) down to the gradient of the decoder's bottom input; fills dcat[*]"""
+        o, lib, s, net = self.ops, self.ops.lib, self.ops.s, self.net
+        dout = dout.contiguous()
+        dp = self.dpre
+        _chk(lib.ammc_tanh_bwd_nhwc_f32(_ptr(dout), _ptr(self.out), self.B, self.cout, self.H, self.W, dp.pix0(),
+                                        *dp.strides, 32, s), "tanh_bwd")
+        grads[net.outc.bias] = o.chan_sum(dp, 32, self.scratch)[:self.cout]
+        o.wgrad(dp, self.u3, self.outc_dwp, n=32, cin=64, ntaps=9, what="outc.wgrad")
+        dw = torch.empty_like(net.outc.weight)
+        _chk(lib.ammc_unpack_conv_wgrad_f32(_ptr(self.outc_dwp), self.cout, 64, 3, 64, _ptr(dw), s), "unpack")
+        grads[net.outc.weight] = dw
+        _chk(lib.ammc_pack_conv_dgrad_weight_f32(_ptr(net.outc.weight.detach()), self.cout, 64, 32, 64,
+                                                 _ptr(self.outc_wdp), s), "pack_dgrad")
+        o.conv(dp, self.outc_wdp, self.du[2], ntaps=9, cin=32, n=64, what="outc.dgrad")
+        for j in (2, 1, 0):
+            lvl = (2, 1, 0)[j]
+            c = CHANS[lvl]
+            m = self.up_mods[j]
+            self.up_dc[j].backward(self.du[j], self.dcat[lvl], None, grads)
+            dys = self.dcat[lvl].slice(c, c)                         # gradient of the ConvTranspose output
+            grads[m.up.bias] = o.chan_sum(dys, c, self.scratch)
+            x_in = self.dec_in if j == 0 else self.up_out[j - 1]
+            o.wgrad(x_in, dys, self.up_dwp[j], n=2 * c, cin=c, ntaps=4, a_step=2, what=f"up{j + 1}.up.wgrad")
+            dwt = torch.empty_like(m.up.weight)
+            _chk(lib.ammc_unpack_convt_wgrad_f32(_ptr(self.up_dwp[j]), 2 * c, c, _ptr(dwt), s), "unpack_convt")
+            grads[m.up.weight] = dwt
+            _chk(lib.ammc_transpose_pad_f32(_ptr(self.up_wp[j]), 4 * c, 2 * c, 4 * c, _ptr(self.up_wT[j]), s), "transpose")
+            dst = self.dbottom if j == 0 else self.du[j - 1]
+            o.conv(dys, self.up_wT[j], dst, ntaps=4, cin=c, n=2 * c, x_step=2, what=f"up{j + 1}.up.dgrad")
+        return self.dbottom
+
+    def memory_backward(self, dq4: Act, ddiff: Optional[torch.Tensor], dq_one: Optional[torch.Tensor], grads) -> Act:
+        """gradient through dec / commit term / enc / residual; returns d(x4)"""
+        o, lib, s, q = self.ops, self.ops.lib, self.ops.s, self.q
+        kd = self.k * self.d
+        grads[q.dec.bias] = o.chan_sum(dq4, 512, self.scratch)
+        o.wgrad(dq4, self.qk, self.dec_dwp, n=512, cin=kd, ntaps=1, what="vq.dec.wgrad")
+        dw = torch.empty_like(q.dec.weight)
+        _chk(lib.ammc_unpack_conv_wgrad_f32(_ptr(self.dec_dwp), 512, kd, 1, _kpad(kd), _ptr(dw), s), "unpack")
+        grads[q.dec.weight] = dw
+        dq = dq_one.contiguous() if dq_one is not None else None
+        _chk(lib.ammc_commit_bwd_f32(_ptr(self.z.buf), _ptr(self.e_md), self.idx.data_ptr(), self.k,
+                                     _ptr(ddiff) if ddiff is not None else None, _ptr(dq) if dq is not None else None,
+                                     _ptr(self.dz.buf), self.n, self.d, s), "commit_bwd")
+        grads[q.enc.bias] = o.chan_sum(self.dz, self.d, self.scratch)
+        o.wgrad(self.dz, self.x4, self.enc_dwp, n=max(self.d, 32), cin=512, ntaps=1, what="vq.enc.wgrad")
+        dwe = torch.empty_like(q.enc.weight)
+        _chk(lib.ammc_unpack_conv_wgrad_f32(_ptr(self.enc_dwp), self.d, 512, 1, 512, _ptr(dwe), s), "unpack")
+        grads[q.enc.weight] = dwe
+        _chk(lib.ammc_transpose_pad_f32(_ptr(self.enc_wp), self.d, 512, _kpad(self.d), _ptr(self.enc_wT), s), "transpose")
+        o.conv(self.dz, self.enc_wT, self.dx4, ntaps=1, cin=_kpad(self.d), n=512, res=dq4, what="vq.enc.dgrad")
+        return self.dx4
+
+    def encode_backward(self, dx4: Act, grads):
+        o, lib, s = self.ops, self.ops.lib, self.ops.s
+        dy = dx4
+        for i in (2, 1, 0):
+            self.down[i].backward(dy, self.dpooled[i], None, grads)
+            sk, dpo, add, out = self.skip[i], self.dpooled[i], self.dcat[i].slice(0, CHANS[i]), self.dskip_tot[i]
+            _chk(lib.ammc_maxpool2x2_bwd_f32(sk.pix0(), *sk.strides, dpo.pix0(), *dpo.strides, add.pix0(), *add.strides,
+                                             out.pix0(), *out.strides, dpo.B, dpo.H, dpo.W, dpo.c, s), "maxpool_bwd")
+            dy = out
+        self.inc.backward(dy, None, None, grads)
+
+
+class TrainEngine:
+    """training-mode forward/backward of `UNet`, `UNetMem_v7` or `twostream`"""
+
+    def __init__(self, module, kind: str):
+        self.module, self.kind = module, kind
+        self._ws: Dict = {}
+        self.generation = 0
+
+    def _get(self, B, H, W, device):
+        key = (B, H, W, device)
+        st = self._ws.get(key)
+        if st is None:
+            ws = _WS(device)
+            ops = _Ops(ws)
+            m = self.module
+            if self.kind == "twostream":
+                r = _Stream(ops, m.rgb, B, H, W, True)
+                o = _Stream(ops, m.op, B, H, W, True)
+                h, w = H >> 3, W >> 3
+                xb, yb = ws.act(B, h, w, 512), ws.act(B, h, w, 512)
+                o2f = _DoubleConv(ops, m.bridge.O2F, o.x4q, xb, r.x4q, "bridge.O2F")
+                f2o = _DoubleConv(ops, m.bridge.F20, r.x4q, yb, o.x4q, "bridge.F20")
+                st = dict(ops=ops, streams=[r, o], o2f=o2f, f2o=f2o, xb=xb, yb=yb,
+                          dzx=ws.act(B, h, w, 512), dzy=ws.act(B, h, w, 512))
+            else:
+                s = _Stream(ops, m, B, H, W, self.kind == "unetmem")
+                st = dict(ops=ops, streams=[s])
+            st["bytes"] = ws.bytes
+            self._ws[key] = st
+        return st
+
+    def forward(self, *inputs: torch.Tensor):
+        x0 = inputs[0]
+        if not x0.is_cuda:
+            raise _lib.AmmcHipError("the HIP path needs CUDA/HIP tensors; there is no CPU fallback")
+        B, _, H, W = x0.shape
+        st = self._get(B, H, W, x0.device)
+        self.generation += 1
+        st["generation"] = self.generation
+        xs = [x.detach().float().contiguous() for x in inputs]
+        streams: List[_Stream] = st["streams"]
+        diffs, qs, outs = [], [], []
+        # same order as the reference's forward (unet.py:981-1007): it fixes the order of the
+        # in-place buffer updates
+        for s, x in zip(streams, xs):
+            s.encode(x)
+            if s.has_vq:
+                d, q = s.memory()
+                diffs.append(d)
+                qs.append(q)
+        if self.kind == "twostream":
+            st["o2f"].forward()
+            st["f2o"].forward()
+            bottoms = [st["xb"], st["yb"]]
+        else:
+            bottoms = [streams[0].bottom]
+        for s, b in zip(streams, bottoms):
+            outs.append(s.decode(b))
+        self._last = st
+        if hasattr(self.module, "_param_epoch"):
+            self.module._param_epoch += 1          # buffers changed through raw pointers: invalidate eval packs
+        if self.kind == "unet":
+            return (outs[0],)
+        if self.kind == "unetmem":
+            return outs[0], diffs[0], qs[0]
+        return outs[0], outs[1], diffs[0], diffs[1], qs[0], qs[1]
+
+    def backward(self, generation: int, gouts) -> Dict:
+        st = self._last
+        if st.get("generation") != generation:
+            raise RuntimeError("HIP training path: backward() called for a forward whose workspace has been reused "
+                               "by a later forward of the same shape (one forward per backward is supported)")
+        streams: List[_Stream] = st["streams"]
+        grads: Dict = {}
+
+        def g(t):
+            return t if t is not None else None
+
+        if self.kind == "twostream":
+            d_rgb, d_op, dd_r, dd_o, dq_r, dq_o = gouts
+            r, o = streams
+            for s, dout in ((r, d_rgb), (o, d_op)):
+                if dout is None:
+                    dout = torch.zeros_like(s.out)
+                s.decode_backward(dout, grads)
+            # x = zx + O2F(zy); y = zy + F20(zx): dzy = dyb + dgrad_O2F(dxb), dzx = dxb + dgrad_F20(dyb)
+            st["o2f"].backward(r.dbottom, st["dzy"], o.dbottom, grads)
+            st["f2o"].backward(o.dbottom, st["dzx"], r.dbottom, grads)
+            dx4r = r.memory_backward(st["dzx"], g(dd_r), g(dq_r), grads)
+            dx4o = o.memory_backward(st["dzy"], g(dd_o), g(dq_o), grads)
+            r.encode_backward(dx4r, grads)
+            o.encode_backward(dx4o, grads)
+        else:
+            s = streams[0]
+            dout = gouts[0] if gouts[0] is not None else torch.zeros_like(s.out)
+            db = s.decode_backward(dout, grads)
+            if self.kind == "unetmem":
+                db = s.memory_backward(db, g(gouts[1]), g(gouts[2]), grads)
+            s.encode_backward(db, grads)
+        return {k.data_ptr(): v for k, v in grads.items()}
+
+
+class HipPathFunction(torch.autograd.Function):
+    """(engine, n_inputs, *inputs, *params) -> the model's outputs, differentiable w.r.t. params"""
+
+    @staticmethod
+    def forward(ctx, engine: TrainEngine, n_inputs: int, *tensors):
+        inputs, params = tensors[:n_inputs], tensors[n_inputs:]
+        outs = engine.forward(*inputs)
+        ctx.engine, ctx.generation, ctx.params, ctx.n_inputs = engine, engine.generation, params, n_inputs
+        ctx.set_materialize_grads(False)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        grads = ctx.engine.backward(ctx.generation, gouts)
+        out = [None, None] + [None] * ctx.n_inputs
+        for p in ctx.params:
+            out.append(grads.get(p.data_ptr()))
+        return tuple(out)

@@ -22,13 +22,26 @@ import torch.nn as nn
 
 from . import ops
 from .engine import EvalEngine
+from .train import HipPathFunction, TrainEngine
 
 
 def _no_training(mod):
     if mod.training:
         raise NotImplementedError(
-            f"{type(mod).__name__}: the training-mode HIP path (batch-stat BatchNorm, EMA codebook update, "
-            "backward kernels) is not built yet; call .eval() - there is no ATen fallback")
+            f"{type(mod).__name__}: training mode is implemented at the model boundaries (UNet, UNetMem_v7, "
+            "twostream: one fused autograd.Function over the HIP kernels), not for a sub-module called on its "
+            "own; call .eval() for a stand-alone block - there is no ATen fallback")
+
+
+def _run(mod, kind: str, n_inputs: int, *inputs):
+    """dispatch a model-boundary forward to the eval plan or to the training Function"""
+    if not mod.training:
+        if mod._engine is None:
+            object.__setattr__(mod, "_engine", EvalEngine(mod, kind))
+        return mod._engine.forward(*inputs)
+    if mod._train_engine is None:
+        object.__setattr__(mod, "_train_engine", TrainEngine(mod, kind))
+    return HipPathFunction.apply(mod._train_engine, n_inputs, *inputs, *mod.parameters())
 
 
 class double_conv(nn.Module):
@@ -89,13 +102,12 @@ class UNet(nn.Module):
         self.up2 = up(256, 128)
         self.up3 = up(128, 64)
         self.outc = nn.Conv2d(64, output_channel, kernel_size=3, padding=1)
-        self._engine = None
+        self._engine = self._train_engine = None
+        self._param_epoch = 0
 
     def forward(self, x):
-        _no_training(self)
-        if self._engine is None:
-            object.__setattr__(self, "_engine", EvalEngine(self, "unet"))
-        return self._engine.forward(x)
+        out = _run(self, "unet", 1, x)
+        return out[0] if self.training else out
 
 
 class Quantize_topk(nn.Module):
@@ -156,13 +168,11 @@ class UNetMem_v7(nn.Module):
         self.up3 = up(128, 64)
         self.outc = nn.Conv2d(64, output_channel, kernel_size=3, padding=1)
         self.vq_down3 = enc_quan_dec_res_topk(512, embed_dim, n_embed, k=k)
-        self._engine = None
+        self._engine = self._train_engine = None
+        self._param_epoch = 0
 
     def forward(self, x):
-        _no_training(self)
-        if self._engine is None:
-            object.__setattr__(self, "_engine", EvalEngine(self, "unetmem"))
-        return self._engine.forward(x)
+        return _run(self, "unetmem", 1, x)
 
 
 class bridge(nn.Module):
@@ -186,15 +196,22 @@ class twostream(nn.Module):
         self.rgb = UNetMem_v7(rgb_in_c, rgb_out_c, embed_dim, n_embed, k, layer_nums, features_root)
         self.op = UNetMem_v7(op_in_c, op_out_c, embed_dim, n_embed, k, layer_nums, features_root)
         self.bridge = bridge(in_c=512)
-        self._engine = None
+        self._engine = self._train_engine = None
+        self._param_epoch = 0
 
     def forward(self, rgb_x, op_x):
-        _no_training(self)
-        if self._engine is None:
-            object.__setattr__(self, "_engine", EvalEngine(self, "twostream"))
-        out = self._engine.forward(rgb_x, op_x)
-        # reference side effects (unet.py:986, 988): attributes nobody reads; kept as NCHW views on request
-        self.quant_befor, self.quant_after = self._engine.bottleneck_views()
+        out = _run(self, "twostream", 2, rgb_x, op_x)
+        if self.training:
+            rgb, op, rd, od, rq, oq = out
+            st = self._train_engine._last["streams"][0]
+            befor, after = st.x4, st.x4q
+            out = (rgb, op, (rd, od), (rq, oq))
+        else:
+            st = self._engine._last["streams"][0]
+            befor, after = st.x4, st.x4q
+        # reference side effects (unet.py:986, 988): attributes nobody reads; NCHW views of the workspace
+        self.quant_befor = befor.interior().permute(0, 3, 1, 2)
+        self.quant_after = after.interior().permute(0, 3, 1, 2)
         return out
 
 

@@ -57,6 +57,8 @@ const char* ammc_error_string(int code);
  *                      `outc` + torch.tanh (unet.py:920, 998-1007): the 2-3 output channels
  *                      ride in a 32-wide MFMA column tile (the VALU form, kept below as
  *                      ammc_conv3x3_out_tanh_f32, is L1-line-bound and 7x slower)
+ *   ntaps=4, x_step=2  gradient of that ConvTranspose2d w.r.t. its input (autograd of unet.py:51)
+ *   ntaps=9 on dY with the flipped/transposed filter: gradient of the 3x3 conv w.r.t. its input
  *   ntaps=1, up=2      nn.ConvTranspose2d(C, C/2, 2, stride 2) + bias (unet.py:47,51):
  *                      N = 4*cgroup columns, column n = (dy*2+dx)*cgroup + co is
  *                      scattered to pixel (2y+dy, 2x+dx); writing into a channel
@@ -71,7 +73,7 @@ typedef struct AmmcConvDesc {
   const float* res;      /* residual added after the activation, or NULL                  */
   int32_t batch, height, width;        /* pixel space of m                               */
   int32_t cin;           /* channels per tap: power of two >= 4                           */
-  int32_t ntaps;         /* 9 (3x3, pad 1 via the halo) or 1                              */
+  int32_t ntaps;         /* 9 (3x3, pad 1 via the halo), 4 (2x2, see x_step) or 1         */
   int32_t n;             /* GEMM N: 32, or a multiple of 64                               */
   int32_t up;            /* 1, or 2 for the ConvTranspose scatter                         */
   int32_t cgroup;        /* channels per (dy,dx) group when up=2 (multiple of 32); else n */
@@ -81,6 +83,8 @@ typedef struct AmmcConvDesc {
   int64_t y_bs, y_rs, y_ps;            /* output strides (of the OUTPUT resolution)      */
   int64_t r_bs, r_rs, r_ps;            /* residual strides                               */
   int64_t y_cs;          /* output channel stride: 0/1 = NHWC; H*W (with y_ps=1, y_rs=W) = NCHW    */
+  int32_t x_step;        /* 0/1; 2 = the input is at twice the resolution of m (with ntaps=4: the  */
+  int32_t reserved2;     /* 2x2 stride-2 gather of the ConvTranspose dgrad)                       */
 } AmmcConvDesc;
 
 int ammc_conv_gemm_f32(const AmmcConvDesc* desc, void* stream);
@@ -142,6 +146,88 @@ int ammc_memory_topk_fwd_f32(const float* x, const float* embed_dm, const float*
                              float* diff_partial, void* stream);
 /* diff = sum(partials) / count, fixed order (deterministic) */
 int ammc_sum_partials_f32(const float* partial, int32_t nparts, float inv_count, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Training mode (autograd of the same path; the reference derives these with torch.autograd)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Weight gradient dWp[n][k] += sum_m G[m][n] * A[m, k], packed layout of ammc_conv_gemm_f32's
+ * weights (the caller zeroes dw; partial tiles are combined with fp32 atomics).
+ *   3x3 conv:      g = gradient of the raw conv output (pixel (0,0)), a = conv input (tap (0,0))
+ *   1x1 conv:      ntaps 1
+ *   ConvTranspose: g = layer input, a = output gradient at 2x resolution (a_step 2, ntaps 4),
+ *                  rows = input channels, k = (dy*2+dx)*co + c_out
+ * zeros: >= 128 floats of zeros (source of out-of-range pixels).  n % 32 == 0. */
+typedef struct AmmcWgradDesc {
+  const float* g;
+  const float* a;
+  float* dw;
+  const float* zeros;
+  int32_t batch, height, width;     /* pixel space of m (resolution of g)                     */
+  int32_t n;                        /* rows of dWp                                            */
+  int32_t cin;                      /* channels per tap of the a side                         */
+  int32_t ntaps;                    /* 9, 4 or 1                                              */
+  int32_t a_step;                   /* 0/1, or 2                                              */
+  int32_t reserved;
+  int64_t g_bs, g_rs, g_ps;
+  int64_t a_bs, a_rs, a_ps;
+} AmmcWgradDesc;
+int ammc_conv_wgrad_f32(const AmmcWgradDesc* desc, void* stream);
+/* packed gradient -> the module's parameter layout */
+int ammc_unpack_conv_wgrad_f32(const float* packed, int32_t cout, int32_t cin, int32_t ksize, int32_t cin_p,
+                               float* out_oihw, void* stream);
+int ammc_unpack_convt_wgrad_f32(const float* packed, int32_t cin, int32_t co, float* out_iohw, void* stream);
+/* filters of the input-gradient convolutions (run through ammc_conv_gemm_f32):
+ * 3x3: [rows>=cin][Kpad], k = tap*cout_p + n, value W[n][c][2-r][2-s];  1x1: transpose, zero padded */
+int ammc_pack_conv_dgrad_weight_f32(const float* w_oihw, int32_t cout, int32_t cin, int32_t cout_p, int32_t rows,
+                                    float* out, void* stream);
+int ammc_transpose_pad_f32(const float* w, int32_t rows, int32_t cols, int32_t rows_p, float* out, void* stream);
+
+/* nn.BatchNorm2d in training mode (unet.py:12,15).  Per-channel reductions write
+ * partial[ammc_chan_reduce_blocks(B*H*W)][Q][C]; the finalizers combine them in fp64, fixed order. */
+int ammc_chan_reduce_blocks(int32_t pixels);
+int ammc_bn_stats_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, int32_t batch, int32_t h, int32_t w,
+                      int32_t c, float* partial /* Q=2: sum, sum of squares */, void* stream);
+int ammc_bn_finalize_f32(const float* partial, int32_t nblocks, int32_t c, float count, const float* gamma,
+                         const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                         float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* y = act(x*scale + shift) + res on interior pixels (BN apply + ReLU + AMFT residual) */
+int ammc_scale_shift_act_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, const float* scale,
+                             const float* shift, const float* res, int64_t r_bs, int64_t r_rs, int64_t r_ps,
+                             float* y, int64_t y_bs, int64_t y_rs, int64_t y_ps, int32_t relu, int32_t batch,
+                             int32_t h, int32_t w, int32_t c, void* stream);
+/* BN (+ReLU) backward: partial Q=2: sum g, sum g*xhat with g = dy*[c*scale+shift > 0]; then
+ * dc = scale*(g - sums[0]/M - xhat*sums[1]/M); sums[0] = dbeta, sums[1] = dgamma.
+ * NOTE: the `gamma`/`beta` arguments take the FOLDED scale (gamma*invstd) and shift produced by
+ * ammc_bn_finalize_f32, so that the ReLU mask is evaluated exactly as in the forward. */
+int ammc_bn_bwd_reduce_f32(const float* c_raw, int64_t c_bs, int64_t c_rs, int64_t c_ps, const float* dy,
+                           int64_t d_bs, int64_t d_rs, int64_t d_ps, const float* mean, const float* invstd,
+                           const float* gamma, const float* beta, int32_t relu, int32_t batch, int32_t h, int32_t w,
+                           int32_t c, float* partial, void* stream);
+int ammc_bn_bwd_apply_f32(const float* c_raw, int64_t c_bs, int64_t c_rs, int64_t c_ps, const float* dy,
+                          int64_t d_bs, int64_t d_rs, int64_t d_ps, const float* mean, const float* invstd,
+                          const float* gamma, const float* beta, const float* sums, int32_t relu, float* dc,
+                          int64_t o_bs, int64_t o_rs, int64_t o_ps, int32_t batch, int32_t h, int32_t w, int32_t c,
+                          void* stream);
+/* per-channel sum over pixels (bias gradients): partial Q=1 */
+int ammc_chan_sum_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, int32_t batch, int32_t h, int32_t w,
+                      int32_t c, float* partial, void* stream);
+int ammc_reduce_partials_f32(const float* partial, int32_t nblocks, int32_t qc, float scale, float* out, void* stream);
+/* nn.MaxPool2d(2) backward (+ `add`, the gradient reaching the same tensor through the skip) */
+int ammc_maxpool2x2_bwd_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, const float* dp, int64_t p_bs,
+                            int64_t p_rs, int64_t p_ps, const float* add, int64_t a_bs, int64_t a_rs, int64_t a_ps,
+                            float* dx, int64_t o_bs, int64_t o_rs, int64_t o_ps, int32_t batch, int32_t h, int32_t w,
+                            int32_t c, void* stream);
+/* torch.tanh backward at the module boundary: NCHW (dout, out) -> NHWC d(pre-tanh), cp channels */
+int ammc_tanh_bwd_nhwc_f32(const float* dout_nchw, const float* out_nchw, int32_t batch, int32_t c, int32_t h,
+                           int32_t w, float* y, int64_t y_bs, int64_t y_rs, int64_t y_ps, int32_t cp, void* stream);
+/* gradient of the commit term and of q_one w.r.t. the encoder output (unet.py:310-311) */
+int ammc_commit_bwd_f32(const float* z, const float* embed_md, const int32_t* idx_topk, int32_t k,
+                        const float* ddiff, const float* dq, float* dz, int32_t n, int32_t d, void* stream);
+/* EMA codebook update (unet.py:298-309), deterministic (no atomics) */
+int ammc_codebook_ema_f32(const float* x, const int32_t* idx_topk, int32_t k, int32_t n, int32_t d, int32_t m,
+                          float decay, float one_minus_decay, float eps, float* cluster_size, float* embed_avg,
+                          float* embed, void* stream);
 
 #ifdef __cplusplus
 }

@@ -65,8 +65,10 @@ def test_no_silent_fallback():
     with pytest.raises(_lib.AmmcHipError):
         net.rgb.inc(torch.zeros(1, 12, 16, 16))
     net.train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(_lib.AmmcHipError):                                   # training mode: HIP only as well
         net(torch.zeros(1, 12, 64, 64), torch.zeros(1, 6, 64, 64))
+    with pytest.raises(NotImplementedError):                                 # stand-alone block in .train()
+        net.rgb.inc(torch.zeros(1, 12, 16, 16))
 
 
 def test_synthetic_data_is_deterministic():
