@@ -1,0 +1,131 @@
+"""Host-side counterparts of the two callers of the path (the reference's harness files do not
+travel and are not importable without cv2/tensorboardX).
+
+* `evaluate_subvideo` / `evaluate_dataset`: the scoring loop of
+  `run_helper/test_helper.py:408-488` - sliding clips in order, batches of 16 (last one
+  short), per-sample PSNR (`utils/utils.py:130-148`), ONE commit value per batch written to
+  every frame of the batch, first `len_clip-1` frames back-filled - and the record dict the
+  reference pickles (`:479-484`).  Multi-GPU: whole batches are sharded across ranks
+  (`parallel.shard_batches`), never split.
+* `generator_loss` / `train_step`: the G-only objective of SURVEY.md 3.2 (the part of
+  `Twostream_vq_Loss`, `models/losses/loss_zoo.py:323-336`, that exercises the path's backward):
+  lam_lp * L2norm(rgb) + lam_lp_op * L2norm(op) + lam_latent * (rgb_diff + op_diff).
+
+The model is any callable with the reference's forward signature; with the HIP modules the
+loop makes one device->host copy per BATCH (the reference syncs once per frame, `:452-453`).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import parallel
+
+EVAL_BATCH = 16            # hard-coded in the reference (test_helper.py:414-417)
+RGB_LEN_CLIP, OP_LEN_CLIP = 5, 4
+
+
+def psnr_per_sample(gen: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
+    """[B] PSNR on the [0,1] range (utils/utils.py:141-148 applied to each sample)"""
+    n = gen.shape[1] * gen.shape[2] * gen.shape[3]
+    sq = ((gt + 1.0) / 2.0 - (gen + 1.0) / 2.0) ** 2
+    return 10.0 * torch.log10(1.0 / ((1.0 / n) * sq.sum(dim=[1, 2, 3])))
+
+
+def subvideo_batches(n_frames: int, batch: int = EVAL_BATCH, rgb_len_clip: int = RGB_LEN_CLIP):
+    """[(first clip, last clip + 1)] of one sub-video, in order, last batch short"""
+    n_clip = n_frames - rgb_len_clip + 1
+    return [(s, min(s + batch, n_clip)) for s in range(0, max(n_clip, 0), batch)]
+
+
+def score_batch(model: Callable, rgb_frames: torch.Tensor, op_frames: torch.Tensor, s: int, e: int,
+                device=None) -> Dict[str, np.ndarray]:
+    """run clips [s, e) of a sub-video as ONE batch; per-clip PSNR and the batch's commit values"""
+    rgb = torch.stack([rgb_frames[i:i + RGB_LEN_CLIP] for i in range(s, e)])
+    op = torch.stack([op_frames[i:i + OP_LEN_CLIP] for i in range(s, e)])
+    if device is not None:
+        rgb, op = rgb.to(device, non_blocking=True), op.to(device, non_blocking=True)
+    b = e - s
+    rgb_in = rgb[:, :-1].reshape(b, -1, *rgb.shape[-2:])
+    op_in = op[:, :-1].reshape(b, -1, *op.shape[-2:])
+    with torch.no_grad():
+        rgb_out, op_out, (rgb_diff, op_diff), _ = model(rgb_in, op_in)
+        stats = torch.cat([psnr_per_sample(rgb_out, rgb[:, -1]), psnr_per_sample(op_out, op[:, -1]),
+                           rgb_diff.reshape(1), op_diff.reshape(1)]).cpu().numpy()
+    return {"rgb_psnr": stats[:b], "op_psnr": stats[b:2 * b], "rgb_comm": stats[2 * b], "op_comm": stats[2 * b + 1]}
+
+
+def assemble_records(n_frames: int, batches, scores: Sequence[Dict[str, np.ndarray]]) -> Dict[str, np.ndarray]:
+    """per-frame arrays of one sub-video from its batch scores (test_helper.py:445-473)"""
+    rec = {k: np.empty((n_frames,), dtype=np.float32) for k in ("rgb_psnr", "rgb_comm", "op_psnr", "op_comm")}
+    for (s, e), sc in zip(batches, scores):
+        for i in range(s, e):
+            rec["rgb_psnr"][i + RGB_LEN_CLIP - 1] = sc["rgb_psnr"][i - s]
+            rec["rgb_comm"][i + RGB_LEN_CLIP - 1] = sc["rgb_comm"]
+            rec["op_psnr"][i + OP_LEN_CLIP - 1] = sc["op_psnr"][i - s]
+            rec["op_comm"][i + OP_LEN_CLIP - 1] = sc["op_comm"]
+    for key, lc in (("rgb_psnr", RGB_LEN_CLIP), ("rgb_comm", RGB_LEN_CLIP), ("op_psnr", OP_LEN_CLIP),
+                    ("op_comm", OP_LEN_CLIP)):
+        rec[key][:lc - 1] = rec[key][lc - 1]
+    rec["op_psnr"][n_frames - 1] = rec["op_psnr"][n_frames - 2]
+    rec["op_comm"][n_frames - 1] = rec["op_comm"][n_frames - 2]
+    return rec
+
+
+def evaluate_subvideo(model: Callable, rgb_frames: torch.Tensor, op_frames: torch.Tensor, device=None):
+    """rgb_frames [T,3,H,W], op_frames [T-1,2,H,W] -> per-frame record arrays"""
+    t = rgb_frames.shape[0]
+    if op_frames.shape[0] != t - 1:
+        raise ValueError("a sub-video of T frames has T-1 flows")
+    batches = subvideo_batches(t)
+    scores = [score_batch(model, rgb_frames, op_frames, s, e, device) for s, e in batches]
+    return assemble_records(t, batches, scores)
+
+
+def evaluate_dataset(model: Callable, videos: Sequence, dataset_name: str = "synthetic", device=None,
+                     rank: int = 0, world: int = 1) -> Optional[dict]:
+    """videos: sequence of (rgb_frames, op_frames) in sorted sub-video order.  Whole batches are
+    sharded over `world` ranks; every rank returns the full record dict (test_helper.py:479-484)."""
+    plan = [(v, s, e) for v, (rgb, _) in enumerate(videos) for s, e in subvideo_batches(rgb.shape[0])]
+    mine = parallel.shard_batches(len(plan), rank, world)
+    local = {}
+    for i in mine:
+        v, s, e = plan[i]
+        local[i] = score_batch(model, videos[v][0], videos[v][1], s, e, device)
+    allsc = parallel.gather_records(local, world)
+    out = {"dataset": dataset_name, "rgb_img_pred_records": [], "rgb_fea_comm_records": [],
+           "op_img_pred_records": [], "op_fea_comm_records": []}
+    for v, (rgb, _) in enumerate(videos):
+        idx = [i for i, p in enumerate(plan) if p[0] == v]
+        rec = assemble_records(rgb.shape[0], [plan[i][1:] for i in idx], [allsc[i] for i in idx])
+        out["rgb_img_pred_records"].append(rec["rgb_psnr"])
+        out["rgb_fea_comm_records"].append(rec["rgb_comm"])
+        out["op_img_pred_records"].append(rec["op_psnr"])
+        out["op_fea_comm_records"].append(rec["op_comm"])
+    return out
+
+
+def generator_loss(out, rgb_t: torch.Tensor, op_t: torch.Tensor, lam_lp: float = 1.0, lam_lp_op: float = 1.0,
+                   lam_latent: float = 1.0) -> torch.Tensor:
+    rgb, op, (rd, od), _ = out[:4]
+    l_rgb = torch.norm(rgb - rgb_t, p=2, dim=1).mean()            # `L2`, losses_utils.py:124-129
+    l_op = torch.norm(op - op_t, p=2, dim=1).mean()
+    return lam_lp * l_rgb + lam_lp_op * l_op + lam_latent * (rd + od).sum()
+
+
+def train_step(model: torch.nn.Module, optimizer: torch.optim.Optimizer, rgb: torch.Tensor, op: torch.Tensor,
+               **lams) -> torch.Tensor:
+    """one G step of the joint training loop (train_helper.py:296-339 without D / FlowNet terms).
+    rgb [B,5,3,H,W], op [B,4,2,H,W]; targets are the last frame of each.  With a
+    `parallel.BucketedGradReducer` attached to the model the gradients are averaged across ranks
+    inside backward (RCCL over xGMI)."""
+    b = rgb.shape[0]
+    rgb_in = rgb[:, :-1].reshape(b, -1, *rgb.shape[-2:])
+    op_in = op[:, :-1].reshape(b, -1, *op.shape[-2:])
+    optimizer.zero_grad(set_to_none=True)
+    loss = generator_loss(model(rgb_in, op_in), rgb[:, -1], op[:, -1], **lams)
+    loss.backward()
+    optimizer.step()
+    return loss.detach()

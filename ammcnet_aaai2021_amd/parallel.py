@@ -1,0 +1,134 @@
+"""One process per GPU: what the path needs from `torch.distributed` (RCCL over xGMI), nothing more.
+
+The reference is single-GPU (no DP/DDP anywhere); these are the builder's
+choices for BASELINE.json's multi-GPU configs:
+
+* **Inference** (configs 2, 5) shards by WHOLE harness batches (16 consecutive clips of one
+  sub-video): the commit score is a per-batch mean (reference unet.py:310), so a batch is
+  never split across GPUs and never re-batched.  No data-path collective; per-frame records
+  are gathered at the end (`gather_records`).
+* **Training** (configs 3, 4) is plain data parallelism: every rank holds the full 25 M-parameter
+  generator, runs the HIP forward/backward on its local clips and averages the gradients with
+  a bucketed all-reduce.  `BucketedGradReducer` is driven by the training engine as each stage
+  of the hand-scheduled backward finishes (decoders -> bridge -> memory -> encoders), so the
+  RCCL traffic of early buckets overlaps the remaining backward kernels.  100 MB of fp32
+  gradients per step is ~1.2 ms on one xGMI link; buckets of ~25 MB keep RCCL's ring/tree
+  protocols in their bandwidth regime without delaying the first launch.
+  BatchNorm statistics and the EMA codebook stay per-rank (stock DDP semantics); buffers are
+  made identical across ranks with `broadcast_state` (rank 0 wins) at start and on demand.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, torch.device]:
+    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torchrun); backend
+    "nccl" (= RCCL on ROCm) when a GPU is visible, else "gloo"."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_gpu = torch.cuda.is_available()
+    dev = torch.device("cuda", local) if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(dev)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        backend = backend or ("nccl" if use_gpu else "gloo")
+        kw = {"device_id": dev} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, dev
+
+
+def shard_batches(n_batches: int, rank: int, world: int) -> List[int]:
+    """indices of the harness batches this rank evaluates (contiguous blocks, so that a
+    sub-video's batches mostly stay on one GPU); every batch is owned by exactly one rank"""
+    base, extra = divmod(n_batches, world)
+    start = rank * base + min(rank, extra)
+    return list(range(start, start + base + (1 if rank < extra else 0)))
+
+
+def gather_records(local: Dict[int, object], world: int) -> Dict[int, object]:
+    """merge {batch index: per-frame records} from all ranks (a few KB; object all-gather)"""
+    if world == 1 or not dist.is_initialized():
+        return dict(local)
+    parts: List[Optional[dict]] = [None] * world
+    dist.all_gather_object(parts, local)
+    out: Dict[int, object] = {}
+    for p in parts:
+        out.update(p)
+    return out
+
+
+def broadcast_state(module: torch.nn.Module, src: int = 0) -> None:
+    """make parameters and buffers (BN running stats, codebook) identical on every rank"""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src)
+    if hasattr(module, "_param_epoch"):
+        module._param_epoch += 1
+
+
+class BucketedGradReducer:
+    """Average gradients across ranks in ~`bucket_mb` MiB buckets, launched as they become ready.
+
+    `push(tensors)` may be called many times during one backward; a bucket is flattened and
+    all-reduced asynchronously as soon as it is full.  `finish()` flushes the tail, waits and
+    scatters the averaged values back IN PLACE into the pushed tensors."""
+
+    def __init__(self, bucket_mb: float = 25.0, group=None):
+        self.bucket_bytes = int(bucket_mb * (1 << 20))
+        self.group = group
+        self._pending: List[torch.Tensor] = []
+        self._pending_bytes = 0
+        self._inflight: List[Tuple[torch.Tensor, List[torch.Tensor], object]] = []
+        self.buckets_launched = 0
+
+    @property
+    def world(self) -> int:
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def push(self, tensors: Iterable[torch.Tensor]) -> None:
+        if self.world == 1:
+            return
+        for t in tensors:
+            self._pending.append(t)
+            self._pending_bytes += t.numel() * t.element_size()
+            if self._pending_bytes >= self.bucket_bytes:
+                self._launch()
+
+    def _launch(self) -> None:
+        if not self._pending:
+            return
+        members = self._pending
+        flat = torch.cat([t.reshape(-1) for t in members])
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._inflight.append((flat, members, work))
+        self._pending, self._pending_bytes = [], 0
+        self.buckets_launched += 1
+
+    def finish(self) -> None:
+        if self.world == 1:
+            return
+        self._launch()
+        inv = 1.0 / self.world
+        for flat, members, work in self._inflight:
+            work.wait()
+            off = 0
+            for t in members:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view_as(t)).mul_(inv)
+                off += n
+        self._inflight = []
+
+
+def attach_reducer(module: torch.nn.Module, reducer: Optional[BucketedGradReducer]) -> None:
+    """let the model's training engine feed `reducer` stage by stage during backward"""
+    object.__setattr__(module, "_grad_reducer", reducer)

@@ -467,9 +467,18 @@ class TrainEngine:
                                "by a later forward of the same shape (one forward per backward is supported)")
         streams: List[_Stream] = st["streams"]
         grads: Dict = {}
+        reducer = getattr(self.module, "_grad_reducer", None)     # parallel.BucketedGradReducer or None
+        sent = set()
 
         def g(t):
             return t if t is not None else None
+
+        def stage_done():
+            """hand the gradients finished since the last call to the all-reduce (overlaps the rest)"""
+            if reducer is not None:
+                new = [v for k, v in grads.items() if id(k) not in sent]
+                sent.update(id(k) for k in grads)
+                reducer.push(new)
 
         if self.kind == "twostream":
             d_rgb, d_op, dd_r, dd_o, dq_r, dq_o = gouts
@@ -478,12 +487,15 @@ class TrainEngine:
                 if dout is None:
                     dout = torch.zeros_like(s.out)
                 s.decode_backward(dout, grads)
+                stage_done()
             # x = zx + O2F(zy); y = zy + F20(zx): dzy = dyb + dgrad_O2F(dxb), dzx = dxb + dgrad_F20(dyb)
             st["o2f"].backward(r.dbottom, st["dzy"], o.dbottom, grads)
             st["f2o"].backward(o.dbottom, st["dzx"], r.dbottom, grads)
+            stage_done()
             dx4r = r.memory_backward(st["dzx"], g(dd_r), g(dq_r), grads)
             dx4o = o.memory_backward(st["dzy"], g(dd_o), g(dq_o), grads)
             r.encode_backward(dx4r, grads)
+            stage_done()
             o.encode_backward(dx4o, grads)
         else:
             s = streams[0]
@@ -492,6 +504,9 @@ class TrainEngine:
             if self.kind == "unetmem":
                 db = s.memory_backward(db, g(gouts[1]), g(gouts[2]), grads)
             s.encode_backward(db, grads)
+        stage_done()
+        if reducer is not None:
+            reducer.finish()
         return {k.data_ptr(): v for k, v in grads.items()}
 
 

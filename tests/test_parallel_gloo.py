@@ -1,0 +1,95 @@
+"""The N>1 paths on CPU: world_size 2, gloo.  Covers the gradient reducer (bucketing, async
+all-reduce, in-place averaging), state broadcast and the batch sharding of inference."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ammcnet_aaai2021_amd import parallel as P
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    r, w, dev = P.init_distributed("gloo")
+    assert (r, w, dev.type) == (rank, world, "cpu")
+    # --- reducer: tensors of odd sizes, several buckets, values depend on the rank
+    torch.manual_seed(0)
+    shapes = [(64, 12, 3, 3), (64,), (128, 64, 3, 3), (3,), (512, 128, 1, 1), (2, 2)]
+    grads = [torch.full(s, float(rank + 1)) + torch.arange(int(torch.tensor(s).prod())).reshape(s) * 1e-3
+             for s in shapes]
+    want = [torch.full(s, 1.5) + torch.arange(int(torch.tensor(s).prod())).reshape(s) * 1e-3 for s in shapes]
+    red = P.BucketedGradReducer(bucket_mb=0.1)
+    red.push(grads[:3])
+    red.push(grads[3:])
+    red.finish()
+    ok = all(torch.allclose(g, w_) for g, w_ in zip(grads, want)) and red.buckets_launched >= 2
+    # --- broadcast_state: rank 1 starts different, ends equal to rank 0
+    lin = torch.nn.BatchNorm2d(4)
+    with torch.no_grad():
+        lin.weight.fill_(rank + 1.0)
+        lin.running_mean.fill_(rank + 3.0)
+    P.broadcast_state(lin, 0)
+    ok = ok and float(lin.weight[0]) == 1.0 and float(lin.running_mean[0]) == 3.0
+    # --- inference sharding: whole batches, each owned once; records gathered everywhere
+    mine = P.shard_batches(7, rank, world)
+    rec = P.gather_records({i: [i * 10, rank] for i in mine}, world)
+    ok = ok and sorted(rec) == list(range(7)) and all(rec[i][0] == i * 10 for i in rec)
+    # --- a data-parallel step on a tiny torch model equals the single-process large-batch step
+    torch.manual_seed(1)
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.Tanh(), torch.nn.Conv2d(4, 2, 1))
+    P.broadcast_state(model, 0)
+    x = torch.arange(2 * world * 3 * 4 * 4, dtype=torch.float32).reshape(2 * world, 3, 4, 4).sin()
+    xs = x[rank * 2:(rank + 1) * 2]
+    model(xs).square().mean().backward()
+    red = P.BucketedGradReducer(bucket_mb=25)
+    red.push([p.grad for p in model.parameters()])
+    red.finish()
+    ref = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.Tanh(), torch.nn.Conv2d(4, 2, 1))
+    ref.load_state_dict(model.state_dict())
+    ref(x).square().mean().backward()
+    ok = ok and all(torch.allclose(p.grad, q_.grad, atol=1e-6) for p, q_ in zip(model.parameters(), ref.parameters()))
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
+
+
+def test_shard_batches_partition():
+    for n in (0, 1, 5, 16, 123):
+        for world in (1, 2, 3, 8):
+            parts = [P.shard_batches(n, r, world) for r in range(world)]
+            flat = [i for p in parts for i in p]
+            assert flat == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_single_process_reducer_is_a_no_op():
+    g = [torch.ones(3)]
+    red = P.BucketedGradReducer()
+    red.push(g)
+    red.finish()
+    assert torch.equal(g[0], torch.ones(3)) and red.buckets_launched == 0
