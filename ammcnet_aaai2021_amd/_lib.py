@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libammc_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 
@@ -65,6 +65,9 @@ SIGNATURES = {
     "ammc_memory_topk_blocks": (C.c_int, [_i32]),
     "ammc_memory_topk_fwd_f32": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
     "ammc_sum_partials_f32": (C.c_int, [_p, _i32, _f32, _p, _p]),
+    "ammc_pack_codebook_f16": (C.c_int, [_p, _i32, _i32, _p, _p, _p]),
+    "ammc_memory_topk_f16_blocks": (C.c_int, [_i32]),
+    "ammc_memory_topk_fwd_f16": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
     "ammc_conv_wgrad_f32": (C.c_int, [C.POINTER(AmmcWgradDesc), _p]),
     "ammc_unpack_conv_wgrad_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
     "ammc_unpack_convt_wgrad_f32": (C.c_int, [_p, _i32, _i32, _p, _p]),

@@ -1,0 +1,278 @@
+// Memory addressing with fp16 MFMA operands and fp32 accumulation: the stress form of
+// `Quantize_topk.forward` (reference Code/models/unet.py:282-297, 310-313) for large memories
+// (BASELINE.json config 5: 8192 slots x 512-d features).  Same outputs as memory_topk.hip; the
+// distance GEMM runs on v_mfma_f32_32x32x16_f16 (16x the fp32 MFMA rate), so the slot RANKING is
+// computed from fp16-rounded features/slots, while the gathered rows, q_one and the commit
+// distance use the fp32 codebook.  It is not the parity path: indices can differ from the
+// fp32 result where two slots are closer than fp16 rounding noise (tests bound that).
+//
+//   - a workgroup (8 waves) owns 128 feature rows, staged once into LDS as fp16 with the 16-B
+//     slots XOR-swizzled by row (conflict-free ds_read_b128 of the B fragments);
+//   - the codebook is pre-packed k-blocked, [D/8][Mpad][8 halfs]: the A fragment of a lane
+//     (8 consecutive features of one slot) is ONE coalesced 16-B global load, 512 B per half
+//     wave; loads run a ring of PF steps ahead of the MFMAs - the codebook (8 MB at config 5)
+//     streams from L2 / Infinity Cache and never touches LDS;
+//   - wave w contracts slot tiles w, w+8, ...; each lane keeps the running top-K of its feature
+//     row in registers; the 16 partial lists per row are merged through LDS.
+// Roofline: MFMA fp16 (2*d*m flop per row against ~2*d + 4*k*d bytes): AI in the thousands.
+#include "ammc_common.h"
+#include <hip/hip_fp16.h>
+#include <math.h>
+#include <algorithm>
+
+namespace ammc_impl {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int HBR = 128;          // feature rows per workgroup
+constexpr int HRT = HBR / 32;
+constexpr int HWAVES = 8;
+constexpr int PF = 8;             // A-fragment prefetch depth (k-steps of 16)
+
+template <int K>
+__device__ __forceinline__ void topk_insert16(float (&v)[K], int (&ix)[K], float c, int s) {
+  if (c < v[K - 1] || (c == v[K - 1] && s < ix[K - 1])) {
+    v[K - 1] = c;
+    ix[K - 1] = s;
+#pragma unroll
+    for (int j = K - 1; j > 0; --j) {
+      const bool sw = v[j] < v[j - 1] || (v[j] == v[j - 1] && ix[j] < ix[j - 1]);
+      const float tv = sw ? v[j - 1] : v[j];
+      const int ti = sw ? ix[j - 1] : ix[j];
+      v[j - 1] = sw ? v[j] : v[j - 1];
+      ix[j - 1] = sw ? ix[j] : ix[j - 1];
+      v[j] = tv;
+      ix[j] = ti;
+    }
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(512, 1) void memory_topk_f16_kernel(
+    const float* __restrict__ x, const f16x8* __restrict__ e_kblk /* [d/8][mpad] */,
+    const float* __restrict__ e_md, const float* __restrict__ enorm16, int n, int d, int m, int mpad,
+    int* __restrict__ idx_out, float* __restrict__ q_topk, float* __restrict__ q_one,
+    float* __restrict__ diff_partial) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // region 0: the x tile [HBR][d] halfs (swizzled 16-B slots) during the contraction, then re-used for
+  // the candidate lists [HBR][16][K] (value, index); region 1: |x|^2, final indices, reduction scratch
+  const size_t region0 = max((size_t)HBR * d * 2, (size_t)HBR * 16 * K * 8);
+  _Float16* xs = reinterpret_cast<_Float16*>(smem_raw);
+  float* cand_v = reinterpret_cast<float*>(smem_raw);
+  int* cand_i = reinterpret_cast<int*>(cand_v + HBR * 16 * K);
+  float* xx = reinterpret_cast<float*>(smem_raw + region0);             // [HBR]
+  int* best = reinterpret_cast<int*>(xx + HBR);                         // [HBR][K]
+  float* red = reinterpret_cast<float*>(best + HBR * K);                // [512]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int r0 = blockIdx.x * HBR;
+  const int slots = d >> 3;                                             // 16-B slots (8 halfs) per row
+
+  // ---- stage x as fp16 -----------------------------------------------------------------
+  for (int p = tid; p < HBR * slots; p += 512) {
+    const int row = p / slots, sl = p - row * slots;
+    f16x8 hv;
+    if (r0 + row < n) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(x + (int64_t)(r0 + row) * d + sl * 8);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(x + (int64_t)(r0 + row) * d + sl * 8 + 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { hv[i] = (_Float16)a[i]; hv[4 + i] = (_Float16)b[i]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) hv[i] = (_Float16)0.f;
+    }
+    *reinterpret_cast<f16x8*>(xs + (size_t)row * d + ((sl ^ (row & 15)) << 3)) = hv;
+  }
+  __syncthreads();
+  if (tid < HBR) {
+    float s = 0.f;
+    for (int sl = 0; sl < slots; ++sl) {
+      const f16x8 v = *reinterpret_cast<const f16x8*>(xs + (size_t)tid * d + ((sl ^ (tid & 15)) << 3));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += (float)v[i] * (float)v[i];
+    }
+    xx[tid] = s;
+  }
+  __syncthreads();
+
+  float bv[HRT][K];
+  int bi[HRT][K];
+#pragma unroll
+  for (int t = 0; t < HRT; ++t)
+#pragma unroll
+    for (int j = 0; j < K; ++j) { bv[t][j] = INFINITY; bi[t][j] = 0x7fffffff; }
+  float xnorm[HRT];
+#pragma unroll
+  for (int t = 0; t < HRT; ++t) xnorm[t] = xx[t * 32 + l31];
+
+  const int ntile = mpad >> 5;
+  const int nstep = d >> 4;                               // k-steps of 16 features
+  for (int tile = wave; tile < ntile; tile += HWAVES) {
+    const int s0 = tile << 5;
+    // lane (l31, h) at step t needs features [16t + 8h, +8) of slot s0 + l31: k-block 2t + h
+    const f16x8* ep = e_kblk + (int64_t)h * mpad + s0 + l31;
+    f32x16 acc[HRT];
+#pragma unroll
+    for (int t = 0; t < HRT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    f16x8 ring[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+      if (p < nstep) ring[p] = ep[(int64_t)(2 * p) * mpad];
+    for (int t0 = 0; t0 < nstep; t0 += PF) {
+#pragma unroll
+      for (int p = 0; p < PF; ++p) {
+        const int t = t0 + p;
+        if (t < nstep) {
+          const f16x8 af = ring[p];
+          if (t + PF < nstep) ring[p] = ep[(int64_t)(2 * (t + PF)) * mpad];
+          const int so = (((2 * t + h) ^ (l31 & 15)) << 3);
+#pragma unroll
+          for (int rt = 0; rt < HRT; ++rt) {
+            const f16x8 bf = *reinterpret_cast<const f16x8*>(xs + (size_t)(rt * 32 + l31) * d + so);
+            acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[rt], 0, 0, 0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int s = s0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (s < m) {
+        const float en = enorm16[s];
+#pragma unroll
+        for (int rt = 0; rt < HRT; ++rt) {
+          const float dist = (xnorm[rt] - 2.f * acc[rt][r]) + en;
+          topk_insert16<K>(bv[rt], bi[rt], dist, s);
+        }
+      }
+    }
+  }
+
+  // ---- merge 16 partial lists per row ------------------------------------------------------
+  __syncthreads();                     // every wave is done reading the x tile: region 0 changes hands
+#pragma unroll
+  for (int t = 0; t < HRT; ++t)
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const int o = ((t * 32 + l31) * 16 + wave * 2 + h) * K + j;
+      cand_v[o] = bv[t][j];
+      cand_i[o] = bi[t][j];
+    }
+  __syncthreads();
+  if (tid < HBR) {
+    float v[K];
+    int ix[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { v[j] = INFINITY; ix[j] = 0x7fffffff; }
+    for (int c = 0; c < 16 * K; ++c) topk_insert16<K>(v, ix, cand_v[tid * 16 * K + c], cand_i[tid * 16 * K + c]);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      best[tid * K + j] = ix[j];
+      if (r0 + tid < n) idx_out[(int64_t)(r0 + tid) * K + j] = ix[j];
+    }
+  }
+  __syncthreads();
+
+  // ---- gather (fp32 codebook) + commit distance (fp32 features re-read from HBM) ------------
+  float part = 0.f;
+  const int slots4 = d >> 2;
+  for (int p = tid; p < HBR * K * slots4; p += 512) {
+    const int sl = p % slots4;
+    const int rj = p / slots4;
+    const int j = rj % K, row = rj / K;
+    if (r0 + row >= n) continue;
+    const int s = best[row * K + j];
+    const f32x4 e = *reinterpret_cast<const f32x4*>(e_md + (int64_t)s * d + sl * 4);
+    *reinterpret_cast<f32x4*>(q_topk + ((int64_t)(r0 + row) * K + j) * d + sl * 4) = e;
+    if (j == 0) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (int64_t)(r0 + row) * d + sl * 4);
+      f32x4 q1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float df = e[i] - xv[i];
+        part += df * df;
+        q1[i] = xv[i] + df;
+      }
+      if (q_one) *reinterpret_cast<f32x4*>(q_one + (int64_t)(r0 + row) * d + sl * 4) = q1;
+    }
+  }
+  red[tid] = part;
+  __syncthreads();
+  for (int o = 256; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) diff_partial[blockIdx.x] = red[0];
+}
+
+// [d][m] fp32 -> k-blocked fp16 [d/8][mpad][8] (slots >= m zero) and |half(E_s)|^2
+__global__ __launch_bounds__(256) void pack_codebook_f16_kernel(const float* __restrict__ e_dm, int d, int m, int mpad,
+                                                                _Float16* __restrict__ out, float* __restrict__ enorm16) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= mpad) return;
+  float nrm = 0.f;
+  for (int kb = 0; kb < (d >> 3); ++kb) {
+    f16x8 hv;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float v = s < m ? e_dm[(int64_t)(kb * 8 + i) * m + s] : 0.f;
+      hv[i] = (_Float16)v;
+      nrm += (float)hv[i] * (float)hv[i];
+    }
+    *reinterpret_cast<f16x8*>(out + ((int64_t)kb * mpad + s) * 8) = hv;
+  }
+  if (s < m) enorm16[s] = nrm;
+}
+
+template <int K>
+int launch_topk16(const float* x, const void* e_kblk, const float* e_md, const float* enorm16, int n, int d, int m,
+                  int* idx, float* q_topk, float* q_one, float* diff_partial, hipStream_t stream) {
+  const size_t region0 = std::max((size_t)HBR * d * 2, (size_t)HBR * 16 * K * 8);
+  const size_t lds = region0 + sizeof(float) * (HBR + HBR * K + 512);
+  auto kern = memory_topk_f16_kernel<K>;
+  if (lds > 160 * 1024) return AMMC_EUNSUP;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int mpad = (m + 31) / 32 * 32;
+  hipLaunchKernelGGL(kern, dim3((n + HBR - 1) / HBR), dim3(512), lds, stream, x,
+                     reinterpret_cast<const f16x8*>(e_kblk), e_md, enorm16, n, d, m, mpad, idx, q_topk, q_one,
+                     diff_partial);
+  return ammc_launch_status();
+}
+
+}  // namespace ammc_impl
+using namespace ammc_impl;
+
+extern "C" int ammc_pack_codebook_f16(const float* embed_dm, int32_t d, int32_t m, void* e_kblk_f16, float* enorm16,
+                                      void* stream) {
+  if (!embed_dm || !e_kblk_f16 || !enorm16 || d <= 0 || (d % 16) || m <= 0) return AMMC_EINVAL;
+  const int mpad = (m + 31) / 32 * 32;
+  hipLaunchKernelGGL(pack_codebook_f16_kernel, dim3((mpad + 255) / 256), dim3(256), 0, (hipStream_t)stream, embed_dm, d,
+                     m, mpad, reinterpret_cast<_Float16*>(e_kblk_f16), enorm16);
+  return ammc_launch_status();
+}
+
+extern "C" int ammc_memory_topk_f16_blocks(int32_t n) { return n <= 0 ? 0 : (n + HBR - 1) / HBR; }
+
+extern "C" int ammc_memory_topk_fwd_f16(const float* x, const void* e_kblk_f16, const float* embed_md,
+                                        const float* enorm16, int32_t n, int32_t d, int32_t m, int32_t k,
+                                        int32_t* idx_topk, float* q_topk, float* q_one, float* diff_partial,
+                                        void* stream) {
+  if (!x || !e_kblk_f16 || !embed_md || !enorm16 || !idx_topk || !q_topk || !diff_partial) return AMMC_EINVAL;
+  if (n <= 0 || m <= 0 || k <= 0 || k > m) return AMMC_EINVAL;
+  if (d < 128 || (d % 128) || d > 512) return AMMC_EUNSUP;      // 16 swizzle positions per row need >= 16 slots
+  if (k > 4) return AMMC_EUNSUP;
+  hipStream_t s = (hipStream_t)stream;
+  switch (k) {
+    case 1: return launch_topk16<1>(x, e_kblk_f16, embed_md, enorm16, n, d, m, idx_topk, q_topk, q_one, diff_partial, s);
+    case 2: return launch_topk16<2>(x, e_kblk_f16, embed_md, enorm16, n, d, m, idx_topk, q_topk, q_one, diff_partial, s);
+    case 3: return launch_topk16<3>(x, e_kblk_f16, embed_md, enorm16, n, d, m, idx_topk, q_topk, q_one, diff_partial, s);
+    default: return launch_topk16<4>(x, e_kblk_f16, embed_md, enorm16, n, d, m, idx_topk, q_topk, q_one, diff_partial, s);
+  }
+}

@@ -146,3 +146,32 @@ def vq_block_eval(quan, x: torch.Tensor, residual: bool):
 def embed_rows(embed: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     """`Quantize_topk.embed_code` (unet.py:315-316): rows of the transposed codebook"""
     return embed.t()[ids]
+
+
+def quantize_topk_f16(embed: torch.Tensor, x: torch.Tensor, k: int):
+    """Stress form of the memory addressing (BASELINE.json config 5): fp16 MFMA operands, fp32
+    accumulation.  embed [D,M] fp32, x [..., D] fp32 -> (q_topk [..., k*D], diff, q_one, idx [..., k]).
+    Not the parity path (the slot ranking sees fp16-rounded operands)."""
+    _need_cuda(x)
+    lib = _lib.load()
+    d, m = embed.shape
+    lead = x.shape[:-1]
+    x2 = x.detach().float().contiguous().view(-1, d)
+    n = x2.shape[0]
+    dev = x.device
+    s = _stream(x)
+    mpad = (m + 31) // 32 * 32
+    e_kblk = torch.empty((d // 8, mpad, 8), device=dev, dtype=torch.float16)
+    enorm16 = torch.empty(m, device=dev, dtype=torch.float32)
+    e_md, _ = _Packer(dev).codebook(embed)
+    _lib.check(lib.ammc_pack_codebook_f16(_ptr(embed), d, m, e_kblk.data_ptr(), _ptr(enorm16), s), "pack_codebook_f16")
+    idx = torch.empty((n, k), device=dev, dtype=torch.int32)
+    qk = torch.empty((n, k * d), device=dev, dtype=torch.float32)
+    q1 = torch.empty((n, d), device=dev, dtype=torch.float32)
+    nblk = lib.ammc_memory_topk_f16_blocks(n)
+    part = torch.empty(nblk, device=dev, dtype=torch.float32)
+    diff = torch.empty(1, device=dev, dtype=torch.float32)
+    _lib.check(lib.ammc_memory_topk_fwd_f16(_ptr(x2), e_kblk.data_ptr(), _ptr(e_md), _ptr(enorm16), n, d, m, k,
+                                            idx.data_ptr(), _ptr(qk), _ptr(q1), _ptr(part), s), "memory_topk_f16")
+    _lib.check(lib.ammc_sum_partials_f32(_ptr(part), nblk, 1.0 / float(n * d), _ptr(diff), s), "sum_partials")
+    return qk.view(*lead, k * d), diff[0], q1.view(*lead, d), idx.view(*lead, k)

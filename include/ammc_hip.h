@@ -147,6 +147,19 @@ int ammc_memory_topk_fwd_f32(const float* x, const float* embed_dm, const float*
 /* diff = sum(partials) / count, fixed order (deterministic) */
 int ammc_sum_partials_f32(const float* partial, int32_t nparts, float inv_count, float* out, void* stream);
 
+/* fp16-operand form of the memory addressing for large memories (BASELINE.json config 5: 8192
+ * slots x 512-d): distance GEMM on v_mfma_f32_32x32x16_f16 with fp32 accumulation, everything
+ * else as ammc_memory_topk_fwd_f32 (gather / q_one / commit distance from the fp32 codebook).
+ * Not the parity path: the ranking sees fp16-rounded operands.  d in {128,256,384,512}, k <= 4.
+ * e_kblk_f16: [d/8][roundup(m,32)][8] halfs from ammc_pack_codebook_f16 (which also returns
+ * |half(E_s)|^2); diff_partial has ammc_memory_topk_f16_blocks(n) entries. */
+int ammc_pack_codebook_f16(const float* embed_dm, int32_t d, int32_t m, void* e_kblk_f16, float* enorm16,
+                           void* stream);
+int ammc_memory_topk_f16_blocks(int32_t n);
+int ammc_memory_topk_fwd_f16(const float* x, const void* e_kblk_f16, const float* embed_md, const float* enorm16,
+                             int32_t n, int32_t d, int32_t m, int32_t k, int32_t* idx_topk, float* q_topk,
+                             float* q_one, float* diff_partial, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Training mode (autograd of the same path; the reference derives these with torch.autograd)
  * ---------------------------------------------------------------------------------------- */

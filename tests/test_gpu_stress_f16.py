@@ -1,0 +1,36 @@
+"""Config 5 of BASELINE.json: the fp16-operand memory-addressing kernel (8192 slots x 512-d).
+Metric: index agreement with the fp32 oracle wherever the distance margin
+exceeds fp16 noise, gathered rows bit-exact for agreed indices, commit distance by tolerance."""
+import pytest
+import torch
+
+from ammcnet_aaai2021_amd import ops, synthetic as S
+from oracle import ammc_oracle as O
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("d,m,k,n", [(512, 8192, 2, 1024), (512, 8192, 2, 300), (128, 1000, 3, 513), (256, 4096, 1, 256)])
+def test_memory_topk_f16(d, m, k, n):
+    embed = S.hashed_normal(f"s16:{d}:{m}", (d, m), 0.9)
+    x = S.hashed_normal(f"s16x:{d}:{m}", (1, 1, n, d), 0.8)
+    qk, diff, q1, idx = ops.quantize_topk_f16(embed.to(DEV), x.to(DEV), k)
+    wqk, wdiff, widx, widx1, flat, wq1 = O.quantize_topk(x, embed, k)
+    idx, widx = idx.cpu().reshape(n, k).long(), widx.reshape(n, k)
+    dist = (flat.double().pow(2).sum(1, keepdim=True) - 2 * flat.double() @ embed.double()
+            + embed.double().pow(2).sum(0, keepdim=True))
+    srt = dist.sort(dim=1).values
+    margin = (srt[:, 1:k + 1] - srt[:, :k]).min(dim=1).values
+    scale = flat.double().pow(2).sum(1) + embed.double().pow(2).sum(0).mean()
+    safe = margin > 4e-3 * scale                      # fp16 operands: ~1e-3 relative on the dot products
+    assert torch.equal(idx[safe], widx[safe])
+    agree = (idx == widx).all(dim=1).double().mean()
+    assert agree > 0.9, float(agree)
+    same = (idx == widx).all(dim=1)
+    assert torch.equal(qk.cpu().reshape(n, k * d)[same], wqk.reshape(n, k * d)[same])       # fp32 rows, bit exact
+    # every chosen slot is a true near neighbour: within fp16 noise of the j-th smallest distance
+    chosen = dist.gather(1, idx)
+    assert bool(((chosen - srt[:, :k]).abs() <= 4e-3 * scale[:, None]).all())
+    assert rel_err(diff.cpu(), wdiff) <= 5e-3
