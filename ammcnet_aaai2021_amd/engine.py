@@ -113,9 +113,17 @@ class Plan:
 class _Packer:
     """weight pre-packing through the C ABI"""
 
-    def __init__(self, device):
+    def __init__(self, device, s16: bool = False):
         self.lib = _lib.load()
         self.device = device
+        self.s16 = s16                  # filters as (hi, lo) half pairs for ammc_conv_gemm_s16
+
+    def _split(self, t: torch.Tensor) -> torch.Tensor:
+        if not self.s16:
+            return t
+        out = torch.empty_like(t)
+        _lib.check(self.lib.ammc_split_rows_f32(_ptr(t), t.numel(), _ptr(out), self.stream()), "split_rows")
+        return out
 
     def stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -127,14 +135,14 @@ class _Packer:
         w = w.detach().contiguous()
         _lib.check(self.lib.ammc_pack_conv_weight_f32(_ptr(w), cout, cin, ksize, cin_p, _ptr(out), self.stream()),
                    "pack_conv_weight")
-        return out, cin_p
+        return self._split(out), cin_p
 
     def convt(self, w: torch.Tensor) -> torch.Tensor:
         cin, co = w.shape[0], w.shape[1]
         out = torch.empty((4 * co, cin), device=self.device, dtype=torch.float32)
         w = w.detach().contiguous()
         _lib.check(self.lib.ammc_pack_convt_weight_f32(_ptr(w), cin, co, _ptr(out), self.stream()), "pack_convt")
-        return out
+        return self._split(out)
 
     def outc(self, w: torch.Tensor) -> torch.Tensor:
         cout, cin = w.shape[0], w.shape[1]
@@ -203,10 +211,13 @@ class _StreamPack:
 class _Builder:
     """appends resolved kernel calls to a Plan"""
 
-    def __init__(self, plan: Plan, device):
+    def __init__(self, plan: Plan, device, s16: bool = False):
         self.plan = plan
         self.lib = _lib.load()
         self.device = device
+        self.s16 = s16
+        self.conv_fn = self.lib.ammc_conv_gemm_s16 if s16 else self.lib.ammc_conv_gemm_f32
+        self.kname = "conv_gemm_s16" if s16 else "conv_gemm_f32"
 
     def buf(self, *shape) -> torch.Tensor:
         # zeros once: kernels write interiors only, so the halo stays zero forever
@@ -219,8 +230,9 @@ class _Builder:
 
     def conv(self, x: Act, w: torch.Tensor, y: Act, *, ntaps: int, cin: int, n: int, scale=None, shift=None,
              act=ACT_NONE, res: Optional[Act] = None, up: int = 1, cgroup: Optional[int] = None, name="conv",
-             cin_true: Optional[int] = None):
+             cin_true: Optional[int] = None, y_f32: bool = False):
         d = AmmcConvDesc()
+        d.y_f32 = 1 if (y_f32 and self.s16) else 0
         d.x = x.tap0() if ntaps == 9 else x.pix0()
         d.w = _ptr(w)
         d.y = y.pix0()
@@ -244,8 +256,8 @@ class _Builder:
         flops = 2.0 * m_pix * n * ntaps * ct
         nbytes = 4.0 * m_pix * (ct + n + (n if res is not None else 0))
         tile = "128x32" if n == 32 else "128x128" if n % 128 == 0 else "128x64"
-        self.plan.add(self.lib.ammc_conv_gemm_f32, C.byref(d), name=name, flops=flops, nbytes=nbytes,
-                      kernel=f"conv_gemm_f32<{tile}>")
+        self.plan.add(self.conv_fn, C.byref(d), name=name, flops=flops, nbytes=nbytes,
+                      kernel=f"{self.kname}<{tile}>")
         return d
 
     def outc_desc(self, x: Act, w: torch.Tensor, bias32: torch.Tensor, cout: int) -> AmmcConvDesc:
@@ -254,6 +266,7 @@ class _Builder:
         d.x, d.w, d.shift = x.tap0(), _ptr(w), _ptr(bias32)
         d.batch, d.height, d.width = x.B, x.H, x.W
         d.cin, d.ntaps, d.n, d.up, d.cgroup, d.act, d.n_store = x.c, 9, 32, 1, 32, ACT_TANH, cout
+        d.y_f32 = 1 if self.s16 else 0
         d.x_bs, d.x_rs, d.x_ps = x.strides
         d.y_bs, d.y_rs, d.y_ps, d.y_cs = cout * x.H * x.W, x.W, 1, x.H * x.W
         self.plan.keep.extend([d, w, bias32])
@@ -266,7 +279,8 @@ class _Builder:
                   name=f"{name}.conv1")
 
     def maxpool(self, x: Act, y: Act, name="pool"):
-        self.plan.add(self.lib.ammc_maxpool2x2_f32, x.pix0(), *x.strides, y.pix0(), *y.strides,
+        self.plan.add(self.lib.ammc_maxpool2x2_s16 if self.s16 else self.lib.ammc_maxpool2x2_f32,
+                      x.pix0(), *x.strides, y.pix0(), *y.strides,
                       y.B, y.H, y.W, y.c, name=name, nbytes=4.0 * 5 * y.B * y.H * y.W * y.c, kernel="maxpool2x2")
 
     def convt(self, x: Act, w: torch.Tensor, bias: torch.Tensor, y: Act, name="convt"):
@@ -314,7 +328,7 @@ class StreamGraph:
         n, d, m, k = B * h * w, v["d"], v["m"], v["k"]
         lib = bld.lib
         self.z = bld.act(B, h, w, d, halo=0)
-        bld.conv(self.x4, v["enc_w"], self.z, ntaps=1, cin=512, n=d, shift=v["enc_b"], name="vq.enc")
+        bld.conv(self.x4, v["enc_w"], self.z, ntaps=1, cin=512, n=d, shift=v["enc_b"], name="vq.enc", y_f32=True)
         self.idx = torch.zeros((n, k), device=bld.device, dtype=torch.int32)
         self.qk = bld.act(B, h, w, k * d, halo=0)
         self.q_one = bld.buf(B, h, w, d)
@@ -329,7 +343,14 @@ class StreamGraph:
         bld.plan.add(lib.ammc_sum_partials_f32, _ptr(self.diff_part), nblk, 1.0 / float(n * d), _ptr(self.diff),
                      name="vq.diff")
         self.x4q = bld.act(B, h, w, 512)
-        bld.conv(self.qk, v["dec_w"], self.x4q, ntaps=1, cin=k * d, n=512, shift=v["dec_b"], res=self.x4,
+        if bld.s16:              # the gathered fp32 rows become the S16 operand of `dec`
+            qk_s = bld.act(B, h, w, k * d, halo=0)
+            bld.plan.add(lib.ammc_split_rows_f32, _ptr(self.qk.buf), n * k * d, _ptr(qk_s.buf), name="vq.split",
+                         nbytes=8.0 * n * k * d, kernel="split_rows")
+            self.qk_op = qk_s
+        else:
+            self.qk_op = self.qk
+        bld.conv(self.qk_op, v["dec_w"], self.x4q, ntaps=1, cin=k * d, n=512, shift=v["dec_b"], res=self.x4,
                  name="vq.dec")
         self.bottom = self.x4q
 
@@ -354,9 +375,13 @@ class StreamGraph:
 class EvalEngine:
     """eval-mode forward of `UNet`, `UNetMem_v7` or `twostream` on the HIP kernels"""
 
-    def __init__(self, module, kind: str):
+    def __init__(self, module, kind: str, precision: str = "fp32"):
+        if precision not in ("fp32", "s16"):
+            raise ValueError("precision must be 'fp32' (exact fp32 MFMA) or 's16' (split-fp16 MFMA, fp32-equivalent)")
         self.module = module
         self.kind = kind                      # "unet" | "unetmem" | "twostream"
+        self.precision = precision
+        self.s16 = precision == "s16"
         self.lib = _lib.load()
         self._packs = None
         self._pack_version = None
@@ -379,7 +404,7 @@ class EvalEngine:
         ver = self._version()
         if self._packs is not None and ver == self._pack_version:
             return
-        pk = _Packer(device)
+        pk = _Packer(device, self.s16)
         m = self.module
         if self.kind == "twostream":
             self._packs = dict(rgb=_StreamPack(pk, m.rgb), op=_StreamPack(pk, m.op),
@@ -392,7 +417,7 @@ class EvalEngine:
     # ---- plans ----------------------------------------------------------------------
     def _build(self, B, H, W, device) -> dict:
         plan = Plan()
-        bld = _Builder(plan, device)
+        bld = _Builder(plan, device, self.s16)
         st = {}
         if self.kind == "twostream":
             r = StreamGraph(bld, self._packs["rgb"], B, H, W)
@@ -437,7 +462,17 @@ class EvalEngine:
         `quant_befor` / `quant_after`, unet.py:986,988).  Views of the workspace: valid until the
         next forward of the same shape."""
         s = self._last["streams"][0]
-        return (s.x4.interior().permute(0, 3, 1, 2), s.x4q.interior().permute(0, 3, 1, 2))
+        return self.act_nchw(s.x4), self.act_nchw(s.x4q)
+
+    def act_nchw(self, a: Act) -> torch.Tensor:
+        """an activation of the workspace as an NCHW fp32 tensor (a view for fp32 plans, a decoded copy
+        for S16 plans); halo-free activations (z, qk) are fp32 in both"""
+        if not self.s16 or a.halo == 0:
+            return a.interior().permute(0, 3, 1, 2)
+        y = torch.empty((a.B, a.c, a.H, a.W), device=a.buf.device, dtype=torch.float32)
+        _lib.check(self.lib.ammc_s16_to_nchw_f32(a.pix0(), *a.strides, a.B, a.c, a.H, a.W, _ptr(y),
+                                                 torch.cuda.current_stream(y.device).cuda_stream), "s16_to_nchw")
+        return y
 
     # ---- forward ----------------------------------------------------------------------
     def forward(self, *inputs: torch.Tensor):
@@ -473,7 +508,8 @@ class EvalEngine:
             if x.dtype != torch.float32 or not x.is_contiguous():
                 x = x.float().contiguous()
             keep.append(x)
-            launch(lib.ammc_nchw_to_nhwc_f32, (_ptr(x), B, s.sp.cin, H, W, s.x_in.pix0(), *s.x_in.strides,
+            launch(lib.ammc_nchw_to_s16_f32 if self.s16 else lib.ammc_nchw_to_nhwc_f32,
+                   (_ptr(x), B, s.sp.cin, H, W, s.x_in.pix0(), *s.x_in.strides,
                                                s.sp.inc.cin_p),
                    dict(name="nchw_to_nhwc", kernel="nchw_to_nhwc", flops=0.0,
                         bytes=4.0 * B * H * W * (s.sp.cin + s.sp.inc.cin_p)))
@@ -486,8 +522,8 @@ class EvalEngine:
         for s in streams:
             y = torch.empty((B, s.sp.cout, H, W), device=x0.device, dtype=torch.float32)
             s.outc.y = _ptr(y)
-            launch(lib.ammc_conv_gemm_f32, (C.byref(s.outc),),
-                   dict(name="outc_tanh", kernel="conv_gemm_f32<128x32>", flops=2.0 * B * H * W * 9 * 64 * s.sp.cout,
+            launch(lib.ammc_conv_gemm_s16 if self.s16 else lib.ammc_conv_gemm_f32, (C.byref(s.outc),),
+                   dict(name="outc_tanh", kernel=("conv_gemm_s16" if self.s16 else "conv_gemm_f32") + "<128x32>", flops=2.0 * B * H * W * 9 * 64 * s.sp.cout,
                         bytes=4.0 * B * H * W * (64 + s.sp.cout)))
             outs.append(y)
         if timed:

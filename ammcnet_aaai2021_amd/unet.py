@@ -17,12 +17,19 @@ not on the GPU, forward raises; there is no fallback.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
 from . import ops
 from .engine import EvalEngine
 from .train import HipPathFunction, TrainEngine
+
+
+# Inference arithmetic: "fp32" = exact fp32 MFMA (v_mfma_f32_32x32x2_f32); "s16" = split-fp16 MFMA with
+# fp32 accumulation, fp32-equivalent (conv_gemm_s16.hip).  Per model: `model.precision = "..."`.
+DEFAULT_PRECISION = os.environ.get("AMMC_PRECISION", "fp32")
 
 
 def _no_training(mod):
@@ -36,8 +43,9 @@ def _no_training(mod):
 def _run(mod, kind: str, n_inputs: int, *inputs):
     """dispatch a model-boundary forward to the eval plan or to the training Function"""
     if not mod.training:
-        if mod._engine is None:
-            object.__setattr__(mod, "_engine", EvalEngine(mod, kind))
+        prec = getattr(mod, "precision", None) or DEFAULT_PRECISION
+        if mod._engine is None or mod._engine.precision != prec:
+            object.__setattr__(mod, "_engine", EvalEngine(mod, kind, prec))
         return mod._engine.forward(*inputs)
     if mod._train_engine is None:
         object.__setattr__(mod, "_train_engine", TrainEngine(mod, kind))
@@ -206,13 +214,23 @@ class twostream(nn.Module):
             st = self._train_engine._last["streams"][0]
             befor, after = st.x4, st.x4q
             out = (rgb, op, (rd, od), (rq, oq))
+            self._quant_src = (None, befor, after)
         else:
             st = self._engine._last["streams"][0]
-            befor, after = st.x4, st.x4q
-        # reference side effects (unet.py:986, 988): attributes nobody reads; NCHW views of the workspace
-        self.quant_befor = befor.interior().permute(0, 3, 1, 2)
-        self.quant_after = after.interior().permute(0, 3, 1, 2)
+            self._quant_src = (self._engine, st.x4, st.x4q)
         return out
+
+    # reference side effects (unet.py:986, 988): `quant_befor` / `quant_after`, which nothing reads.
+    # Served lazily as NCHW tensors of the workspace (valid until the next forward of that shape).
+    @property
+    def quant_befor(self):
+        eng, a, _ = self._quant_src
+        return eng.act_nchw(a) if eng is not None else a.interior().permute(0, 3, 1, 2)
+
+    @property
+    def quant_after(self):
+        eng, _, a = self._quant_src
+        return eng.act_nchw(a) if eng is not None else a.interior().permute(0, 3, 1, 2)
 
 
 def get_unet(in_channel, out_channel, embed_dim=0, n_embed=0, k=0):

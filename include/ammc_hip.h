@@ -84,7 +84,7 @@ typedef struct AmmcConvDesc {
   int64_t r_bs, r_rs, r_ps;            /* residual strides                               */
   int64_t y_cs;          /* output channel stride: 0/1 = NHWC; H*W (with y_ps=1, y_rs=W) = NCHW    */
   int32_t x_step;        /* 0/1; 2 = the input is at twice the resolution of m (with ntaps=4: the  */
-  int32_t reserved2;     /* 2x2 stride-2 gather of the ConvTranspose dgrad)                       */
+  int32_t y_f32;         /* (2x2 stride-2 gather of the ConvTranspose dgrad).  y_f32: ammc_conv_gemm_s16 only, 1 = fp32 output */
 } AmmcConvDesc;
 
 int ammc_conv_gemm_f32(const AmmcConvDesc* desc, void* stream);
@@ -146,6 +146,27 @@ int ammc_memory_topk_fwd_f32(const float* x, const float* embed_dm, const float*
                              float* diff_partial, void* stream);
 /* diff = sum(partials) / count, fixed order (deterministic) */
 int ammc_sum_partials_f32(const float* partial, int32_t nparts, float inv_count, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * "S16": fp32-equivalent arithmetic on the fp16 MFMA pipe.  A value v is the pair of halfs
+ * hi = half(v), lo = half((v-hi)*2^11); tensors are NHWC with channels in groups of 8, each group
+ * 32 bytes [8 hi | 8 lo] (4 B/element: strides in ELEMENTS are those of the fp32 layout).
+ * ammc_conv_gemm_s16 takes the same descriptor as ammc_conv_gemm_f32 with x, w and res in S16
+ * and computes a*b as hi*hi + (hi*lo + lo*hi)*2^-11 with three v_mfma_f32_32x32x16_f16 and fp32
+ * accumulation; y is S16 unless y_f32 = 1 (then n_store / y_cs / TANH are available, res/up are
+ * not).  Replaces the same reference calls as ammc_conv_gemm_f32.
+ * ---------------------------------------------------------------------------------------- */
+int ammc_conv_gemm_s16(const AmmcConvDesc* desc, void* stream);
+/* fp32 -> S16, count elements (multiple of 8): packed filters, gathered codebook rows */
+int ammc_split_rows_f32(const float* src, int64_t count, float* dst, void* stream);
+/* module-boundary layout: NCHW fp32 -> S16 NHWC (cp % 8 == 0) and back */
+int ammc_nchw_to_s16_f32(const float* x, int32_t batch, int32_t c, int32_t h, int32_t w, float* y,
+                         int64_t y_bs, int64_t y_rs, int64_t y_ps, int32_t cp, void* stream);
+int ammc_s16_to_nchw_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, int32_t batch, int32_t c,
+                         int32_t h, int32_t w, float* y, void* stream);
+/* nn.MaxPool2d(2) on S16 tensors */
+int ammc_maxpool2x2_s16(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, float* y, int64_t y_bs,
+                        int64_t y_rs, int64_t y_ps, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream);
 
 /* fp16-operand form of the memory addressing for large memories (BASELINE.json config 5: 8192
  * slots x 512-d): distance GEMM on v_mfma_f32_32x32x16_f16 with fp32 accumulation, everything

@@ -1,0 +1,98 @@
+"""The split-fp16 ("S16") inference path: same parity gates as the exact-fp32 path (1e-4 of
+max|ref| on frames and activations, commit scalars 1e-4), against the CPU oracle and the vectors
+recorded from the reference."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ammcnet_aaai2021_amd as A
+from ammcnet_aaai2021_amd import _lib, synthetic as S
+from ammcnet_aaai2021_amd.engine import _ptr
+from oracle import ammc_oracle as O
+from conftest import GOLDEN, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+DEV = "cuda:0"
+
+
+def _net(n_embed=256, k=2):
+    sd = S.make_twostream_state(n_embed=n_embed, k=k)
+    net = A.get_twostream((12, 6), (3, 2), 64, n_embed, k)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    net.precision = "s16"
+    return net, sd
+
+
+def test_split_roundtrip_is_fp32_accurate():
+    """hi + lo*2^-11 reproduces an fp32 tensor to ~2^-22 relative (layout kernels, both directions)"""
+    lib = _lib.load()
+    x = (S.hashed_normal("rt", (2, 16, 12, 20), 3.0) * torch.logspace(-3, 2, 16).view(1, 16, 1, 1)).to(DEV)
+    y = torch.zeros((2, 14, 22, 16), device=DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    ps, rs = 16, 22 * 16
+    assert lib.ammc_nchw_to_s16_f32(_ptr(x), 2, 16, 12, 20, _ptr(y, rs + ps), 14 * rs, rs, ps, 16, s) == 0
+    back = torch.empty_like(x)
+    assert lib.ammc_s16_to_nchw_f32(_ptr(y, rs + ps), 14 * rs, rs, ps, 2, 16, 12, 20, _ptr(back), s) == 0
+    # normal range: 2^-22 relative; below the fp16 normal range (|v| < 6.1e-5) the pair still resolves
+    # 2^-12 of the fp16 subnormal spacing, i.e. 1.5e-11 absolute
+    assert bool(((back - x).abs() <= 2.0 ** -21 * x.abs() + 2e-11).all())
+    assert float(y[:, 0].abs().max()) == 0.0 and float(y[:, :, 0].abs().max()) == 0.0      # halo untouched
+
+
+@pytest.mark.parametrize("name", ["twostream_64_b2_eval", "twostream_64_b2_m2000_eval", "twostream_256_b2_eval"])
+def test_twostream_s16_vs_oracle_and_golden(name):
+    d = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    cfg = json.loads(str(d["cfg"]))
+    net, sd = _net(cfg["n_embed"], cfg["k"])
+    rgb_x, op_x, rgb_t, _ = S.make_clips(cfg["batch"], cfg["hw"], cfg["hw"], tag=cfg["tag"])
+    rgb, op, (rd, od), (rq, oq) = net(rgb_x.to(DEV), op_x.to(DEV))
+    assert net._engine.precision == "s16"
+    rgb, op, rd, od, rq, oq = (t.cpu() for t in (rgb, op, rd, od, rq, oq))
+    step = int(d["out_step"])
+    errs = dict(rgb=rel_err(rgb[..., ::step, ::step], d["rgb"]), op=rel_err(op[..., ::step, ::step], d["op"]),
+                rd=rel_err(rd, d["rgb_diff"]), od=rel_err(od, d["op_diff"]), rq=rel_err(rq, d["rgb_q"]),
+                oq=rel_err(oq, d["op_q"]))
+    assert max(errs.values()) <= TOL, errs
+    if cfg["hw"] <= 64:
+        with torch.no_grad():
+            w = O.twostream_forward(O.clone_state(sd), rgb_x, op_x, cfg["k"])
+        assert rel_err(rgb, w[0]) <= TOL and rel_err(op, w[1]) <= TOL
+        eng, st = net._engine, net._engine._last
+        r = st["streams"][0]
+        for ref_name, act in (("rgb.inc", r.skip[0]), ("rgb.down2", r.skip[2]), ("rgb.down3", r.x4),
+                              ("rgb.vq_down3", r.x4q), ("rgb.bridge", st["bridge"][0]), ("op.bridge", st["bridge"][1]),
+                              ("rgb.up3", r.u3)):
+            want = d[f"st.{ref_name}"]
+            got = eng.act_nchw(act).cpu()
+            stp = got.shape[-1] // want.shape[-1]
+            assert rel_err(got[..., ::stp, ::stp], want) <= TOL, ref_name
+        assert net.quant_befor.shape == (2, 512, 8, 8)
+
+
+def test_s16_and_fp32_paths_agree_and_switch():
+    net, sd = _net()
+    rgb_x, op_x, _, _ = S.make_clips(3, 64, 64, tag="sw")
+    a = net(rgb_x.to(DEV), op_x.to(DEV))
+    net.precision = "fp32"
+    b = net(rgb_x.to(DEV), op_x.to(DEV))
+    assert net._engine.precision == "fp32"
+    assert rel_err(a[0].cpu(), b[0].cpu()) <= 2e-5 and rel_err(a[2][0].cpu(), b[2][0].cpu()) <= 2e-5
+    net.precision = "s16"
+    c = net(rgb_x.to(DEV), op_x.to(DEV))
+    assert torch.equal(a[0], c[0])                                   # deterministic
+
+
+def test_unet_and_unetmem_s16():
+    d = np.load(os.path.join(GOLDEN, "unet_64_b2_eval.npz"))
+    cfg = json.loads(str(d["cfg"]))
+    net = A.get_unet(12, 3)
+    net.load_state_dict(S.make_unet_state(12, 3))
+    net = net.to(DEV).eval()
+    net.precision = "s16"
+    x = S.make_clips(cfg["batch"], cfg["hw"], cfg["hw"], tag=cfg["tag"])[0]
+    assert rel_err(net(x.to(DEV)).cpu(), d["y"]) <= TOL
