@@ -22,6 +22,7 @@
 // feeds the memory kernel, the NCHW `outc` frames) keep the direct per-lane store.
 #include "ammc_common.h"
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 
 namespace ammc_s16 {
 
@@ -30,6 +31,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 struct ConvArgs {
   AmmcConvDesc d;
   int M, kpad, nchunks, cin_log2, n_tiles;
+  int dbg;       // AMMC_S16_DBG (profiling experiments only): 1 = no DMA in the loop, 2 = no MFMA
 };
 
 constexpr float LO_SCALE = 2048.f;
@@ -49,47 +51,29 @@ __device__ __forceinline__ void join8(const f16x8& hi, const f16x8& lo, float (&
   for (int i = 0; i < 8; ++i) v[i] = (float)hi[i] + (float)lo[i] * LO_INV;
 }
 
-template <int AJ, int BJ>
-__device__ __forceinline__ void issue_chunk(const AmmcConvDesc& d, int cin_log2, int sl, int c,
-                                            const float* const (&a_src)[AJ], const float* const (&b_src)[BJ],
-                                            float* adst, float* bdst) {
-  const int k = c * 32 + 4 * sl;
-  int64_t toff;
-  if (d.ntaps == 9) {
-    int tap = k >> cin_log2;
-    tap = tap < 8 ? tap : 8;
-    const int r = (tap * 11) >> 5;
-    const int s = tap - 3 * r;
-    toff = (int64_t)r * d.x_rs + (int64_t)s * d.x_ps + (k & (d.cin - 1));
-  } else if (d.ntaps == 4) {
-    int tap = k >> cin_log2;
-    tap = tap < 3 ? tap : 3;
-    toff = (int64_t)(tap >> 1) * d.x_rs + (int64_t)(tap & 1) * d.x_ps + (k & (d.cin - 1));
-  } else {
-    toff = k;
-  }
-#pragma unroll
-  for (int j = 0; j < AJ; ++j)
-    __builtin_amdgcn_global_load_lds(a_src[j] + toff, adst + j * 1024, 16, 0, 0);
-#pragma unroll
-  for (int j = 0; j < BJ; ++j)
-    __builtin_amdgcn_global_load_lds(b_src[j] + c * 32, bdst + j * 1024, 16, 0, 0);
-}
-
-template <int WGM, int WGN, int TM, int TN>
-__global__ __launch_bounds__(256, 2) void conv_gemm_s16_kernel(ConvArgs a) {
+// BD ("B direct"): the filter fragments bypass LDS.  The filter is then pre-packed k-blocked,
+// [Kpad/8][N][8 hi | 8 lo], so a lane's fragment (8 consecutive k of one output channel) is 32
+// contiguous bytes and a half-wave reads 1 KiB contiguous from L2 straight into VGPRs, one chunk
+// ahead.  With both operands in LDS the kernel is LDS-bandwidth bound (4-byte operands at the
+// 16-bit MFMA rate: DMA writes + fragment reads saturate the 128-256 B/clk LDS port at ~40 % MFMA
+// utilisation); taking B out halves that traffic.
+template <int WGM, int WGN, int TM, int TN, int NS, bool BD>
+__global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_gemm_s16_kernel(ConvArgs a) {
+  constexpr int NT = 64 * WGM * WGN;        // threads: one wave per (wm, wn)
   constexpr int BM = WGM * TM * 32;
   constexpr int BN = WGN * TN * 32;
   constexpr int A_STAGE = BM * 32;
   constexpr int B_STAGE = BN * 32;
-  constexpr int AJ = BM / 32;
-  constexpr int BJ = BN / 32;
-  constexpr int STAGES = 2 * A_STAGE + 2 * B_STAGE;              // floats
+  constexpr int AJ = BM * 8 / NT;           // 16-B DMA pieces per thread per stage
+  constexpr int BJ = BN * 8 / NT;
+  constexpr int RJ = NT / 8;                // tile rows covered by one round of pieces
+  constexpr int JS = NT * 4;                // floats between a thread's consecutive pieces
+  constexpr int STAGES = NS * (A_STAGE + (BD ? 0 : B_STAGE));    // floats; NS = 2 or 3 LDS stages
   constexpr int TILE = BM * BN;                                  // floats of the parked output tile
   constexpr int REGION = STAGES > TILE ? STAGES : TILE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
-  float* Bs = smem + 2 * A_STAGE;
+  float* Bs = smem + NS * A_STAGE;
   int* tab_out = reinterpret_cast<int*>(smem + REGION);          // [BM]
   int* tab_res = tab_out + BM;
 
@@ -113,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_s16_kernel(ConvArgs a) {
   const float* a_src[AJ];
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
-    int m = m0 + j * 32 + (tid >> 3);
+    int m = m0 + j * RJ + (tid >> 3);
     m = m < a.M ? m : a.M - 1;
     const int x = m % W;
     const int t = m / W;
@@ -124,10 +108,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_s16_kernel(ConvArgs a) {
   const float* b_src[BJ];
 #pragma unroll
   for (int j = 0; j < BJ; ++j)
-    b_src[j] = d.w + (int64_t)(n0 + j * 32 + (tid >> 3)) * a.kpad + 4 * sl;
+    b_src[j] = d.w + (int64_t)(n0 + j * RJ + (tid >> 3)) * a.kpad + 4 * sl;
 
   // output / residual pixel offsets of the tile rows (used by both epilogues)
-  for (int i = tid; i < BM; i += 256) {
+  for (int i = tid; i < BM; i += NT) {
     const int m = m0 + i;
     int o = -1, r = 0;
     if (m < a.M) {
@@ -142,9 +126,39 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_s16_kernel(ConvArgs a) {
     tab_res[i] = r;
   }
 
-#define S16_ISSUE(c, stage) \
-  issue_chunk<AJ, BJ>(d, a.cin_log2, sl, (c), a_src, b_src, As + (stage) * A_STAGE + wave * 256, \
-                      Bs + (stage) * B_STAGE + wave * 256)
+  // DMA of one K chunk (32 k-values of every tile row) into an LDS stage: per thread AJ + BJ pieces of
+  // 16 B; the destination is the wave-uniform base of the wave's 1-KiB piece (the DMA adds lane * 16 B)
+#define S16_ISSUE(c, stage)                                                                               \
+  {                                                                                                       \
+    const int k_ = (c) * 32 + 4 * sl;                                                                     \
+    int64_t toff_;                                                                                        \
+    if (d.ntaps == 9) {                                                                                   \
+      int tap_ = k_ >> a.cin_log2;                                                                        \
+      tap_ = tap_ < 8 ? tap_ : 8; /* K padding: the filter is zero there */                               \
+      const int r_ = (tap_ * 11) >> 5;                                                                    \
+      toff_ = (int64_t)r_ * d.x_rs + (int64_t)(tap_ - 3 * r_) * d.x_ps + (k_ & (d.cin - 1));              \
+    } else if (d.ntaps == 4) {                                                                            \
+      int tap_ = k_ >> a.cin_log2;                                                                        \
+      tap_ = tap_ < 3 ? tap_ : 3;                                                                         \
+      toff_ = (int64_t)(tap_ >> 1) * d.x_rs + (int64_t)(tap_ & 1) * d.x_ps + (k_ & (d.cin - 1));          \
+    } else {                                                                                              \
+      toff_ = k_;                                                                                         \
+    }                                                                                                     \
+    float* adst_ = As + (stage) * A_STAGE + wave * 256;                                                   \
+    float* bdst_ = Bs + (stage) * B_STAGE + wave * 256;                                                   \
+    /* the builtin's operands must not be type-dependent expressions (elements of a_src[AJ]): hipcc's    \
+       host pass then fails the kernel's instantiation silently and the host stub disappears */          \
+    _Pragma("unroll") for (int j = 0; j < AJ; ++j) {                                                      \
+      const float* src_ = a_src[j] + toff_;                                                               \
+      float* dst_ = adst_ + j * JS;                                                                       \
+      __builtin_amdgcn_global_load_lds(src_, dst_, 16, 0, 0);                                             \
+    }                                                                                                     \
+    if (!BD) _Pragma("unroll") for (int j = 0; j < BJ; ++j) {                                             \
+      const float* src_ = b_src[j] + (c) * 32;                                                            \
+      float* dst_ = bdst_ + j * JS;                                                                       \
+      __builtin_amdgcn_global_load_lds(src_, dst_, 16, 0, 0);                                             \
+    }                                                                                                     \
+  }
 
   f32x16 hh[TM][TN], xx[TM][TN];
 #pragma unroll
@@ -158,43 +172,131 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_s16_kernel(ConvArgs a) {
   const int a_row = (wm * TM * 32 + l31) * 32;
   const int b_row = (wn * TN * 32 + l31) * 32;
 
-  S16_ISSUE(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  // leave only the newest chunk's DMA (AJ + BJ instructions of this thread) in flight.  Literal counts:
+  // a template-dependent asm operand makes hipcc drop the kernel's host stub.
+#define S16_WAIT_NEWEST()                                            \
+  {                                                                  \
+    if (AJ + BJ == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      \
+    else if (AJ + BJ == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); \
+    else if (AJ + BJ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   \
+  }
 
-  for (int c = 0; c < a.nchunks; ++c) {
-    const int stage = c & 1;
-    if (c + 1 < a.nchunks) S16_ISSUE(c + 1, stage ^ 1);
-    const float* Ac = As + stage * A_STAGE + a_row;
-    const float* Bc = Bs + stage * B_STAGE + b_row;
+#define S16_COMPUTE(stage)                                                                               \
+  {                                                                                                      \
+    const float* Ac = As + (stage) * A_STAGE + a_row;                                                    \
+    const float* Bc = Bs + (stage) * B_STAGE + b_row;                                                    \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                      \
+      const int g = 2 * s + h; /* channel group of this lane half */                                     \
+      const int so_hi = ((2 * g) ^ swz) << 2;                                                            \
+      const int so_lo = ((2 * g + 1) ^ swz) << 2;                                                        \
+      f16x8 ah[TM], al[TM], bh[TN], bl[TN];                                                              \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                   \
+        ah[i] = *reinterpret_cast<const f16x8*>(Ac + i * 1024 + so_hi);                                  \
+        al[i] = *reinterpret_cast<const f16x8*>(Ac + i * 1024 + so_lo);                                  \
+      }                                                                                                  \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                   \
+        bh[j] = *reinterpret_cast<const f16x8*>(Bc + j * 1024 + so_hi);                                  \
+        bl[j] = *reinterpret_cast<const f16x8*>(Bc + j * 1024 + so_lo);                                  \
+      }                                                                                                  \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) {    \
+        hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], hh[i][j], 0, 0, 0);             \
+        xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], xx[i][j], 0, 0, 0);             \
+        xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], xx[i][j], 0, 0, 0);             \
+      }                                                                                                  \
+    }                                                                                                    \
+  }
+
+  if (BD) {
+    // ---- B-direct pipeline: A through two LDS stages, B fragments of the NEXT chunk in registers --------
+    const float* wl[TN];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int g = 2 * s + h;                                   // channel group of this lane half
-      const int so_hi = ((2 * g) ^ swz) << 2;
-      const int so_lo = ((2 * g + 1) ^ swz) << 2;
-      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        ah[i] = *reinterpret_cast<const f16x8*>(Ac + i * 1024 + so_hi);
-        al[i] = *reinterpret_cast<const f16x8*>(Ac + i * 1024 + so_lo);
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        bh[j] = *reinterpret_cast<const f16x8*>(Bc + j * 1024 + so_hi);
-        bl[j] = *reinterpret_cast<const f16x8*>(Bc + j * 1024 + so_lo);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], hh[i][j], 0, 0, 0);
-          xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], xx[i][j], 0, 0, 0);
-          xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], xx[i][j], 0, 0, 0);
-        }
-    }
+    for (int j = 0; j < TN; ++j)
+      wl[j] = d.w + ((int64_t)h * d.n + n0 + (wn * TN + j) * 32 + l31) * 8;
+    const int64_t kb_stride = (int64_t)d.n * 8;                 // floats between consecutive k-blocks
+    f16x8 b0h[2][TN], b0l[2][TN], b1h[2][TN], b1l[2][TN];
+#define S16_LOADB(c, BH, BL)                                                                   \
+  _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int j = 0; j < TN; ++j) { \
+    const float* p_ = wl[j] + ((int64_t)(c) * 4 + 2 * s) * kb_stride;                          \
+    BH[s][j] = *reinterpret_cast<const f16x8*>(p_);                                            \
+    BL[s][j] = *reinterpret_cast<const f16x8*>(p_ + 4);                                        \
+  }
+#define S16_COMPUTE_BD(stage, BH, BL)                                                                    \
+  {                                                                                                      \
+    const float* Ac = As + (stage) * A_STAGE + a_row;                                                    \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                      \
+      const int g = 2 * s + h;                                                                           \
+      const int so_hi = ((2 * g) ^ swz) << 2;                                                            \
+      const int so_lo = ((2 * g + 1) ^ swz) << 2;                                                        \
+      f16x8 ah[TM], al[TM];                                                                              \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                   \
+        ah[i] = *reinterpret_cast<const f16x8*>(Ac + i * 1024 + so_hi);                                  \
+        al[i] = *reinterpret_cast<const f16x8*>(Ac + i * 1024 + so_lo);                                  \
+      }                                                                                                  \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) {    \
+        hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], BH[s][j], hh[i][j], 0, 0, 0);          \
+        xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], BL[s][j], xx[i][j], 0, 0, 0);          \
+        xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], BH[s][j], xx[i][j], 0, 0, 0);          \
+      }                                                                                                  \
+    }                                                                                                    \
+  }
+    S16_ISSUE(0, 0);
+    S16_LOADB(0, b0h, b0l);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    for (int c = 0; c < a.nchunks; c += 2) {
+      if (c + 1 < a.nchunks) {
+        S16_ISSUE(c + 1, 1);
+        S16_LOADB(c + 1, b1h, b1l);
+      }
+      S16_COMPUTE_BD(0, b0h, b0l);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (c + 1 < a.nchunks) {
+        if (c + 2 < a.nchunks) {
+          S16_ISSUE(c + 2, 0);
+          S16_LOADB(c + 2, b0h, b0l);
+        }
+        S16_COMPUTE_BD(1, b1h, b1l);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+    }
+#undef S16_LOADB
+#undef S16_COMPUTE_BD
+  } else if (NS == 2) {
+    // two stages: the DMA of chunk c+1 flies while chunk c is contracted; one full drain per chunk
+    S16_ISSUE(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int c = 0; c < a.nchunks; ++c) {
+      const int stage = c & 1;
+      if (c + 1 < a.nchunks && a.dbg != 1) S16_ISSUE(c + 1, stage ^ 1);
+      if (a.dbg != 2) S16_COMPUTE(stage);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
+    // three stages: chunks c+1 and c+2 are in flight while chunk c is contracted.  The DMA of a chunk is
+    // AJ+BJ instructions per thread, so `vmcnt(AJ+BJ)` retires everything but the newest chunk; raw
+    // s_barrier (a __syncthreads() would drain vmcnt(0) and serialise the pipeline again).
+    S16_ISSUE(0, 0);
+    if (a.nchunks > 1) S16_ISSUE(1, 1);
+    if (a.nchunks > 1) { S16_WAIT_NEWEST(); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    __builtin_amdgcn_s_barrier();
+    int stage = 0;
+    for (int c = 0; c < a.nchunks; ++c) {
+      const int nxt = stage + 2 >= 3 ? stage - 1 : stage + 2;
+      if (c + 2 < a.nchunks && a.dbg != 1) S16_ISSUE(c + 2, nxt);
+      if (a.dbg != 2) S16_COMPUTE(stage);
+      if (c + 2 < a.nchunks) { S16_WAIT_NEWEST(); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      stage = stage == 2 ? 0 : stage + 1;
+    }
+    __syncthreads();
   }
+#undef S16_COMPUTE
 #undef S16_ISSUE
 
   const int nstore = d.n_store > 0 ? d.n_store : d.n;
@@ -241,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_s16_kernel(ConvArgs a) {
   }
   __syncthreads();
   constexpr int CG = BN / 8;                                     // channel groups per tile row
-  for (int item = tid; item < BM * CG; item += 256) {
+  for (int item = tid; item < BM * CG; item += NT) {
     const int row = item / CG;
     const int cg = item - row * CG;
     const int o = tab_out[row];
@@ -291,14 +393,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_s16_kernel(ConvArgs a) {
   }
 }
 
-template <int WGM, int WGN, int TM, int TN>
+template <int WGM, int WGN, int TM, int TN, int NS = 2, bool BD = false>
 int launch(const ConvArgs& a, hipStream_t stream) {
   constexpr int BM = WGM * TM * 32;
   constexpr int BN = WGN * TN * 32;
-  constexpr int STAGES = 2 * BM * 32 + 2 * BN * 32;
+  constexpr int STAGES = NS * (BM * 32 + (BD ? 0 : BN * 32));
   constexpr int TILE = BM * BN;
   constexpr size_t lds = (size_t)((STAGES > TILE ? STAGES : TILE) + 2 * BM) * sizeof(float);
-  auto kern = conv_gemm_s16_kernel<WGM, WGN, TM, TN>;
+  auto kern = conv_gemm_s16_kernel<WGM, WGN, TM, TN, NS, BD>;
+  static_assert(lds <= 160 * 1024, "LDS budget");
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -307,7 +410,7 @@ int launch(const ConvArgs& a, hipStream_t stream) {
   ConvArgs b = a;
   b.n_tiles = a.d.n / BN;
   const int m_tiles = (a.M + BM - 1) / BM;
-  hipLaunchKernelGGL(kern, dim3(m_tiles * b.n_tiles), dim3(256), lds, stream, b);
+  hipLaunchKernelGGL(kern, dim3(m_tiles * b.n_tiles), dim3(64 * WGM * WGN), lds, stream, b);
   return ammc_launch_status();
 }
 
@@ -325,6 +428,26 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
   split8(v, hi, lo);
   *reinterpret_cast<f16x8*>(dst + g * 8) = hi;
   *reinterpret_cast<f16x8*>(dst + g * 8 + 4) = lo;
+}
+
+// packed filter [N][Kpad] fp32 -> k-blocked S16 [Kpad/8][N][8 hi | 8 lo] (the BD kernels' layout)
+__global__ __launch_bounds__(256) void split_kblk_kernel(const float* __restrict__ src, int N, int kpad,
+                                                         float* __restrict__ dst) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;       // one thread per (n, k-block)
+  const int kblocks = kpad >> 3;
+  if (g >= (int64_t)N * kblocks) return;
+  const int kb = (int)(g % kblocks);
+  const int n = (int)(g / kblocks);
+  const f32x4 a0 = *reinterpret_cast<const f32x4*>(src + (int64_t)n * kpad + kb * 8);
+  const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + (int64_t)n * kpad + kb * 8 + 4);
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[i] = a0[i]; v[4 + i] = a1[i]; }
+  f16x8 hi, lo;
+  split8(v, hi, lo);
+  float* o = dst + ((int64_t)kb * N + n) * 8;
+  *reinterpret_cast<f16x8*>(o) = hi;
+  *reinterpret_cast<f16x8*>(o + 4) = lo;
 }
 
 // NCHW fp32 -> S16 NHWC (explicit strides), channels c..cp-1 zero; one thread per (pixel, group of 8)
@@ -448,15 +571,39 @@ extern "C" int ammc_conv_gemm_s16(const AmmcConvDesc* desc, void* stream) {
   a.nchunks = a.kpad / 32;
   a.cin_log2 = ammc_ilog2(d.cin);
   a.n_tiles = 0;
+  static const int dbg = getenv("AMMC_S16_DBG") ? atoi(getenv("AMMC_S16_DBG")) : 0;
+  static const int big = getenv("AMMC_S16_BIG") ? atoi(getenv("AMMC_S16_BIG")) : 1;
+  a.dbg = dbg;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (d.w_kblk) {                                   // k-blocked filter: B fragments bypass LDS
+    if (d.n == 32) return launch<4, 1, 1, 1, 2, true>(a, s);
+    if (d.n % 128 == 0) return launch<2, 2, 2, 2, 2, true>(a, s);
+    // N = 64: a 256 x 64 tile keeps the 64x64 wave tile (A fragment reads per MFMA as in the 128x128 kernel);
+    // with B out of LDS it still fits two workgroups per CU
+    return M >= 4096 ? launch<4, 1, 2, 2, 2, true>(a, s) : launch<4, 1, 1, 2, 2, true>(a, s);
+  }
   if (d.n == 32) return launch<4, 1, 1, 1>(a, s);
-  if (d.n % 128 == 0) return launch<2, 2, 2, 2>(a, s);
-  return launch<4, 1, 1, 2>(a, s);
+  // 256-row tiles (8 waves, one workgroup per CU) move 25 % / 17 % fewer LDS-DMA bytes per FLOP than the
+  // 128-row ones; they pay off once there are enough tiles to fill the chip
+  const bool many = M >= (int64_t)256 * 512 / (d.n >= 256 ? d.n / 128 : 1);
+  if (d.n % 128 == 0) {
+    if (big == 3 && many) return launch<4, 2, 2, 2, 3>(a, s);
+    return (big && many) ? launch<4, 2, 2, 2>(a, s) : launch<2, 2, 2, 2>(a, s);
+  }
+  if (big == 3 && many) return launch<8, 1, 1, 2, 3>(a, s);
+  return (big == 2 && many) ? launch<8, 1, 1, 2>(a, s) : launch<4, 1, 1, 2>(a, s);
 }
 
 extern "C" int ammc_split_rows_f32(const float* src, int64_t count, float* dst, void* stream) {
   if (!src || !dst || count <= 0 || (count & 7) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return AMMC_EINVAL;
   hipLaunchKernelGGL(split_rows_kernel, dim3(nblk(count >> 3)), dim3(256), 0, (hipStream_t)stream, src, count >> 3, dst);
+  return ammc_launch_status();
+}
+
+extern "C" int ammc_split_kblk_f32(const float* src, int32_t n, int32_t kpad, float* dst, void* stream) {
+  if (!src || !dst || n <= 0 || kpad <= 0 || (kpad & 31) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return AMMC_EINVAL;
+  hipLaunchKernelGGL(split_kblk_kernel, dim3(nblk((int64_t)n * (kpad >> 3))), dim3(256), 0, (hipStream_t)stream, src, n,
+                     kpad, dst);
   return ammc_launch_status();
 }
 

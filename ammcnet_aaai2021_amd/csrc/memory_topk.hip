@@ -26,7 +26,7 @@
 
 namespace ammc_impl {
 
-constexpr int BR = 128;     // feature rows per workgroup
+constexpr int BR = 64;      // feature rows per workgroup
 constexpr int RT = BR / 32;
 
 template <int K>

@@ -18,6 +18,7 @@ reads the skip slice in place.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -26,6 +27,8 @@ from . import _lib
 from ._lib import ACT_NONE, ACT_RELU, ACT_TANH, AmmcConvDesc
 
 BN_EPS = 1e-5
+# S16 kernels: filter fragments straight from L2 into registers (k-blocked filter) instead of through LDS
+S16_BDIRECT = os.environ.get("AMMC_S16_BDIRECT", "0") != "0"   # measured: no faster than LDS-staged B
 
 
 def _ptr(t: torch.Tensor, elem_off: int = 0) -> int:
@@ -119,10 +122,15 @@ class _Packer:
         self.s16 = s16                  # filters as (hi, lo) half pairs for ammc_conv_gemm_s16
 
     def _split(self, t: torch.Tensor) -> torch.Tensor:
+        """packed filter [N][Kpad] -> S16; k-blocked when the B-direct kernels are used"""
         if not self.s16:
             return t
         out = torch.empty_like(t)
-        _lib.check(self.lib.ammc_split_rows_f32(_ptr(t), t.numel(), _ptr(out), self.stream()), "split_rows")
+        if S16_BDIRECT:
+            _lib.check(self.lib.ammc_split_kblk_f32(_ptr(t), t.shape[0], t.shape[1], _ptr(out), self.stream()),
+                       "split_kblk")
+        else:
+            _lib.check(self.lib.ammc_split_rows_f32(_ptr(t), t.numel(), _ptr(out), self.stream()), "split_rows")
         return out
 
     def stream(self) -> int:
@@ -233,6 +241,7 @@ class _Builder:
              cin_true: Optional[int] = None, y_f32: bool = False):
         d = AmmcConvDesc()
         d.y_f32 = 1 if (y_f32 and self.s16) else 0
+        d.w_kblk = 1 if (self.s16 and S16_BDIRECT) else 0
         d.x = x.tap0() if ntaps == 9 else x.pix0()
         d.w = _ptr(w)
         d.y = y.pix0()
@@ -267,6 +276,7 @@ class _Builder:
         d.batch, d.height, d.width = x.B, x.H, x.W
         d.cin, d.ntaps, d.n, d.up, d.cgroup, d.act, d.n_store = x.c, 9, 32, 1, 32, ACT_TANH, cout
         d.y_f32 = 1 if self.s16 else 0
+        d.w_kblk = 1 if (self.s16 and S16_BDIRECT) else 0
         d.x_bs, d.x_rs, d.x_ps = x.strides
         d.y_bs, d.y_rs, d.y_ps, d.y_cs = cout * x.H * x.W, x.W, 1, x.H * x.W
         self.plan.keep.extend([d, w, bias32])
