@@ -265,6 +265,8 @@ class _Builder:
         flops = 2.0 * m_pix * n * ntaps * ct
         nbytes = 4.0 * m_pix * (ct + n + (n if res is not None else 0))
         tile = "128x32" if n == 32 else "128x128" if n % 128 == 0 else "128x64"
+        if self.s16 and n % 128 == 0 and m_pix >= 256 * 512 // (n // 128 if n >= 256 else 1):
+            tile = "256x128"      # mirrors the dispatch in ammc_conv_gemm_s16 (labels must match rocprof's kernels)
         self.plan.add(self.conv_fn, C.byref(d), name=name, flops=flops, nbytes=nbytes,
                       kernel=f"{self.kname}<{tile}>")
         return d
