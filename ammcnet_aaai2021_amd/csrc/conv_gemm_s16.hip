@@ -182,6 +182,43 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_gemm_s16_kernel(ConvAr
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   \
   }
 
+  // Fragment reads as inline asm: hipcc's waitcnt pass treats an in-flight LDS-DMA as a pending LDS write
+  // and puts `s_waitcnt vmcnt(0)` in front of every compiler-visible ds_read, which drains a multi-stage
+  // pipeline every chunk.  The asm reads are invisible to it; ordering is ours: the data of this stage was
+  // retired by the counted vmcnt + s_barrier of the previous iteration; lgkmcnt(0) + sched_barrier keep the
+  // MFMAs behind the reads (guide rule 18).
+#define S16_LDS_ADDR(p) ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(p))
+#define S16_COMPUTE_ASM(stage)                                                                           \
+  {                                                                                                      \
+    const uint32_t abase_ = S16_LDS_ADDR(As + (stage) * A_STAGE + a_row);                                \
+    const uint32_t bbase_ = S16_LDS_ADDR(Bs + (stage) * B_STAGE + b_row);                                \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                      \
+      const int g = 2 * s + h;                                                                           \
+      const uint32_t so_hi = (uint32_t)(((2 * g) ^ swz) << 4);                                           \
+      const uint32_t so_lo = (uint32_t)(((2 * g + 1) ^ swz) << 4);                                       \
+      f32x4 ahv[TM], alv[TM], bhv[TN], blv[TN];                                                          \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                   \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(ahv[i]) : "v"(abase_ + i * 4096 + so_hi));            \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(alv[i]) : "v"(abase_ + i * 4096 + so_lo));            \
+      }                                                                                                  \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                   \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(bhv[j]) : "v"(bbase_ + j * 4096 + so_hi));            \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(blv[j]) : "v"(bbase_ + j * 4096 + so_lo));            \
+      }                                                                                                  \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                                 \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) {    \
+        const f16x8 ah_ = __builtin_bit_cast(f16x8, ahv[i]);                                             \
+        const f16x8 al_ = __builtin_bit_cast(f16x8, alv[i]);                                             \
+        const f16x8 bh_ = __builtin_bit_cast(f16x8, bhv[j]);                                             \
+        const f16x8 bl_ = __builtin_bit_cast(f16x8, blv[j]);                                             \
+        hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bh_, hh[i][j], 0, 0, 0);                 \
+        xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bl_, xx[i][j], 0, 0, 0);                 \
+        xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al_, bh_, xx[i][j], 0, 0, 0);                 \
+      }                                                                                                  \
+    }                                                                                                    \
+  }
+
 #define S16_COMPUTE(stage)                                                                               \
   {                                                                                                      \
     const float* Ac = As + (stage) * A_STAGE + a_row;                                                    \
@@ -288,7 +325,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_gemm_s16_kernel(ConvAr
     for (int c = 0; c < a.nchunks; ++c) {
       const int nxt = stage + 2 >= 3 ? stage - 1 : stage + 2;
       if (c + 2 < a.nchunks && a.dbg != 1) S16_ISSUE(c + 2, nxt);
-      if (a.dbg != 2) S16_COMPUTE(stage);
+      if (a.dbg != 2) S16_COMPUTE_ASM(stage);
       if (c + 2 < a.nchunks) { S16_WAIT_NEWEST(); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -297,6 +334,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_gemm_s16_kernel(ConvAr
     __syncthreads();
   }
 #undef S16_COMPUTE
+#undef S16_COMPUTE_ASM
 #undef S16_ISSUE
 
   const int nstore = d.n_store > 0 ? d.n_store : d.n;

@@ -129,3 +129,68 @@ def train_step(model: torch.nn.Module, optimizer: torch.optim.Optimizer, rgb: to
     loss.backward()
     optimizer.step()
     return loss.detach()
+
+
+# ---- score fusion and frame-level AUC (the step after the records) ------------------------------
+
+LAM_MAP = {"avenue": (0.04, 0.65), "ped2": (0.01, 0.55), "shanghaitech": (0.13, 0.60)}   # test_helper.py:565-569
+DECIDABLE_IDX = 4                                                                          # eval_metric.py:17
+
+
+def _minmax_concat(records: Sequence[np.ndarray]) -> np.ndarray:
+    """per-video min-max normalisation, drop the first DECIDABLE_IDX frames, global min-max
+    (`norm_score`, main/eval_metric.py:405-417)"""
+    parts = []
+    for r in records:
+        r = np.array(r, dtype=np.float32)
+        r = r - r.min()
+        r = r / r.max()
+        parts.append(r[DECIDABLE_IDX:])
+    s = np.concatenate(parts)
+    s = s - s.min()
+    return s / s.max()
+
+
+def roc_auc(labels: np.ndarray, scores: np.ndarray, pos_label: int = 0) -> float:
+    """area under the ROC curve by the trapezoid rule over distinct thresholds (what
+    sklearn.metrics.roc_curve + auc compute; ties share one threshold)"""
+    y = (np.asarray(labels) == pos_label)
+    s = np.asarray(scores, dtype=np.float64)
+    order = np.argsort(-s, kind="mergesort")
+    y, s = y[order], s[order]
+    distinct = np.where(np.diff(s))[0]
+    idx = np.r_[distinct, y.size - 1]
+    tps = np.cumsum(y)[idx].astype(np.float64)
+    fps = (1 + idx - tps).astype(np.float64)
+    tps, fps = np.r_[0.0, tps], np.r_[0.0, fps]
+    return float(np.trapz(tps / tps[-1], fps / fps[-1]))
+
+
+def fuse_scores_auc(records: dict, gt: Sequence[np.ndarray], lam=None) -> dict:
+    """`img_pred_fea_comm_single_auc` (main/eval_metric.py:382-439): normality score
+    (1-l1)*psnr_n + l1*(1 - commit_n), one-tap smoothing s'_i = (1-l2) s_{i-1} + l2 s_i (from the
+    UNSMOOTHED neighbour), ROC with the normal class (label 0) positive, AUC rounded to 3 d.p.
+    `records` is the dict of `evaluate_dataset`; `gt[i]` the per-frame labels of video i (1 = anomalous)."""
+    l1, l2 = lam if lam is not None else LAM_MAP[records["dataset"]]
+    labels = np.concatenate([np.asarray(g)[DECIDABLE_IDX:] for g in gt])
+    img = _minmax_concat(records["rgb_img_pred_records"])
+    fea = _minmax_concat(records["rgb_fea_comm_records"])
+    scores = (1 - l1) * img + l1 * (1.0 - fea)
+    smooth = scores.copy()
+    smooth[1:] = (1 - l2) * scores[:-1] + l2 * scores[1:]
+    auc = roc_auc(labels, smooth, pos_label=0)
+    return {"auc": round(auc, 3), "auc_raw": auc, "lam": (l1, l2), "scores": smooth}
+
+
+def weights_init_normal(model: torch.nn.Module) -> None:
+    """the reference's training-from-scratch init (utils/utils.py:328-334): Conv* ~ N(0, 0.02),
+    BatchNorm2d gamma ~ N(1, 0.02), beta = 0; applied by class name exactly as there"""
+    for m in model.modules():
+        cn = m.__class__.__name__
+        if cn.find("Conv") != -1 and hasattr(m, "weight") and isinstance(m.weight, torch.nn.Parameter):
+            torch.nn.init.normal_(m.weight.data, 0.0, 0.02)
+        elif cn.find("BatchNorm2d") != -1:
+            torch.nn.init.normal_(m.weight.data, 1.0, 0.02)
+            torch.nn.init.constant_(m.bias.data, 0.0)
+    if hasattr(model, "_param_epoch"):
+        model._param_epoch += 1

@@ -240,6 +240,48 @@ def main():
     twostream_eval(ref, 64, 2, 2000, "twostream_64_b2_m2000_eval", full=True)
     twostream_eval(ref, 256, 2, 256, "twostream_256_b2_eval", full=False)
     twostream_train(ref, 64, 2, "twostream_64_b2_train")
+    score_fusion_golden()
+
+
+
+def score_fusion_golden(name="score_fusion_ped2"):
+    """AUC of the reference's own score fusion (`main/eval_metric.py:382-439`,
+    `img_pred_fea_comm_single_auc`) on the authors' shipped ped2 records with SYNTHETIC frame labels
+    (ground truth is absent), for the three (lambda_fea, lambda_smooth) pairs of
+    `run_helper/test_helper.py:565-569`.  The records travel with the fixture (32 KB)."""
+    spec = importlib.util.spec_from_file_location("ref_eval", f"{REF}/main/eval_metric.py")
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
+    p = f"{REF}/ammcnet_os/model_result_save/ped2/img_pred_fea_comm_rgb_auc/save_pickle/ped2"
+    with open(p, "rb") as fp:
+        d = pickle.load(fp)
+    lens = [len(r) for r in d["rgb_img_pred_records"]]
+    # synthetic labels: 1 = anomalous, 0 = normal (the reference scores normality: pos_label=0), correlated with
+    # low PSNR so that the AUC is informative
+    gt = []
+    for i, r in enumerate(d["rgb_img_pred_records"]):
+        r = np.asarray(r, dtype=np.float64)
+        noise = S.hashed_uniform(f"{name}:gt{i}", (len(r),), 0.0, 1.0).numpy()
+        z = (r - r.min()) / (r.max() - r.min() + 1e-12)
+        gt.append((z + 0.35 * noise <= 0.55).astype(np.int8))
+    out = {"lens": np.array(lens)}
+    for key in ("rgb_img_pred_records", "rgb_fea_comm_records"):
+        out[key] = np.concatenate([np.asarray(r, dtype=np.float32) for r in d[key]])
+    out["gt"] = np.concatenate(gt)
+
+    def fake_load(loss_file=None):          # records are normalised in place by the reference: hand out copies
+        cp = lambda rs: [np.array(r, dtype=np.float32) for r in rs]
+        return ("ped2", cp(d["rgb_img_pred_records"]), cp(d["rgb_fea_comm_records"]),
+                cp(d["op_img_pred_records"]), cp(d["op_fea_comm_records"]), [g.copy() for g in gt])
+
+    ev.load_img_pred_fea_comm_gt = fake_load
+    lams = {"avenue": (0.04, 0.65), "ped2": (0.01, 0.55), "shanghaitech": (0.13, 0.60)}
+    for k, lam in lams.items():
+        res = ev.img_pred_fea_comm_single_auc(os.path.join(HERE, "make_golden.py"), lam)
+        out[f"auc.{k}"] = np.float64(res["auc"])
+        out[f"lam.{k}"] = np.array(lam)
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    print(name, {k: float(v) for k, v in out.items() if k.startswith("auc.")})
 
 
 if __name__ == "__main__":

@@ -72,3 +72,38 @@ def test_generator_loss_equals_oracle():
     rt, ot = S.hashed_uniform("c", (2, 3, 8, 8)), S.hashed_uniform("d", (2, 2, 8, 8))
     assert torch.allclose(Hn.generator_loss(out, rt, ot, lam_lp=2.0, lam_latent=0.5),
                           O.generator_loss(out, rt, ot, lam_lp=2.0, lam_latent=0.5))
+
+
+def test_score_fusion_auc_matches_reference_golden():
+    """`fuse_scores_auc` against the AUCs the reference's own `img_pred_fea_comm_single_auc` produced on the
+    authors' shipped ped2 records with synthetic labels (tests/golden/make_golden.py:score_fusion_golden)"""
+    d = np.load(os.path.join(GOLDEN, "score_fusion_ped2.npz"))
+    lens = d["lens"]
+    cuts = np.cumsum(lens)[:-1]
+    rec = {"dataset": "ped2",
+           "rgb_img_pred_records": np.split(d["rgb_img_pred_records"], cuts),
+           "rgb_fea_comm_records": np.split(d["rgb_fea_comm_records"], cuts)}
+    gt = np.split(d["gt"], cuts)
+    for key in ("avenue", "ped2", "shanghaitech"):
+        got = Hn.fuse_scores_auc(rec, gt, tuple(d[f"lam.{key}"]))
+        assert got["auc"] == float(d[f"auc.{key}"]), (key, got["auc_raw"])
+    assert Hn.fuse_scores_auc(rec, gt)["lam"] == Hn.LAM_MAP["ped2"]
+    # the AUC routine itself against scikit-learn, including tied scores
+    from sklearn import metrics
+    rng = np.random.default_rng(0)
+    y = rng.integers(0, 2, 500)
+    s = np.round(rng.normal(size=500) + y * 0.7, 1)
+    fpr, tpr, _ = metrics.roc_curve(y, s, pos_label=0)
+    assert abs(Hn.roc_auc(y, s, 0) - metrics.auc(fpr, tpr)) < 1e-12
+
+
+def test_weights_init_normal_statistics():
+    import ammcnet_aaai2021_amd as A
+    net = A.get_twostream((12, 6), (3, 2), 64, 256, 2)
+    torch.manual_seed(0)
+    Hn.weights_init_normal(net)
+    w = net.rgb.down2.mpconv[1].conv[0].weight
+    assert abs(float(w.std()) - 0.02) < 1e-3 and abs(float(w.mean())) < 1e-3
+    bn = net.bridge.O2F.conv[1]
+    assert abs(float(bn.weight.mean()) - 1.0) < 5e-3 and float(bn.bias.abs().max()) == 0.0
+    assert abs(float(net.rgb.up1.up.weight.std()) - 0.02) < 1e-3          # ConvTranspose2d matches "Conv" too
