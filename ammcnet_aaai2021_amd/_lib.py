@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libammc_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 
@@ -30,7 +30,7 @@ class AmmcConvDesc(C.Structure):
         ("x_bs", _i64), ("x_rs", _i64), ("x_ps", _i64),
         ("y_bs", _i64), ("y_rs", _i64), ("y_ps", _i64),
         ("r_bs", _i64), ("r_rs", _i64), ("r_ps", _i64),
-        ("y_cs", _i64), ("x_step", _i32), ("y_f32", _i32), ("w_kblk", _i32), ("reserved3", _i32),
+        ("y_cs", _i64), ("x_step", _i32), ("y_f32", _i32), ("w_kblk", _i32), ("reserved3", _i32), ("overflow_flag", _p),
     ]
 
 

@@ -425,6 +425,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_gemm_s16_kernel(ConvAr
     }
     f16x8 hi, lo;
     split8(v, hi, lo);
+    if (d.overflow_flag) {                       // |v| beyond the half range: hi is +-inf from here on
+      bool bad = false;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bad |= !(fabsf(v[i]) <= 65504.f);
+      if (bad) atomicOr(d.overflow_flag, 1);
+    }
     float* yp = d.y + o + goff + co;
     *reinterpret_cast<f16x8*>(yp) = hi;
     *reinterpret_cast<f16x8*>(yp + 4) = lo;

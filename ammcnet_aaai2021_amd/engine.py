@@ -224,6 +224,7 @@ class _Builder:
         self.lib = _lib.load()
         self.device = device
         self.s16 = s16
+        self.overflow = torch.zeros(1, device=device, dtype=torch.int32) if s16 else None   # set by S16 epilogues
         self.conv_fn = self.lib.ammc_conv_gemm_s16 if s16 else self.lib.ammc_conv_gemm_f32
         self.kname = "conv_gemm_s16" if s16 else "conv_gemm_f32"
 
@@ -242,6 +243,7 @@ class _Builder:
         d = AmmcConvDesc()
         d.y_f32 = 1 if (y_f32 and self.s16) else 0
         d.w_kblk = 1 if (self.s16 and S16_BDIRECT) else 0
+        d.overflow_flag = self.overflow.data_ptr() if self.s16 else None
         d.x = x.tap0() if ntaps == 9 else x.pix0()
         d.w = _ptr(w)
         d.y = y.pix0()
@@ -458,6 +460,7 @@ class EvalEngine:
             s.decode()
             st = dict(streams=[s])
         st["plan"] = plan
+        st["overflow"] = bld.overflow
         return st
 
     def _get(self, B, H, W, device) -> dict:
@@ -475,6 +478,16 @@ class EvalEngine:
         next forward of the same shape."""
         s = self._last["streams"][0]
         return self.act_nchw(s.x4), self.act_nchw(s.x4q)
+
+    def overflowed(self, reset: bool = True) -> bool:
+        """did an S16 activation of the last forward leave the half range?  (one device sync)"""
+        flag = self._last.get("overflow")
+        if flag is None:
+            return False
+        hit = bool(flag.item())
+        if hit and reset:
+            flag.zero_()
+        return hit
 
     def act_nchw(self, a: Act) -> torch.Tensor:
         """an activation of the workspace as an NCHW fp32 tensor (a view for fp32 plans, a decoded copy

@@ -163,7 +163,8 @@ def roc_auc(labels: np.ndarray, scores: np.ndarray, pos_label: int = 0) -> float
     tps = np.cumsum(y)[idx].astype(np.float64)
     fps = (1 + idx - tps).astype(np.float64)
     tps, fps = np.r_[0.0, tps], np.r_[0.0, fps]
-    return float(np.trapz(tps / tps[-1], fps / fps[-1]))
+    trapezoid = getattr(np, "trapezoid", None) or np.trapz
+    return float(trapezoid(tps / tps[-1], fps / fps[-1]))
 
 
 def fuse_scores_auc(records: dict, gt: Sequence[np.ndarray], lam=None) -> dict:

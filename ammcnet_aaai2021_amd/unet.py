@@ -46,7 +46,17 @@ def _run(mod, kind: str, n_inputs: int, *inputs):
         prec = getattr(mod, "precision", None) or DEFAULT_PRECISION
         if mod._engine is None or mod._engine.precision != prec:
             object.__setattr__(mod, "_engine", EvalEngine(mod, kind, prec))
-        return mod._engine.forward(*inputs)
+        out = mod._engine.forward(*inputs)
+        if prec == "s16" and getattr(mod, "s16_guard", False):
+            # S16 carries |v| <= 65504 in the hi half; the conv epilogues raise a device flag beyond that.  Reading
+            # it costs one device sync per forward, so the guard is opt-in (`model.s16_guard = True`): on overflow
+            # the batch is recomputed on the exact-fp32 kernels.
+            if mod._engine.overflowed():
+                if getattr(mod, "_engine_fp32", None) is None:
+                    object.__setattr__(mod, "_engine_fp32", EvalEngine(mod, kind, "fp32"))
+                out = mod._engine_fp32.forward(*inputs)
+                object.__setattr__(mod, "s16_fallbacks", getattr(mod, "s16_fallbacks", 0) + 1)
+        return out
     if mod._train_engine is None:
         object.__setattr__(mod, "_train_engine", TrainEngine(mod, kind))
     return HipPathFunction.apply(mod._train_engine, n_inputs, *inputs, *mod.parameters())

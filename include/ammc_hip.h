@@ -87,6 +87,7 @@ typedef struct AmmcConvDesc {
   int32_t y_f32;         /* (2x2 stride-2 gather of the ConvTranspose dgrad).  y_f32: ammc_conv_gemm_s16 only, 1 = fp32 output */
   int32_t w_kblk;        /* ammc_conv_gemm_s16 only: 1 = w is k-blocked (ammc_split_kblk_f32), fragments bypass LDS */
   int32_t reserved3;
+  int32_t* overflow_flag; /* ammc_conv_gemm_s16 only, may be NULL: set to 1 when an S16 output exceeds the half range */
 } AmmcConvDesc;
 
 int ammc_conv_gemm_f32(const AmmcConvDesc* desc, void* stream);

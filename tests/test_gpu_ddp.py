@@ -1,0 +1,77 @@
+"""Data-parallel training step with the HIP path: two processes sharing the one GPU of the test box,
+gloo as the transport (RCCL needs one device per rank; the reducer code is backend-agnostic).
+Checks the reducer being fed by the backward stages, bucket launches, and that the averaged gradients
+equal the oracle's average of the two per-rank gradients (stock DDP semantics: per-rank BN statistics)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    import ammcnet_aaai2021_amd as A
+    from ammcnet_aaai2021_amd import harness as Hn, parallel as P, synthetic as S
+    from oracle import ammc_oracle as O
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    sd = S.make_twostream_state(tag="ddp" if rank == 0 else "ddp-other")     # rank 1 starts different on purpose
+    net = A.get_twostream((12, 6), (3, 2), 64, 256, 2)
+    net.load_state_dict(sd)
+    net = net.to(dev).train()
+    P.broadcast_state(net, 0)
+    red = P.BucketedGradReducer(bucket_mb=8)
+    P.attach_reducer(net, red)
+    rgb_x, op_x, rgb_t, op_t = S.make_clips(2 * world, 64, 64, tag="ddpclips")
+    sl = slice(2 * rank, 2 * rank + 2)
+    out = net(rgb_x[sl].to(dev), op_x[sl].to(dev))
+    Hn.generator_loss(out, rgb_t[sl].to(dev), op_t[sl].to(dev)).backward()
+    torch.cuda.synchronize()
+    ok, detail = True, ""
+    if rank == 0:
+        sd0 = S.make_twostream_state(tag="ddp")
+        grads = None
+        for r in range(world):
+            msd = O.clone_state(sd0, requires_grad=True)
+            s2 = slice(2 * r, 2 * r + 2)
+            O.generator_loss(O.twostream_forward(msd, rgb_x[s2], op_x[s2], 2, training=True), rgb_t[s2], op_t[s2]).backward()
+            g = {k: v.grad for k, v in msd.items() if v.requires_grad}
+            grads = g if grads is None else {k: grads[k] + g[k] for k in g}
+        errs = []
+        for name, p in net.named_parameters():
+            w = grads[name] / world
+            errs.append(float((p.grad.cpu().double() - w.double()).norm() / w.double().norm().clamp_min(1e-30)))
+        import numpy as np
+        ok = max(errs) <= 1e-2 and float(np.median(errs)) <= 2e-3 and red.buckets_launched >= 3
+        detail = f"max {max(errs):.2e} median {np.median(errs):.2e} buckets {red.buckets_launched}"
+    q.put((rank, ok, detail))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_step_on_one_gpu():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] for r in res), res

@@ -96,3 +96,18 @@ def test_unet_and_unetmem_s16():
     net.precision = "s16"
     x = S.make_clips(cfg["batch"], cfg["hw"], cfg["hw"], tag=cfg["tag"])[0]
     assert rel_err(net(x.to(DEV)).cpu(), d["y"]) <= TOL
+
+
+def test_s16_overflow_guard_recomputes_on_fp32():
+    """activations beyond the fp16 range: the guarded S16 model falls back to the exact-fp32 kernels"""
+    net, sd = _net()
+    big = {k: (v * 3e5 if k.endswith("rgb.inc.conv.conv.1.weight") else v) for k, v in sd.items()}   # huge BN gamma
+    net.load_state_dict(big)
+    rgb_x, op_x, _, _ = S.make_clips(1, 64, 64, tag="ovf")
+    net(rgb_x.to(DEV), op_x.to(DEV))
+    assert net._engine.overflowed()                                  # unguarded S16 left the half range here
+    net.s16_guard = True
+    out = net(rgb_x.to(DEV), op_x.to(DEV))
+    with torch.no_grad():
+        w = O.twostream_forward(O.clone_state(big), rgb_x, op_x, 2)
+    assert net.s16_fallbacks == 1 and rel_err(out[0].cpu(), w[0]) <= TOL
