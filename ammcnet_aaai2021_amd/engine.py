@@ -219,18 +219,33 @@ class _StreamPack:
 class _Builder:
     """appends resolved kernel calls to a Plan"""
 
-    def __init__(self, plan: Plan, device, s16: bool = False):
+    def __init__(self, plan: Plan, device, s16: bool = False, arena: Optional[List[torch.Tensor]] = None):
         self.plan = plan
         self.lib = _lib.load()
         self.device = device
         self.s16 = s16
+        # buffers of a plan built earlier for the same frame size and a batch at least as large: the build order
+        # is deterministic, so allocation i of this plan can be the first B images of allocation i of that one
+        # (explicit batch strides everywhere; halos are zero and never written).  A short last batch of a
+        # sub-video then costs no new multi-GB workspace.
+        self.arena = arena
+        self.made: List[torch.Tensor] = []
         self.overflow = torch.zeros(1, device=device, dtype=torch.int32) if s16 else None   # set by S16 epilogues
         self.conv_fn = self.lib.ammc_conv_gemm_s16 if s16 else self.lib.ammc_conv_gemm_f32
         self.kname = "conv_gemm_s16" if s16 else "conv_gemm_f32"
 
     def buf(self, *shape) -> torch.Tensor:
         # zeros once: kernels write interiors only, so the halo stays zero forever
-        t = torch.zeros(shape, device=self.device, dtype=torch.float32)
+        i = len(self.made)
+        t = None
+        if self.arena is not None and i < len(self.arena):
+            big = self.arena[i]
+            if big.dim() >= 3 and len(shape) == big.dim() and tuple(big.shape[1:]) == tuple(shape[1:]) \
+                    and big.shape[0] >= shape[0]:
+                t = big[:shape[0]]
+        if t is None:
+            t = torch.zeros(shape, device=self.device, dtype=torch.float32)
+        self.made.append(t)
         self.plan.keep.append(t)
         return t
 
@@ -400,6 +415,7 @@ class EvalEngine:
         self._packs = None
         self._pack_version = None
         self._plans: Dict[Tuple, dict] = {}
+        self._arenas: Dict[Tuple, Tuple[int, List[torch.Tensor]]] = {}
         self._timed = False          # bench.py: bracket every launch with HIP events
         self.timings = []
 
@@ -427,11 +443,14 @@ class EvalEngine:
             self._packs = dict(net=_StreamPack(pk, m))
         self._pack_version = ver
         self._plans.clear()               # plans hold pointers to the old packs
+        self._arenas.clear()
 
     # ---- plans ----------------------------------------------------------------------
     def _build(self, B, H, W, device) -> dict:
         plan = Plan()
-        bld = _Builder(plan, device, self.s16)
+        akey = (H, W, device)
+        arena = self._arenas.get(akey)
+        bld = _Builder(plan, device, self.s16, arena[1] if arena is not None and arena[0] >= B else None)
         st = {}
         if self.kind == "twostream":
             r = StreamGraph(bld, self._packs["rgb"], B, H, W)
@@ -461,6 +480,8 @@ class EvalEngine:
             st = dict(streams=[s])
         st["plan"] = plan
         st["overflow"] = bld.overflow
+        if arena is None or arena[0] < B:
+            self._arenas[akey] = (B, bld.made)
         return st
 
     def _get(self, B, H, W, device) -> dict:

@@ -91,9 +91,13 @@ def evaluate_dataset(model: Callable, videos: Sequence, dataset_name: str = "syn
     plan = [(v, s, e) for v, (rgb, _) in enumerate(videos) for s, e in subvideo_batches(rgb.shape[0])]
     mine = parallel.shard_batches(len(plan), rank, world)
     local = {}
+    resident = (None, None)                 # one sub-video at a time lives on the device (<= ~150 MB for 180 frames)
     for i in mine:
         v, s, e = plan[i]
-        local[i] = score_batch(model, videos[v][0], videos[v][1], s, e, device)
+        if device is not None and resident[0] != v:
+            resident = (v, (videos[v][0].to(device, non_blocking=True), videos[v][1].to(device, non_blocking=True)))
+        rgb_v, op_v = resident[1] if device is not None else videos[v]
+        local[i] = score_batch(model, rgb_v, op_v, s, e, None)
     allsc = parallel.gather_records(local, world)
     out = {"dataset": dataset_name, "rgb_img_pred_records": [], "rgb_fea_comm_records": [],
            "op_img_pred_records": [], "op_fea_comm_records": []}
