@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libammc_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 
@@ -90,6 +90,8 @@ SIGNATURES = {
     "ammc_maxpool2x2_bwd_f32": (C.c_int, [_p] + _s3 + [_p] + _s3 + [_p] + _s3 + [_p] + _s3 + [_i32] * 4 + [_p]),
     "ammc_tanh_bwd_nhwc_f32": (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _p] + _s3 + [_i32, _p]),
     "ammc_commit_bwd_f32": (C.c_int, [_p, _p, _p, _i32, _p, _p, _p, _i32, _i32, _p]),
+    "ammc_codebook_count_f32": (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _p, _p, _p]),
+    "ammc_codebook_ema_apply_f32": (C.c_int, [_p, _p, _i32, _i32, _f32, _f32, _f32, _p, _p, _p, _p]),
     "ammc_codebook_ema_f32": (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _p, _p, _p, _p]),
 }
 

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void commit_bwd_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void ema_accumulate_kernel(const float* __restrict__ x, const int* __restrict__ idx,
                                                              int k, int N, int D, int M, float decay, float omd,
                                                              float* __restrict__ cluster_size,
-                                                             float* __restrict__ embed_avg /* [D][M] */) {
+                                                             float* __restrict__ embed_avg /* [D][M] */, int raw) {
   const int slot = blockIdx.x;
   __shared__ int hits[256];
   __shared__ int wcount[4];
@@ -307,11 +307,25 @@ __global__ __launch_bounds__(256) void ema_accumulate_kernel(const float* __rest
       for (int i = 0; i < nh; ++i) sum += x[(int64_t)hits[i] * D + d];
     __syncthreads();
   }
+  if (raw) {            // counts[M] / sums[D][M] only: the EMA is applied after a cross-rank all-reduce
+    if (threadIdx.x == 0) cluster_size[slot] = (float)count;
+    for (int d = threadIdx.x; d < D; d += 256) embed_avg[(int64_t)d * M + slot] = sum;
+    return;
+  }
   if (threadIdx.x == 0) cluster_size[slot] = decay * cluster_size[slot] + omd * (float)count;
   for (int d = threadIdx.x; d < D; d += 256) {
     // note: with D > 256 the loop above accumulates several features into one `sum`; guarded on the host (D <= 256)
     embed_avg[(int64_t)d * M + slot] = decay * embed_avg[(int64_t)d * M + slot] + omd * sum;
   }
+}
+
+// EMA from (all-reduced) raw counts / sums
+__global__ __launch_bounds__(256) void ema_apply_kernel(const float* __restrict__ counts, const float* __restrict__ sums,
+                                                        int D, int M, float decay, float omd,
+                                                        float* __restrict__ cluster_size, float* __restrict__ embed_avg) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < M) cluster_size[i] = decay * cluster_size[i] + omd * counts[i];
+  if (i < (int64_t)D * M) embed_avg[i] = decay * embed_avg[i] + omd * sums[i];
 }
 
 // step 2: n = sum(cluster_size); embed = embed_avg / ((cs + eps) / (n + M eps) * n)
@@ -486,7 +500,27 @@ int ammc_codebook_ema_f32(const float* x, const int32_t* idx_topk, int32_t k, in
   if (!x || !idx_topk || !cluster_size || !embed_avg || !embed || n <= 0 || d <= 0 || m <= 0 || k <= 0) return AMMC_EINVAL;
   if (d > 256) return AMMC_EUNSUP;
   hipLaunchKernelGGL(ema_accumulate_kernel, dim3(m), dim3(256), 0, (hipStream_t)stream, x, idx_topk, k, n, d, m, decay,
-                     one_minus_decay, cluster_size, embed_avg);
+                     one_minus_decay, cluster_size, embed_avg, 0);
+  hipLaunchKernelGGL(ema_normalize_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, cluster_size, embed_avg, d, m,
+                     eps, embed);
+  return ammc_launch_status();
+}
+
+int ammc_codebook_count_f32(const float* x, const int32_t* idx_topk, int32_t k, int32_t n, int32_t d, int32_t m,
+                            float* counts, float* sums, void* stream) {
+  if (!x || !idx_topk || !counts || !sums || n <= 0 || d <= 0 || m <= 0 || k <= 0) return AMMC_EINVAL;
+  if (d > 256) return AMMC_EUNSUP;
+  hipLaunchKernelGGL(ema_accumulate_kernel, dim3(m), dim3(256), 0, (hipStream_t)stream, x, idx_topk, k, n, d, m, 0.f, 0.f,
+                     counts, sums, 1);
+  return ammc_launch_status();
+}
+
+int ammc_codebook_ema_apply_f32(const float* counts, const float* sums, int32_t d, int32_t m, float decay,
+                                float one_minus_decay, float eps, float* cluster_size, float* embed_avg, float* embed,
+                                void* stream) {
+  if (!counts || !sums || !cluster_size || !embed_avg || !embed || d <= 0 || m <= 0) return AMMC_EINVAL;
+  hipLaunchKernelGGL(ema_apply_kernel, dim3(nblk((int64_t)d * m)), dim3(256), 0, (hipStream_t)stream, counts, sums, d, m,
+                     decay, one_minus_decay, cluster_size, embed_avg);
   hipLaunchKernelGGL(ema_normalize_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, cluster_size, embed_avg, d, m,
                      eps, embed);
   return ammc_launch_status();

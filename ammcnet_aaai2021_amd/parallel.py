@@ -132,3 +132,12 @@ class BucketedGradReducer:
 def attach_reducer(module: torch.nn.Module, reducer: Optional[BucketedGradReducer]) -> None:
     """let the model's training engine feed `reducer` stage by stage during backward"""
     object.__setattr__(module, "_grad_reducer", reducer)
+
+
+def sync_statistics(module: torch.nn.Module, enabled: bool = True, group=None) -> None:
+    """Large-batch-exact data parallelism: BatchNorm batch statistics (forward sums and the
+    two backward sums per layer, [2C] floats each) and the per-slot counts / feature sums of the EMA codebook
+    update are all-reduced across ranks, so N ranks x B clips reproduce ONE step on N*B clips (running statistics
+    and codebook identical on every rank).  Ranks must hold equal batch sizes.  Off by default: the stock
+    behaviour keeps statistics per rank."""
+    object.__setattr__(module, "_sync_stats", (bool(enabled), group))

@@ -60,6 +60,19 @@ class _Ops:
     def __init__(self, ws: _WS):
         self.ws, self.lib, self.dev = ws, ws.lib, ws.device
         self.zeros = ws.buf(1024)
+        self.sync_group = None          # set per step by TrainEngine: a process group, or False for "no sync"
+
+    @property
+    def sync_world(self) -> int:
+        """> 1 when BatchNorm statistics / EMA counts are to be all-reduced across ranks (parallel.sync_statistics)"""
+        import torch.distributed as dist
+        if self.sync_group is False or not dist.is_initialized():
+            return 1
+        return dist.get_world_size(self.sync_group)
+
+    def all_reduce(self, t: torch.Tensor) -> None:
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.sync_group)
 
     @property
     def s(self):
@@ -133,7 +146,15 @@ class _ConvBN:
         c = self.craw
         _chk(lib.ammc_bn_stats_f32(c.pix0(), *c.strides, c.B, c.H, c.W, self.cout, _ptr(self.partial), s), "bn_stats")
         bn = self.bn
-        _chk(lib.ammc_bn_finalize_f32(_ptr(self.partial), self.nblk, self.cout, float(c.B * c.H * c.W),
+        part, nblk, count = self.partial, self.nblk, float(c.B * c.H * c.W)
+        world = o.sync_world
+        if world > 1:
+            # synchronised statistics: [2C] sums of every rank are added, the finalizer sees the global batch
+            tot = torch.empty(2 * self.cout, device=o.dev, dtype=torch.float32)
+            _chk(lib.ammc_reduce_partials_f32(_ptr(self.partial), self.nblk, 2 * self.cout, 1.0, _ptr(tot), s), "reduce")
+            o.all_reduce(tot)
+            part, nblk, count = tot, 1, count * world
+        _chk(lib.ammc_bn_finalize_f32(_ptr(part), nblk, self.cout, count,
                                       _ptr(bn.weight.detach()), _ptr(bn.bias.detach()), float(bn.eps),
                                       float(bn.momentum if bn.momentum is not None else BN_MOMENTUM),
                                       _ptr(bn.running_mean), _ptr(bn.running_var), _ptr(self.mean),
@@ -156,6 +177,14 @@ class _ConvBN:
         _chk(lib.ammc_reduce_partials_f32(_ptr(self.partial), self.nblk, 2 * self.cout, 1.0, _ptr(sums), s), "reduce")
         grads[self.bn.bias] = sums[:self.cout]
         grads[self.bn.weight] = sums[self.cout:]
+        world = o.sync_world
+        if world > 1:
+            # the input gradient needs the sums over the GLOBAL batch; the kernel divides by the local pixel
+            # count, so hand it global_sums / world (equal batch per rank).  dgamma / dbeta stay local: the
+            # gradient all-reduce averages them like every other parameter.
+            g = sums.clone()
+            o.all_reduce(g)
+            sums = g.mul_(1.0 / world)
         _chk(lib.ammc_bn_bwd_apply_f32(c.pix0(), *c.strides, dy.pix0(), *dy.strides, _ptr(self.mean), _ptr(self.invstd),
                                        _ptr(self.scale), _ptr(self.shift), _ptr(sums), 1, self.dc.pix0(),
                                        *self.dc.strides, c.B, c.H, c.W, self.cout, s), "bn_bwd_apply")
@@ -288,9 +317,20 @@ class _Stream:
              "diff")
         # EMA update AFTER the lookups (they use the pre-update codebook, unet.py:291-309); e_md keeps the
         # pre-update rows, which is what the backward's commit gradient needs
-        _chk(lib.ammc_codebook_ema_f32(_ptr(self.z.buf), self.idx.data_ptr(), self.k, self.n, self.d, self.m,
-                                       float(qz.decay), float(1 - qz.decay), float(qz.eps), _ptr(qz.cluster_size),
-                                       _ptr(qz.embed_avg), _ptr(qz.embed), s), "codebook_ema")
+        if o.sync_world > 1:
+            counts = torch.empty(self.m, device=o.dev, dtype=torch.float32)
+            sums = torch.empty((self.d, self.m), device=o.dev, dtype=torch.float32)
+            _chk(lib.ammc_codebook_count_f32(_ptr(self.z.buf), self.idx.data_ptr(), self.k, self.n, self.d, self.m,
+                                             _ptr(counts), _ptr(sums), s), "codebook_count")
+            o.all_reduce(counts)
+            o.all_reduce(sums)
+            _chk(lib.ammc_codebook_ema_apply_f32(_ptr(counts), _ptr(sums), self.d, self.m, float(qz.decay),
+                                                 float(1 - qz.decay), float(qz.eps), _ptr(qz.cluster_size),
+                                                 _ptr(qz.embed_avg), _ptr(qz.embed), s), "codebook_ema_apply")
+        else:
+            _chk(lib.ammc_codebook_ema_f32(_ptr(self.z.buf), self.idx.data_ptr(), self.k, self.n, self.d, self.m,
+                                           float(qz.decay), float(1 - qz.decay), float(qz.eps), _ptr(qz.cluster_size),
+                                           _ptr(qz.embed_avg), _ptr(qz.embed), s), "codebook_ema")
         o.conv(self.qk, self.dec_wp, self.x4q, ntaps=1, cin=self.k * self.d, n=512, shift=q.dec.bias.detach(),
                res=self.x4, what="vq.dec")
         return diff, self.q_one.clone()
@@ -430,6 +470,8 @@ class TrainEngine:
             raise _lib.AmmcHipError("the HIP path needs CUDA/HIP tensors; there is no CPU fallback")
         B, _, H, W = x0.shape
         st = self._get(B, H, W, x0.device)
+        sync = getattr(self.module, "_sync_stats", None)          # parallel.sync_statistics(model, group)
+        st["ops"].sync_group = sync[1] if sync and sync[0] else False
         self.generation += 1
         st["generation"] = self.generation
         xs = [x.detach().float().contiguous() for x in inputs]

@@ -263,6 +263,13 @@ int ammc_tanh_bwd_nhwc_f32(const float* dout_nchw, const float* out_nchw, int32_
 /* gradient of the commit term and of q_one w.r.t. the encoder output (unet.py:310-311) */
 int ammc_commit_bwd_f32(const float* z, const float* embed_md, const int32_t* idx_topk, int32_t k,
                         const float* ddiff, const float* dq, float* dz, int32_t n, int32_t d, void* stream);
+/* the same update in two halves, for data-parallel training with synchronised statistics: per-slot counts [m]
+ * and feature sums [d][m] of this rank (all-reduce them), then the EMA + renormalisation */
+int ammc_codebook_count_f32(const float* x, const int32_t* idx_topk, int32_t k, int32_t n, int32_t d, int32_t m,
+                            float* counts, float* sums, void* stream);
+int ammc_codebook_ema_apply_f32(const float* counts, const float* sums, int32_t d, int32_t m, float decay,
+                                float one_minus_decay, float eps, float* cluster_size, float* embed_avg, float* embed,
+                                void* stream);
 /* EMA codebook update (unet.py:298-309), deterministic (no atomics) */
 int ammc_codebook_ema_f32(const float* x, const int32_t* idx_topk, int32_t k, int32_t n, int32_t d, int32_t m,
                           float decay, float one_minus_decay, float eps, float* cluster_size, float* embed_avg,

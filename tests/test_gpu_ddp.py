@@ -75,3 +75,60 @@ def test_two_rank_training_step_on_one_gpu():
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] for r in res), res
+
+
+def _worker_sync(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import numpy as np
+    import torch.distributed as dist
+    import ammcnet_aaai2021_amd as A
+    from ammcnet_aaai2021_amd import harness as Hn, parallel as P, synthetic as S
+    from oracle import ammc_oracle as O
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    sd = S.make_twostream_state(tag="sync")
+    net = A.get_twostream((12, 6), (3, 2), 64, 256, 2)
+    net.load_state_dict(sd)
+    net = net.to(dev).train()
+    red = P.BucketedGradReducer(bucket_mb=8)
+    P.attach_reducer(net, red)
+    P.sync_statistics(net, True)
+    rgb_x, op_x, rgb_t, op_t = S.make_clips(2 * world, 64, 64, tag="syncclips")
+    sl = slice(2 * rank, 2 * rank + 2)
+    out = net(rgb_x[sl].to(dev), op_x[sl].to(dev))
+    Hn.generator_loss(out, rgb_t[sl].to(dev), op_t[sl].to(dev)).backward()
+    torch.cuda.synchronize()
+    ok, detail = True, ""
+    if rank == 0:
+        # ONE step of the oracle on the whole batch of 2*world clips
+        msd = O.clone_state(sd, requires_grad=True)
+        O.generator_loss(O.twostream_forward(msd, rgb_x, op_x, 2, training=True), rgb_t, op_t).backward()
+        errs = []
+        for name, p in net.named_parameters():
+            w = msd[name].grad
+            errs.append(float((p.grad.cpu().double() - w.double()).norm() / w.double().norm().clamp_min(1e-30)))
+        nsd = net.state_dict()
+        berr = max(float((nsd[k].cpu().double() - v.double()).abs().max() / v.double().abs().max().clamp_min(1e-30))
+                   for k, v in msd.items() if not v.requires_grad and v.is_floating_point())
+        ok = max(errs) <= 1e-2 and float(np.median(errs)) <= 2e-3 and berr <= 1e-4
+        detail = f"grad max {max(errs):.2e} median {np.median(errs):.2e}; buffers {berr:.2e}"
+    q.put((rank, ok, detail))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_with_synchronised_statistics_equal_one_large_batch():
+    """2 ranks x 2 clips with synced BN / EMA statistics == one oracle step on 4 clips
+    (gradients, BN running statistics, EMA codebook)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sync, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] for r in res), res
