@@ -32,6 +32,7 @@ struct ConvArgs {
   AmmcConvDesc d;
   int M, kpad, nchunks, cin_log2, n_tiles;
   int dbg;       // AMMC_S16_DBG (profiling experiments only): 1 = no DMA in the loop, 2 = no MFMA
+  int ksplit;    // > 1: split-K over workgroups (small-M layers); partial tiles go to d.splitk_ws
 };
 
 constexpr float LO_SCALE = 2048.f;
@@ -85,9 +86,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_gemm_s16_kernel(ConvAr
   const int h = lane >> 5;
   const int l31 = lane & 31;
 
-  const int logical = ammc_xcd_remap(blockIdx.x, gridDim.x);
+  const int logical0 = ammc_xcd_remap(blockIdx.x, gridDim.x);
+  const int ks = logical0 % a.ksplit;                  // K slice of this workgroup (split-K; 1 slice normally)
+  const int logical = logical0 / a.ksplit;
   const int n0 = (logical % a.n_tiles) * BN;
   const int m0 = (logical / a.n_tiles) * BM;
+  const int c_per = (a.nchunks + a.ksplit - 1) / a.ksplit;
+  const int c_lo = ks * c_per;
+  const int c_hi = min(c_lo + c_per, a.nchunks);
 
   const AmmcConvDesc& d = a.d;
   const int W = d.width, H = d.height;
@@ -303,12 +309,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_gemm_s16_kernel(ConvAr
 #undef S16_COMPUTE_BD
   } else if (NS == 2) {
     // two stages: the DMA of chunk c+1 flies while chunk c is contracted; one full drain per chunk
-    S16_ISSUE(0, 0);
+    if (c_lo < c_hi) S16_ISSUE(c_lo, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int c = 0; c < a.nchunks; ++c) {
-      const int stage = c & 1;
-      if (c + 1 < a.nchunks && a.dbg != 1) S16_ISSUE(c + 1, stage ^ 1);
+    for (int c = c_lo; c < c_hi; ++c) {
+      const int stage = (c - c_lo) & 1;
+      if (c + 1 < c_hi && a.dbg != 1) S16_ISSUE(c + 1, stage ^ 1);
       if (a.dbg != 2) S16_COMPUTE(stage);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -338,6 +344,24 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_gemm_s16_kernel(ConvAr
 #undef S16_ISSUE
 
   const int nstore = d.n_store > 0 ? d.n_store : d.n;
+
+  if (a.ksplit > 1) {
+    // ---- split-K: this slice's partial tile, fp32 [ksplit][M][N]; ammc_s16 splitk_epilogue_kernel finishes ------
+    float* slab = d.splitk_ws + (int64_t)ks * a.M * d.n;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int ncol = n0 + (wn * TN + j) * 32 + l31;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < a.M) slab[(int64_t)m * d.n + ncol] = hh[i][j][r] + xx[i][j][r] * LO_INV;
+        }
+      }
+    }
+    return;
+  }
 
   if (d.y_f32) {
     // ---- direct fp32 store (channels on lanes), NHWC or NCHW through y_cs ------------------
@@ -437,6 +461,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_gemm_s16_kernel(ConvAr
   }
 }
 
+__global__ void splitk_epilogue_kernel(ConvArgs a);
+
 template <int WGM, int WGN, int TM, int TN, int NS = 2, bool BD = false>
 int launch(const ConvArgs& a, hipStream_t stream) {
   constexpr int BM = WGM * TM * 32;
@@ -454,8 +480,64 @@ int launch(const ConvArgs& a, hipStream_t stream) {
   ConvArgs b = a;
   b.n_tiles = a.d.n / BN;
   const int m_tiles = (a.M + BM - 1) / BM;
-  hipLaunchKernelGGL(kern, dim3(m_tiles * b.n_tiles), dim3(64 * WGM * WGN), lds, stream, b);
+  hipLaunchKernelGGL(kern, dim3(m_tiles * b.n_tiles * b.ksplit), dim3(64 * WGM * WGN), lds, stream, b);
+  if (b.ksplit > 1)
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)(((int64_t)b.M * (b.d.n >> 3) + 255) / 256)), dim3(256), 0,
+                       stream, b);
   return ammc_launch_status();
+}
+
+// split-K second half: sum the K slices of 8 consecutive channels of one pixel, then the usual epilogue
+// (scale/shift, ReLU, S16 residual, split, one 32-byte store)
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(ConvArgs a) {
+  const AmmcConvDesc& d = a.d;
+  const int CG = d.n >> 3;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (int64_t)a.M * CG) return;
+  const int cg = (int)(gid % CG);
+  const int m = (int)(gid / CG);
+  const int x = m % d.width, t = m / d.width, y = t % d.height, b = t / d.height;
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = 0.f;
+  for (int ks = 0; ks < a.ksplit; ++ks) {
+    const float* p = d.splitk_ws + ((int64_t)ks * a.M + m) * d.n + cg * 8;
+    const f32x4 t0 = *reinterpret_cast<const f32x4*>(p);
+    const f32x4 t1 = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] += t0[i]; v[4 + i] += t1[i]; }
+  }
+  const int ncol0 = cg * 8;
+  if (d.scale) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] *= d.scale[ncol0 + i];
+  }
+  if (d.shift) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += d.shift[ncol0 + i];
+  }
+  if (d.act == AMMC_ACT_RELU) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+  }
+  if (d.res) {
+    const float* rp = d.res + ((int64_t)b * d.r_bs + (int64_t)y * d.r_rs + (int64_t)x * d.r_ps) + ncol0;
+    float rv[8];
+    join8(*reinterpret_cast<const f16x8*>(rp), *reinterpret_cast<const f16x8*>(rp + 4), rv);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += rv[i];
+  }
+  f16x8 hi, lo;
+  split8(v, hi, lo);
+  if (d.overflow_flag) {
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bad |= !(fabsf(v[i]) <= 65504.f);
+    if (bad) atomicOr(d.overflow_flag, 1);
+  }
+  float* yp = d.y + ((int64_t)b * d.y_bs + (int64_t)y * d.y_rs + (int64_t)x * d.y_ps) + ncol0;
+  *reinterpret_cast<f16x8*>(yp) = hi;
+  *reinterpret_cast<f16x8*>(yp + 4) = lo;
 }
 
 // fp32 [rows][cols] (cols % 8 == 0) -> S16 groups [8 hi | 8 lo], same shape in bytes
@@ -618,7 +700,22 @@ extern "C" int ammc_conv_gemm_s16(const AmmcConvDesc* desc, void* stream) {
   static const int dbg = getenv("AMMC_S16_DBG") ? atoi(getenv("AMMC_S16_DBG")) : 0;
   static const int big = getenv("AMMC_S16_BIG") ? atoi(getenv("AMMC_S16_BIG")) : 1;
   a.dbg = dbg;
+  a.ksplit = 1;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // split-K for layers that cannot fill the chip (small batch: 32x32 / 64x64 levels with K up to 4608): each K
+  // slice is its own workgroup writing an fp32 partial tile; a streaming kernel sums the slices and finishes
+  if (d.splitk_ws && !d.y_f32 && !d.w_kblk && d.up == 1 && d.n % 128 == 0 && a.nchunks >= 16) {
+    const int64_t tiles = ((M + 127) / 128) * (d.n / 128);
+    if (tiles < 192) {
+      int ksp = (int)((512 + tiles - 1) / tiles);
+      if (ksp > a.nchunks / 4) ksp = a.nchunks / 4;
+      while (ksp > 1 && (int64_t)ksp * M * d.n > d.splitk_ws_floats) --ksp;
+      if (ksp > 1) {
+        a.ksplit = ksp;
+        return launch<2, 2, 2, 2>(a, s);
+      }
+    }
+  }
   if (d.w_kblk) {                                   // k-blocked filter: B fragments bypass LDS
     if (d.n == 32) return launch<4, 1, 1, 1, 2, true>(a, s);
     if (d.n % 128 == 0) return launch<2, 2, 2, 2, 2, true>(a, s);

@@ -231,6 +231,8 @@ class _Builder:
         self.arena = arena
         self.made: List[torch.Tensor] = []
         self.overflow = torch.zeros(1, device=device, dtype=torch.int32) if s16 else None   # set by S16 epilogues
+        # fp32 scratch for split-K on small-M layers (latency at small batch); shared by all layers of a plan
+        self.splitk = torch.empty(8 << 20, device=device, dtype=torch.float32) if s16 else None
         self.conv_fn = self.lib.ammc_conv_gemm_s16 if s16 else self.lib.ammc_conv_gemm_f32
         self.kname = "conv_gemm_s16" if s16 else "conv_gemm_f32"
 
@@ -259,6 +261,8 @@ class _Builder:
         d.y_f32 = 1 if (y_f32 and self.s16) else 0
         d.w_kblk = 1 if (self.s16 and S16_BDIRECT) else 0
         d.overflow_flag = self.overflow.data_ptr() if self.s16 else None
+        if self.s16 and os.environ.get("AMMC_S16_SPLITK", "1") != "0":
+            d.splitk_ws, d.splitk_ws_floats = self.splitk.data_ptr(), self.splitk.numel()
         d.x = x.tap0() if ntaps == 9 else x.pix0()
         d.w = _ptr(w)
         d.y = y.pix0()
@@ -480,6 +484,7 @@ class EvalEngine:
             st = dict(streams=[s])
         st["plan"] = plan
         st["overflow"] = bld.overflow
+        st["splitk"] = bld.splitk
         if arena is None or arena[0] < B:
             self._arenas[akey] = (B, bld.made)
         return st

@@ -88,6 +88,8 @@ typedef struct AmmcConvDesc {
   int32_t w_kblk;        /* ammc_conv_gemm_s16 only: 1 = w is k-blocked (ammc_split_kblk_f32), fragments bypass LDS */
   int32_t reserved3;
   int32_t* overflow_flag; /* ammc_conv_gemm_s16 only, may be NULL: set to 1 when an S16 output exceeds the half range */
+  float* splitk_ws;      /* ammc_conv_gemm_s16 only, may be NULL: fp32 workspace that lets small-M layers split K    */
+  int64_t splitk_ws_floats; /* over workgroups ([ksplit][M][N] partial tiles + a finishing kernel)                   */
 } AmmcConvDesc;
 
 int ammc_conv_gemm_f32(const AmmcConvDesc* desc, void* stream);
