@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libammc_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 
@@ -31,7 +31,7 @@ class AmmcConvDesc(C.Structure):
         ("y_bs", _i64), ("y_rs", _i64), ("y_ps", _i64),
         ("r_bs", _i64), ("r_rs", _i64), ("r_ps", _i64),
         ("y_cs", _i64), ("x_step", _i32), ("y_f32", _i32), ("w_kblk", _i32), ("reserved3", _i32), ("overflow_flag", _p),
-        ("splitk_ws", _p), ("splitk_ws_floats", _i64),
+        ("splitk_ws", _p), ("splitk_ws_floats", _i64), ("sq_target", _p), ("sq_acc", _p),
     ]
 
 

@@ -178,6 +178,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(ConvArgs a) {
   }
   __syncthreads();
 
+  const int b_first = (int)((int64_t)m0 / ((int64_t)H * W));
+  float sq0 = 0.f;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int ncol = n0 + (wn * TN + j) * 32 + l31;
@@ -203,10 +205,22 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(ConvArgs a) {
           if (d.act == AMMC_ACT_RELU) v = v > 0.f ? v : 0.f;
           else if (d.act == AMMC_ACT_TANH) v = tanhf(v);
           if (d.res) v += d.res[tab_res[row] + co];
-          d.y[o + goff + (int64_t)co * ycs] = v;
+          const int64_t addr = o + goff + (int64_t)co * ycs;
+          d.y[addr] = v;
+          if (d.sq_target) {                       // fused squared error of `psnr_error` (outc only)
+            const float df = 0.5f * (d.sq_target[addr] - v);
+            const int bs = (int)(((int64_t)m0 + row) / ((int64_t)H * W));
+            if (bs == b_first) sq0 += df * df;
+            else unsafeAtomicAdd(d.sq_acc + bs, df * df);
+          }
         }
       }
     }
+  }
+  if (d.sq_target) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq0 += __shfl_xor(sq0, off);
+    if (lane == 0) unsafeAtomicAdd(d.sq_acc + b_first, sq0);
   }
 }
 

@@ -366,6 +366,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_gemm_s16_kernel(ConvAr
   if (d.y_f32) {
     // ---- direct fp32 store (channels on lanes), NHWC or NCHW through y_cs ------------------
     const int64_t ycs = d.y_cs > 0 ? d.y_cs : 1;
+    const int b_first = (int)((int64_t)m0 / ((int64_t)H * W));     // sample of the tile's first row
+    float sq0 = 0.f;                                                 // squared error of this lane, sample b_first
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int ncol = n0 + (wn * TN + j) * 32 + l31;
@@ -381,10 +383,22 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_gemm_s16_kernel(ConvAr
             float v = (hh[i][j][r] + xx[i][j][r] * LO_INV) * sc + sh;
             if (d.act == AMMC_ACT_RELU) v = v > 0.f ? v : 0.f;
             else if (d.act == AMMC_ACT_TANH) v = tanhf(v);
-            d.y[o + (int64_t)ncol * ycs] = v;
+            const int64_t addr = o + (int64_t)ncol * ycs;
+            d.y[addr] = v;
+            if (d.sq_target) {
+              const float df = 0.5f * (d.sq_target[addr] - v);
+              const int bs = (int)(((int64_t)m0 + row) / ((int64_t)H * W));
+              if (bs == b_first) sq0 += df * df;
+              else unsafeAtomicAdd(d.sq_acc + bs, df * df);          // a tile that straddles two samples
+            }
           }
         }
       }
+    }
+    if (d.sq_target) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) sq0 += __shfl_xor(sq0, off);
+      if (lane == 0) unsafeAtomicAdd(d.sq_acc + b_first, sq0);
     }
     return;
   }

@@ -526,7 +526,10 @@ class EvalEngine:
         return y
 
     # ---- forward ----------------------------------------------------------------------
-    def forward(self, *inputs: torch.Tensor):
+    def forward(self, *inputs: torch.Tensor, targets=None):
+        """`targets`: optional per-stream NCHW tensors shaped like the predicted frames (None entries allowed);
+        the `outc` epilogue then also accumulates the per-sample squared error of `psnr_error`
+        (utils/utils.py:141-148) and `self.last_psnr` holds one [B] tensor (or None) per stream."""
         x0 = inputs[0]
         if not x0.is_cuda:
             raise _lib.AmmcHipError("the HIP path needs CUDA/HIP tensors (module and inputs on the GPU); "
@@ -570,9 +573,22 @@ class EvalEngine:
                 launch(fn, args, meta)
         else:
             st["plan"].run(stream)
-        for s in streams:
+        sq = []
+        for si, s in enumerate(streams):
             y = torch.empty((B, s.sp.cout, H, W), device=x0.device, dtype=torch.float32)
             s.outc.y = _ptr(y)
+            tgt = targets[si] if targets is not None and si < len(targets) else None
+            if tgt is not None:
+                if tuple(tgt.shape) != tuple(y.shape):
+                    raise ValueError(f"target shape {tuple(tgt.shape)} != prediction shape {tuple(y.shape)}")
+                tgt = tgt.detach().float().contiguous()
+                acc = torch.zeros(B, device=x0.device, dtype=torch.float32)
+                keep.extend([tgt, acc])
+                s.outc.sq_target, s.outc.sq_acc = _ptr(tgt), _ptr(acc)
+                sq.append(acc)
+            else:
+                s.outc.sq_target, s.outc.sq_acc = None, None
+                sq.append(None)
             launch(lib.ammc_conv_gemm_s16 if self.s16 else lib.ammc_conv_gemm_f32, (C.byref(s.outc),),
                    dict(name="outc_tanh", kernel=("conv_gemm_s16" if self.s16 else "conv_gemm_f32") + "<128x32>", flops=2.0 * B * H * W * 9 * 64 * s.sp.cout,
                         bytes=4.0 * B * H * W * (64 + s.sp.cout)))
@@ -581,6 +597,8 @@ class EvalEngine:
             torch.cuda.synchronize()
             self.timings = [(m, e0.elapsed_time(e1)) for m, e0, e1 in recs]
         self._last = st
+        n_el = [float(s.sp.cout * H * W) for s in streams]
+        self.last_psnr = [10.0 * torch.log10(n / a) if a is not None else None for a, n in zip(sq, n_el)]
         if self.kind == "unet":
             return outs[0]
         diffs = tuple(s.diff.clone() for s in streams)

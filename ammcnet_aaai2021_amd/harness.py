@@ -51,9 +51,13 @@ def score_batch(model: Callable, rgb_frames: torch.Tensor, op_frames: torch.Tens
     rgb_in = rgb[:, :-1].reshape(b, -1, *rgb.shape[-2:])
     op_in = op[:, :-1].reshape(b, -1, *op.shape[-2:])
     with torch.no_grad():
-        rgb_out, op_out, (rgb_diff, op_diff), _ = model(rgb_in, op_in)
-        stats = torch.cat([psnr_per_sample(rgb_out, rgb[:, -1]), psnr_per_sample(op_out, op[:, -1]),
-                           rgb_diff.reshape(1), op_diff.reshape(1)]).cpu().numpy()
+        if hasattr(model, "forward_scored") and rgb_in.is_cuda:
+            # the HIP model accumulates the squared errors inside the `outc` kernel
+            (_, _, (rgb_diff, op_diff), _), rgb_psnr, op_psnr = model.forward_scored(rgb_in, op_in, rgb[:, -1], op[:, -1])
+        else:
+            rgb_out, op_out, (rgb_diff, op_diff), _ = model(rgb_in, op_in)
+            rgb_psnr, op_psnr = psnr_per_sample(rgb_out, rgb[:, -1]), psnr_per_sample(op_out, op[:, -1])
+        stats = torch.cat([rgb_psnr, op_psnr, rgb_diff.reshape(1), op_diff.reshape(1)]).cpu().numpy()
     return {"rgb_psnr": stats[:b], "op_psnr": stats[b:2 * b], "rgb_comm": stats[2 * b], "op_comm": stats[2 * b + 1]}
 
 

@@ -230,6 +230,21 @@ class twostream(nn.Module):
             self._quant_src = (self._engine, st.x4, st.x4q)
         return out
 
+    def forward_scored(self, rgb_x, op_x, rgb_target, op_target=None):
+        """eval forward + per-sample PSNR of the predicted frames against `rgb_target` (and `op_target`), with the
+        squared error accumulated inside the `outc` kernel (the scoring tail of
+        run_helper/test_helper.py:445-454 without re-reading the frames).  Returns (forward's 4-tuple,
+        rgb_psnr [B], op_psnr [B] or None)."""
+        if self.training:
+            raise NotImplementedError("forward_scored is an evaluation entry: call .eval() first")
+        prec = getattr(self, "precision", None) or DEFAULT_PRECISION
+        if self._engine is None or self._engine.precision != prec:
+            object.__setattr__(self, "_engine", EvalEngine(self, "twostream", prec))
+        out = self._engine.forward(rgb_x, op_x, targets=(rgb_target, op_target))
+        st = self._engine._last["streams"][0]
+        self._quant_src = (self._engine, st.x4, st.x4q)
+        return out, self._engine.last_psnr[0], self._engine.last_psnr[1]
+
     # reference side effects (unet.py:986, 988): `quant_befor` / `quant_after`, which nothing reads.
     # Served lazily as NCHW tensors of the workspace (valid until the next forward of that shape).
     @property

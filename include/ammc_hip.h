@@ -90,6 +90,9 @@ typedef struct AmmcConvDesc {
   int32_t* overflow_flag; /* ammc_conv_gemm_s16 only, may be NULL: set to 1 when an S16 output exceeds the half range */
   float* splitk_ws;      /* ammc_conv_gemm_s16 only, may be NULL: fp32 workspace that lets small-M layers split K    */
   int64_t splitk_ws_floats; /* over workgroups ([ksplit][M][N] partial tiles + a finishing kernel)                   */
+  const float* sq_target; /* fp32-output epilogues only (outc), may be NULL: a tensor laid out like y; the kernel adds   */
+  float* sq_acc;          /* sum(((t+1)/2 - (y+1)/2)^2) of every stored element to sq_acc[sample] (fp32 atomics): the  */
+                          /* per-sample squared error of `psnr_error` (utils/utils.py:141-148) without re-reading y     */
 } AmmcConvDesc;
 
 int ammc_conv_gemm_f32(const AmmcConvDesc* desc, void* stream);

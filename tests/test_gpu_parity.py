@@ -285,3 +285,25 @@ def test_harness_dataset_eval_on_hip_model():
             assert rel_err(a, b) <= TOL, key
     gt = [(S.hashed_uniform(f"gt{i}", (r.shape[0],), 0, 1) > 0.7).numpy().astype(np.int8) for i, (r, _) in enumerate(vids)]
     assert abs(Hn.fuse_scores_auc(rec, gt)["auc_raw"] - Hn.fuse_scores_auc(want, gt)["auc_raw"]) <= 1e-3
+
+
+@pytest.mark.parametrize("prec", ["fp32", "s16"])
+def test_fused_psnr_in_outc_epilogue(prec):
+    """per-sample PSNR from the squared error accumulated inside the `outc` kernel"""
+    net, sd = _twostream(256, 2)
+    net.precision = prec
+    rgb_x, op_x, rgb_t, op_t = S.make_clips(3, 64, 72, tag="psnr")       # 64*72 = 36 tiles of 128 pixels per sample
+    out, rp, opp = net.forward_scored(rgb_x.to(DEV), op_x.to(DEV), rgb_t.to(DEV), op_t.to(DEV))
+    with torch.no_grad():
+        w = O.twostream_forward(O.clone_state(sd), rgb_x, op_x, 2)
+    want_r = torch.stack([O.psnr_error(w[0][i:i + 1], rgb_t[i:i + 1]) for i in range(3)])
+    want_o = torch.stack([O.psnr_error(w[1][i:i + 1], op_t[i:i + 1]) for i in range(3)])
+    assert rel_err(rp.cpu(), want_r) <= 1e-5 and rel_err(opp.cpu(), want_o) <= 1e-5
+    assert rel_err(out[0].cpu(), w[0]) <= TOL
+    # a frame size whose samples are not a whole number of tiles: tiles straddle two samples
+    rgb_x, op_x, rgb_t, op_t = S.make_clips(3, 40, 40, tag="psnr2")
+    out, rp, _ = net.forward_scored(rgb_x.to(DEV), op_x.to(DEV), rgb_t.to(DEV))
+    with torch.no_grad():
+        w = O.twostream_forward(O.clone_state(sd), rgb_x, op_x, 2)
+    want_r = torch.stack([O.psnr_error(w[0][i:i + 1], rgb_t[i:i + 1]) for i in range(3)])
+    assert rel_err(rp.cpu(), want_r) <= 1e-5
