@@ -10,9 +10,9 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libammc_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
-ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU = 0, 1, 2, 3
 
 _p = C.c_void_p
 _i32 = C.c_int32
@@ -80,6 +80,8 @@ SIGNATURES = {
     "ammc_unpack_convt_wgrad_f32": (C.c_int, [_p, _i32, _i32, _p, _p]),
     "ammc_pack_conv_dgrad_weight_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
     "ammc_transpose_pad_f32": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
+    "ammc_pack_conv4_dgrad_weight_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _p, _p]),
+    "ammc_lrelu_bwd_f32": (C.c_int, [_p] + _s3 + [_p] + _s3 + [_i32, _i32, _i32, _i32, _f32, _p]),
     "ammc_chan_reduce_blocks": (C.c_int, [_i32]),
     "ammc_bn_stats_f32": (C.c_int, [_p] + _s3 + [_i32, _i32, _i32, _i32, _p, _p]),
     "ammc_bn_finalize_f32": (C.c_int, [_p, _i32, _i32, _f32, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _p]),

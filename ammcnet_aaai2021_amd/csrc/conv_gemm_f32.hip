@@ -53,6 +53,10 @@ __device__ __forceinline__ void issue_chunk(const AmmcConvDesc& d, int cin_log2,
     int tap = k >> cin_log2;
     tap = tap < 3 ? tap : 3;
     toff = (int64_t)(tap >> 1) * d.x_rs + (int64_t)(tap & 1) * d.x_ps + (k & (d.cin - 1));
+  } else if (d.ntaps == 16) {                   // 4x4 window (PixelDiscriminator, pix2pix_networks.py:604-621)
+    int tap = k >> cin_log2;
+    tap = tap < 15 ? tap : 15;
+    toff = (int64_t)(tap >> 2) * d.x_rs + (int64_t)(tap & 3) * d.x_ps + (k & (d.cin - 1));
   } else {
     toff = k;
   }
@@ -204,6 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(ConvArgs a) {
           float v = acc[i][j][r] * sc + sh;
           if (d.act == AMMC_ACT_RELU) v = v > 0.f ? v : 0.f;
           else if (d.act == AMMC_ACT_TANH) v = tanhf(v);
+          else if (d.act == AMMC_ACT_LRELU) v = v > 0.f ? v : 0.1f * v;
           if (d.res) v += d.res[tab_res[row] + co];
           const int64_t addr = o + goff + (int64_t)co * ycs;
           d.y[addr] = v;
@@ -252,7 +257,7 @@ extern "C" int ammc_conv_gemm_f32(const AmmcConvDesc* desc, void* stream) {
   if (!desc || !desc->x || !desc->w || !desc->y) return AMMC_EINVAL;
   const AmmcConvDesc& d = *desc;
   if (d.batch <= 0 || d.height <= 0 || d.width <= 0) return AMMC_EINVAL;
-  if (d.ntaps != 9 && d.ntaps != 1 && d.ntaps != 4) return AMMC_EINVAL;
+  if (d.ntaps != 9 && d.ntaps != 1 && d.ntaps != 4 && d.ntaps != 16) return AMMC_EINVAL;
   if (d.ntaps != 1 && (d.cin < 4 || (d.cin & (d.cin - 1)))) return AMMC_EUNSUP;   // power of two
   if (d.x_step < 0 || d.x_step > 2) return AMMC_EINVAL;
   if (d.ntaps == 1 && (d.cin <= 0 || d.cin % 32)) return AMMC_EUNSUP;

@@ -212,7 +212,7 @@ int ammc_maxpool2x2_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps
 
 int ammc_pack_conv_weight_f32(const float* w_oihw, int32_t cout, int32_t cin, int32_t ksize,
                               int32_t cin_p, float* out, void* stream) {
-  if (!w_oihw || !out || cout <= 0 || cin <= 0 || cin_p < cin || (ksize != 1 && ksize != 3)) return AMMC_EINVAL;
+  if (!w_oihw || !out || cout <= 0 || cin <= 0 || cin_p < cin || (ksize != 1 && ksize != 3 && ksize != 4)) return AMMC_EINVAL;
   const int ks2 = ksize * ksize;
   const int kpad = ((ks2 * cin_p + 31) / 32) * 32;
   const int64_t total = (int64_t)cout * kpad;

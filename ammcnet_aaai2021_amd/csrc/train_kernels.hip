@@ -376,6 +376,56 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
   out[gid] = r < rows ? w[(int64_t)r * cols + c] : 0.f;
 }
 
+// Input-gradient filters of the PixelDiscriminator's 4x4 convolutions (pix2pix_networks.py:604-621, padding 2).
+// stride 1: one [rows][16*cout_p] matrix, the window flipped (k = tap'*cout_p + n, tap' = 15 - tap).
+// stride 2: four matrices [phase = py*2+px][rows][4*cout_p]; input pixel (2q'+py, 2r'+px) gathers the 2x2 block
+//           of output gradients (q'+dr, r'+ds) through filter tap (py + 2(1-dr), px + 2(1-ds)).
+__global__ __launch_bounds__(256) void pack_conv4_dgrad_weight_kernel(const float* __restrict__ w, int cout, int cin,
+                                                                      int cout_p, int kpad, int rows, int stride,
+                                                                      float* __restrict__ out) {
+  const int phases = stride == 2 ? 4 : 1;
+  const int64_t total = (int64_t)phases * rows * kpad;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int k = (int)(gid % kpad);
+  const int c = (int)((gid / kpad) % rows);
+  const int ph = (int)(gid / ((int64_t)kpad * rows));
+  const int tap = k / cout_p, n = k % cout_p;
+  float v = 0.f;
+  if (n < cout && c < cin) {
+    if (stride == 2) {
+      if (tap < 4) {
+        const int r = (ph >> 1) + 2 * (1 - (tap >> 1));
+        const int s = (ph & 1) + 2 * (1 - (tap & 1));
+        v = w[((int64_t)n * cin + c) * 16 + r * 4 + s];
+      }
+    } else if (tap < 16) {
+      v = w[((int64_t)n * cin + c) * 16 + (15 - tap)];
+    }
+  }
+  out[gid] = v;
+}
+
+// g *= (y > 0 ? 1 : slope): autograd of nn.LeakyReLU written on the layer OUTPUT (sign(y) == sign(pre-activation))
+__global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* __restrict__ y, int64_t y_bs, int64_t y_rs,
+                                                        int64_t y_ps, float* __restrict__ g, int64_t g_bs, int64_t g_rs,
+                                                        int64_t g_ps, int B, int H, int W, int C4, float slope) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (int64_t)B * H * W * C4) return;
+  const int c4 = (int)(gid % C4);
+  int64_t t = gid / C4;
+  const int x = (int)(t % W);
+  t /= W;
+  const int yy = (int)(t % H);
+  const int b = (int)(t / H);
+  const f32x4 yv = *reinterpret_cast<const f32x4*>(y + b * y_bs + yy * y_rs + x * y_ps + c4 * 4);
+  float* gp = g + b * g_bs + yy * g_rs + x * g_ps + c4 * 4;
+  f32x4 gv = *reinterpret_cast<const f32x4*>(gp);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) gv[i] = yv[i] > 0.f ? gv[i] : gv[i] * slope;
+  *reinterpret_cast<f32x4*>(gp) = gv;
+}
+
 inline unsigned nblk(int64_t total) { return (unsigned)((total + 255) / 256); }
 
 }  // namespace ammc_impl
@@ -532,6 +582,28 @@ int ammc_pack_conv_dgrad_weight_f32(const float* w_oihw, int32_t cout, int32_t c
   const int kpad = ((9 * cout_p + 31) / 32) * 32;
   hipLaunchKernelGGL(pack_conv_dgrad_weight_kernel, dim3(nblk((int64_t)rows * kpad)), dim3(256), 0,
                      (hipStream_t)stream, w_oihw, cout, cin, cout_p, kpad, rows, out);
+  return ammc_launch_status();
+}
+
+int ammc_pack_conv4_dgrad_weight_f32(const float* w_oihw, int32_t cout, int32_t cin, int32_t cout_p, int32_t rows,
+                                     int32_t stride, float* out, void* stream) {
+  if (!w_oihw || !out || cout <= 0 || cin <= 0 || cout_p < cout || rows < cin || (stride != 1 && stride != 2))
+    return AMMC_EINVAL;
+  const int taps = stride == 2 ? 4 : 16;
+  const int kpad = ((taps * cout_p + 31) / 32) * 32;
+  const int64_t total = (int64_t)(stride == 2 ? 4 : 1) * rows * kpad;
+  hipLaunchKernelGGL(pack_conv4_dgrad_weight_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, w_oihw, cout,
+                     cin, cout_p, kpad, rows, stride, out);
+  return ammc_launch_status();
+}
+
+int ammc_lrelu_bwd_f32(const float* y, int64_t y_bs, int64_t y_rs, int64_t y_ps, float* g, int64_t g_bs, int64_t g_rs,
+                       int64_t g_ps, int32_t batch, int32_t h, int32_t w, int32_t c, float slope, void* stream) {
+  if (!y || !g || batch <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3)) return AMMC_EINVAL;
+  if (((uintptr_t)y | (uintptr_t)g) & 15) return AMMC_EINVAL;
+  if ((y_bs | y_rs | y_ps | g_bs | g_rs | g_ps) & 3) return AMMC_EINVAL;
+  hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(nblk((int64_t)batch * h * w * (c >> 2))), dim3(256), 0, (hipStream_t)stream,
+                     y, y_bs, y_rs, y_ps, g, g_bs, g_rs, g_ps, batch, h, w, c >> 2, slope);
   return ammc_launch_status();
 }
 

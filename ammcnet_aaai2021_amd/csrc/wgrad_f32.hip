@@ -8,6 +8,7 @@
 // OIHW / IOHW parameter gradients.  The same kernel serves
 //   3x3 conv      ntaps 9          (autograd of unet.py:11,14)
 //   1x1 conv      ntaps 1          (enc / dec, unet.py:321-323)
+//   4x4 conv      ntaps 16, a_step 1|2 (PixelDiscriminator, pix2pix_networks.py:604-621)
 //   ConvTranspose ntaps 4, a_step 2: rows = input channels, columns = (dy,dx,c_out), "G" is the
 //                 layer INPUT and "A" the output gradient gathered 2x2 stride 2 (unet.py:47)
 //
@@ -75,7 +76,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(WgradArgs a) {
       int tap = k >> a.cin_log2;
       tap = tap < d.ntaps - 1 ? tap : d.ntaps - 1;
       int r, s;
-      if (d.ntaps == 9) { r = (tap * 11) >> 5; s = tap - 3 * r; } else { r = tap >> 1; s = tap & 1; }
+      if (d.ntaps == 9) { r = (tap * 11) >> 5; s = tap - 3 * r; }
+      else if (d.ntaps == 16) { r = tap >> 2; s = tap & 3; }
+      else { r = tap >> 1; s = tap & 1; }
       a_toff[j] = (int64_t)r * d.a_rs + (int64_t)s * d.a_ps + (k & (d.cin - 1));
     }
   }
@@ -227,7 +230,7 @@ extern "C" int ammc_conv_wgrad_f32(const AmmcWgradDesc* desc, void* stream) {
   if (!desc || !desc->g || !desc->a || !desc->dw || !desc->zeros) return AMMC_EINVAL;
   const AmmcWgradDesc& d = *desc;
   if (d.batch <= 0 || d.height <= 0 || d.width <= 0 || d.n <= 0 || (d.n % 32)) return AMMC_EINVAL;
-  if (d.ntaps != 9 && d.ntaps != 4 && d.ntaps != 1) return AMMC_EINVAL;
+  if (d.ntaps != 9 && d.ntaps != 4 && d.ntaps != 1 && d.ntaps != 16) return AMMC_EINVAL;
   if (d.ntaps != 1 && (d.cin < 4 || (d.cin & (d.cin - 1)))) return AMMC_EUNSUP;
   if (d.ntaps == 1 && (d.cin <= 0 || d.cin % 32)) return AMMC_EUNSUP;
   if (((uintptr_t)d.g | (uintptr_t)d.a | (uintptr_t)d.zeros) & 15) return AMMC_EINVAL;
@@ -247,7 +250,7 @@ extern "C" int ammc_conv_wgrad_f32(const AmmcWgradDesc* desc, void* stream) {
 
 extern "C" int ammc_unpack_conv_wgrad_f32(const float* packed, int32_t cout, int32_t cin, int32_t ksize,
                                           int32_t cin_p, float* out_oihw, void* stream) {
-  if (!packed || !out_oihw || cout <= 0 || cin <= 0 || cin_p < cin || (ksize != 1 && ksize != 3)) return AMMC_EINVAL;
+  if (!packed || !out_oihw || cout <= 0 || cin <= 0 || cin_p < cin || (ksize != 1 && ksize != 3 && ksize != 4)) return AMMC_EINVAL;
   const int ks2 = ksize * ksize;
   const int kpad = ((ks2 * cin_p + 31) / 32) * 32;
   const int64_t total = (int64_t)cout * cin * ks2;

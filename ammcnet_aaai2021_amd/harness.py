@@ -139,6 +139,89 @@ def train_step(model: torch.nn.Module, optimizer: torch.optim.Optimizer, rgb: to
     return loss.detach()
 
 
+# ---- the remaining loss terms and the alternating G / D step -----------------------------------
+
+LAMS_ANOPRED = dict(lam_adv=0.05, lam_gdl=1.0, lam_flow=2.0, lam_lp=1.0, lam_lp_op=1.0, lam_latent=1.0)
+"""the reference reads its lambdas from per-dataset .ini files that are not shipped (constant_train.py:282-292);
+these are the values of the ano_pred recipe the training loop was taken from"""
+
+
+def gradient_loss(gen: torch.Tensor, gt: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
+    """`Gradient_Loss` (losses_utils.py:30-61): the [-1,1] filters sum over channels, zero pad on the left / top"""
+    def dxy(t):
+        s = t.sum(1, keepdim=True)
+        dx = torch.cat([s[..., :1], s[..., 1:] - s[..., :-1]], dim=-1)
+        dy = torch.cat([s[..., :1, :], s[..., 1:, :] - s[..., :-1, :]], dim=-2)
+        return dx, dy
+    gx, gy = dxy(gen)
+    tx, ty = dxy(gt)
+    ex, ey = (tx - gx).abs(), (ty - gy).abs()
+    if alpha != 1:
+        ex, ey = ex ** alpha, ey ** alpha
+    return (ex + ey).mean()
+
+
+def adversarial_loss(fake_outputs: torch.Tensor) -> torch.Tensor:
+    """`Adversarial_Loss` (losses_utils.py:100-104)"""
+    return ((fake_outputs - 1) ** 2 / 2).mean()
+
+
+def discriminate_loss(real_outputs: torch.Tensor, fake_outputs: torch.Tensor) -> torch.Tensor:
+    """`Discriminate_Loss` (losses_utils.py:106-110)"""
+    return ((real_outputs - 1) ** 2 / 2).mean() + (fake_outputs ** 2 / 2).mean()
+
+
+def flow_loss(gen_flows: torch.Tensor, gt_flows: torch.Tensor) -> torch.Tensor:
+    """`Flow_Loss` (losses_utils.py:10-15)"""
+    return (gen_flows - gt_flows).abs().mean()
+
+
+def generator_loss_full(out, rgb_t, op_t, d_gen, flow_pred=None, flow_gt=None, lam_adv=0.05, lam_gdl=1.0, lam_flow=2.0,
+                        lam_lp=1.0, lam_lp_op=1.0, lam_latent=1.0) -> torch.Tensor:
+    """`Twostream_vq_Loss.forward` (loss_zoo.py:310-336); the FlowNet2-SD term enters only through precomputed
+    flows"""
+    rgb = out[0]
+    loss = generator_loss(out, rgb_t, op_t, lam_lp, lam_lp_op, lam_latent) + lam_adv * adversarial_loss(d_gen) + \
+        lam_gdl * gradient_loss(rgb, rgb_t)
+    if flow_pred is not None:
+        loss = loss + lam_flow * flow_loss(flow_pred, flow_gt)
+    return loss
+
+
+def train_step_gan(generator: torch.nn.Module, discriminator: torch.nn.Module, optimizer_G, optimizer_D,
+                   rgb: torch.Tensor, op: torch.Tensor, flow_fn: Optional[Callable] = None, **lams):
+    """One iteration of the joint loop (train_helper.py:296-339): G forward, D(G(x)) for the adversarial term, the D
+    update on (target, detached prediction), then the G update.  The gradient that reaches G through D uses the
+    filters D had when `d_gen` was computed (before its update), i.e. the exact derivative of the loss value.
+    `flow_fn(prev_frame, frame) -> flow` stands in for FlowNet2-SD when given."""
+    b = rgb.shape[0]
+    rgb_in = rgb[:, :-1].reshape(b, -1, *rgb.shape[-2:])
+    op_in = op[:, :-1].reshape(b, -1, *op.shape[-2:])
+    rgb_t, op_t = rgb[:, -1], op[:, -1]
+    out = generator(rgb_in, op_in)
+    flow_pred = flow_gt = None
+    if flow_fn is not None:
+        with torch.no_grad():
+            flow_pred, flow_gt = flow_fn(rgb[:, -2], out[0].detach()), flow_fn(rgb[:, -2], rgb_t)
+    d_params = [p for p in discriminator.parameters() if p.requires_grad]
+    for p in d_params:                 # the G step needs dL/d(frame) through D, not D's weight gradients
+        p.requires_grad_(False)
+    try:
+        d_gen = discriminator(out[0])
+    finally:
+        for p in d_params:
+            p.requires_grad_(True)
+    g_loss = generator_loss_full(out, rgb_t, op_t, d_gen, flow_pred, flow_gt, **lams)
+    d_loss = discriminate_loss(discriminator(rgb_t), discriminator(out[0].detach()))
+    optimizer_D.zero_grad(set_to_none=True)
+    d_loss.backward()
+    optimizer_D.step()
+    optimizer_G.zero_grad(set_to_none=True)
+    g_loss.backward()
+    optimizer_G.step()
+    return g_loss.detach(), d_loss.detach()
+
+
 # ---- score fusion and frame-level AUC (the step after the records) ------------------------------
 
 LAM_MAP = {"avenue": (0.04, 0.65), "ped2": (0.01, 0.55), "shanghaitech": (0.13, 0.60)}   # test_helper.py:565-569

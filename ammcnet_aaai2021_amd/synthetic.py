@@ -159,6 +159,30 @@ def make_unet_state(cin=12, cout=3, tag="ammc-unet") -> "OrderedDict[str, torch.
     return sd
 
 
+def discriminator_schema(input_nc=3, num_filters=(128, 256, 512, 512)):
+    """state_dict entries of `PixelDiscriminator(input_nc, num_filters, use_norm=False)`
+    (reference pix2pix_networks.py:604-631): convs at net.0, net.2, ..., LeakyReLU in between"""
+    chans = [input_nc] + list(num_filters[:-1])
+    for i in range(len(chans) - 1):
+        yield f"net.{2 * i}.weight", (chans[i + 1], chans[i], 4, 4)
+        yield f"net.{2 * i}.bias", (chans[i + 1],)
+    last = 2 * (len(chans) - 1)
+    yield f"net.{last}.weight", (1, num_filters[-1], 4, 4)
+    yield f"net.{last}.bias", (1,)
+
+
+def make_discriminator_state(input_nc=3, num_filters=(128, 256, 512, 512), tag="ammc-d"):
+    sd = OrderedDict()
+    for key, shape in discriminator_schema(input_nc, num_filters):
+        t = f"{tag}:{key}"
+        if len(shape) == 1:
+            sd[key] = hashed_uniform(t, shape, -0.1, 0.1)
+        else:
+            bound = (6.0 / (shape[1] * 16)) ** 0.5
+            sd[key] = hashed_uniform(t, shape, -bound, bound)
+    return sd
+
+
 # ----------------------------------------------------------------------------
 # synthetic clips (SURVEY.md 8(d); reference loader two_stream_dataset.py:72-99)
 # ----------------------------------------------------------------------------

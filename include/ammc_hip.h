@@ -35,6 +35,7 @@ extern "C" {
 #define AMMC_ACT_NONE 0
 #define AMMC_ACT_RELU 1
 #define AMMC_ACT_TANH 2
+#define AMMC_ACT_LRELU 3   /* nn.LeakyReLU(0.1), pix2pix_networks.py:606 */
 
 /* library / device identification ---------------------------------------- */
 int ammc_abi_version(void);                    /* bumps on any signature change */
@@ -226,6 +227,18 @@ int ammc_unpack_convt_wgrad_f32(const float* packed, int32_t cin, int32_t co, fl
 int ammc_pack_conv_dgrad_weight_f32(const float* w_oihw, int32_t cout, int32_t cin, int32_t cout_p, int32_t rows,
                                     float* out, void* stream);
 int ammc_transpose_pad_f32(const float* w, int32_t rows, int32_t cols, int32_t rows_p, float* out, void* stream);
+
+/* PixelDiscriminator (Code/models/pix2pix_networks.py:580-631): Conv2d(k 4, padding 2, stride 2|1, bias) + LeakyReLU(0.1).
+ * Forward and weight gradient run through ammc_conv_gemm_f32 / ammc_conv_wgrad_f32 with ntaps 16 (x_step / a_step =
+ * the stride, x / a = the corner of a 2-pixel halo).  Input gradient: stride 1 = one 16-tap conv with the flipped
+ * filter; stride 2 = four 2x2-tap convs over the output gradient, one per input-pixel parity (py, px), written
+ * through doubled y strides.  This packs those filters: stride 1 -> [rows][16*cout_p], stride 2 ->
+ * [4][rows][4*cout_p] (phase = py*2+px). */
+int ammc_pack_conv4_dgrad_weight_f32(const float* w_oihw, int32_t cout, int32_t cin, int32_t cout_p, int32_t rows,
+                                     int32_t stride, float* out, void* stream);
+/* g *= (y > 0 ? 1 : slope) in place: autograd of nn.LeakyReLU evaluated on the layer output */
+int ammc_lrelu_bwd_f32(const float* y, int64_t y_bs, int64_t y_rs, int64_t y_ps, float* g, int64_t g_bs, int64_t g_rs,
+                       int64_t g_ps, int32_t batch, int32_t h, int32_t w, int32_t c, float slope, void* stream);
 
 /* nn.BatchNorm2d in training mode (unet.py:12,15).  Per-channel reductions write
  * partial[ammc_chan_reduce_blocks(B*H*W)][Q][C]; the finalizers combine them in fp64, fixed order. */

@@ -276,6 +276,60 @@ def generator_loss(out, rgb_t: torch.Tensor, op_t: torch.Tensor,
         lam_latent * (rd + od).sum()
 
 
+# ---- PixelDiscriminator and the remaining generator / discriminator loss terms -------------
+
+def pixel_discriminator(sd: State, x: torch.Tensor) -> torch.Tensor:
+    """`PixelDiscriminator.forward` with use_norm=False (pix2pix_networks.py:604-631):
+    Conv2d(k 4, padding 2, stride 2, bias) + LeakyReLU(0.1) for every entry of num_filters[:-1],
+    then Conv2d(num_filters[-1] -> 1, k 4, stride 1, padding 2).  `sd` holds net.{0,2,4,...}.{weight,bias}."""
+    idx = sorted({int(k.split(".")[1]) for k in sd if k.startswith("net.")})
+    for i in idx[:-1]:
+        x = F.leaky_relu(F.conv2d(x, sd[f"net.{i}.weight"], sd[f"net.{i}.bias"], stride=2, padding=2), 0.1)
+    i = idx[-1]
+    return F.conv2d(x, sd[f"net.{i}.weight"], sd[f"net.{i}.bias"], stride=1, padding=2)
+
+
+def gradient_loss(gen: torch.Tensor, gt: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
+    """`Gradient_Loss` (losses_utils.py:30-61): backward differences with a zero on the left / top, SUMMED over
+    the channels by the [-1, 1] filters (one output channel), |gt - gen| ** alpha, mean over [B,1,H,W]."""
+    def dxy(t):
+        s = t.sum(1, keepdim=True)
+        dx = s - F.pad(s, (1, 0, 0, 0))[..., :, :-1]
+        dy = s - F.pad(s, (0, 0, 1, 0))[..., :-1, :]
+        return dx, dy
+    gx, gy = dxy(gen)
+    tx, ty = dxy(gt)
+    return ((tx - gx).abs() ** alpha + (ty - gy).abs() ** alpha).mean()
+
+
+def adversarial_loss(fake_outputs: torch.Tensor) -> torch.Tensor:
+    """`Adversarial_Loss` (losses_utils.py:100-104), least-squares GAN"""
+    return ((fake_outputs - 1) ** 2 / 2).mean()
+
+
+def discriminate_loss(real_outputs: torch.Tensor, fake_outputs: torch.Tensor) -> torch.Tensor:
+    """`Discriminate_Loss` (losses_utils.py:106-110)"""
+    return ((real_outputs - 1) ** 2 / 2).mean() + (fake_outputs ** 2 / 2).mean()
+
+
+def flow_loss(gen_flows: torch.Tensor, gt_flows: torch.Tensor) -> torch.Tensor:
+    """`Flow_Loss` (losses_utils.py:10-15)"""
+    return (gen_flows - gt_flows).abs().mean()
+
+
+def generator_loss_full(out, rgb_t, op_t, d_gen, flow_pred=None, flow_gt=None, lam_adv=0.05, lam_gdl=1.0,
+                        lam_flow=2.0, lam_lp=1.0, lam_lp_op=1.0, lam_latent=1.0) -> torch.Tensor:
+    """`Twostream_vq_Loss.forward` (loss_zoo.py:310-336).  The FlowNet2-SD term (out of scope)
+    enters only through precomputed flows; the latent term is the sum of the two commit scores (see
+    `generator_loss`)."""
+    rgb, op, (rd, od), _ = out[:4]
+    loss = lam_adv * adversarial_loss(d_gen) + lam_gdl * gradient_loss(rgb, rgb_t) + \
+        lam_lp * intensity_l2(rgb, rgb_t) + lam_lp_op * intensity_l2(op, op_t) + lam_latent * (rd + od).sum()
+    if flow_pred is not None:
+        loss = loss + lam_flow * flow_loss(flow_pred, flow_gt)
+    return loss
+
+
 def clone_state(sd: State, requires_grad: bool = False) -> State:
     out = {}
     for key, v in sd.items():

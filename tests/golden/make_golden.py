@@ -229,6 +229,81 @@ def param_counts(ref, name="param_counts"):
                    "twostream_state_keys": list(net.state_dict().keys())}, fp, indent=0)
 
 
+def load_ref_losses_and_d():
+    """`PixelDiscriminator` imports cleanly by path; `losses_utils` does a package-relative import of the training
+    constants (argparse + .ini files that are not shipped), so it is loaded inside a synthetic package whose
+    `main.constant_train` is a two-attribute stand-in for that CONFIG object (no reference logic is replaced)."""
+    spec = importlib.util.spec_from_file_location("ref_pix2pix", f"{REF}/models/pix2pix_networks.py")
+    p2p = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(p2p)
+    for name in ("refpkg", "refpkg.main", "refpkg.models", "refpkg.models.losses"):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+    ct = types.ModuleType("refpkg.main.constant_train")
+    ct.const = types.SimpleNamespace(gpu_idx=os.environ.get("CUDA_VISIBLE_DEVICES", "0"))
+    sys.modules["refpkg.main.constant_train"] = ct
+    spec = importlib.util.spec_from_file_location("refpkg.models.losses.losses_utils",
+                                                  f"{REF}/models/losses/losses_utils.py")
+    lu = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = lu
+    spec.loader.exec_module(lu)
+    return p2p, lu
+
+
+def discriminator_and_losses(name="discriminator_64_b2"):
+    """PixelDiscriminator forward + the LSGAN / gradient-difference losses of the reference, with the gradients
+    autograd derives for them.  `Gradient_Loss.forward` calls `.cuda()` on its filters; that
+    method is made a no-op for the duration of the call (there is no GPU in the authoring container)."""
+    p2p, lu = load_ref_losses_and_d()
+    sd = S.make_discriminator_state()
+    net = p2p.PixelDiscriminator(3, [128, 256, 512, 512], use_norm=False)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    _, _, real, _ = S.make_clips(2, 64, 64, tag=name)
+    fake = (real + 0.3 * S.hashed_uniform(name + ":fake", tuple(real.shape))).clamp(-1, 1)
+    fake.requires_grad_(True)
+    out = {}
+    # generator side: adversarial + gradient-difference terms, gradient w.r.t. the fake frame and D's parameters
+    d_gen = net(fake)
+    adv = lu.Adversarial_Loss()(d_gen)
+    adv.backward()
+    out["d_gen"] = d_gen.detach().numpy()
+    out["adv"] = np.float64(adv.item())
+    out["adv_dfake"] = fake.grad.clone().numpy()
+    for k, p in net.named_parameters():
+        g = p.grad.detach()
+        out["adv_dW:" + k] = g.numpy().copy() if g.numel() <= 4096 else g.flatten()[::97].numpy().copy()
+        out["adv_dWnorm:" + k] = np.float64(g.double().norm().item())
+    net.zero_grad()
+    fake.grad = None
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        gdl = lu.Gradient_Loss(1, 3)(fake, real)
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    gdl.backward()
+    out["gdl"] = np.float64(gdl.item())
+    out["gdl_dfake"] = fake.grad.clone().numpy()
+    # discriminator side
+    net.zero_grad()
+    d_real, d_fake = net(real), net(fake.detach())
+    dl = lu.Discriminate_Loss()(d_real, d_fake)
+    dl.backward()
+    out["d_real"] = d_real.detach().numpy()
+    out["d_loss"] = np.float64(dl.item())
+    for k, p in net.named_parameters():
+        g = p.grad.detach()
+        out["dis_dW:" + k] = g.numpy().copy() if g.numel() <= 4096 else g.flatten()[::97].numpy().copy()
+        out["dis_dWnorm:" + k] = np.float64(g.double().norm().item())
+    out["flow_loss"] = np.float64(lu.Flow_Loss()(fake.detach()[:, :2], real[:, :2]).item())
+    out["param_count"] = np.int64(sum(p.numel() for p in net.parameters()))
+    out["state_keys"] = np.array(list(net.state_dict().keys()))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if not k.startswith(("adv_dW", "dis_dW"))})
+
+
 def main():
     torch.set_num_threads(8)
     ref = load_ref_unet()
@@ -241,6 +316,7 @@ def main():
     twostream_eval(ref, 256, 2, 256, "twostream_256_b2_eval", full=False)
     twostream_train(ref, 64, 2, "twostream_64_b2_train")
     score_fusion_golden()
+    discriminator_and_losses()
 
 
 

@@ -178,3 +178,41 @@ def test_oracle_vs_live_reference():
         got = O.twostream_forward(O.clone_state(sd), rgb_x, op_x, 2)
     assert rel_err(got[0], want[0]) <= TOL and rel_err(got[1], want[1]) <= TOL
     assert rel_err(got[2][0], want[2][0]) <= TOL and rel_err(got[3][1], want[3][1]) <= TOL
+
+
+def test_discriminator_and_losses_golden():
+    """oracle restatements of PixelDiscriminator / LSGAN / gradient-difference losses against
+    values and autograd gradients recorded from the reference classes (tests/golden/make_golden.py)."""
+    g = np.load(os.path.join(GOLDEN, "discriminator_64_b2.npz"))
+    name = "discriminator_64_b2"
+    sd = S.make_discriminator_state()
+    assert list(sd.keys()) == list(g["state_keys"]) and sum(v.numel() for v in sd.values()) == int(g["param_count"])
+    _, _, real, _ = S.make_clips(2, 64, 64, tag=name)
+    fake = (real + 0.3 * S.hashed_uniform(name + ":fake", tuple(real.shape))).clamp(-1, 1).requires_grad_(True)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    d_gen = O.pixel_discriminator(sdg, fake)
+    assert rel_err(d_gen.detach().numpy(), g["d_gen"]) < 1e-5
+    adv = O.adversarial_loss(d_gen)
+    assert abs(adv.item() - float(g["adv"])) < 1e-6 * max(1.0, abs(float(g["adv"])))
+    adv.backward()
+    assert rel_err(fake.grad.numpy(), g["adv_dfake"]) < 1e-4
+    for k, v in sdg.items():
+        gr = v.grad
+        ref = g["adv_dW:" + k]
+        got = gr.numpy() if gr.numel() <= 4096 else gr.flatten()[::97].numpy()
+        assert rel_err(got, ref) < 1e-4, k
+        assert abs(gr.double().norm().item() - float(g["adv_dWnorm:" + k])) < 1e-4 * float(g["adv_dWnorm:" + k])
+    fake.grad = None
+    gdl = O.gradient_loss(fake, real)
+    assert abs(gdl.item() - float(g["gdl"])) < 1e-6
+    gdl.backward()
+    assert rel_err(fake.grad.numpy(), g["gdl_dfake"]) < 1e-5
+    sdd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    d_real, d_fake = O.pixel_discriminator(sdd, real), O.pixel_discriminator(sdd, fake.detach())
+    assert rel_err(d_real.detach().numpy(), g["d_real"]) < 1e-5
+    dl = O.discriminate_loss(d_real, d_fake)
+    assert abs(dl.item() - float(g["d_loss"])) < 1e-6 * max(1.0, abs(float(g["d_loss"])))
+    dl.backward()
+    for k, v in sdd.items():
+        assert abs(v.grad.double().norm().item() - float(g["dis_dWnorm:" + k])) < 1e-4 * float(g["dis_dWnorm:" + k])
+    assert abs(O.flow_loss(fake.detach()[:, :2], real[:, :2]).item() - float(g["flow_loss"])) < 1e-6
