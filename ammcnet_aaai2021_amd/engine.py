@@ -29,6 +29,10 @@ from ._lib import ACT_NONE, ACT_RELU, ACT_TANH, AmmcConvDesc
 BN_EPS = 1e-5
 # S16 kernels: filter fragments straight from L2 into registers (k-blocked filter) instead of through LDS
 S16_BDIRECT = os.environ.get("AMMC_S16_BDIRECT", "0") != "0"   # measured: no faster than LDS-staged B
+# AMMC_GRAPH=1: eval forwards replay a captured hipGraph (one host call per forward).  Off by default: measured
+# on MI355X the ~100 launches of a forward are NOT launch-bound (batch 1: 1.58 ms eager vs 1.58 ms replayed; the
+# chain of dependent small kernels is the floor), and a replay costs an extra copy of the inputs into static buffers.
+USE_GRAPH = os.environ.get("AMMC_GRAPH", "0") != "0"
 
 
 def _ptr(t: torch.Tensor, elem_off: int = 0) -> int:
@@ -421,6 +425,7 @@ class EvalEngine:
         self._plans: Dict[Tuple, dict] = {}
         self._arenas: Dict[Tuple, Tuple[int, List[torch.Tensor]]] = {}
         self._timed = False          # bench.py: bracket every launch with HIP events
+        self.use_graph = USE_GRAPH   # replay one captured hipGraph per forward (AMMC_GRAPH=0: ~100 eager launches)
         self.timings = []
 
     # ---- parameters ---------------------------------------------------------------
@@ -526,6 +531,65 @@ class EvalEngine:
         return y
 
     # ---- forward ----------------------------------------------------------------------
+    def _launch_all(self, st, B, H, W, xs, ys, tgts, accs, stream, launch):
+        """every launch of one forward, in order: input layout, the plan, the two `outc` layers"""
+        lib = self.lib
+        streams: List[StreamGraph] = st["streams"]
+        for s, x in zip(streams, xs):
+            launch(lib.ammc_nchw_to_s16_f32 if self.s16 else lib.ammc_nchw_to_nhwc_f32,
+                   (_ptr(x), B, s.sp.cin, H, W, s.x_in.pix0(), *s.x_in.strides, s.sp.inc.cin_p),
+                   dict(name="nchw_to_nhwc", kernel="nchw_to_nhwc", flops=0.0,
+                        bytes=4.0 * B * H * W * (s.sp.cin + s.sp.inc.cin_p)))
+        plan = st["plan"]
+        for (fn, args, _), meta in zip(plan.calls, plan.meta):
+            launch(fn, args, meta)
+        for s, y, tgt, acc in zip(streams, ys, tgts, accs):
+            s.outc.y = _ptr(y)
+            if tgt is not None:
+                s.outc.sq_target, s.outc.sq_acc = _ptr(tgt), _ptr(acc)
+            else:
+                s.outc.sq_target, s.outc.sq_acc = None, None
+            launch(lib.ammc_conv_gemm_s16 if self.s16 else lib.ammc_conv_gemm_f32, (C.byref(s.outc),),
+                   dict(name="outc_tanh", kernel=("conv_gemm_s16" if self.s16 else "conv_gemm_f32") + "<128x32>",
+                        flops=2.0 * B * H * W * 9 * 64 * s.sp.cout, bytes=4.0 * B * H * W * (64 + s.sp.cout)))
+
+    def _graph_for(self, st, B, H, W, device, tflags):
+        """hipGraph of one forward over static input / output buffers (captured once per plan and target
+        pattern): a replay is ONE host call instead of ~100 ctypes launches, which is what bounds small batches."""
+        graphs = st.setdefault("graphs", {})
+        g = graphs.get(tflags)
+        if g is not None:
+            return g
+        streams = st["streams"]
+        g = dict(x=[torch.zeros(B, s.sp.cin, H, W, device=device) for s in streams],
+                 y=[torch.empty(B, s.sp.cout, H, W, device=device) for s in streams])
+        g["t"] = [torch.zeros(B, s.sp.cout, H, W, device=device) if f else None for s, f in zip(streams, tflags)]
+        g["acc"] = [torch.zeros(B, device=device) if f else None for f in tflags]
+
+        def run_on(stream_handle):
+            def launch(fn, args, meta):
+                rc = fn(*args, stream_handle)
+                if rc != 0:
+                    _lib.check(rc, meta["name"])
+            for a in g["acc"]:
+                if a is not None:
+                    a.zero_()
+            self._launch_all(st, B, H, W, g["x"], g["y"], g["t"], g["acc"], stream_handle, launch)
+
+        cur = torch.cuda.current_stream(device)
+        side = torch.cuda.Stream(device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):                    # eager warm-up: one-off function attributes, lazy module load
+            run_on(side.cuda_stream)
+        cur.wait_stream(side)
+        torch.cuda.synchronize(device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            run_on(torch.cuda.current_stream(device).cuda_stream)
+        g["graph"] = graph
+        graphs[tflags] = g
+        return g
+
     def forward(self, *inputs: torch.Tensor, targets=None):
         """`targets`: optional per-stream NCHW tensors shaped like the predicted frames (None entries allowed);
         the `outc` epilogue then also accumulates the per-sample squared error of `psnr_error`
@@ -537,65 +601,54 @@ class EvalEngine:
         B, _, H, W = x0.shape
         st = self._get(B, H, W, x0.device)
         stream = torch.cuda.current_stream(x0.device).cuda_stream
-        lib = self.lib
         streams: List[StreamGraph] = st["streams"]
-        outs = []
-        keep = []
         timed = self._timed
         recs = []
-
-        def launch(fn, args, meta):
-            if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            rc = fn(*args, stream)
-            if timed:
-                e1.record()
-                recs.append((meta, e0, e1))
-            if rc != 0:
-                _lib.check(rc, meta["name"])
-
-        for s, x in zip(streams, inputs):
+        tg = []
+        for si, (s, x) in enumerate(zip(streams, inputs)):
             if x.shape[1] != s.sp.cin or x.shape[0] != B or x.shape[2] != H or x.shape[3] != W:
                 raise ValueError(f"input shape {tuple(x.shape)} does not match the model ({s.sp.cin} channels)")
-            x = x.detach()
-            if x.dtype != torch.float32 or not x.is_contiguous():
-                x = x.float().contiguous()
-            keep.append(x)
-            launch(lib.ammc_nchw_to_s16_f32 if self.s16 else lib.ammc_nchw_to_nhwc_f32,
-                   (_ptr(x), B, s.sp.cin, H, W, s.x_in.pix0(), *s.x_in.strides,
-                                               s.sp.inc.cin_p),
-                   dict(name="nchw_to_nhwc", kernel="nchw_to_nhwc", flops=0.0,
-                        bytes=4.0 * B * H * W * (s.sp.cin + s.sp.inc.cin_p)))
-        if timed:
-            plan = st["plan"]
-            for (fn, args, _), meta in zip(plan.calls, plan.meta):
-                launch(fn, args, meta)
-        else:
-            st["plan"].run(stream)
-        sq = []
-        for si, s in enumerate(streams):
-            y = torch.empty((B, s.sp.cout, H, W), device=x0.device, dtype=torch.float32)
-            s.outc.y = _ptr(y)
             tgt = targets[si] if targets is not None and si < len(targets) else None
-            if tgt is not None:
-                if tuple(tgt.shape) != tuple(y.shape):
-                    raise ValueError(f"target shape {tuple(tgt.shape)} != prediction shape {tuple(y.shape)}")
-                tgt = tgt.detach().float().contiguous()
-                acc = torch.zeros(B, device=x0.device, dtype=torch.float32)
-                keep.extend([tgt, acc])
-                s.outc.sq_target, s.outc.sq_acc = _ptr(tgt), _ptr(acc)
-                sq.append(acc)
-            else:
-                s.outc.sq_target, s.outc.sq_acc = None, None
-                sq.append(None)
-            launch(lib.ammc_conv_gemm_s16 if self.s16 else lib.ammc_conv_gemm_f32, (C.byref(s.outc),),
-                   dict(name="outc_tanh", kernel=("conv_gemm_s16" if self.s16 else "conv_gemm_f32") + "<128x32>", flops=2.0 * B * H * W * 9 * 64 * s.sp.cout,
-                        bytes=4.0 * B * H * W * (64 + s.sp.cout)))
-            outs.append(y)
-        if timed:
-            torch.cuda.synchronize()
-            self.timings = [(m, e0.elapsed_time(e1)) for m, e0, e1 in recs]
+            if tgt is not None and tuple(tgt.shape) != (B, s.sp.cout, H, W):
+                raise ValueError(f"target shape {tuple(tgt.shape)} != prediction shape {(B, s.sp.cout, H, W)}")
+            tg.append(tgt)
+
+        use_graph = self.use_graph and not timed and not torch.cuda.is_current_stream_capturing()
+        if use_graph:
+            g = self._graph_for(st, B, H, W, x0.device, tuple(t is not None for t in tg))
+            for dst, x in zip(g["x"], inputs):
+                dst.copy_(x.detach())
+            for dst, t in zip(g["t"], tg):
+                if t is not None:
+                    dst.copy_(t.detach())
+            g["graph"].replay()
+            outs = [y.clone() for y in g["y"]]
+            sq = [a.clone() if a is not None else None for a in g["acc"]]
+        else:
+            def launch(fn, args, meta):
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                rc = fn(*args, stream)
+                if timed:
+                    e1.record()
+                    recs.append((meta, e0, e1))
+                if rc != 0:
+                    _lib.check(rc, meta["name"])
+
+            xs, keep = [], []
+            for x in inputs[:len(streams)]:
+                x = x.detach()
+                if x.dtype != torch.float32 or not x.is_contiguous():
+                    x = x.float().contiguous()
+                xs.append(x)
+            outs = [torch.empty((B, s.sp.cout, H, W), device=x0.device, dtype=torch.float32) for s in streams]
+            tt = [t.detach().float().contiguous() if t is not None else None for t in tg]
+            sq = [torch.zeros(B, device=x0.device, dtype=torch.float32) if t is not None else None for t in tg]
+            self._launch_all(st, B, H, W, xs, outs, tt, sq, stream, launch)
+            if timed:
+                torch.cuda.synchronize()
+                self.timings = [(m, e0.elapsed_time(e1)) for m, e0, e1 in recs]
         self._last = st
         n_el = [float(s.sp.cout * H * W) for s in streams]
         self.last_psnr = [10.0 * torch.log10(n / a) if a is not None else None for a, n in zip(sq, n_el)]

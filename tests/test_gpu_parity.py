@@ -307,3 +307,27 @@ def test_fused_psnr_in_outc_epilogue(prec):
         w = O.twostream_forward(O.clone_state(sd), rgb_x, op_x, 2)
     want_r = torch.stack([O.psnr_error(w[0][i:i + 1], rgb_t[i:i + 1]) for i in range(3)])
     assert rel_err(rp.cpu(), want_r) <= 1e-5
+
+
+def test_hipgraph_replay_matches_eager():
+    """`engine.use_graph`: one captured hipGraph per (shape, target pattern); replays must reproduce the eager
+    launches bit for bit, with and without the fused PSNR targets, across changing inputs"""
+    net = A.get_twostream((12, 6), (3, 2), 64, 256, 2)
+    net.load_state_dict(S.make_twostream_state())
+    net = net.to(DEV).eval()
+    for tag in ("graph-a", "graph-b"):
+        rgb_x, op_x, rgb_t, op_t = (t.to(DEV) for t in S.make_clips(2, 64, 64, tag=tag))
+        want = net(rgb_x, op_x)
+        eng = net._engine
+        want_s = net.forward_scored(rgb_x, op_x, rgb_t, op_t)
+        eng.use_graph = True
+        got = net(rgb_x, op_x)
+        got_s = net.forward_scored(rgb_x, op_x, rgb_t, op_t)
+        eng.use_graph = False
+        assert net._engine is eng
+        for a, b in ((want[0], got[0]), (want[1], got[1]), (want[2][0], got[2][0]), (want[2][1], got[2][1]),
+                     (want[3][0], got[3][0]), (want[3][1], got[3][1]), (want_s[0][0], got_s[0][0])):
+            assert torch.equal(a, b)
+        # the squared-error accumulation uses float atomics across workgroups: order-dependent in the last bits
+        assert torch.allclose(want_s[1], got_s[1], rtol=1e-5, atol=0)
+        assert torch.allclose(want_s[2], got_s[2], rtol=1e-5, atol=0)
