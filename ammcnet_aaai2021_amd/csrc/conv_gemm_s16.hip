@@ -59,7 +59,7 @@ __device__ __forceinline__ void join8(const f16x8& hi, const f16x8& lo, float (&
 // 16-bit MFMA rate: DMA writes + fragment reads saturate the 128-256 B/clk LDS port at ~40 % MFMA
 // utilisation); taking B out halves that traffic.
 template <int WGM, int WGN, int TM, int TN, int NS, bool BD>
-__global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_gemm_s16_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN >= 1024 ? 1 : 2)) void conv_gemm_s16_kernel(ConvArgs a) {
   constexpr int NT = 64 * WGM * WGN;        // threads: one wave per (wm, wn)
   constexpr int BM = WGM * TM * 32;
   constexpr int BN = WGN * TN * 32;
@@ -477,6 +477,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_gemm_s16_kernel(ConvAr
 
 __global__ void splitk_epilogue_kernel(ConvArgs a);
 
+// conv_tap_s16.hip: the halo-patch kernel for stride-1 3x3 layers; -12345 = not its case
+int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream);
+
 template <int WGM, int WGN, int TM, int TN, int NS = 2, bool BD = false>
 int launch(const ConvArgs& a, hipStream_t stream) {
   constexpr int BM = WGM * TM * 32;
@@ -716,6 +719,10 @@ extern "C" int ammc_conv_gemm_s16(const AmmcConvDesc* desc, void* stream) {
   a.dbg = dbg;
   a.ksplit = 1;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (d.ntaps == 9) {
+    const int rc = conv_tap_s16_try(d, a.kpad, s);
+    if (rc != -12345) return rc;
+  }
   // split-K for layers that cannot fill the chip (small batch: 32x32 / 64x64 levels with K up to 4608): each K
   // slice is its own workgroup writing an fp32 partial tile; a streaming kernel sums the slices and finishes
   if (d.splitk_ws && !d.y_f32 && !d.w_kblk && d.up == 1 && d.n % 128 == 0 && a.nchunks >= 16) {
@@ -743,6 +750,7 @@ extern "C" int ammc_conv_gemm_s16(const AmmcConvDesc* desc, void* stream) {
   const bool many = M >= (int64_t)256 * 512 / (d.n >= 256 ? d.n / 128 : 1);
   if (d.n % 128 == 0) {
     if (big == 3 && many) return launch<4, 2, 2, 2, 3>(a, s);
+    if (big == 4 && many) return launch<8, 2, 1, 2>(a, s);     // 16 waves, 32x64 wave tiles
     return (big && many) ? launch<4, 2, 2, 2>(a, s) : launch<2, 2, 2, 2>(a, s);
   }
   if (big == 3 && many) return launch<8, 1, 1, 2, 3>(a, s);

@@ -1,0 +1,322 @@
+// 3x3 convolution (S16 operands, see conv_gemm_s16.hip) with the input tile resident in LDS across the nine taps.
+//
+// Why: the implicit-GEMM kernel re-fetches the A operand once per tap (K order tap-major), and measurement says its
+// time IS that traffic: with every MFMA removed it still takes 75-96 % of its time, at ~10-12 TB/s of L2 -> LDS DMA
+// summed over the chip (`AMMC_S16_DBG=2`).  Here a workgroup owns a spatial patch of 8 x 32
+// output pixels of one image and all (or 128) output channels.  For every block of 32 input channels the 10 x 34
+// halo patch is DMA'd into LDS ONCE (43.5 KB instead of 9 x 32 KB); tap (r, s) is then just a shifted LDS address:
+// an MFMA row tile is one image row of 32 pixels, whose A fragments for tap (r, s) are the 32 consecutive halo
+// pixels starting at (y + r, s).  Only the filter slice (16 KB for 128 output channels) is streamed per tap.
+// L2 -> LDS bytes per FLOP drop 2.3x (128 filters) to 3.7x (64 filters).
+//
+// LDS: halo patch, two stages (one per 32-channel block; the next block's patch arrives in six rounds spread over
+// taps 0..5 of the current one), filter slices, three stages (two slices in flight, counted vmcnt waits).  Rows are 128 B (32 channels of one pixel / one filter);
+// the 16-byte slots of row `p` are XOR-swizzled with (p >> 1) & 7 as in the GEMM kernels, which keeps both the
+// lane-linear DMA writes and the ds_read_b128 fragment reads (32 consecutive rows, any start parity) conflict free.
+// One workgroup (8 waves) per CU; accumulators: two fp32 sets (hi*hi, cross terms) per 32x32 tile.
+//
+// Serves: stride-1 3x3 convs with Cin % 32 == 0, W % 32 == 0, H % 8 == 0, N = 64 or a multiple of 128, S16 output
+// (every double_conv layer of the network at 256x256 except the two first ones).  Everything else stays on
+// conv_gemm_s16_kernel; ammc_conv_gemm_s16 dispatches.
+#include "ammc_common.h"
+#include <hip/hip_fp16.h>
+#include <stdlib.h>
+
+namespace ammc_s16 {
+
+typedef _Float16 f16x8t __attribute__((ext_vector_type(8)));
+
+struct TapArgs {
+  AmmcConvDesc d;
+  int tiles_x, tiles_y, n_tiles, ncc, kpad, dbg;
+};
+
+constexpr float T_LO_SCALE = 2048.f;
+constexpr float T_LO_INV = 1.f / 2048.f;
+constexpr int T_TH = 8, T_TW = 32, T_HW = T_TW + 2, T_HP = (T_TH + 2) * T_HW;     // 340 halo pixels
+constexpr int T_APIECES = T_HP * 8;                                              // 2720 16-byte pieces
+constexpr int T_AROUNDS = (T_APIECES + 511) / 512;                               // 6 rounds of 512 threads
+constexpr int T_ASTAGE = T_AROUNDS * 512 * 4;    // floats; padded to whole rounds so that EVERY wave issues every
+                                                 // round (the counted vmcnt waits below need wave-uniform counts)
+constexpr int T_NB = 3;                          // filter-slice stages: slices t+1 and t+2 fly during step t
+
+template <int WGM, int WGN, int TM, int TN>
+__global__ __launch_bounds__(512, 1) void conv_tap_s16_kernel(TapArgs a) {
+  static_assert(WGM * WGN == 8 && WGM * TM == T_TH, "8 waves, 8 image rows");
+  constexpr int BM = T_TH * T_TW;           // 256 output pixels
+  constexpr int BN = WGN * TN * 32;
+  constexpr int B_STAGE = BN * 32;          // floats
+  constexpr int BJ = BN * 8 / 512;          // filter pieces per thread per tap
+  constexpr int STAGES = 2 * T_ASTAGE + T_NB * B_STAGE;
+  constexpr int TILE = BM * BN;
+  constexpr int REGION = STAGES > TILE ? STAGES : TILE;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * T_ASTAGE;
+  int* tab_out = reinterpret_cast<int*>(smem + REGION);          // [BM]
+  int* tab_res = tab_out + BM;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WGN;
+  const int wn = wave % WGN;
+  const int h = lane >> 5;
+  const int l31 = lane & 31;
+  const AmmcConvDesc& d = a.d;
+
+  const int logical = ammc_xcd_remap(blockIdx.x, gridDim.x);
+  const int n0 = (logical % a.n_tiles) * BN;
+  int sp = logical / a.n_tiles;
+  const int tx = sp % a.tiles_x;
+  sp /= a.tiles_x;
+  const int ty = sp % a.tiles_y;
+  const int b = sp / a.tiles_y;
+  const int y0 = ty * T_TH, x0 = tx * T_TW;
+
+  // d.x is the halo corner of pixel (0,0); the patch of this workgroup starts at image pixel (y0 - 1, x0 - 1)
+  const float* xpatch = d.x + ((int64_t)b * d.x_bs + (int64_t)y0 * d.x_rs + (int64_t)x0 * d.x_ps);
+
+  // halo-patch DMA pieces of this thread: piece p = j*512 + tid -> halo pixel p >> 3, physical slot p & 7
+  int a_off[T_AROUNDS];
+#pragma unroll
+  for (int j = 0; j < T_AROUNDS; ++j) {
+    int p = j * 512 + tid;
+    p = p < T_APIECES ? p : T_APIECES - 1;
+    const int hp = p >> 3;
+    const int ls = (p & 7) ^ ((hp >> 1) & 7);
+    const int hy = hp / T_HW;
+    const int hx = hp - hy * T_HW;
+    a_off[j] = (int)((int64_t)hy * d.x_rs + (int64_t)hx * d.x_ps) + 4 * ls;
+  }
+  const int sl = (tid & 7) ^ ((tid >> 4) & 7);
+  const float* b_src[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) b_src[j] = d.w + (int64_t)(n0 + j * 64 + (tid >> 3)) * a.kpad + 4 * sl;
+
+  for (int i = tid; i < BM; i += 512) {
+    const int y = y0 + (i >> 5), x = x0 + (i & 31);
+    tab_out[i] = (int)((int64_t)b * d.y_bs + (int64_t)y * d.y_rs + (int64_t)x * d.y_ps);
+    tab_res[i] = (int)((int64_t)b * d.r_bs + (int64_t)y * d.r_rs + (int64_t)x * d.r_ps);
+  }
+
+  // (macros, not lambdas / dependent expressions: see the hipcc notes in DESIGN.md section 8)
+#define TAP_ISSUE_A(j, cc, stage)                                                     \
+  {                                                                                   \
+    const float* src_ = xpatch + a_off[j] + (cc) * 32;                                \
+    float* dst_ = As + (stage) * T_ASTAGE + ((j) * 512 + wave * 64) * 4;              \
+    __builtin_amdgcn_global_load_lds(src_, dst_, 16, 0, 0);                           \
+  }
+#define TAP_ISSUE_B(chunk, stage)                                                     \
+  _Pragma("unroll") for (int j_ = 0; j_ < BJ; ++j_) {                                 \
+    const float* src_ = b_src[j_] + (chunk) * 32;                                     \
+    float* dst_ = Bs + (stage) * B_STAGE + (j_ * 512 + wave * 64) * 4;                \
+    __builtin_amdgcn_global_load_lds(src_, dst_, 16, 0, 0);                           \
+  }
+
+  f32x16 hh[TM][TN], xx[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { hh[i][j][r] = 0.f; xx[i][j][r] = 0.f; }
+
+  const int swzb = (l31 >> 1) & 7;
+  const int b_row = (wn * TN * 32 + l31) * 32;
+  int hpb[TM];                                  // halo pixel of this lane's output pixel for tap (0,0)
+#pragma unroll
+  for (int i = 0; i < TM; ++i) hpb[i] = (wm * TM + i) * T_HW + l31;
+
+#define TAP_COMPUTE(tap, astage, bstage)                                                                   \
+  {                                                                                                        \
+    const float* Ac = As + (astage) * T_ASTAGE;                                                            \
+    const float* Bc = Bs + (bstage) * B_STAGE + b_row;                                                     \
+    int arow_[TM], aswz_[TM];                                                                              \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                       \
+      const int hp_ = hpb[i] + ((tap) / 3) * T_HW + ((tap) % 3);                                           \
+      arow_[i] = hp_ * 32;                                                                                 \
+      aswz_[i] = (hp_ >> 1) & 7;                                                                           \
+    }                                                                                                      \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                        \
+      const int g = 2 * s + h;                                                                             \
+      f16x8t ah[TM], al[TM], bh[TN], bl[TN];                                                               \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                     \
+        ah[i] = *reinterpret_cast<const f16x8t*>(Ac + arow_[i] + (((2 * g) ^ aswz_[i]) << 2));             \
+        al[i] = *reinterpret_cast<const f16x8t*>(Ac + arow_[i] + (((2 * g + 1) ^ aswz_[i]) << 2));         \
+      }                                                                                                    \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                     \
+        bh[j] = *reinterpret_cast<const f16x8t*>(Bc + j * 1024 + (((2 * g) ^ swzb) << 2));                 \
+        bl[j] = *reinterpret_cast<const f16x8t*>(Bc + j * 1024 + (((2 * g + 1) ^ swzb) << 2));             \
+      }                                                                                                    \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) {      \
+        hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], hh[i][j], 0, 0, 0);               \
+        xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], xx[i][j], 0, 0, 0);               \
+        xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], xx[i][j], 0, 0, 0);               \
+      }                                                                                                    \
+    }                                                                                                      \
+  }
+
+  // one step = one tap of one 32-channel block.  In flight while step t is contracted: the filter slices of steps
+  // t+1 and t+2 (three stages) and, during taps 0..5, one round of the next block's halo patch.  Every wave issues
+  // the same instructions in the same order, so `vmcnt(n)` with n = what was issued after slice t+1 retires exactly
+  // slice t+1 and everything older.  Literal counts only (a dependent asm operand loses the kernel's host stub).
+#define TAP_WAIT(n)                                                              \
+  {                                                                              \
+    if ((n) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               \
+    else if ((n) == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");          \
+    else if ((n) == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");          \
+    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                        \
+  }
+#define TAP_STEP(tap)                                                                                      \
+  {                                                                                                        \
+    if ((tap) < T_AROUNDS && !lastcc) { TAP_ISSUE_A((tap) < T_AROUNDS ? (tap) : 0, cc + 1, (cc + 1) & 1); } \
+    const int bs2_ = bs + 2 >= T_NB ? bs + 2 - T_NB : bs + 2;                                              \
+    if ((tap) < 7) {                                                                                       \
+      TAP_ISSUE_B(((tap) + 2) * a.ncc + cc, bs2_);                                                         \
+    } else if (!lastcc) {                                                                                  \
+      TAP_ISSUE_B(((tap) - 7) * a.ncc + cc + 1, bs2_);                                                     \
+    }                                                                                                      \
+    if (a.dbg != 2) TAP_COMPUTE(tap, cc & 1, bs);                                                          \
+    if (!lastcc) {                                                                                         \
+      TAP_WAIT(BJ + ((tap) < T_AROUNDS ? 1 : 0));                                                          \
+    } else {                                                                                               \
+      TAP_WAIT((tap) < 7 ? BJ : 0);                                                                        \
+    }                                                                                                      \
+    __builtin_amdgcn_s_barrier();                                                                          \
+    asm volatile("" ::: "memory");                                                                         \
+    bs = bs + 1 == T_NB ? 0 : bs + 1;                                                                      \
+  }
+
+#pragma unroll
+  for (int j = 0; j < T_AROUNDS; ++j) { TAP_ISSUE_A(j, 0, 0); }
+  TAP_ISSUE_B(0, 0);
+  TAP_ISSUE_B(a.ncc, 1);
+  TAP_WAIT(BJ);
+  __syncthreads();
+  int bs = 0;
+  for (int cc = 0; cc < a.ncc; ++cc) {
+    const bool lastcc = cc + 1 == a.ncc;
+    TAP_STEP(0) TAP_STEP(1) TAP_STEP(2) TAP_STEP(3) TAP_STEP(4) TAP_STEP(5) TAP_STEP(6) TAP_STEP(7) TAP_STEP(8)
+  }
+  __syncthreads();
+#undef TAP_WAIT
+#undef TAP_STEP
+#undef TAP_COMPUTE
+#undef TAP_ISSUE_A
+#undef TAP_ISSUE_B
+
+  // ---- epilogue: park the tile in LDS, then 8 channels of one pixel per thread (as conv_gemm_s16_kernel) ------
+  float* T = smem;                                               // [BM][BN]
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = (wn * TN + j) * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        T[row * BN + col] = hh[i][j][r] + xx[i][j][r] * T_LO_INV;
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int CG = BN / 8;
+  for (int item = tid; item < BM * CG; item += 512) {
+    const int row = item / CG;
+    const int cg = item - row * CG;
+    const int ncol0 = n0 + cg * 8;
+    float v[8];
+    {
+      const f32x4 t0 = *reinterpret_cast<const f32x4*>(T + row * BN + cg * 8);
+      const f32x4 t1 = *reinterpret_cast<const f32x4*>(T + row * BN + cg * 8 + 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[i] = t0[i]; v[4 + i] = t1[i]; }
+    }
+    if (d.scale) {
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.scale + ncol0);
+      const f32x4 s1 = *reinterpret_cast<const f32x4*>(d.scale + ncol0 + 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[i] *= s0[i]; v[4 + i] *= s1[i]; }
+    }
+    if (d.shift) {
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.shift + ncol0);
+      const f32x4 s1 = *reinterpret_cast<const f32x4*>(d.shift + ncol0 + 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[i] += s0[i]; v[4 + i] += s1[i]; }
+    }
+    if (d.act == AMMC_ACT_RELU) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+    }
+    if (d.res) {
+      const float* rp = d.res + tab_res[row] + ncol0;
+      const f16x8t rh = *reinterpret_cast<const f16x8t*>(rp);
+      const f16x8t rl = *reinterpret_cast<const f16x8t*>(rp + 4);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += (float)rh[i] + (float)rl[i] * T_LO_INV;
+    }
+    f16x8t hi, lo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const _Float16 hv = (_Float16)v[i];
+      hi[i] = hv;
+      lo[i] = (_Float16)((v[i] - (float)hv) * T_LO_SCALE);
+    }
+    if (d.overflow_flag) {
+      bool bad = false;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bad |= !(fabsf(v[i]) <= 65504.f);
+      if (bad) atomicOr(d.overflow_flag, 1);
+    }
+    float* yp = d.y + tab_out[row] + ncol0;
+    *reinterpret_cast<f16x8t*>(yp) = hi;
+    *reinterpret_cast<f16x8t*>(yp + 4) = lo;
+  }
+}
+
+template <int WGM, int WGN, int TM, int TN>
+static int launch_tap(const TapArgs& a, hipStream_t stream) {
+  constexpr int BN = WGN * TN * 32;
+  constexpr int STAGES = 2 * T_ASTAGE + T_NB * BN * 32;
+  constexpr int TILE = 256 * BN;
+  constexpr size_t lds = (size_t)((STAGES > TILE ? STAGES : TILE) + 2 * 256) * sizeof(float);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  auto kern = conv_tap_s16_kernel<WGM, WGN, TM, TN>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds);
+  if (e != hipSuccess) return (int)e;
+  TapArgs b = a;
+  b.n_tiles = a.d.n / BN;
+  const int grid = a.d.batch * a.tiles_y * a.tiles_x * b.n_tiles;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, b);
+  return ammc_launch_status();
+}
+
+// Called by ammc_conv_gemm_s16 (conv_gemm_s16.hip) after its argument checks.  Returns TAP_SKIP when the descriptor is
+// not this kernel's case (the caller then runs the implicit-GEMM kernel), else the launch status.
+int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream) {
+  static const int mode = getenv("AMMC_S16_TAP") ? atoi(getenv("AMMC_S16_TAP")) : 1;
+  static const int dbg = getenv("AMMC_S16_DBG") ? atoi(getenv("AMMC_S16_DBG")) : 0;
+  constexpr int TAP_SKIP = -12345;
+  if (!mode) return TAP_SKIP;
+  if (d.ntaps != 9 || d.up != 1 || d.x_step > 1 || d.y_f32 || d.w_kblk) return TAP_SKIP;
+  if (d.cin % 32 || d.width % T_TW || d.height % T_TH) return TAP_SKIP;
+  if (d.n != 64 && d.n % 128) return TAP_SKIP;
+  const int64_t tiles = (int64_t)d.batch * (d.height / T_TH) * (d.width / T_TW) * (d.n == 64 ? 1 : d.n / 128);
+  if (tiles < 192) return TAP_SKIP;                       // cannot fill the chip: the split-K path of the GEMM kernel is better
+  const int64_t patch = (int64_t)(T_TH + 1) * d.x_rs + (int64_t)(T_TW + 1) * d.x_ps;
+  if (patch >= (1LL << 30)) return TAP_SKIP;
+  TapArgs a;
+  a.d = d;
+  a.tiles_x = d.width / T_TW;
+  a.tiles_y = d.height / T_TH;
+  a.ncc = d.cin / 32;
+  a.kpad = kpad;
+  a.dbg = dbg;
+  a.n_tiles = 0;
+  if (d.n == 64) return launch_tap<8, 1, 1, 2>(a, stream);
+  return launch_tap<4, 2, 2, 2>(a, stream);
+}
+
+}  // namespace ammc_s16

@@ -1,0 +1,87 @@
+"""The halo-patch 3x3 kernel (csrc/conv_tap_s16.hip) through `ammc_conv_gemm_s16`, against an fp64 convolution of
+the same S16-rounded operands: shapes that the dispatcher sends to it (>= 192 tiles, Cin % 32 == 0, W % 32 == 0,
+H % 8 == 0, N = 64 | 128k) with folded-BN scale/shift, ReLU, an S16 residual, and a channel-sliced input (the
+concat buffers of the decoder).  Tolerance 2e-6 of max|ref| (fp32-equivalent arithmetic, fp32 accumulation)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ammcnet_aaai2021_amd import _lib, synthetic as S
+from ammcnet_aaai2021_amd._lib import ACT_NONE, ACT_RELU, AmmcConvDesc
+from ammcnet_aaai2021_amd.engine import Act, _ptr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _s16_act(x: torch.Tensor, c_total=None, c_off=0) -> Act:
+    """NCHW fp32 (device) -> halo-1 S16 activation occupying channels [c_off, c_off + C) of a wider buffer"""
+    lib = _lib.load()
+    B, Cc, H, W = x.shape
+    c_total = c_total or Cc
+    a = Act(torch.zeros(B, H + 2, W + 2, c_total, device=DEV), B, H, W, Cc, c_off, 1)
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.ammc_nchw_to_s16_f32(_ptr(x), B, Cc, H, W, a.pix0(), *a.strides, Cc, s), "nchw_to_s16")
+    return a
+
+
+def _s16_read(a: Act) -> torch.Tensor:
+    lib = _lib.load()
+    y = torch.empty(a.B, a.c, a.H, a.W, device=DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.ammc_s16_to_nchw_f32(a.pix0(), *a.strides, a.B, a.c, a.H, a.W, _ptr(y), s), "s16_to_nchw")
+    return y
+
+
+@pytest.mark.parametrize("B,H,W,cin,n,relu,res,sliced", [
+    (12, 64, 64, 64, 64, True, False, False),        # N = 64: 8 waves x (32 x 64)
+    (6, 64, 64, 32, 256, False, False, False),       # two N tiles, a single channel block
+    (6, 128, 64, 128, 128, True, True, False),       # four channel blocks, residual epilogue
+    (24, 32, 32, 64, 128, True, False, True),        # one tile per image, input = slice of a 128-channel buffer
+    (1, 256, 256, 64, 64, True, False, False),       # the 256x256 level of the network
+])
+def test_conv_tap_s16_vs_fp64(B, H, W, cin, n, relu, res, sliced):
+    lib = _lib.load()
+    tag = f"tap-{B}-{H}-{W}-{cin}-{n}"
+    x = S.hashed_uniform(tag + "x", (B, cin, H, W)).to(DEV)
+    w = (S.hashed_uniform(tag + "w", (n, cin, 3, 3)) * (2.0 / (9 * cin)) ** 0.5).to(DEV)
+    scale = S.hashed_uniform(tag + "s", (n,), 0.7, 1.3).to(DEV)
+    shift = S.hashed_uniform(tag + "b", (n,), -0.2, 0.2).to(DEV)
+    xa = _s16_act(x, 2 * cin if sliced else cin, cin if sliced else 0)
+    ra = _s16_act(S.hashed_uniform(tag + "r", (B, n, H, W)).to(DEV)) if res else None
+    ya = Act(torch.zeros(B, H + 2, W + 2, n, device=DEV), B, H, W, n, 0, 1)
+    wp = torch.empty(n, 9 * cin, device=DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.ammc_pack_conv_weight_f32(_ptr(w), n, cin, 3, cin, _ptr(wp), s), "pack")
+    ws = torch.empty_like(wp)
+    _lib.check(lib.ammc_split_rows_f32(_ptr(wp), wp.numel(), _ptr(ws), s), "split")
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    d = AmmcConvDesc()
+    d.x, d.w, d.y = xa.tap0(), _ptr(ws), ya.pix0()
+    d.scale, d.shift = _ptr(scale), _ptr(shift)
+    d.res = ra.pix0() if res else None
+    d.batch, d.height, d.width, d.cin, d.ntaps, d.n, d.up, d.cgroup = B, H, W, cin, 9, n, 1, n
+    d.act = ACT_RELU if relu else ACT_NONE
+    d.x_bs, d.x_rs, d.x_ps = xa.strides
+    d.y_bs, d.y_rs, d.y_ps = ya.strides
+    if res:
+        d.r_bs, d.r_rs, d.r_ps = ra.strides
+    d.overflow_flag = flag.data_ptr()
+    _lib.check(lib.ammc_conv_gemm_s16(C.byref(d), s), "conv_gemm_s16")
+    got = _s16_read(ya).double().cpu()
+    # reference on the operands as the kernel sees them (S16 round trip of x, w and the residual)
+    xr = _s16_read(xa).double().cpu()
+    wr = torch.empty_like(wp)
+    wsa = Act(ws.view(1, 1, n, 9 * cin), 1, 1, n, 9 * cin, 0, 0)
+    wr = _s16_read(wsa).view(9 * cin, n).t().reshape(n, 9, cin).permute(0, 2, 1).reshape(n, cin, 3, 3).double().cpu()
+    want = F.conv2d(xr, wr, padding=1) * scale.double().cpu().view(1, -1, 1, 1) + shift.double().cpu().view(1, -1, 1, 1)
+    if relu:
+        want = want.clamp_min(0)
+    if res:
+        want = want + _s16_read(ra).double().cpu()
+    err = float((got - want).abs().max() / want.abs().max())
+    assert err <= 2e-6, err
+    assert int(flag.item()) == 0
+    assert float(ya.buf[:, 0].abs().max()) == 0.0 and float(ya.buf[:, :, 0].abs().max()) == 0.0     # halo untouched
