@@ -40,19 +40,22 @@ constexpr int T_ASTAGE = T_AROUNDS * 512 * 4;    // floats; padded to whole roun
                                                  // round (the counted vmcnt waits below need wave-uniform counts)
 constexpr int T_NB = 3;                          // filter-slice stages: slices t+1 and t+2 fly during step t
 
-template <int WGM, int WGN, int TM, int TN>
-__global__ __launch_bounds__(512, 1) void conv_tap_s16_kernel(TapArgs a) {
+// AS = halo-patch stages.  2: the next channel block's patch is prefetched during the current one (one workgroup per
+// CU).  1: the patch is reloaded at every channel-block boundary and TWO workgroups share a CU (<= 80 KB of LDS,
+// <= 128 VGPRs), so one's loads and epilogue overlap the other's MFMAs - for layers with little work per patch.
+template <int WGM, int WGN, int TM, int TN, int AS>
+__global__ __launch_bounds__(512, (AS == 1 ? 2 : 1)) void conv_tap_s16_kernel(TapArgs a) {
   static_assert(WGM * WGN == 8 && WGM * TM == T_TH, "8 waves, 8 image rows");
   constexpr int BM = T_TH * T_TW;           // 256 output pixels
   constexpr int BN = WGN * TN * 32;
-  constexpr int B_STAGE = BN * 32;          // floats
-  constexpr int BJ = BN * 8 / 512;          // filter pieces per thread per tap
-  constexpr int STAGES = 2 * T_ASTAGE + T_NB * B_STAGE;
+  constexpr int BJ = BN * 8 >= 512 ? BN * 8 / 512 : 1;     // filter pieces per thread per tap (every wave issues:
+  constexpr int B_STAGE = BJ * 64 * 32;                    // a 32-filter slice is padded to 64 rows; floats)
+  constexpr int STAGES = AS * T_ASTAGE + T_NB * B_STAGE;
   constexpr int TILE = BM * BN;
   constexpr int REGION = STAGES > TILE ? STAGES : TILE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
-  float* Bs = smem + 2 * T_ASTAGE;
+  float* Bs = smem + AS * T_ASTAGE;
   int* tab_out = reinterpret_cast<int*>(smem + REGION);          // [BM]
   int* tab_res = tab_out + BM;
 
@@ -92,7 +95,11 @@ __global__ __launch_bounds__(512, 1) void conv_tap_s16_kernel(TapArgs a) {
   const int sl = (tid & 7) ^ ((tid >> 4) & 7);
   const float* b_src[BJ];
 #pragma unroll
-  for (int j = 0; j < BJ; ++j) b_src[j] = d.w + (int64_t)(n0 + j * 64 + (tid >> 3)) * a.kpad + 4 * sl;
+  for (int j = 0; j < BJ; ++j) {
+    int row = n0 + j * 64 + (tid >> 3);
+    row = row < d.n ? row : d.n - 1;                         // padding rows of a 32-filter slice: any valid address
+    b_src[j] = d.w + (int64_t)row * a.kpad + 4 * sl;
+  }
 
   for (int i = tid; i < BM; i += 512) {
     const int y = y0 + (i >> 5), x = x0 + (i & 31);
@@ -170,20 +177,23 @@ __global__ __launch_bounds__(512, 1) void conv_tap_s16_kernel(TapArgs a) {
   }
 #define TAP_STEP(tap)                                                                                      \
   {                                                                                                        \
-    if ((tap) < T_AROUNDS && !lastcc) { TAP_ISSUE_A((tap) < T_AROUNDS ? (tap) : 0, cc + 1, (cc + 1) & 1); } \
+    if (AS == 2 && (tap) < T_AROUNDS && !lastcc && a.dbg < 3) { TAP_ISSUE_A((tap) < T_AROUNDS ? (tap) : 0, cc + 1, (cc + 1) & 1); } \
     const int bs2_ = bs + 2 >= T_NB ? bs + 2 - T_NB : bs + 2;                                              \
-    if ((tap) < 7) {                                                                                       \
+    if (a.dbg >= 3) {                                                                                      \
+    } else if ((tap) < 7) {                                                                                \
       TAP_ISSUE_B(((tap) + 2) * a.ncc + cc, bs2_);                                                         \
     } else if (!lastcc) {                                                                                  \
       TAP_ISSUE_B(((tap) - 7) * a.ncc + cc + 1, bs2_);                                                     \
     }                                                                                                      \
-    if (a.dbg != 2) TAP_COMPUTE(tap, cc & 1, bs);                                                          \
-    if (!lastcc) {                                                                                         \
-      TAP_WAIT(BJ + ((tap) < T_AROUNDS ? 1 : 0));                                                          \
+    if (a.dbg != 2) TAP_COMPUTE(tap, (AS == 2 ? (cc & 1) : 0), bs);                                                          \
+    if (a.dbg >= 3) {                                                                                      \
+      TAP_WAIT(0);                                                                                         \
+    } else if (!lastcc) {                                                                                  \
+      TAP_WAIT(BJ + (AS == 2 && (tap) < T_AROUNDS ? 1 : 0));                                                          \
     } else {                                                                                               \
       TAP_WAIT((tap) < 7 ? BJ : 0);                                                                        \
     }                                                                                                      \
-    __builtin_amdgcn_s_barrier();                                                                          \
+    if (a.dbg != 4) __builtin_amdgcn_s_barrier();                                                          \
     asm volatile("" ::: "memory");                                                                         \
     bs = bs + 1 == T_NB ? 0 : bs + 1;                                                                      \
   }
@@ -197,6 +207,12 @@ __global__ __launch_bounds__(512, 1) void conv_tap_s16_kernel(TapArgs a) {
   int bs = 0;
   for (int cc = 0; cc < a.ncc; ++cc) {
     const bool lastcc = cc + 1 == a.ncc;
+    if (AS == 1 && cc > 0) {                     // single patch stage: everyone is past tap 8 of the previous block
+      _Pragma("unroll") for (int j = 0; j < T_AROUNDS; ++j) { TAP_ISSUE_A(j, cc, 0); }
+      TAP_WAIT(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
     TAP_STEP(0) TAP_STEP(1) TAP_STEP(2) TAP_STEP(3) TAP_STEP(4) TAP_STEP(5) TAP_STEP(6) TAP_STEP(7) TAP_STEP(8)
   }
   __syncthreads();
@@ -205,6 +221,44 @@ __global__ __launch_bounds__(512, 1) void conv_tap_s16_kernel(TapArgs a) {
 #undef TAP_COMPUTE
 #undef TAP_ISSUE_A
 #undef TAP_ISSUE_B
+
+  if (d.y_f32) {
+    // ---- direct fp32 store (channels on lanes), NHWC or NCHW through y_cs; tanh and the fused squared error of
+    // `psnr_error` for the output layer (as in conv_gemm_s16_kernel; a patch lies inside one sample) --------------
+    const int nstore = d.n_store > 0 ? d.n_store : d.n;
+    const int64_t ycs = d.y_cs > 0 ? d.y_cs : 1;
+    float sq0 = 0.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int ncol = n0 + (wn * TN + j) * 32 + l31;
+      const float sc = d.scale ? d.scale[ncol] : 1.f;
+      const float sh = d.shift ? d.shift[ncol] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (ncol < nstore) {
+            float v = (hh[i][j][r] + xx[i][j][r] * T_LO_INV) * sc + sh;
+            if (d.act == AMMC_ACT_RELU) v = v > 0.f ? v : 0.f;
+            else if (d.act == AMMC_ACT_TANH) v = tanhf(v);
+            const int64_t addr = tab_out[row] + (int64_t)ncol * ycs;
+            d.y[addr] = v;
+            if (d.sq_target) {
+              const float df = 0.5f * (d.sq_target[addr] - v);
+              sq0 += df * df;
+            }
+          }
+        }
+      }
+    }
+    if (d.sq_target) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) sq0 += __shfl_xor(sq0, off);
+      if (lane == 0) unsafeAtomicAdd(d.sq_acc + b, sq0);
+    }
+    return;
+  }
 
   // ---- epilogue: park the tile in LDS, then 8 channels of one pixel per thread (as conv_gemm_s16_kernel) ------
   float* T = smem;                                               // [BM][BN]
@@ -275,14 +329,15 @@ __global__ __launch_bounds__(512, 1) void conv_tap_s16_kernel(TapArgs a) {
   }
 }
 
-template <int WGM, int WGN, int TM, int TN>
+template <int WGM, int WGN, int TM, int TN, int AS = 2>
 static int launch_tap(const TapArgs& a, hipStream_t stream) {
   constexpr int BN = WGN * TN * 32;
-  constexpr int STAGES = 2 * T_ASTAGE + T_NB * BN * 32;
+  constexpr int BJ = BN * 8 >= 512 ? BN * 8 / 512 : 1;
+  constexpr int STAGES = AS * T_ASTAGE + T_NB * BJ * 64 * 32;
   constexpr int TILE = 256 * BN;
   constexpr size_t lds = (size_t)((STAGES > TILE ? STAGES : TILE) + 2 * 256) * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = conv_tap_s16_kernel<WGM, WGN, TM, TN>;
+  auto kern = conv_tap_s16_kernel<WGM, WGN, TM, TN, AS>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) return (int)e;
@@ -300,10 +355,11 @@ int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream) {
   static const int dbg = getenv("AMMC_S16_DBG") ? atoi(getenv("AMMC_S16_DBG")) : 0;
   constexpr int TAP_SKIP = -12345;
   if (!mode) return TAP_SKIP;
-  if (d.ntaps != 9 || d.up != 1 || d.x_step > 1 || d.y_f32 || d.w_kblk) return TAP_SKIP;
+  if (d.ntaps != 9 || d.up != 1 || d.x_step > 1 || d.w_kblk || d.res && d.y_f32) return TAP_SKIP;
   if (d.cin % 32 || d.width % T_TW || d.height % T_TH) return TAP_SKIP;
-  if (d.n != 64 && d.n % 128) return TAP_SKIP;
-  const int64_t tiles = (int64_t)d.batch * (d.height / T_TH) * (d.width / T_TW) * (d.n == 64 ? 1 : d.n / 128);
+  if (d.n != 32 && d.n != 64 && d.n % 128) return TAP_SKIP;
+  if (d.n == 32 && !d.y_f32) return TAP_SKIP;
+  const int64_t tiles = (int64_t)d.batch * (d.height / T_TH) * (d.width / T_TW) * (d.n <= 64 ? 1 : d.n / 128);
   if (tiles < 192) return TAP_SKIP;                       // cannot fill the chip: the split-K path of the GEMM kernel is better
   const int64_t patch = (int64_t)(T_TH + 1) * d.x_rs + (int64_t)(T_TW + 1) * d.x_ps;
   if (patch >= (1LL << 30)) return TAP_SKIP;
@@ -315,6 +371,7 @@ int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream) {
   a.kpad = kpad;
   a.dbg = dbg;
   a.n_tiles = 0;
+  if (d.n == 32) return launch_tap<8, 1, 1, 1, 1>(a, stream);       // the output layer: 2-3 filters, fp32 NCHW + tanh
   if (d.n == 64) return launch_tap<8, 1, 1, 2>(a, stream);
   return launch_tap<4, 2, 2, 2>(a, stream);
 }
