@@ -44,7 +44,8 @@ constexpr int T_NB = 3;                          // filter-slice stages: slices 
 // CU).  1: the patch is reloaded at every channel-block boundary and TWO workgroups share a CU (<= 80 KB of LDS,
 // <= 128 VGPRs), so one's loads and epilogue overlap the other's MFMAs - for layers with little work per patch.
 template <int WGM, int WGN, int TM, int TN, int AS>
-__global__ __launch_bounds__(512, (AS == 1 ? 2 : 1)) void conv_tap_s16_kernel(TapArgs a) {
+// (hipcc: the second __launch_bounds__ argument is the minimum number of WAVES PER SIMD, i.e. 512 / it VGPRs)
+__global__ __launch_bounds__(512, (AS == 1 ? 4 : 2)) void conv_tap_s16_kernel(TapArgs a) {
   static_assert(WGM * WGN == 8 && WGM * TM == T_TH, "8 waves, 8 image rows");
   constexpr int BM = T_TH * T_TW;           // 256 output pixels
   constexpr int BN = WGN * TN * 32;
@@ -121,13 +122,25 @@ __global__ __launch_bounds__(512, (AS == 1 ? 2 : 1)) void conv_tap_s16_kernel(Ta
     __builtin_amdgcn_global_load_lds(src_, dst_, 16, 0, 0);                           \
   }
 
-  f32x16 hh[TM][TN], xx[TM][TN];
+  // SA (the two-workgroups-per-CU variants): ONE accumulator set.  The 2^-11 of the cross terms is applied to the
+  // A-side fragments on the fly (hi * 2^-11 and lo * 2^-11 in half precision: exact above 2^-3, an absolute 2^-25
+  // below, i.e. far under the fp32 rounding of the sum), which halves the accumulator registers.
+  constexpr bool SA = AS == 1;
+  constexpr int XM = SA ? 1 : TM, XN = SA ? 1 : TN;
+  f32x16 hh[TM][TN], xx[XM][XN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { hh[i][j][r] = 0.f; xx[i][j][r] = 0.f; }
+      for (int r = 0; r < 16; ++r) hh[i][j][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < XM; ++i)
+#pragma unroll
+    for (int j = 0; j < XN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xx[i][j][r] = 0.f;
+#define TAP_ACC(i, j, r) (SA ? hh[i][j][r] : hh[i][j][r] + xx[(SA ? 0 : (i))][(SA ? 0 : (j))][r] * T_LO_INV)
 
   const int swzb = (l31 >> 1) & 7;
   const int b_row = (wn * TN * 32 + l31) * 32;
@@ -141,7 +154,8 @@ __global__ __launch_bounds__(512, (AS == 1 ? 2 : 1)) void conv_tap_s16_kernel(Ta
     const float* Bc = Bs + (bstage) * B_STAGE + b_row;                                                     \
     int arow_[TM], aswz_[TM];                                                                              \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                       \
-      const int hp_ = hpb[i] + ((tap) / 3) * T_HW + ((tap) % 3);                                           \
+      int hp_ = hpb[i] + ((tap) / 3) * T_HW + ((tap) % 3);                                                 \
+      if (AS == 1) asm volatile("" : "+v"(hp_)); /* keep the per-tap addresses out of loop-invariant registers */ \
       arow_[i] = hp_ * 32;                                                                                 \
       aswz_[i] = (hp_ >> 1) & 7;                                                                           \
     }                                                                                                      \
@@ -157,9 +171,17 @@ __global__ __launch_bounds__(512, (AS == 1 ? 2 : 1)) void conv_tap_s16_kernel(Ta
         bl[j] = *reinterpret_cast<const f16x8t*>(Bc + j * 1024 + (((2 * g + 1) ^ swzb) << 2));             \
       }                                                                                                    \
       _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) {      \
-        hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], hh[i][j], 0, 0, 0);               \
-        xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], xx[i][j], 0, 0, 0);               \
-        xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], xx[i][j], 0, 0, 0);               \
+        if (SA) {                                                                                          \
+          const f16x8t ah2_ = ah[i] * (_Float16)T_LO_INV;                                                  \
+          const f16x8t al2_ = al[i] * (_Float16)T_LO_INV;                                                  \
+          hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], hh[i][j], 0, 0, 0);             \
+          hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah2_, bl[j], hh[i][j], 0, 0, 0);              \
+          hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al2_, bh[j], hh[i][j], 0, 0, 0);              \
+        } else {                                                                                           \
+          hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], hh[i][j], 0, 0, 0);             \
+          xx[SA ? 0 : i][SA ? 0 : j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], xx[SA ? 0 : i][SA ? 0 : j], 0, 0, 0); \
+          xx[SA ? 0 : i][SA ? 0 : j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], xx[SA ? 0 : i][SA ? 0 : j], 0, 0, 0); \
+        }                                                                                                  \
       }                                                                                                    \
     }                                                                                                      \
   }
@@ -239,7 +261,7 @@ __global__ __launch_bounds__(512, (AS == 1 ? 2 : 1)) void conv_tap_s16_kernel(Ta
         for (int r = 0; r < 16; ++r) {
           const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
           if (ncol < nstore) {
-            float v = (hh[i][j][r] + xx[i][j][r] * T_LO_INV) * sc + sh;
+            float v = TAP_ACC(i, j, r) * sc + sh;
             if (d.act == AMMC_ACT_RELU) v = v > 0.f ? v : 0.f;
             else if (d.act == AMMC_ACT_TANH) v = tanhf(v);
             const int64_t addr = tab_out[row] + (int64_t)ncol * ycs;
@@ -270,7 +292,7 @@ __global__ __launch_bounds__(512, (AS == 1 ? 2 : 1)) void conv_tap_s16_kernel(Ta
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        T[row * BN + col] = hh[i][j][r] + xx[i][j][r] * T_LO_INV;
+        T[row * BN + col] = TAP_ACC(i, j, r);
       }
     }
   }
@@ -372,7 +394,7 @@ int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream) {
   a.dbg = dbg;
   a.n_tiles = 0;
   if (d.n == 32) return launch_tap<8, 1, 1, 1, 1>(a, stream);       // the output layer: 2-3 filters, fp32 NCHW + tanh
-  if (d.n == 64) return launch_tap<8, 1, 1, 2>(a, stream);
+  if (d.n == 64) return mode == 2 ? launch_tap<8, 1, 1, 2, 2>(a, stream) : launch_tap<8, 1, 1, 2, 1>(a, stream);
   return launch_tap<4, 2, 2, 2>(a, stream);
 }
 
