@@ -747,7 +747,9 @@ extern "C" int ammc_conv_gemm_s16(const AmmcConvDesc* desc, void* stream) {
   if (d.n == 32) return launch<4, 1, 1, 1>(a, s);
   // 256-row tiles (8 waves, one workgroup per CU) move 25 % / 17 % fewer LDS-DMA bytes per FLOP than the
   // 128-row ones; they pay off once there are enough tiles to fill the chip
-  const bool many = M >= (int64_t)256 * 512 / (d.n >= 256 ? d.n / 128 : 1);
+  // ... and the K loop is long enough to amortise a prologue/epilogue that nothing overlaps (one workgroup per CU);
+  // short-K layers (ConvTranspose, K = Cin <= 512) keep the 128-row tiles, three workgroups per CU
+  const bool many = M >= (int64_t)256 * 512 / (d.n >= 256 ? d.n / 128 : 1) && a.nchunks > 16;
   if (d.n % 128 == 0) {
     if (big == 3 && many) return launch<4, 2, 2, 2, 3>(a, s);
     if (big == 4 && many) return launch<8, 2, 1, 2>(a, s);     // 16 waves, 32x64 wave tiles

@@ -71,6 +71,20 @@ class Act:
         return self.buf[:, h:h + self.H, h:h + self.W, self.c_off:self.c_off + self.c]
 
 
+def _tap_eligible(x: "Act", ntaps: int, cin: int, n: int, up: int = 1, y_f32: int = 0) -> bool:
+    """does csrc/conv_tap_s16.hip (the halo-patch 3x3 kernel) take this S16 layer?  Mirrors `conv_tap_s16_try`."""
+    if os.environ.get("AMMC_S16_TAP", "1") == "0" or S16_BDIRECT:
+        return False
+    if ntaps != 9 or up != 1 or cin % 32 or x.W % 32 or x.H % 8:
+        return False
+    if n == 32:
+        if not y_f32:
+            return False
+    elif n != 64 and n % 128:
+        return False
+    return x.B * (x.H // 8) * (x.W // 32) * (1 if n <= 64 else n // 128) >= 192
+
+
 def _kpad(k: int) -> int:
     return (k + 31) // 32 * 32
 
@@ -290,10 +304,14 @@ class _Builder:
         flops = 2.0 * m_pix * n * ntaps * ct
         nbytes = 4.0 * m_pix * (ct + n + (n if res is not None else 0))
         tile = "128x32" if n == 32 else "128x128" if n % 128 == 0 else "128x64"
-        if self.s16 and n % 128 == 0 and m_pix >= 256 * 512 // (n // 128 if n >= 256 else 1):
-            tile = "256x128"      # mirrors the dispatch in ammc_conv_gemm_s16 (labels must match rocprof's kernels)
+        kname = self.kname
+        # the labels mirror the dispatch in ammc_conv_gemm_s16 / conv_tap_s16_try (they must match rocprof's kernels)
+        if self.s16 and n % 128 == 0 and m_pix >= 256 * 512 // (n // 128 if n >= 256 else 1) and ntaps * cin > 512:
+            tile = "256x128"
+        if self.s16 and _tap_eligible(x, ntaps, cin, n, up, d.y_f32):
+            kname, tile = "conv_tap_s16", ("256x64" if n == 64 else "256x128")
         self.plan.add(self.conv_fn, C.byref(d), name=name, flops=flops, nbytes=nbytes,
-                      kernel=f"{self.kname}<{tile}>")
+                      kernel=f"{kname}<{tile}>")
         return d
 
     def outc_desc(self, x: Act, w: torch.Tensor, bias32: torch.Tensor, cout: int) -> AmmcConvDesc:
@@ -550,7 +568,8 @@ class EvalEngine:
             else:
                 s.outc.sq_target, s.outc.sq_acc = None, None
             launch(lib.ammc_conv_gemm_s16 if self.s16 else lib.ammc_conv_gemm_f32, (C.byref(s.outc),),
-                   dict(name="outc_tanh", kernel=("conv_gemm_s16" if self.s16 else "conv_gemm_f32") + "<128x32>",
+                   dict(name="outc_tanh", kernel=("conv_tap_s16<256x32>" if self.s16 and _tap_eligible(s.x_in, 9, 64, 32, 1, 1)
+                                                  else ("conv_gemm_s16" if self.s16 else "conv_gemm_f32") + "<128x32>"),
                         flops=2.0 * B * H * W * 9 * 64 * s.sp.cout, bytes=4.0 * B * H * W * (64 + s.sp.cout)))
 
     def _graph_for(self, st, B, H, W, device, tflags):

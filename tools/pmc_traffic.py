@@ -1,0 +1,43 @@
+"""HBM-side bytes per launch of every conv kernel from the FETCH_SIZE / WRITE_SIZE passes of tools/profile_bench.sh
+(separate rocprofv3 --pmc runs), keyed by the labels bench.py uses:
+
+    python tools/pmc_traffic.py gpurun_out/prof_<tag> <precision> > profiles/rNN_<precision>_pmc_traffic.json
+
+FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B: MI355X_MICROARCH.md, HBM section); rocprofv3 reports KB."""
+import csv, glob, json, re, sys
+from collections import defaultdict
+
+root, prec = sys.argv[1], sys.argv[2]
+
+
+def label(name):
+    m = re.search(r"(conv_gemm_s16|conv_gemm_f32|conv_tap_s16)_kernel<([^>]*)>", name)
+    if not m:
+        return None
+    t = [int(v) if v.strip().lstrip("-").isdigit() else 0 for v in m.group(2).split(",")]
+    bn = t[1] * t[3] * 32
+    bm = 256 if m.group(1) == "conv_tap_s16" else t[0] * t[2] * 32
+    return f"{m.group(1)}<{bm}x{bn}>"
+
+
+acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+for path in glob.glob(f"{root}/pmc_fetch/**/*counter_collection.csv", recursive=True) + \
+        glob.glob(f"{root}/pmc_write/**/*counter_collection.csv", recursive=True):
+    with open(path) as fp:
+        for row in csv.DictReader(fp):
+            lb = label(row["Kernel_Name"])
+            if lb and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                a = acc[lb][row["Counter_Name"]]
+                a[0] += float(row["Counter_Value"])
+                a[1] += 1
+out = {"source": f"tools/profile_bench.sh (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes) of "
+                 f"`python3 bench.py --steps 5 --warmup 2` (precision {prec}); tools/pmc_traffic.py", "kernels": {}}
+for lb, c in acc.items():
+    f, w = c["FETCH_SIZE"], c["WRITE_SIZE"]
+    if not f[1] or not w[1]:
+        continue
+    fk, wk = f[0] / f[1], w[0] / w[1]
+    out["kernels"][lb] = {"dispatches": f[1], "fetch_kb_raw": fk, "write_kb": wk,
+                          "traffic_bytes_per_launch": (2.0 * fk + wk) * 1024.0,
+                          "note": "FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B), WRITE_SIZE as is; rocprofv3 reports KB"}
+print(json.dumps(out, indent=1))
