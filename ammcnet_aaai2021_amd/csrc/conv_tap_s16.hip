@@ -35,9 +35,8 @@ constexpr float T_LO_SCALE = 2048.f;
 constexpr float T_LO_INV = 1.f / 2048.f;
 constexpr int T_TH = 8, T_TW = 32, T_HW = T_TW + 2, T_HP = (T_TH + 2) * T_HW;     // 340 halo pixels
 constexpr int T_APIECES = T_HP * 8;                                              // 2720 16-byte pieces
-constexpr int T_AROUNDS = (T_APIECES + 511) / 512;                               // 6 rounds of 512 threads
-constexpr int T_ASTAGE = T_AROUNDS * 512 * 4;    // floats; padded to whole rounds so that EVERY wave issues every
-                                                 // round (the counted vmcnt waits below need wave-uniform counts)
+// the patch stage is padded to whole rounds of the workgroup's threads so that EVERY wave issues every round (the
+// counted vmcnt waits below need wave-uniform counts): 6 rounds of 512 threads, 11 of 256
 constexpr int T_NB = 3;                          // filter-slice stages: slices t+1 and t+2 fly during step t
 
 // AS = halo-patch stages.  2: the next channel block's patch is prefetched during the current one (one workgroup per
@@ -45,12 +44,16 @@ constexpr int T_NB = 3;                          // filter-slice stages: slices 
 // <= 128 VGPRs), so one's loads and epilogue overlap the other's MFMAs - for layers with little work per patch.
 template <int WGM, int WGN, int TM, int TN, int AS>
 // (hipcc: the second __launch_bounds__ argument is the minimum number of WAVES PER SIMD, i.e. 512 / it VGPRs)
-__global__ __launch_bounds__(512, (AS == 1 ? 4 : 2)) void conv_tap_s16_kernel(TapArgs a) {
-  static_assert(WGM * WGN == 8 && WGM * TM == T_TH, "8 waves, 8 image rows");
+__global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)) void conv_tap_s16_kernel(TapArgs a) {
+  static_assert((WGM * WGN == 8 || WGM * WGN == 4) && WGM * TM == T_TH, "4 or 8 waves, 8 image rows");
+  constexpr int NT = 64 * WGM * WGN;
+  constexpr int T_AROUNDS = (T_APIECES + NT - 1) / NT;
+  constexpr int T_ASTAGE = T_AROUNDS * NT * 4;             // floats
+  static_assert(AS == 1 || T_AROUNDS <= 6, "two patch stages: one round per tap 0..5");
   constexpr int BM = T_TH * T_TW;           // 256 output pixels
   constexpr int BN = WGN * TN * 32;
-  constexpr int BJ = BN * 8 >= 512 ? BN * 8 / 512 : 1;     // filter pieces per thread per tap (every wave issues:
-  constexpr int B_STAGE = BJ * 64 * 32;                    // a 32-filter slice is padded to 64 rows; floats)
+  constexpr int BJ = BN * 8 >= NT ? BN * 8 / NT : 1;       // filter pieces per thread per tap (every wave issues:
+  constexpr int B_STAGE = BJ * (NT / 8) * 32;                    // a 32-filter slice is padded to 64 rows; floats)
   constexpr int STAGES = AS * T_ASTAGE + T_NB * B_STAGE;
   constexpr int TILE = BM * BN;
   constexpr int REGION = STAGES > TILE ? STAGES : TILE;
@@ -81,11 +84,11 @@ __global__ __launch_bounds__(512, (AS == 1 ? 4 : 2)) void conv_tap_s16_kernel(Ta
   // d.x is the halo corner of pixel (0,0); the patch of this workgroup starts at image pixel (y0 - 1, x0 - 1)
   const float* xpatch = d.x + ((int64_t)b * d.x_bs + (int64_t)y0 * d.x_rs + (int64_t)x0 * d.x_ps);
 
-  // halo-patch DMA pieces of this thread: piece p = j*512 + tid -> halo pixel p >> 3, physical slot p & 7
+  // halo-patch DMA pieces of this thread: piece p = j*NT + tid -> halo pixel p >> 3, physical slot p & 7
   int a_off[T_AROUNDS];
 #pragma unroll
   for (int j = 0; j < T_AROUNDS; ++j) {
-    int p = j * 512 + tid;
+    int p = j * NT + tid;
     p = p < T_APIECES ? p : T_APIECES - 1;
     const int hp = p >> 3;
     const int ls = (p & 7) ^ ((hp >> 1) & 7);
@@ -97,12 +100,12 @@ __global__ __launch_bounds__(512, (AS == 1 ? 4 : 2)) void conv_tap_s16_kernel(Ta
   const float* b_src[BJ];
 #pragma unroll
   for (int j = 0; j < BJ; ++j) {
-    int row = n0 + j * 64 + (tid >> 3);
+    int row = n0 + j * (NT / 8) + (tid >> 3);
     row = row < d.n ? row : d.n - 1;                         // padding rows of a 32-filter slice: any valid address
     b_src[j] = d.w + (int64_t)row * a.kpad + 4 * sl;
   }
 
-  for (int i = tid; i < BM; i += 512) {
+  for (int i = tid; i < BM; i += NT) {
     const int y = y0 + (i >> 5), x = x0 + (i & 31);
     tab_out[i] = (int)((int64_t)b * d.y_bs + (int64_t)y * d.y_rs + (int64_t)x * d.y_ps);
     tab_res[i] = (int)((int64_t)b * d.r_bs + (int64_t)y * d.r_rs + (int64_t)x * d.r_ps);
@@ -112,13 +115,13 @@ __global__ __launch_bounds__(512, (AS == 1 ? 4 : 2)) void conv_tap_s16_kernel(Ta
 #define TAP_ISSUE_A(j, cc, stage)                                                     \
   {                                                                                   \
     const float* src_ = xpatch + a_off[j] + (cc) * 32;                                \
-    float* dst_ = As + (stage) * T_ASTAGE + ((j) * 512 + wave * 64) * 4;              \
+    float* dst_ = As + (stage) * T_ASTAGE + ((j) * NT + wave * 64) * 4;               \
     __builtin_amdgcn_global_load_lds(src_, dst_, 16, 0, 0);                           \
   }
 #define TAP_ISSUE_B(chunk, stage)                                                     \
   _Pragma("unroll") for (int j_ = 0; j_ < BJ; ++j_) {                                 \
     const float* src_ = b_src[j_] + (chunk) * 32;                                     \
-    float* dst_ = Bs + (stage) * B_STAGE + (j_ * 512 + wave * 64) * 4;                \
+    float* dst_ = Bs + (stage) * B_STAGE + (j_ * NT + wave * 64) * 4;                 \
     __builtin_amdgcn_global_load_lds(src_, dst_, 16, 0, 0);                           \
   }
 
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(512, (AS == 1 ? 4 : 2)) void conv_tap_s16_kernel(Ta
   }
   __syncthreads();
   constexpr int CG = BN / 8;
-  for (int item = tid; item < BM * CG; item += 512) {
+  for (int item = tid; item < BM * CG; item += NT) {
     const int row = item / CG;
     const int cg = item - row * CG;
     const int ncol0 = n0 + cg * 8;
@@ -354,8 +357,10 @@ __global__ __launch_bounds__(512, (AS == 1 ? 4 : 2)) void conv_tap_s16_kernel(Ta
 template <int WGM, int WGN, int TM, int TN, int AS = 2>
 static int launch_tap(const TapArgs& a, hipStream_t stream) {
   constexpr int BN = WGN * TN * 32;
-  constexpr int BJ = BN * 8 >= 512 ? BN * 8 / 512 : 1;
-  constexpr int STAGES = AS * T_ASTAGE + T_NB * BJ * 64 * 32;
+  constexpr int NT = 64 * WGM * WGN;
+  constexpr int T_ASTAGE = (T_APIECES + NT - 1) / NT * NT * 4;
+  constexpr int BJ = BN * 8 >= NT ? BN * 8 / NT : 1;
+  constexpr int STAGES = AS * T_ASTAGE + T_NB * BJ * (NT / 8) * 32;
   constexpr int TILE = 256 * BN;
   constexpr size_t lds = (size_t)((STAGES > TILE ? STAGES : TILE) + 2 * 256) * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS budget");
@@ -366,7 +371,7 @@ static int launch_tap(const TapArgs& a, hipStream_t stream) {
   TapArgs b = a;
   b.n_tiles = a.d.n / BN;
   const int grid = a.d.batch * a.tiles_y * a.tiles_x * b.n_tiles;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, b);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, stream, b);
   return ammc_launch_status();
 }
 
@@ -394,7 +399,11 @@ int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream) {
   a.dbg = dbg;
   a.n_tiles = 0;
   if (d.n == 32) return launch_tap<8, 1, 1, 1, 1>(a, stream);       // the output layer: 2-3 filters, fp32 NCHW + tanh
-  if (d.n == 64) return mode == 2 ? launch_tap<8, 1, 1, 2, 2>(a, stream) : launch_tap<8, 1, 1, 2, 1>(a, stream);
+  if (d.n == 64) {
+    if (mode == 2) return launch_tap<8, 1, 1, 2, 2>(a, stream);
+    if (mode == 3) return launch_tap<8, 1, 1, 2, 1>(a, stream);
+    return launch_tap<4, 1, 2, 2, 1>(a, stream);       // 4 waves of 64x64 (2 image rows x 64 filters), 2 workgroups per CU
+  }
   return launch_tap<4, 2, 2, 2>(a, stream);
 }
 

@@ -309,7 +309,7 @@ class _Builder:
         if self.s16 and n % 128 == 0 and m_pix >= 256 * 512 // (n // 128 if n >= 256 else 1) and ntaps * cin > 512:
             tile = "256x128"
         if self.s16 and _tap_eligible(x, ntaps, cin, n, up, d.y_f32):
-            kname, tile = "conv_tap_s16", ("256x64" if n == 64 else "256x128")
+            kname, tile = "conv_tap_s16", ("256x64" if n == 64 else "256x128")   # 256x32 = outc, labelled in forward
         self.plan.add(self.conv_fn, C.byref(d), name=name, flops=flops, nbytes=nbytes,
                       kernel=f"{kname}<{tile}>")
         return d
