@@ -37,7 +37,6 @@ constexpr int T_TH = 8, T_TW = 32, T_HW = T_TW + 2, T_HP = (T_TH + 2) * T_HW;   
 constexpr int T_APIECES = T_HP * 8;                                              // 2720 16-byte pieces
 // the patch stage is padded to whole rounds of the workgroup's threads so that EVERY wave issues every round (the
 // counted vmcnt waits below need wave-uniform counts): 6 rounds of 512 threads, 11 of 256
-constexpr int T_NB = 3;                          // filter-slice stages: slices t+1 and t+2 fly during step t
 
 // AS = halo-patch stages.  2: the next channel block's patch is prefetched during the current one (one workgroup per
 // CU).  1: the patch is reloaded at every channel-block boundary and TWO workgroups share a CU (<= 80 KB of LDS,
@@ -54,8 +53,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
   constexpr int BN = WGN * TN * 32;
   constexpr int BJ = BN * 8 >= NT ? BN * 8 / NT : 1;       // filter pieces per thread per tap (every wave issues:
   constexpr int B_STAGE = BJ * (NT / 8) * 32;                    // a 32-filter slice is padded to 64 rows; floats)
-  constexpr int STAGES = AS * T_ASTAGE + T_NB * B_STAGE;
-  constexpr int TILE = BM * BN;
+  // filter-slice stages: 3 = slices t+1 and t+2 fly during step t; the 4-wave 128-filter variant keeps 2 (one slice
+  // ahead) so that two workgroups fit a CU, and parks its output tile in two 64-column halves for the same reason
+  constexpr int NB = (NT == 256 && BN == 128) ? 2 : 3;
+  constexpr int PD = NB - 1;
+  constexpr int EPC = (NT == 256 && BN == 128) ? 64 : BN;
+  constexpr int STAGES = AS * T_ASTAGE + NB * B_STAGE;
+  constexpr int TILE = BM * EPC;
   constexpr int REGION = STAGES > TILE ? STAGES : TILE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
@@ -203,31 +207,31 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
 #define TAP_STEP(tap)                                                                                      \
   {                                                                                                        \
     if (AS == 2 && (tap) < T_AROUNDS && !lastcc && a.dbg < 3) { TAP_ISSUE_A((tap) < T_AROUNDS ? (tap) : 0, cc + 1, (cc + 1) & 1); } \
-    const int bs2_ = bs + 2 >= T_NB ? bs + 2 - T_NB : bs + 2;                                              \
+    const int bsp_ = bs + PD >= NB ? bs + PD - NB : bs + PD;                                               \
     if (a.dbg >= 3) {                                                                                      \
-    } else if ((tap) < 7) {                                                                                \
-      TAP_ISSUE_B(((tap) + 2) * a.ncc + cc, bs2_);                                                         \
+    } else if ((tap) + PD < 9) {                                                                           \
+      TAP_ISSUE_B(((tap) + PD) * a.ncc + cc, bsp_);                                                        \
     } else if (!lastcc) {                                                                                  \
-      TAP_ISSUE_B(((tap) - 7) * a.ncc + cc + 1, bs2_);                                                     \
+      TAP_ISSUE_B(((tap) + PD - 9) * a.ncc + cc + 1, bsp_);                                                \
     }                                                                                                      \
-    if (a.dbg != 2) TAP_COMPUTE(tap, (AS == 2 ? (cc & 1) : 0), bs);                                                          \
+    if (a.dbg != 2) TAP_COMPUTE(tap, (AS == 2 ? (cc & 1) : 0), bs);                                        \
     if (a.dbg >= 3) {                                                                                      \
       TAP_WAIT(0);                                                                                         \
     } else if (!lastcc) {                                                                                  \
-      TAP_WAIT(BJ + (AS == 2 && (tap) < T_AROUNDS ? 1 : 0));                                                          \
+      TAP_WAIT((PD - 1) * BJ + (AS == 2 && (tap) < T_AROUNDS ? 1 : 0));                                    \
     } else {                                                                                               \
-      TAP_WAIT((tap) < 7 ? BJ : 0);                                                                        \
+      TAP_WAIT(((PD - 1) < (7 - (tap)) ? (PD - 1) : ((7 - (tap)) > 0 ? (7 - (tap)) : 0)) * BJ);            \
     }                                                                                                      \
     if (a.dbg != 4) __builtin_amdgcn_s_barrier();                                                          \
     asm volatile("" ::: "memory");                                                                         \
-    bs = bs + 1 == T_NB ? 0 : bs + 1;                                                                      \
+    bs = bs + 1 == NB ? 0 : bs + 1;                                                                        \
   }
 
 #pragma unroll
   for (int j = 0; j < T_AROUNDS; ++j) { TAP_ISSUE_A(j, 0, 0); }
   TAP_ISSUE_B(0, 0);
-  TAP_ISSUE_B(a.ncc, 1);
-  TAP_WAIT(BJ);
+  if (PD == 2) { TAP_ISSUE_B(a.ncc, 1); }
+  TAP_WAIT((PD - 1) * BJ);
   __syncthreads();
   int bs = 0;
   for (int cc = 0; cc < a.ncc; ++cc) {
@@ -286,71 +290,76 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
   }
 
   // ---- epilogue: park the tile in LDS, then 8 channels of one pixel per thread (as conv_gemm_s16_kernel) ------
-  float* T = smem;                                               // [BM][BN]
+  float* T = smem;                                               // [BM][EPC]
+  constexpr int CG = EPC / 8;
+  for (int c0 = 0; c0 < BN; c0 += EPC) {
+    if (c0 > 0) __syncthreads();
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = (wn * TN + j) * 32 + l31;
+    for (int j = 0; j < TN; ++j) {
+      const int col = (wn * TN + j) * 32 + l31;
+      if (col >= c0 && col < c0 + EPC) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        T[row * BN + col] = TAP_ACC(i, j, r);
+          for (int r = 0; r < 16; ++r) {
+            const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            T[row * EPC + col - c0] = TAP_ACC(i, j, r);
+          }
+        }
       }
     }
-  }
-  __syncthreads();
-  constexpr int CG = BN / 8;
-  for (int item = tid; item < BM * CG; item += NT) {
-    const int row = item / CG;
-    const int cg = item - row * CG;
-    const int ncol0 = n0 + cg * 8;
-    float v[8];
-    {
-      const f32x4 t0 = *reinterpret_cast<const f32x4*>(T + row * BN + cg * 8);
-      const f32x4 t1 = *reinterpret_cast<const f32x4*>(T + row * BN + cg * 8 + 4);
+    __syncthreads();
+    for (int item = tid; item < BM * CG; item += NT) {
+      const int row = item / CG;
+      const int cg = item - row * CG;
+      const int ncol0 = n0 + c0 + cg * 8;
+      float v[8];
+      {
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(T + row * EPC + cg * 8);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(T + row * EPC + cg * 8 + 4);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { v[i] = t0[i]; v[4 + i] = t1[i]; }
-    }
-    if (d.scale) {
-      const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.scale + ncol0);
-      const f32x4 s1 = *reinterpret_cast<const f32x4*>(d.scale + ncol0 + 4);
+        for (int i = 0; i < 4; ++i) { v[i] = t0[i]; v[4 + i] = t1[i]; }
+      }
+      if (d.scale) {
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.scale + ncol0);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(d.scale + ncol0 + 4);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { v[i] *= s0[i]; v[4 + i] *= s1[i]; }
-    }
-    if (d.shift) {
-      const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.shift + ncol0);
-      const f32x4 s1 = *reinterpret_cast<const f32x4*>(d.shift + ncol0 + 4);
+        for (int i = 0; i < 4; ++i) { v[i] *= s0[i]; v[4 + i] *= s1[i]; }
+      }
+      if (d.shift) {
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.shift + ncol0);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(d.shift + ncol0 + 4);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { v[i] += s0[i]; v[4 + i] += s1[i]; }
-    }
-    if (d.act == AMMC_ACT_RELU) {
+        for (int i = 0; i < 4; ++i) { v[i] += s0[i]; v[4 + i] += s1[i]; }
+      }
+      if (d.act == AMMC_ACT_RELU) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
-    }
-    if (d.res) {
-      const float* rp = d.res + tab_res[row] + ncol0;
-      const f16x8t rh = *reinterpret_cast<const f16x8t*>(rp);
-      const f16x8t rl = *reinterpret_cast<const f16x8t*>(rp + 4);
+        for (int i = 0; i < 8; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+      }
+      if (d.res) {
+        const float* rp = d.res + tab_res[row] + ncol0;
+        const f16x8t rh = *reinterpret_cast<const f16x8t*>(rp);
+        const f16x8t rl = *reinterpret_cast<const f16x8t*>(rp + 4);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] += (float)rh[i] + (float)rl[i] * T_LO_INV;
-    }
-    f16x8t hi, lo;
+        for (int i = 0; i < 8; ++i) v[i] += (float)rh[i] + (float)rl[i] * T_LO_INV;
+      }
+      f16x8t hi, lo;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const _Float16 hv = (_Float16)v[i];
-      hi[i] = hv;
-      lo[i] = (_Float16)((v[i] - (float)hv) * T_LO_SCALE);
-    }
-    if (d.overflow_flag) {
-      bool bad = false;
+      for (int i = 0; i < 8; ++i) {
+        const _Float16 hv = (_Float16)v[i];
+        hi[i] = hv;
+        lo[i] = (_Float16)((v[i] - (float)hv) * T_LO_SCALE);
+      }
+      if (d.overflow_flag) {
+        bool bad = false;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) bad |= !(fabsf(v[i]) <= 65504.f);
-      if (bad) atomicOr(d.overflow_flag, 1);
+        for (int i = 0; i < 8; ++i) bad |= !(fabsf(v[i]) <= 65504.f);
+        if (bad) atomicOr(d.overflow_flag, 1);
+      }
+      float* yp = d.y + tab_out[row] + ncol0;
+      *reinterpret_cast<f16x8t*>(yp) = hi;
+      *reinterpret_cast<f16x8t*>(yp + 4) = lo;
     }
-    float* yp = d.y + tab_out[row] + ncol0;
-    *reinterpret_cast<f16x8t*>(yp) = hi;
-    *reinterpret_cast<f16x8t*>(yp + 4) = lo;
   }
 }
 
@@ -360,8 +369,10 @@ static int launch_tap(const TapArgs& a, hipStream_t stream) {
   constexpr int NT = 64 * WGM * WGN;
   constexpr int T_ASTAGE = (T_APIECES + NT - 1) / NT * NT * 4;
   constexpr int BJ = BN * 8 >= NT ? BN * 8 / NT : 1;
-  constexpr int STAGES = AS * T_ASTAGE + T_NB * BJ * (NT / 8) * 32;
-  constexpr int TILE = 256 * BN;
+  constexpr int NB = (NT == 256 && BN == 128) ? 2 : 3;
+  constexpr int EPC = (NT == 256 && BN == 128) ? 64 : BN;
+  constexpr int STAGES = AS * T_ASTAGE + NB * BJ * (NT / 8) * 32;
+  constexpr int TILE = 256 * EPC;
   constexpr size_t lds = (size_t)((STAGES > TILE ? STAGES : TILE) + 2 * 256) * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto kern = conv_tap_s16_kernel<WGM, WGN, TM, TN, AS>;
@@ -404,6 +415,10 @@ int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream) {
     if (mode == 3) return launch_tap<8, 1, 1, 2, 1>(a, stream);
     return launch_tap<4, 1, 2, 2, 1>(a, stream);       // 4 waves of 64x64 (2 image rows x 64 filters), 2 workgroups per CU
   }
+  // 4 waves of 64x128 (one accumulator set), two workgroups per CU: fewer LDS reads per MFMA and the neighbour's
+  // MFMAs behind every prologue / epilogue - once there are two workgroups for every CU (measured: 128x128 layers
+  // +10 %, 64x64 +6 %, but 32x32 at batch 16 = one workgroup per CU -19 %)
+  if (mode == 4 || (mode == 1 && tiles >= 512)) return launch_tap<4, 1, 2, 4, 1>(a, stream);
   return launch_tap<4, 2, 2, 2>(a, stream);
 }
 
