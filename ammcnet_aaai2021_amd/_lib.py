@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libammc_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU = 0, 1, 2, 3
 
@@ -32,6 +32,7 @@ class AmmcConvDesc(C.Structure):
         ("r_bs", _i64), ("r_rs", _i64), ("r_ps", _i64),
         ("y_cs", _i64), ("x_step", _i32), ("y_f32", _i32), ("w_kblk", _i32), ("reserved3", _i32), ("overflow_flag", _p),
         ("splitk_ws", _p), ("splitk_ws_floats", _i64), ("sq_target", _p), ("sq_acc", _p),
+        ("pool_y", _p), ("pool_bs", _i64), ("pool_rs", _i64), ("pool_ps", _i64),
     ]
 
 

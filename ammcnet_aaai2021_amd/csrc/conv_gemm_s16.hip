@@ -723,6 +723,7 @@ extern "C" int ammc_conv_gemm_s16(const AmmcConvDesc* desc, void* stream) {
     const int rc = conv_tap_s16_try(d, a.kpad, s);
     if (rc != -12345) return rc;
   }
+  if (d.pool_y) return AMMC_EUNSUP;                 // the fused max-pool output exists in the halo-patch kernel only
   // split-K for layers that cannot fill the chip (small batch: 32x32 / 64x64 levels with K up to 4608): each K
   // slice is its own workgroup writing an fp32 partial tile; a streaming kernel sums the slices and finishes
   if (d.splitk_ws && !d.y_f32 && !d.w_kblk && d.up == 1 && d.n % 128 == 0 && a.nchunks >= 16) {

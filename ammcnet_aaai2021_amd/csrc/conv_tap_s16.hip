@@ -360,6 +360,45 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
       *reinterpret_cast<f16x8t*>(yp) = hi;
       *reinterpret_cast<f16x8t*>(yp + 4) = lo;
     }
+    if (d.pool_y) {
+      // fused nn.MaxPool2d(2) (unet.py:36): the patch holds whole 2x2 windows (8 rows x 32 pixels).  Same values as
+      // pooling the stored tensor: the S16 rounding is monotone, so it commutes with max.
+      for (int item = tid; item < (BM / 4) * CG; item += NT) {
+        const int pp = item / CG;
+        const int cg = item - pp * CG;
+        const int py = pp >> 4, px = pp & 15;
+        const int ncol0 = n0 + c0 + cg * 8;
+        float sc[8], sh[8], m[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          sc[i] = d.scale ? d.scale[ncol0 + i] : 1.f;
+          sh[i] = d.shift ? d.shift[ncol0 + i] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = (2 * py + (q >> 1)) * 32 + 2 * px + (q & 1);
+          const f32x4 t0 = *reinterpret_cast<const f32x4*>(T + row * EPC + cg * 8);
+          const f32x4 t1 = *reinterpret_cast<const f32x4*>(T + row * EPC + cg * 8 + 4);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            float v = (i < 4 ? t0[i] : t1[i - 4]) * sc[i] + sh[i];
+            if (d.act == AMMC_ACT_RELU) v = v > 0.f ? v : 0.f;
+            m[i] = q == 0 ? v : (v > m[i] ? v : m[i]);
+          }
+        }
+        f16x8t hi, lo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const _Float16 hv = (_Float16)m[i];
+          hi[i] = hv;
+          lo[i] = (_Float16)((m[i] - (float)hv) * T_LO_SCALE);
+        }
+        float* yp = d.pool_y + ((int64_t)b * d.pool_bs + (int64_t)((y0 >> 1) + py) * d.pool_rs +
+                                (int64_t)((x0 >> 1) + px) * d.pool_ps) + ncol0;
+        *reinterpret_cast<f16x8t*>(yp) = hi;
+        *reinterpret_cast<f16x8t*>(yp + 4) = lo;
+      }
+    }
   }
 }
 
@@ -397,6 +436,7 @@ int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream) {
   if (d.cin % 32 || d.width % T_TW || d.height % T_TH) return TAP_SKIP;
   if (d.n != 32 && d.n != 64 && d.n % 128) return TAP_SKIP;
   if (d.n == 32 && !d.y_f32) return TAP_SKIP;
+  if (d.pool_y && (d.y_f32 || d.res || ((uintptr_t)d.pool_y & 31) || ((d.pool_bs | d.pool_rs | d.pool_ps) & 7))) return AMMC_EINVAL;
   const int64_t tiles = (int64_t)d.batch * (d.height / T_TH) * (d.width / T_TW) * (d.n <= 64 ? 1 : d.n / 128);
   if (tiles < 192) return TAP_SKIP;                       // cannot fill the chip: the split-K path of the GEMM kernel is better
   const int64_t patch = (int64_t)(T_TH + 1) * d.x_rs + (int64_t)(T_TW + 1) * d.x_ps;

@@ -274,8 +274,11 @@ class _Builder:
 
     def conv(self, x: Act, w: torch.Tensor, y: Act, *, ntaps: int, cin: int, n: int, scale=None, shift=None,
              act=ACT_NONE, res: Optional[Act] = None, up: int = 1, cgroup: Optional[int] = None, name="conv",
-             cin_true: Optional[int] = None, y_f32: bool = False):
+             cin_true: Optional[int] = None, y_f32: bool = False, pool: Optional[Act] = None):
         d = AmmcConvDesc()
+        if pool is not None:                 # fused 2x2 max-pool output (the halo-patch kernel only; the caller checked)
+            d.pool_y = pool.pix0()
+            d.pool_bs, d.pool_rs, d.pool_ps = pool.strides
         d.y_f32 = 1 if (y_f32 and self.s16) else 0
         d.w_kblk = 1 if (self.s16 and S16_BDIRECT) else 0
         d.overflow_flag = self.overflow.data_ptr() if self.s16 else None
@@ -327,11 +330,16 @@ class _Builder:
         self.plan.keep.extend([d, w, bias32])
         return d
 
-    def double_conv(self, x: Act, p: _DoubleConvPack, mid: Act, y: Act, res: Optional[Act] = None, name="dc"):
+    def double_conv(self, x: Act, p: _DoubleConvPack, mid: Act, y: Act, res: Optional[Act] = None, name="dc",
+                    pool: Optional[Act] = None) -> bool:
+        """`pool`: where the 2x2 max-pool of the output goes; returns True when the second conv stored it itself"""
         self.conv(x, p.w0, mid, ntaps=9, cin=p.cin_p, n=p.cout, scale=p.s0, shift=p.b0, act=ACT_RELU,
                   name=f"{name}.conv0", cin_true=p.cin)
+        fused = pool is not None and res is None and self.s16 and _tap_eligible(mid, 9, p.cout, p.cout) and \
+            os.environ.get("AMMC_FUSE_POOL", "1") != "0"
         self.conv(mid, p.w1, y, ntaps=9, cin=p.cout, n=p.cout, scale=p.s1, shift=p.b1, act=ACT_RELU, res=res,
-                  name=f"{name}.conv1")
+                  name=f"{name}.conv1", pool=pool if fused else None)
+        return fused
 
     def maxpool(self, x: Act, y: Act, name="pool"):
         self.plan.add(self.lib.ammc_maxpool2x2_s16 if self.s16 else self.lib.ammc_maxpool2x2_f32,
@@ -366,15 +374,20 @@ class StreamGraph:
         bld, sp = self.bld, self.sp
         B, H, W = self.B, self.H, self.W
         chans = (64, 128, 256, 512)
+        # every encoder level stores its skip tensor and, for the `down` block that follows (unet.py:36), the 2x2
+        # max-pool of it: from the conv's own epilogue where the halo-patch kernel runs the layer, else by a pool launch
         mid = bld.act(B, H, W, 64)
-        bld.double_conv(self.x_in, sp.inc, mid, self.skip[0], name="inc")
+        pooled = bld.act(B, H >> 1, W >> 1, chans[0])
+        fused = bld.double_conv(self.x_in, sp.inc, mid, self.skip[0], name="inc", pool=pooled)
         for i in range(3):
             h, w = H >> (i + 1), W >> (i + 1)
-            pooled = bld.act(B, h, w, chans[i])
-            bld.maxpool(self.skip[i], pooled, name=f"down{i + 1}.pool")
+            if not fused:
+                bld.maxpool(self.skip[i], pooled, name=f"down{i + 1}.pool")
             mid = bld.act(B, h, w, chans[i + 1])
             out = self.skip[i + 1] if i < 2 else self.x4
-            bld.double_conv(pooled, sp.down[i], mid, out, name=f"down{i + 1}")
+            nxt = bld.act(B, h >> 1, w >> 1, chans[i + 1]) if i < 2 else None
+            fused = bld.double_conv(pooled, sp.down[i], mid, out, name=f"down{i + 1}", pool=nxt)
+            pooled = nxt
 
     def memory(self):
         """enc 1x1 -> fused distance/top-k/gather -> dec 1x1 + residual  (unet.py:318-331, 379-387)"""

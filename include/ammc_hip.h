@@ -94,6 +94,10 @@ typedef struct AmmcConvDesc {
   const float* sq_target; /* fp32-output epilogues only (outc), may be NULL: a tensor laid out like y; the kernel adds   */
   float* sq_acc;          /* sum(((t+1)/2 - (y+1)/2)^2) of every stored element to sq_acc[sample] (fp32 atomics): the  */
                           /* per-sample squared error of `psnr_error` (utils/utils.py:141-148) without re-reading y     */
+  float* pool_y;          /* ammc_conv_gemm_s16, S16 3x3 layers that its halo-patch kernel serves (Cin % 32 == 0, W % 32  */
+  int64_t pool_bs, pool_rs, pool_ps; /* == 0, H % 8 == 0, >= 192 patches; no residual), may be NULL: also store the 2x2   */
+                          /* max-pooled output (nn.MaxPool2d(2) of the `down` block that follows, unet.py:36) at half     */
+                          /* resolution; AMMC_EUNSUP when the layer is not that kernel's                                  */
 } AmmcConvDesc;
 
 int ammc_conv_gemm_f32(const AmmcConvDesc* desc, void* stream);

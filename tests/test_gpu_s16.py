@@ -111,3 +111,24 @@ def test_s16_overflow_guard_recomputes_on_fp32():
     with torch.no_grad():
         w = O.twostream_forward(O.clone_state(big), rgb_x, op_x, 2)
     assert net.s16_fallbacks == 1 and rel_err(out[0].cpu(), w[0]) <= TOL
+
+
+def test_fused_maxpool_matches_pool_kernel(monkeypatch):
+    """the halo-patch kernel's second output (2x2 max-pool of the layer it just computed) against
+    the stand-alone pooling kernel: all three encoder levels fuse at batch 8, 256x256.  The pooled VALUES are the same
+    (the S16 rounding is monotone, so it commutes with max); a value on a half-precision rounding tie may get another
+    (hi, lo) pair for the same number, which moves later fp32 accumulations in the last bit: 2e-6 of max|ref|."""
+    rgb_x, op_x, _, _ = (t.to(DEV) for t in S.make_clips(8, 256, 256, tag="fusepool"))
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("AMMC_FUSE_POOL", flag)
+        net, _ = _net()
+        with torch.no_grad():
+            out = net(rgb_x, op_x)
+        names = [m["name"] for m in net._engine._last["plan"].meta]
+        assert (sum("pool" in n for n in names) == 0) == (flag == "1")
+        outs.append(out)
+    a, b = outs
+    for x, y in ((a[0], b[0]), (a[1], b[1]), (a[3][0], b[3][0]), (a[3][1], b[3][1])):
+        assert float((x - y).abs().max() / y.abs().max()) <= 2e-6
+    assert abs(float(a[2][0]) - float(b[2][0])) <= 1e-6 * abs(float(b[2][0]))
