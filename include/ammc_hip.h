@@ -244,6 +244,16 @@ int ammc_pack_conv4_dgrad_weight_f32(const float* w_oihw, int32_t cout, int32_t 
 int ammc_lrelu_bwd_f32(const float* y, int64_t y_bs, int64_t y_rs, int64_t y_ps, float* g, int64_t g_bs, int64_t g_rs,
                        int64_t g_ps, int32_t batch, int32_t h, int32_t w, int32_t c, float slope, void* stream);
 
+/* Device half of the input pipeline (Code/dataset/two_stream_dataset.py:72-99, 503-506): per frame, once.
+ * frames: uint8 [n][h][w][3] (RGB; bgr != 0: as decoded by cv2 / TurboJPEG, the cvtColor of :76 is folded in) ->
+ *   cv2.resize INTER_LINEAR (8-bit fixed point) -> /255 -> (x - 0.5) / 0.5 -> float32 [n][3][oh][ow].
+ * flows: float32 [n][h][w][2] (.flo payload, flowlib.py:589-611) -> cv2.resize INTER_LINEAR (float) ->
+ *   c0 = u / oh, c1 = c0 / ow (the loader derives channel 1 from the scaled channel 0, :94-95) -> [n][2][oh][ow]. */
+int ammc_frames_u8_to_f32(const uint8_t* src, int32_t n, int32_t h, int32_t w, float* dst, int32_t oh, int32_t ow,
+                          int32_t bgr, void* stream);
+int ammc_flows_to_f32(const float* src, int32_t n, int32_t h, int32_t w, float* dst, int32_t oh, int32_t ow,
+                      void* stream);
+
 /* nn.BatchNorm2d in training mode (unet.py:12,15).  Per-channel reductions write
  * partial[ammc_chan_reduce_blocks(B*H*W)][Q][C]; the finalizers combine them in fp64, fixed order. */
 int ammc_chan_reduce_blocks(int32_t pixels);

@@ -1,0 +1,66 @@
+"""CPU side of the input pipeline: the `.flo` reader and the oracle's restatement of the loaders
+(`oracle/pipeline_oracle.py`, which follows two_stream_dataset.py:72-99 and OpenCV's published INTER_LINEAR)."""
+import numpy as np
+import pytest
+
+from ammcnet_aaai2021_amd import pipeline as P
+from oracle import pipeline_oracle as PO
+
+
+def test_flo_roundtrip_and_errors(tmp_path):
+    rng = np.random.default_rng(3)
+    flow = rng.normal(0, 2, (7, 11, 2)).astype(np.float32)
+    path = str(tmp_path / "a.flo")
+    PO.write_flo(path, flow)
+    assert np.array_equal(P.read_flo(path), flow) and np.array_equal(PO.read_flo(path), flow)
+    raw = open(path, "rb").read()
+    assert raw[:4] == np.float32(202021.25).tobytes() and len(raw) == 12 + flow.nbytes      # Middlebury layout
+    bad = str(tmp_path / "bad.flo")
+    open(bad, "wb").write(b"\x00" * 64)
+    with pytest.raises(ValueError):
+        P.read_flo(bad)
+    open(bad, "wb").write(raw[:40])
+    with pytest.raises(ValueError):
+        P.read_flo(bad)
+
+
+def test_oracle_resize_known_answers():
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (24, 36, 3), dtype=np.uint8)
+    assert np.array_equal(PO.resize_linear_u8(img, 24, 36), img)                            # same size = identity
+    flat = np.full((9, 13, 3), 77, np.uint8)
+    assert np.array_equal(PO.resize_linear_u8(flat, 256, 256), np.full((256, 256, 3), 77, np.uint8))
+    # exact 2x downscale of a horizontal ramp: destination x samples source 2x + 0.5 = the mean of two neighbours
+    ramp = np.tile(np.arange(0, 64, dtype=np.uint8)[None, :, None] * 4, (8, 1, 3))
+    half = PO.resize_linear_u8(ramp, 4, 32)
+    want = ((ramp[0, 0::2, 0].astype(np.int32) + ramp[0, 1::2, 0] + 1) // 2)                 # .5 rounds up (+2 >> 2)
+    assert np.array_equal(half[0, :, 0], want.astype(np.uint8))
+    f = rng.normal(0, 1, (10, 14, 2)).astype(np.float32)
+    assert np.array_equal(PO.resize_linear_f32(f, 10, 14), f)
+    up = PO.resize_linear_f32(f, 20, 28)
+    assert up.min() >= f.min() - 1e-6 and up.max() <= f.max() + 1e-6                          # convex combinations
+
+
+def test_oracle_loaders_follow_the_reference():
+    rng = np.random.default_rng(7)
+    frame = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
+    x = PO.load_frame(frame, (32, 32))
+    assert x.shape == (3, 32, 32) and x.dtype == np.float32 and -1.0 <= x.min() and x.max() <= 1.0
+    assert np.array_equal(PO.load_frame(np.zeros((8, 8, 3), np.uint8), (8, 8)), np.full((3, 8, 8), -1, np.float32))
+    flow = rng.normal(0, 2, (48, 64, 2)).astype(np.float32)
+    y = PO.load_op(flow, (32, 32))
+    assert y.shape == (2, 32, 32)
+    assert np.array_equal(y[1], (y[0] * np.float32(1.0) / np.float32(32)).astype(np.float32))    # channel 1 from channel 0
+    c = PO.clips(np.arange(7 * 2, dtype=np.float32).reshape(7, 2, 1, 1), 5)
+    assert c.shape == (3, 5, 2, 1, 1) and c[2, 0, 0, 0, 0] == 4.0
+
+
+def test_pipeline_refuses_cpu_tensors():
+    import torch
+    from ammcnet_aaai2021_amd import _lib
+    with pytest.raises(_lib.AmmcHipError):
+        P.frames_to_device(torch.zeros(1, 8, 8, 3, dtype=torch.uint8))
+    with pytest.raises(_lib.AmmcHipError):
+        P.flows_to_device(torch.zeros(1, 8, 8, 2))
+    with pytest.raises(_lib.AmmcHipError):
+        P.SubVideoStager([], "cpu")
