@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libammc_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU = 0, 1, 2, 3
 
@@ -69,6 +69,8 @@ SIGNATURES = {
     "ammc_sum_partials_f32": (C.c_int, [_p, _i32, _f32, _p, _p]),
     "ammc_conv_gemm_s16": (C.c_int, [C.POINTER(AmmcConvDesc), _p]),
     "ammc_split_rows_f32": (C.c_int, [_p, _i64, _p, _p]),
+    "ammc_absmax_bits_f32": (C.c_int, [_p, _i64, _p, _p]),
+    "ammc_split_rows_scaled_f32": (C.c_int, [_p, _i64, _p, _p, _p, _i32, _p]),
     "ammc_split_kblk_f32": (C.c_int, [_p, _i32, _i32, _p, _p]),
     "ammc_nchw_to_s16_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _i64, _i64, _i64, _i32, _p]),
     "ammc_s16_to_nchw_f32": (C.c_int, [_p, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _p, _p]),

@@ -383,6 +383,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN >= 1024 ? 1 : 2)) v
             float v = (hh[i][j][r] + xx[i][j][r] * LO_INV) * sc + sh;
             if (d.act == AMMC_ACT_RELU) v = v > 0.f ? v : 0.f;
             else if (d.act == AMMC_ACT_TANH) v = tanhf(v);
+            if (d.res) v += d.res[tab_res[row] + ncol];             // fp32 outputs take an fp32 NHWC residual
             const int64_t addr = o + (int64_t)ncol * ycs;
             d.y[addr] = v;
             if (d.sq_target) {
@@ -573,6 +574,52 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
   *reinterpret_cast<f16x8*>(dst + g * 8 + 4) = lo;
 }
 
+// ---- gradients as S16 operands (training): the split needs its input inside the half range, and gradients of a
+// mean-reduced loss sit around 1 / (pixels), where `hi` would be a subnormal.  absmax_bits finds the largest |v| of a
+// tensor (its fp32 bit pattern: positive floats order like ints), split_rows_scaled multiplies by the power of two
+// that puts it at 2^10 (exact) before splitting and writes the inverse into a per-column vector that the consuming
+// convolution applies as its epilogue `scale`.
+__global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restrict__ src, int64_t ngroups,
+                                                          int* __restrict__ out_bits) {
+  float m = 0.f;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (int64_t)gridDim.x * 256) {
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(src + g * 8);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + g * 8 + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m = fmaxf(m, fmaxf(fabsf(a0[i]), fabsf(a1[i])));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0 && m > 0.f && m < INFINITY) atomicMax(out_bits, __float_as_int(m));
+}
+
+__device__ __forceinline__ float pow2_to_1024(int amax_bits) {
+  int e = ((amax_bits >> 23) & 255) - 127;                  // floor(log2(max |v|)); an all-zero tensor keeps factor 1
+  if (amax_bits == 0) e = 10;
+  int fe = 10 - e;
+  fe = fe < -60 ? -60 : (fe > 60 ? 60 : fe);
+  return __int_as_float((fe + 127) << 23);
+}
+
+__global__ __launch_bounds__(256) void split_rows_scaled_kernel(const float* __restrict__ src, int64_t ngroups,
+                                                                float* __restrict__ dst, const int* __restrict__ amax_bits,
+                                                                float* __restrict__ inv_scale, int n) {
+  const float f = pow2_to_1024(amax_bits[0]);
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < n; i += 256) inv_scale[i] = 1.f / f;        // a power of two: exact
+  if (g >= ngroups) return;
+  const f32x4 a0 = *reinterpret_cast<const f32x4*>(src + g * 8);
+  const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + g * 8 + 4);
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[i] = a0[i] * f; v[4 + i] = a1[i] * f; }
+  f16x8 hi, lo;
+  split8(v, hi, lo);
+  *reinterpret_cast<f16x8*>(dst + g * 8) = hi;
+  *reinterpret_cast<f16x8*>(dst + g * 8 + 4) = lo;
+}
+
 // packed filter [N][Kpad] fp32 -> k-blocked S16 [Kpad/8][N][8 hi | 8 lo] (the BD kernels' layout)
 __global__ __launch_bounds__(256) void split_kblk_kernel(const float* __restrict__ src, int N, int kpad,
                                                          float* __restrict__ dst) {
@@ -696,11 +743,11 @@ extern "C" int ammc_conv_gemm_s16(const AmmcConvDesc* desc, void* stream) {
   if (d.n_store < 0 || d.n_store > d.n || d.y_cs < 0) return AMMC_EINVAL;
   if (d.up != 1 && d.up != 2) return AMMC_EINVAL;
   if (d.up == 2 && (d.cgroup <= 0 || d.cgroup % 32 || d.n != 4 * d.cgroup)) return AMMC_EINVAL;
-  if (d.y_f32 && (d.res || d.up != 1)) return AMMC_EUNSUP;
+  if (d.y_f32 && d.up != 1) return AMMC_EUNSUP;
   if (!d.y_f32 && (d.n_store || d.y_cs > 1 || d.act == AMMC_ACT_TANH)) return AMMC_EUNSUP;
   if (((uintptr_t)d.x | (uintptr_t)d.w) & 15) return AMMC_EINVAL;
   if (!d.y_f32 && (((uintptr_t)d.y & 31) || ((d.y_bs | d.y_rs | d.y_ps) & 7))) return AMMC_EINVAL;
-  if (d.res && (((uintptr_t)d.res & 31) || ((d.r_bs | d.r_rs | d.r_ps) & 7))) return AMMC_EINVAL;
+  if (d.res && !d.y_f32 && (((uintptr_t)d.res & 31) || ((d.r_bs | d.r_rs | d.r_ps) & 7))) return AMMC_EINVAL;
   if ((d.x_bs | d.x_rs | d.x_ps) & 7) return AMMC_EINVAL;
   const int64_t M = (int64_t)d.batch * d.height * d.width;
   if (M >= (1LL << 31)) return AMMC_EUNSUP;
@@ -763,6 +810,24 @@ extern "C" int ammc_conv_gemm_s16(const AmmcConvDesc* desc, void* stream) {
 extern "C" int ammc_split_rows_f32(const float* src, int64_t count, float* dst, void* stream) {
   if (!src || !dst || count <= 0 || (count & 7) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return AMMC_EINVAL;
   hipLaunchKernelGGL(split_rows_kernel, dim3(nblk(count >> 3)), dim3(256), 0, (hipStream_t)stream, src, count >> 3, dst);
+  return ammc_launch_status();
+}
+
+extern "C" int ammc_absmax_bits_f32(const float* src, int64_t count, int32_t* out_bits, void* stream) {
+  if (!src || !out_bits || count <= 0 || (count & 7) || ((uintptr_t)src & 15)) return AMMC_EINVAL;
+  const int64_t groups = count >> 3;
+  const unsigned blocks = (unsigned)(groups < 256 * 2048 ? (groups + 255) / 256 : 2048);
+  hipLaunchKernelGGL(absmax_bits_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, groups, out_bits);
+  return ammc_launch_status();
+}
+
+extern "C" int ammc_split_rows_scaled_f32(const float* src, int64_t count, float* dst, const int32_t* amax_bits,
+                                          float* inv_scale, int32_t n, void* stream) {
+  if (!src || !dst || !amax_bits || !inv_scale || n <= 0 || count <= 0 || (count & 7) ||
+      (((uintptr_t)src | (uintptr_t)dst) & 15))
+    return AMMC_EINVAL;
+  hipLaunchKernelGGL(split_rows_scaled_kernel, dim3(nblk(count >> 3)), dim3(256), 0, (hipStream_t)stream, src, count >> 3,
+                     dst, amax_bits, inv_scale, n);
   return ammc_launch_status();
 }
 

@@ -271,6 +271,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
             float v = TAP_ACC(i, j, r) * sc + sh;
             if (d.act == AMMC_ACT_RELU) v = v > 0.f ? v : 0.f;
             else if (d.act == AMMC_ACT_TANH) v = tanhf(v);
+            if (d.res) v += d.res[tab_res[row] + ncol];             // fp32 outputs take an fp32 NHWC residual
             const int64_t addr = tab_out[row] + (int64_t)ncol * ycs;
             d.y[addr] = v;
             if (d.sq_target) {
@@ -432,7 +433,7 @@ int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream) {
   static const int dbg = getenv("AMMC_S16_DBG") ? atoi(getenv("AMMC_S16_DBG")) : 0;
   constexpr int TAP_SKIP = -12345;
   if (!mode) return TAP_SKIP;
-  if (d.ntaps != 9 || d.up != 1 || d.x_step > 1 || d.w_kblk || d.res && d.y_f32) return TAP_SKIP;
+  if (d.ntaps != 9 || d.up != 1 || d.x_step > 1 || d.w_kblk) return TAP_SKIP;
   if (d.cin % 32 || d.width % T_TW || d.height % T_TH) return TAP_SKIP;
   if (d.n != 32 && d.n != 64 && d.n % 128) return TAP_SKIP;
   if (d.n == 32 && !d.y_f32) return TAP_SKIP;

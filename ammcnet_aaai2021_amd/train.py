@@ -16,6 +16,7 @@ gradients; the vq residual passes the gradient through unchanged.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -26,6 +27,10 @@ from .engine import Act, _cin_pad, _kpad, _ptr
 
 BN_MOMENTUM = 0.1
 CHANS = (64, 128, 256, 512)
+# 3x3 convolutions of the training path (forward and input-gradient): "s16" = the fp32-equivalent split-fp16 kernels
+# of the inference path (operands converted per launch, fp32 outputs; everything else - statistics, weight gradients,
+# 1x1 / transposed convs - stays on the fp32 kernels), "fp32" = exact fp32 MFMA throughout
+TRAIN_PRECISION = os.environ.get("AMMC_TRAIN_PRECISION", "s16")
 
 
 class _WS:
@@ -61,6 +66,50 @@ class _Ops:
         self.ws, self.lib, self.dev = ws, ws.lib, ws.device
         self.zeros = ws.buf(1024)
         self.sync_group = None          # set per step by TrainEngine: a process group, or False for "no sync"
+        self.s16 = TRAIN_PRECISION == "s16"
+        self._shadows: Dict[int, torch.Tensor] = {}
+        self.overflow = ws.buf(1, dtype=torch.int32)
+        self.amax = ws.buf(1, dtype=torch.int32)
+
+    def shadow(self, a: Act) -> Act:
+        """the S16 twin of an fp32 NHWC buffer (same geometry, allocated once per underlying buffer)"""
+        key = a.buf.data_ptr()
+        buf = self._shadows.get(key)
+        if buf is None:
+            buf = self._shadows[key] = self.ws.buf(*a.buf.shape)
+        return Act(buf, a.B, a.H, a.W, a.c, a.c_off, a.halo)
+
+    def conv_s16(self, x: Act, w: torch.Tensor, y: Act, *, ntaps, cin, n, res: Optional[Act] = None, what="conv",
+                 rescale: bool = False):
+        """3x3 conv on the split-fp16 MFMA kernels: x (fp32, any channel slice of its buffer) is re-encoded into its S16
+        twin, the packed filter likewise; fp32 output (+ fp32 residual).  ammc_conv_gemm_s16 picks the kernel.
+        `rescale` (gradients): x is first brought into the half range by a power of two found on the device."""
+        lib, s = self.lib, self.s
+        xs = self.shadow(x)
+        inv = None
+        if rescale:
+            self.amax.zero_()
+            inv = torch.empty(n, device=self.dev, dtype=torch.float32)
+            _chk(lib.ammc_absmax_bits_f32(_ptr(x.buf), x.buf.numel(), self.amax.data_ptr(), s), "absmax")
+            _chk(lib.ammc_split_rows_scaled_f32(_ptr(x.buf), x.buf.numel(), _ptr(xs.buf), self.amax.data_ptr(), _ptr(inv),
+                                                n, s), "split_rows_scaled(x)")
+        else:
+            _chk(lib.ammc_split_rows_f32(_ptr(x.buf), x.buf.numel(), _ptr(xs.buf), s), "split_rows(x)")
+        w16 = torch.empty_like(w)
+        _chk(lib.ammc_split_rows_f32(_ptr(w), w.numel(), _ptr(w16), s), "split_rows(w)")
+        d = AmmcConvDesc()
+        d.x = xs.tap0() if ntaps == 9 else xs.pix0()
+        d.w, d.y = _ptr(w16), y.pix0()
+        d.res = res.pix0() if res is not None else None
+        d.scale = _ptr(inv) if inv is not None else None
+        d.batch, d.height, d.width = y.B, y.H, y.W
+        d.cin, d.ntaps, d.n, d.up, d.cgroup, d.act, d.y_f32 = cin, ntaps, n, 1, n, ACT_NONE, 1
+        d.x_bs, d.x_rs, d.x_ps = xs.strides
+        d.y_bs, d.y_rs, d.y_ps = y.strides
+        if res is not None:
+            d.r_bs, d.r_rs, d.r_ps = res.strides
+        d.overflow_flag = self.overflow.data_ptr()
+        _chk(lib.ammc_conv_gemm_s16(C.byref(d), s), what)
 
     @property
     def sync_world(self) -> int:
@@ -142,7 +191,8 @@ class _ConvBN:
         o, lib, s = self.ops, self.ops.lib, self.ops.s
         w = self.conv.weight.detach()
         _chk(lib.ammc_pack_conv_weight_f32(_ptr(w), self.cout, self.cin, 3, self.cin_p, _ptr(self.wp), s), "pack")
-        o.conv(self.x, self.wp, self.craw, ntaps=9, cin=self.cin_p, n=self.cout, what=self.name)
+        (o.conv_s16 if o.s16 and self.cin_p >= 8 else o.conv)(self.x, self.wp, self.craw, ntaps=9, cin=self.cin_p,
+                                                              n=self.cout, what=self.name)
         c = self.craw
         _chk(lib.ammc_bn_stats_f32(c.pix0(), *c.strides, c.B, c.H, c.W, self.cout, _ptr(self.partial), s), "bn_stats")
         bn = self.bn
@@ -196,7 +246,11 @@ class _ConvBN:
             w = self.conv.weight.detach()
             _chk(lib.ammc_pack_conv_dgrad_weight_f32(_ptr(w), self.cout, self.cin, self.cout, self.rows,
                                                      _ptr(self.wdp), s), "pack_dgrad")
-            o.conv(self.dc, self.wdp, da, ntaps=9, cin=self.cout, n=self.rows, res=da_res, what=self.name + ".dgrad")
+            if o.s16:
+                o.conv_s16(self.dc, self.wdp, da, ntaps=9, cin=self.cout, n=self.rows, res=da_res,
+                           what=self.name + ".dgrad", rescale=True)
+            else:
+                o.conv(self.dc, self.wdp, da, ntaps=9, cin=self.cout, n=self.rows, res=da_res, what=self.name + ".dgrad")
 
 
 class _DoubleConv:

@@ -71,7 +71,7 @@ typedef struct AmmcConvDesc {
   float* y;              /* output, offset to pixel (0,0,0) (+halo) and channel offset     */
   const float* scale;    /* [N] or NULL (=1)                                              */
   const float* shift;    /* [N] or NULL (=0)                                              */
-  const float* res;      /* residual added after the activation, or NULL                  */
+  const float* res;      /* residual added after the activation, or NULL (S16 kernels: S16, or fp32 NHWC when y_f32) */
   int32_t batch, height, width;        /* pixel space of m                               */
   int32_t cin;           /* channels per tap: power of two >= 4                           */
   int32_t ntaps;         /* 9 (3x3, pad 1 via the halo), 4 (2x2, see x_step) or 1         */
@@ -174,6 +174,13 @@ int ammc_conv_gemm_s16(const AmmcConvDesc* desc, void* stream);
 int ammc_split_kblk_f32(const float* src, int32_t n, int32_t kpad, float* dst, void* stream);
 /* fp32 -> S16, count elements (multiple of 8): packed filters, gathered codebook rows */
 int ammc_split_rows_f32(const float* src, int64_t count, float* dst, void* stream);
+/* Gradient tensors as S16 operands (what autograd derives for the 3x3 convs, train_helper.py:337-339): the largest
+ * |v| of the tensor as its fp32 bit pattern (atomicMax into *out_bits, zeroed by the caller), then the split of
+ * v * 2^k with k chosen so that the maximum lands at 2^10; inv_scale[0..n) = 2^-k is the epilogue scale of the
+ * convolution that consumes the tensor. */
+int ammc_absmax_bits_f32(const float* src, int64_t count, int32_t* out_bits, void* stream);
+int ammc_split_rows_scaled_f32(const float* src, int64_t count, float* dst, const int32_t* amax_bits, float* inv_scale,
+                               int32_t n, void* stream);
 /* module-boundary layout: NCHW fp32 -> S16 NHWC (cp % 8 == 0) and back */
 int ammc_nchw_to_s16_f32(const float* x, int32_t batch, int32_t c, int32_t h, int32_t w, float* y,
                          int64_t y_bs, int64_t y_rs, int64_t y_ps, int32_t cp, void* stream);
