@@ -82,7 +82,21 @@ def _tap_eligible(x: "Act", ntaps: int, cin: int, n: int, up: int = 1, y_f32: in
             return False
     elif n != 64 and n % 128:
         return False
-    return x.B * (x.H // 8) * (x.W // 32) * (1 if n <= 64 else n // 128) >= 192
+    return _tap_tiles(x, n) >= 192
+
+
+def _tap_tiles(x: "Act", n: int) -> int:
+    return x.B * (x.H // 8) * (x.W // 32) * (1 if n <= 64 else n // 128)
+
+
+def _tap_variant(x: "Act", n: int) -> str:
+    """template arguments <WGM, WGN, TM, TN, AS> of the conv_tap_s16_kernel instance `conv_tap_s16_try` launches
+    (the bench's kernel labels must name rocprof's kernels one to one)"""
+    if n == 32:
+        return "8, 1, 1, 1, 1"
+    if n == 64:
+        return "4, 1, 2, 2, 1"
+    return "4, 1, 2, 4, 1" if _tap_tiles(x, n) >= 512 else "4, 2, 2, 2, 2"
 
 
 def _kpad(k: int) -> int:
@@ -312,7 +326,7 @@ class _Builder:
         if self.s16 and n % 128 == 0 and m_pix >= 256 * 512 // (n // 128 if n >= 256 else 1) and ntaps * cin > 512:
             tile = "256x128"
         if self.s16 and _tap_eligible(x, ntaps, cin, n, up, d.y_f32):
-            kname, tile = "conv_tap_s16", ("256x64" if n == 64 else "256x128")   # 256x32 = outc, labelled in forward
+            kname, tile = "conv_tap_s16", _tap_variant(x, n)
         self.plan.add(self.conv_fn, C.byref(d), name=name, flops=flops, nbytes=nbytes,
                       kernel=f"{kname}<{tile}>")
         return d
@@ -581,7 +595,7 @@ class EvalEngine:
             else:
                 s.outc.sq_target, s.outc.sq_acc = None, None
             launch(lib.ammc_conv_gemm_s16 if self.s16 else lib.ammc_conv_gemm_f32, (C.byref(s.outc),),
-                   dict(name="outc_tanh", kernel=("conv_tap_s16<256x32>" if self.s16 and _tap_eligible(s.x_in, 9, 64, 32, 1, 1)
+                   dict(name="outc_tanh", kernel=("conv_tap_s16<8, 1, 1, 1, 1>" if self.s16 and _tap_eligible(s.x_in, 9, 64, 32, 1, 1)
                                                   else ("conv_gemm_s16" if self.s16 else "conv_gemm_f32") + "<128x32>"),
                         flops=2.0 * B * H * W * 9 * 64 * s.sp.cout, bytes=4.0 * B * H * W * (64 + s.sp.cout)))
 

@@ -9,7 +9,7 @@ no multi-GPU semantics; inference shards by whole batches and needs no collectiv
 `scaling` is "weak" and `value` is the sum over ranks.
 
 Besides the contract fields the JSON line carries
-  roofline      algorithmic FLOPs of the dominant kernel (S16: conv_tap_s16<256x128>; --precision fp32:
+  roofline      algorithmic FLOPs of the dominant kernel (S16: conv_tap_s16<4, 1, 2, 4, 1>; --precision fp32:
                 conv_gemm_f32<128x128>) per launch divided by its average launch duration (HIP events on the
                 launch stream), against the dense fp16 (2500) / fp32 (157.3 TFLOP/s) MFMA peak of MI355X
   cpu_baseline  the CPU oracle (oracle/ammc_oracle.py, "port") timed on this host on a

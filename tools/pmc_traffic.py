@@ -14,10 +14,10 @@ def label(name):
     m = re.search(r"(conv_gemm_s16|conv_gemm_f32|conv_tap_s16)_kernel<([^>]*)>", name)
     if not m:
         return None
+    if m.group(1) == "conv_tap_s16":                   # labelled by its template arguments <WGM, WGN, TM, TN, AS>
+        return "conv_tap_s16<" + ", ".join(v.strip() for v in m.group(2).split(",")) + ">"
     t = [int(v) if v.strip().lstrip("-").isdigit() else 0 for v in m.group(2).split(",")]
-    bn = t[1] * t[3] * 32
-    bm = 256 if m.group(1) == "conv_tap_s16" else t[0] * t[2] * 32
-    return f"{m.group(1)}<{bm}x{bn}>"
+    return f"{m.group(1)}<{t[0] * t[2] * 32}x{t[1] * t[3] * 32}>"
 
 
 acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
