@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libammc_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU = 0, 1, 2, 3
 
@@ -79,6 +79,7 @@ SIGNATURES = {
     "ammc_memory_topk_f16_blocks": (C.c_int, [_i32]),
     "ammc_memory_topk_fwd_f16": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
     "ammc_conv_wgrad_f32": (C.c_int, [C.POINTER(AmmcWgradDesc), _p]),
+    "ammc_conv_wgrad_s16": (C.c_int, [C.POINTER(AmmcWgradDesc), _p, _p]),
     "ammc_unpack_conv_wgrad_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
     "ammc_unpack_convt_wgrad_f32": (C.c_int, [_p, _i32, _i32, _p, _p]),
     "ammc_pack_conv_dgrad_weight_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),

@@ -31,6 +31,7 @@ CHANS = (64, 128, 256, 512)
 # of the inference path (operands converted per launch, fp32 outputs; everything else - statistics, weight gradients,
 # 1x1 / transposed convs - stays on the fp32 kernels), "fp32" = exact fp32 MFMA throughout
 TRAIN_PRECISION = os.environ.get("AMMC_TRAIN_PRECISION", "s16")
+WGRAD_S16 = os.environ.get("AMMC_WGRAD_S16", "1") != "0"          # the 3x3 weight gradients as well (wgrad_s16.hip)
 
 
 class _WS:
@@ -79,22 +80,40 @@ class _Ops:
             buf = self._shadows[key] = self.ws.buf(*a.buf.shape)
         return Act(buf, a.B, a.H, a.W, a.c, a.c_off, a.halo)
 
-    def conv_s16(self, x: Act, w: torch.Tensor, y: Act, *, ntaps, cin, n, res: Optional[Act] = None, what="conv",
-                 rescale: bool = False):
-        """3x3 conv on the split-fp16 MFMA kernels: x (fp32, any channel slice of its buffer) is re-encoded into its S16
-        twin, the packed filter likewise; fp32 output (+ fp32 residual).  ammc_conv_gemm_s16 picks the kernel.
-        `rescale` (gradients): x is first brought into the half range by a power of two found on the device."""
+    def to_s16(self, x: Act, rescale: bool = False):
+        """re-encode the fp32 buffer behind `x` into its S16 twin; `rescale` (gradients): first bring it into the half
+        range by a power of two found on the device.  Returns (twin, inverse scale [1] or None)."""
         lib, s = self.lib, self.s
         xs = self.shadow(x)
         inv = None
         if rescale:
             self.amax.zero_()
-            inv = torch.empty(n, device=self.dev, dtype=torch.float32)
+            inv = torch.empty(1024, device=self.dev, dtype=torch.float32)
             _chk(lib.ammc_absmax_bits_f32(_ptr(x.buf), x.buf.numel(), self.amax.data_ptr(), s), "absmax")
             _chk(lib.ammc_split_rows_scaled_f32(_ptr(x.buf), x.buf.numel(), _ptr(xs.buf), self.amax.data_ptr(), _ptr(inv),
-                                                n, s), "split_rows_scaled(x)")
+                                                1024, s), "split_rows_scaled(x)")
         else:
             _chk(lib.ammc_split_rows_f32(_ptr(x.buf), x.buf.numel(), _ptr(xs.buf), s), "split_rows(x)")
+        return xs, inv
+
+    def wgrad_s16(self, g16: Act, a16: Act, dw: torch.Tensor, inv, *, n, cin, what="wgrad"):
+        """3x3 weight gradient from the S16 twins of the output gradient and of the layer input"""
+        dw.zero_()
+        d = AmmcWgradDesc()
+        d.g, d.a, d.dw, d.zeros = g16.pix0(), a16.tap0(), _ptr(dw), _ptr(self.zeros)
+        d.batch, d.height, d.width = g16.B, g16.H, g16.W
+        d.n, d.cin, d.ntaps, d.a_step = n, cin, 9, 1
+        d.g_bs, d.g_rs, d.g_ps = g16.strides
+        d.a_bs, d.a_rs, d.a_ps = a16.strides
+        _chk(self.lib.ammc_conv_wgrad_s16(C.byref(d), _ptr(inv) if inv is not None else None, self.s), what)
+
+    def conv_s16(self, x: Act, w: torch.Tensor, y: Act, *, ntaps, cin, n, res: Optional[Act] = None, what="conv",
+                 rescale: bool = False, pre=None):
+        """3x3 conv on the split-fp16 MFMA kernels: x (fp32, any channel slice of its buffer) is re-encoded into its S16
+        twin (or `pre` = what `to_s16` returned for it), the packed filter likewise; fp32 output (+ fp32 residual).
+        ammc_conv_gemm_s16 picks the kernel."""
+        lib, s = self.lib, self.s
+        xs, inv = pre if pre is not None else self.to_s16(x, rescale)
         w16 = torch.empty_like(w)
         _chk(lib.ammc_split_rows_f32(_ptr(w), w.numel(), _ptr(w16), s), "split_rows(w)")
         d = AmmcConvDesc()
@@ -238,7 +257,13 @@ class _ConvBN:
         _chk(lib.ammc_bn_bwd_apply_f32(c.pix0(), *c.strides, dy.pix0(), *dy.strides, _ptr(self.mean), _ptr(self.invstd),
                                        _ptr(self.scale), _ptr(self.shift), _ptr(sums), 1, self.dc.pix0(),
                                        *self.dc.strides, c.B, c.H, c.W, self.cout, s), "bn_bwd_apply")
-        o.wgrad(self.dc, self.x, self.dwp, n=self.cout, cin=self.cin_p, ntaps=9, what=self.name + ".wgrad")
+        pre = None
+        if o.s16 and self.cin_p >= 8 and WGRAD_S16:
+            pre = o.to_s16(self.dc, rescale=True)             # shared by the weight- and the input-gradient launches
+            o.wgrad_s16(pre[0], o.shadow(self.x), self.dwp, pre[1], n=self.cout, cin=self.cin_p,
+                        what=self.name + ".wgrad")            # shadow(x): the twin the forward conv left behind
+        else:
+            o.wgrad(self.dc, self.x, self.dwp, n=self.cout, cin=self.cin_p, ntaps=9, what=self.name + ".wgrad")
         dw = torch.empty_like(self.conv.weight)
         _chk(lib.ammc_unpack_conv_wgrad_f32(_ptr(self.dwp), self.cout, self.cin, 3, self.cin_p, _ptr(dw), s), "unpack")
         grads[self.conv.weight] = dw
@@ -248,7 +273,7 @@ class _ConvBN:
                                                      _ptr(self.wdp), s), "pack_dgrad")
             if o.s16:
                 o.conv_s16(self.dc, self.wdp, da, ntaps=9, cin=self.cout, n=self.rows, res=da_res,
-                           what=self.name + ".dgrad", rescale=True)
+                           what=self.name + ".dgrad", rescale=True, pre=pre)
             else:
                 o.conv(self.dc, self.wdp, da, ntaps=9, cin=self.cout, n=self.rows, res=da_res, what=self.name + ".dgrad")
 

@@ -1,0 +1,58 @@
+"""`ammc_conv_wgrad_s16` (csrc/wgrad_s16.hip: fp16 MFMA, transposed LDS fragment reads) against an fp64 weight gradient
+of the same operands: dW[n][c][r][s] = sum_m G[m][n] * A[m + (r, s)][c].  Includes a gradient-sized G (1e-7) that goes
+through the device-side power-of-two rescaling, a first-layer shape (16 input channels, K padding) and a pixel count
+that is not a multiple of the 32-pixel chunk.  Tolerance 3e-6 of max|ref| (fp32-equivalent operands, fp32 atomics)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ammcnet_aaai2021_amd import _lib, synthetic as S
+from ammcnet_aaai2021_amd._lib import AmmcWgradDesc
+from ammcnet_aaai2021_amd.engine import Act, _ptr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("B,H,W,cin,n,gmag", [(2, 32, 32, 64, 128, 1.0), (3, 20, 24, 128, 64, 3e-7), (2, 16, 16, 16, 64, 1e-6),
+                                               (1, 9, 7, 32, 32, 1.0), (4, 64, 64, 64, 64, 2e-8)])
+def test_wgrad_s16_vs_fp64(B, H, W, cin, n, gmag):
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    tag = f"wg-{B}-{H}-{W}-{cin}-{n}"
+    a = S.hashed_uniform(tag + "a", (B, H, W, cin)).to(DEV)
+    g = (S.hashed_uniform(tag + "g", (B, H, W, n)) * gmag).to(DEV)
+    A32 = Act(torch.zeros(B, H + 2, W + 2, cin, device=DEV), B, H, W, cin, 0, 1)
+    A32.interior().copy_(a)
+    G32 = Act(torch.zeros(B, H + 2, W + 2, n, device=DEV), B, H, W, n, 0, 1)
+    G32.interior().copy_(g)
+    A16 = Act(torch.empty_like(A32.buf), B, H, W, cin, 0, 1)
+    G16 = Act(torch.empty_like(G32.buf), B, H, W, n, 0, 1)
+    _lib.check(lib.ammc_split_rows_f32(_ptr(A32.buf), A32.buf.numel(), _ptr(A16.buf), s), "split a")
+    amax = torch.zeros(1, dtype=torch.int32, device=DEV)
+    inv = torch.empty(8, device=DEV)
+    _lib.check(lib.ammc_absmax_bits_f32(_ptr(G32.buf), G32.buf.numel(), amax.data_ptr(), s), "absmax")
+    _lib.check(lib.ammc_split_rows_scaled_f32(_ptr(G32.buf), G32.buf.numel(), _ptr(G16.buf), amax.data_ptr(), _ptr(inv),
+                                              8, s), "split g")
+    factor = 1.0 / float(inv[0])
+    assert 1024.0 <= float(g.abs().max()) * factor < 2048.0                   # the maximum lands in [2^10, 2^11)
+    kpad = (9 * cin + 31) // 32 * 32
+    dwp = torch.zeros(max(n, 32), kpad, device=DEV)
+    zeros = torch.zeros(1024, device=DEV)
+    d = AmmcWgradDesc()
+    d.g, d.a, d.dw, d.zeros = G16.pix0(), A16.tap0(), _ptr(dwp), _ptr(zeros)
+    d.batch, d.height, d.width, d.n, d.cin, d.ntaps, d.a_step = B, H, W, n, cin, 9, 1
+    d.g_bs, d.g_rs, d.g_ps = G16.strides
+    d.a_bs, d.a_rs, d.a_ps = A16.strides
+    _lib.check(lib.ammc_conv_wgrad_s16(C.byref(d), _ptr(inv), s), "wgrad_s16")
+    dw = torch.empty(n, cin, 3, 3, device=DEV)
+    _lib.check(lib.ammc_unpack_conv_wgrad_f32(_ptr(dwp), n, cin, 3, cin, _ptr(dw), s), "unpack")
+    # fp64 reference: the weight gradient of conv2d(a, w) against the upstream gradient g
+    a64 = a.double().cpu().permute(0, 3, 1, 2).contiguous()
+    g64 = g.double().cpu().permute(0, 3, 1, 2).contiguous()
+    w = torch.zeros(n, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(a64, w, padding=1) * g64).sum().backward()
+    err = float((dw.double().cpu() - w.grad).abs().max() / w.grad.abs().max())
+    assert err <= 3e-6, err
