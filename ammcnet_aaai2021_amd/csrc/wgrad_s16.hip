@@ -14,8 +14,9 @@
 // LDS: two stages of [32 pixels][BR] + [32 pixels][BC] 4-byte slots by LDS-DMA, as wgrad_f32.  The 32-byte group index
 // is XORed with (pixel & 3) << 1 in the image, which makes the transposed reads (4 pixel rows x 2 groups per half
 // wave) conflict free; the DMA applies the same permutation on its source side.
-// A workgroup (4 waves) owns 128 rows (n) x 64 columns (k) of dWp and a slice of the pixels; fp32 atomics combine the
-// slices.  G may carry a power-of-two scale (ammc_split_rows_scaled_f32): `g_inv_scale` undoes it.
+// A workgroup (8 waves as 4 x 2, each 32 rows x 64 columns) owns 128 rows (n) x 128 columns (k) of dWp and a slice of
+// the pixels; fp32 atomics combine the slices.  The kernel is bound by its LDS-DMA traffic (16 MAC per staged byte).
+// G may carry a power-of-two scale (ammc_split_rows_scaled_f32): `g_inv_scale` undoes it.
 #include "ammc_common.h"
 #include <hip/hip_fp16.h>
 
@@ -32,9 +33,10 @@ struct WgradS16Args {
   int row_tiles, col_tiles, msplit, chunks_per_block, nchunks;
 };
 
-constexpr int WS_BR = 128, WS_BC = 64;          // tile of dWp: rows (n) x columns (k)
+constexpr int WS_BR = 128, WS_BC = 128;         // tile of dWp: rows (n) x columns (k)
+constexpr int WS_NT = 512;                      // 8 waves
 constexpr int WS_GS = WS_BR / 4, WS_AS = WS_BC / 4;      // 16-byte slots per pixel row
-constexpr int WS_GJ = 32 * WS_GS / 256, WS_AJ = 32 * WS_AS / 256;
+constexpr int WS_GJ = 32 * WS_GS / WS_NT, WS_AJ = 32 * WS_AS / WS_NT;
 constexpr int WS_GSTAGE = 32 * WS_BR, WS_ASTAGE = 32 * WS_BC;   // floats
 
 __device__ __forceinline__ u32x2 ds_read_tr16(uint32_t addr) {
@@ -43,7 +45,7 @@ __device__ __forceinline__ u32x2 ds_read_tr16(uint32_t addr) {
   return v;
 }
 
-__global__ __launch_bounds__(256, 2) void wgrad_s16_kernel(WgradS16Args a) {
+__global__ __launch_bounds__(WS_NT, 2) void wgrad_s16_kernel(WgradS16Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Gs = smem;                              // [2][32][BR]
   float* As = smem + 2 * WS_GSTAGE;              // [2][32][BC]
@@ -51,6 +53,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s16_kernel(WgradS16Args a) {
   const AmmcWgradDesc& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
 
   int bid = blockIdx.x;
   const int ms = bid % a.msplit;
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s16_kernel(WgradS16Args a) {
   int a_px[WS_AJ];
 #pragma unroll
   for (int j = 0; j < WS_AJ; ++j) {
-    const int p = j * 256 + tid;
+    const int p = j * WS_NT + tid;
     a_px[j] = p / WS_AS;
     const int ls = (p % WS_AS) ^ ((a_px[j] & 3) << 2);
     int k = col0 + 4 * ls;
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s16_kernel(WgradS16Args a) {
   int g_px[WS_GJ], g_col[WS_GJ];
 #pragma unroll
   for (int j = 0; j < WS_GJ; ++j) {
-    const int p = j * 256 + tid;
+    const int p = j * WS_NT + tid;
     g_px[j] = p / WS_GS;
     g_col[j] = row0 + 4 * ((p % WS_GS) ^ ((g_px[j] & 3) << 2));
   }
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s16_kernel(WgradS16Args a) {
       } else {                                                                                          \
         src = d.zeros + (g_col[j] - row0);                                                              \
       }                                                                                                 \
-      __builtin_amdgcn_global_load_lds(src, gdst + j * 1024, 16, 0, 0);                                 \
+      __builtin_amdgcn_global_load_lds(src, gdst + j * (WS_NT * 4), 16, 0, 0);                                 \
     }                                                                                                   \
     _Pragma("unroll") for (int j = 0; j < WS_AJ; ++j) {                                                 \
       int m = (chunk) * 32 + a_px[j];                                                                   \
@@ -109,11 +112,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_s16_kernel(WgradS16Args a) {
       const int x = m % W, t = m / W;                                                                   \
       const int y = t % H, b = t / H;                                                                   \
       const float* src = d.a + ((int64_t)b * d.a_bs + (int64_t)y * d.a_rs + (int64_t)x * d.a_ps) + a_toff[j]; \
-      __builtin_amdgcn_global_load_lds(src, adst + j * 1024, 16, 0, 0);                                 \
+      __builtin_amdgcn_global_load_lds(src, adst + j * (WS_NT * 4), 16, 0, 0);                                 \
     }                                                                                                   \
   }
 
-  // wave `wave` owns G channels [32*wave, +32) = 4 groups = 2 operands, and all 64 A channels = 8 groups = 4 operands
+  // wave (wm, wn) owns G channels [32 wm, +32) = 4 groups = 2 operands and A columns [64 wn, +64) = 8 groups = 4 operands
   f32x16 acc[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -130,12 +133,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_s16_kernel(WgradS16Args a) {
   uint32_t g_off[2], a_off[4];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int g = (wave * 4 + 2 * i + gi) ^ (q << 1);
+    const int g = (wm * 4 + 2 * i + gi) ^ (q << 1);
     g_off[i] = (uint32_t)(g * 32 + 8 * p);
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int g = (2 * j + gi) ^ (q << 1);
+    const int g = (wn * 8 + 2 * j + gi) ^ (q << 1);
     a_off[j] = (uint32_t)(g * 32 + 8 * p);
   }
   const uint32_t g_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)Gs;
@@ -198,14 +201,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_s16_kernel(WgradS16Args a) {
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int col = col0 + 16 * j + 8 * (l31 >> 4) + (l31 & 7);
+      const int col = col0 + 64 * wn + 16 * j + 8 * (l31 >> 4) + (l31 & 7);
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) {
         const int r = (rr & 3) + 8 * (rr >> 2);                       // registers with plane(G) = hi
         const float t = acc[i][j][r] + acc[i][j][r + 4] * LO;         // (hi + lo * 2^-11) of G against this lane's A plane
         const float other = __shfl_xor(t, 8);                         // the same against the other A plane
         if (a_hi) {
-          const int row = row0 + wave * 32 + 16 * i + 8 * (r >> 3) + (r & 3) + 4 * h;
+          const int row = row0 + wm * 32 + 16 * i + 8 * (r >> 3) + (r & 3) + 4 * h;
           if (row < d.n && col < a.kpad)
             unsafeAtomicAdd(d.dw + (int64_t)row * a.kpad + col, (t + other * LO) * inv);
         }
@@ -245,12 +248,12 @@ extern "C" int ammc_conv_wgrad_s16(const AmmcWgradDesc* desc, const float* g_inv
   a.col_tiles = (a.kpad + WS_BC - 1) / WS_BC;
   a.nchunks = (a.M + 31) / 32;
   const int tiles = a.row_tiles * a.col_tiles;
-  int msplit = (4 * 256 + tiles - 1) / tiles;             // ~4 workgroups per CU, at least 8 chunks (256 pixels) each
+  int msplit = (2 * 256 + tiles - 1) / tiles;             // ~2 workgroups per CU, at least 8 chunks (256 pixels) each
   const int max_split = (a.nchunks + 7) / 8;
   if (msplit > max_split) msplit = max_split;
   if (msplit < 1) msplit = 1;
   a.chunks_per_block = (a.nchunks + msplit - 1) / msplit;
   a.msplit = (a.nchunks + a.chunks_per_block - 1) / a.chunks_per_block;
-  hipLaunchKernelGGL(wgrad_s16_kernel, dim3(tiles * a.msplit), dim3(256), lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(wgrad_s16_kernel, dim3(tiles * a.msplit), dim3(WS_NT), lds, (hipStream_t)stream, a);
   return ammc_launch_status();
 }
