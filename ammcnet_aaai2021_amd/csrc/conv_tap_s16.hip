@@ -155,6 +155,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
 #pragma unroll
   for (int i = 0; i < TM; ++i) hpb[i] = (wm * TM + i) * T_HW + l31;
 
+#ifndef AMMC_TAP_SETPRIO
+#define AMMC_TAP_SETPRIO 0
+#endif
+#if AMMC_TAP_SETPRIO
+#define TAP_PRIO(v) __builtin_amdgcn_s_setprio(v)
+#else
+#define TAP_PRIO(v)
+#endif
 #define TAP_COMPUTE(tap, astage, bstage)                                                                   \
   {                                                                                                        \
     const float* Ac = As + (astage) * T_ASTAGE;                                                            \
@@ -177,18 +185,29 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
         bh[j] = *reinterpret_cast<const f16x8t*>(Bc + j * 1024 + (((2 * g) ^ swzb) << 2));                 \
         bl[j] = *reinterpret_cast<const f16x8t*>(Bc + j * 1024 + (((2 * g + 1) ^ swzb) << 2));             \
       }                                                                                                    \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) {      \
-        if (SA) {                                                                                          \
-          const f16x8t ah2_ = ah[i] * (_Float16)T_LO_INV;                                                  \
-          const f16x8t al2_ = al[i] * (_Float16)T_LO_INV;                                                  \
+      if (SA) {                                                                                            \
+        /* one accumulator set: three passes over the tiles, so that MFMAs on the same accumulator are TM*TN apart */ \
+        f16x8t ah2_[TM], al2_[TM];                                                                         \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                   \
+          ah2_[i] = ah[i] * (_Float16)T_LO_INV;                                                            \
+          al2_[i] = al[i] * (_Float16)T_LO_INV;                                                            \
+        }                                                                                                  \
+        TAP_PRIO(1);                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)      \
           hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], hh[i][j], 0, 0, 0);             \
-          hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah2_, bl[j], hh[i][j], 0, 0, 0);              \
-          hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al2_, bh[j], hh[i][j], 0, 0, 0);              \
-        } else {                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)      \
+          hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah2_[i], bl[j], hh[i][j], 0, 0, 0);           \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)      \
+          hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al2_[i], bh[j], hh[i][j], 0, 0, 0);           \
+        TAP_PRIO(0);                                                                                       \
+      } else {                                                                                             \
+        TAP_PRIO(1);                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) {    \
           hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], hh[i][j], 0, 0, 0);             \
           xx[SA ? 0 : i][SA ? 0 : j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], xx[SA ? 0 : i][SA ? 0 : j], 0, 0, 0); \
           xx[SA ? 0 : i][SA ? 0 : j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], xx[SA ? 0 : i][SA ? 0 : j], 0, 0, 0); \
         }                                                                                                  \
+        TAP_PRIO(0);                                                                                       \
       }                                                                                                    \
     }                                                                                                      \
   }
