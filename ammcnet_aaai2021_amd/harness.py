@@ -286,3 +286,38 @@ def weights_init_normal(model: torch.nn.Module) -> None:
             torch.nn.init.constant_(m.bias.data, 0.0)
     if hasattr(model, "_param_epoch"):
         model._param_epoch += 1
+
+
+# ---- checkpoint tooling (utils/utils.py:182-263): same file names and key conventions as the reference ------------
+
+def save_checkpoint(state_dict: dict, model_dir: str, step: int) -> str:
+    """`saver` (utils.py:182-189): <model_dir>/step_<step+1, 6 digits>.pth"""
+    import os
+    os.makedirs(model_dir, exist_ok=True)
+    path = os.path.join(model_dir, "step_{}.pth".format(str(step + 1).zfill(6)))
+    torch.save(state_dict, path)
+    return path
+
+
+def load_latest_checkpoint(model: torch.nn.Module, model_dir: str, map_location="cpu"):
+    """`loader` (utils.py:192-203): the lexicographically last file of the directory; returns (model, step)"""
+    import os
+    names = sorted(os.listdir(model_dir))
+    if not names:
+        raise FileNotFoundError(f"no checkpoint in {model_dir}")
+    path = os.path.join(model_dir, names[-1])
+    model.load_state_dict(torch.load(path, map_location=map_location))
+    return model, int(path.split("_")[-1].split(".")[0])
+
+
+def load_pretrained_branches(model: torch.nn.Module, rgb_ckpt, op_ckpt, map_location="cpu"):
+    """`loader_rgb_op_branch` (utils.py:236-263): the two-stage recipe of the reference README - single-stream
+    `UNetMem_v7` checkpoints (paths or state dicts) go into the `rgb.` / `op.` branches of `twostream`, keys the joint
+    model does not have are dropped, the bridge keeps its initialisation.  Returns (model, 0) like the reference."""
+    def as_dict(c):
+        return torch.load(c, map_location=map_location) if isinstance(c, (str, bytes)) or hasattr(c, "__fspath__") else c
+    own = model.state_dict()
+    for prefix, ck in (("rgb", as_dict(rgb_ckpt)), ("op", as_dict(op_ckpt))):
+        own.update({f"{prefix}.{k}": v for k, v in ck.items() if f"{prefix}.{k}" in own})
+    model.load_state_dict(own)
+    return model, 0

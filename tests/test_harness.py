@@ -107,3 +107,36 @@ def test_weights_init_normal_statistics():
     bn = net.bridge.O2F.conv[1]
     assert abs(float(bn.weight.mean()) - 1.0) < 5e-3 and float(bn.bias.abs().max()) == 0.0
     assert abs(float(net.rgb.up1.up.weight.std()) - 0.02) < 1e-3          # ConvTranspose2d matches "Conv" too
+
+
+def test_checkpoint_tooling_follows_the_reference_conventions(tmp_path):
+    """saver / loader / loader_rgb_op_branch (utils/utils.py:182-263): file names, latest-file rule, branch prefixes"""
+    import ammcnet_aaai2021_amd as A
+    from ammcnet_aaai2021_amd import harness as Hn, synthetic as S
+    two = A.get_twostream((12, 6), (3, 2), 64, 256, 2)
+    two.load_state_dict(S.make_twostream_state(tag="ckpt-a"))
+    d = str(tmp_path / "generator")
+    assert Hn.save_checkpoint(two.state_dict(), d, 999).endswith("step_001000.pth")
+    two.load_state_dict(S.make_twostream_state(tag="ckpt-b"))
+    p = Hn.save_checkpoint(two.state_dict(), d, 1999)
+    fresh = A.get_twostream((12, 6), (3, 2), 64, 256, 2)
+    fresh, step = Hn.load_latest_checkpoint(fresh, d)
+    assert step == 2000 and p.endswith("step_002000.pth")
+    want = S.make_twostream_state(tag="ckpt-b")
+    assert all(torch.equal(v, want[k]) for k, v in fresh.state_dict().items())
+    # two-stage recipe: single-stream checkpoints into the branches, bridge untouched
+    rgb = A.get_unet_vq_topk_res(12, 3, 64, 256, 2)
+    op = A.get_unet_vq_topk_res(6, 2, 64, 256, 2)
+    sa = S.make_twostream_state(tag="ckpt-a")
+    rgb.load_state_dict({k[4:]: v for k, v in sa.items() if k.startswith("rgb.")})
+    op.load_state_dict({k[3:]: v for k, v in sa.items() if k.startswith("op.")})
+    torch.save(rgb.state_dict(), tmp_path / "rgb.pth")
+    joint = A.get_twostream((12, 6), (3, 2), 64, 256, 2)
+    joint.load_state_dict(S.make_twostream_state(tag="ckpt-b"))
+    extra = dict(op.state_dict(), not_in_the_joint_model=torch.zeros(1))
+    joint, step = Hn.load_pretrained_branches(joint, str(tmp_path / "rgb.pth"), extra)
+    assert step == 0
+    got = joint.state_dict()
+    for k, v in got.items():
+        src = want if k.startswith("bridge.") else sa
+        assert torch.equal(v, src[k]), k
