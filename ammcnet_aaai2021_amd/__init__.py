@@ -8,6 +8,7 @@ from .unet import (UNet, UNetMem_v7, Quantize_topk, bridge, double_conv, down,  
                    get_unet_vq_topk_res, inconv, twostream, up)
 
 from .discriminator import PixelDiscriminator  # noqa: F401
+from .flownet import FlowNet2SD  # noqa: F401
 
-__all__ = ["PixelDiscriminator", "UNet", "UNetMem_v7", "Quantize_topk", "bridge", "double_conv", "down", "enc_quan_dec_res_topk",
+__all__ = ["FlowNet2SD", "PixelDiscriminator", "UNet", "UNetMem_v7", "Quantize_topk", "bridge", "double_conv", "down", "enc_quan_dec_res_topk",
            "enc_quan_dec_topk", "get_twostream", "get_unet", "get_unet_vq_topk_res", "inconv", "twostream", "up"]

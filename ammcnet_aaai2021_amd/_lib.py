@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libammc_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU = 0, 1, 2, 3
 
@@ -84,7 +84,10 @@ SIGNATURES = {
     "ammc_unpack_convt_wgrad_f32": (C.c_int, [_p, _i32, _i32, _p, _p]),
     "ammc_pack_conv_dgrad_weight_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
     "ammc_transpose_pad_f32": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
-    "ammc_pack_conv4_dgrad_weight_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _p, _p]),
+    "ammc_pack_conv4_dgrad_weight_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
+    "ammc_flownet_prep_f32": (C.c_int, [_p, _i32, _i32, _i32, _p] + _s3 + [_f32, _p]),
+    "ammc_lrelu_f32": (C.c_int, [_p] + _s3 + [_i32, _i32, _i32, _i32, _f32, _p]),
+    "ammc_upsample4_bilinear_f32": (C.c_int, [_p] + _s3 + [_i32, _i32, _i32, _i32, _f32, _p, _p]),
     "ammc_lrelu_bwd_f32": (C.c_int, [_p] + _s3 + [_p] + _s3 + [_i32, _i32, _i32, _i32, _f32, _p]),
     "ammc_frames_u8_to_f32": (C.c_int, [_p, _i32, _i32, _i32, _p, _i32, _i32, _i32, _p]),
     "ammc_flows_to_f32": (C.c_int, [_p, _i32, _i32, _i32, _p, _i32, _i32, _p]),

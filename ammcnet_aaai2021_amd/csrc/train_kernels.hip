@@ -378,10 +378,12 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
 
 // Input-gradient filters of the PixelDiscriminator's 4x4 convolutions (pix2pix_networks.py:604-621, padding 2).
 // stride 1: one [rows][16*cout_p] matrix, the window flipped (k = tap'*cout_p + n, tap' = 15 - tap).
-// stride 2: four matrices [phase = py*2+px][rows][4*cout_p]; input pixel (2q'+py, 2r'+px) gathers the 2x2 block
-//           of output gradients (q'+dr, r'+ds) through filter tap (py + 2(1-dr), px + 2(1-ds)).
+// stride 2: four matrices [phase = py*2+px][rows][4*cout_p]; input pixel (2q'+py, 2r'+px) gathers the 2x2 block of
+//           output gradients ((py+pad)/2 - 1 + q' + dr, ...) through filter tap ((py+pad) % 2 + 2(1-dr), ...);
+//           pad = the convolution's padding (2: PixelDiscriminator; 1: ConvTranspose2d(k 4, s 2, p 1) of FlowNet2-SD,
+//           whose forward IS this input gradient).
 __global__ __launch_bounds__(256) void pack_conv4_dgrad_weight_kernel(const float* __restrict__ w, int cout, int cin,
-                                                                      int cout_p, int kpad, int rows, int stride,
+                                                                      int cout_p, int kpad, int rows, int stride, int pad,
                                                                       float* __restrict__ out) {
   const int phases = stride == 2 ? 4 : 1;
   const int64_t total = (int64_t)phases * rows * kpad;
@@ -395,8 +397,8 @@ __global__ __launch_bounds__(256) void pack_conv4_dgrad_weight_kernel(const floa
   if (n < cout && c < cin) {
     if (stride == 2) {
       if (tap < 4) {
-        const int r = (ph >> 1) + 2 * (1 - (tap >> 1));
-        const int s = (ph & 1) + 2 * (1 - (tap & 1));
+        const int r = (((ph >> 1) + pad) & 1) + 2 * (1 - (tap >> 1));
+        const int s = (((ph & 1) + pad) & 1) + 2 * (1 - (tap & 1));
         v = w[((int64_t)n * cin + c) * 16 + r * 4 + s];
       }
     } else if (tap < 16) {
@@ -586,14 +588,15 @@ int ammc_pack_conv_dgrad_weight_f32(const float* w_oihw, int32_t cout, int32_t c
 }
 
 int ammc_pack_conv4_dgrad_weight_f32(const float* w_oihw, int32_t cout, int32_t cin, int32_t cout_p, int32_t rows,
-                                     int32_t stride, float* out, void* stream) {
-  if (!w_oihw || !out || cout <= 0 || cin <= 0 || cout_p < cout || rows < cin || (stride != 1 && stride != 2))
+                                     int32_t stride, int32_t pad, float* out, void* stream) {
+  if (!w_oihw || !out || cout <= 0 || cin <= 0 || cout_p < cout || rows < cin || (stride != 1 && stride != 2) ||
+      pad < 0 || pad > 2)
     return AMMC_EINVAL;
   const int taps = stride == 2 ? 4 : 16;
   const int kpad = ((taps * cout_p + 31) / 32) * 32;
   const int64_t total = (int64_t)(stride == 2 ? 4 : 1) * rows * kpad;
   hipLaunchKernelGGL(pack_conv4_dgrad_weight_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, w_oihw, cout,
-                     cin, cout_p, kpad, rows, stride, out);
+                     cin, cout_p, kpad, rows, stride, pad, out);
   return ammc_launch_status();
 }
 

@@ -160,7 +160,7 @@ class DiscEngine:
             _chk(lib.ammc_pack_conv_weight_f32(_ptr(w), L.cout, L.cin, 4, L.cin_p, _ptr(slot.wp[i]), s), "pack_w")
             slot.bp[i][:L.cout].copy_(b)
             if keep and (i > 0 or need_dx):
-                _chk(lib.ammc_pack_conv4_dgrad_weight_f32(_ptr(w), L.cout, L.cin, L.gc, L.rows, L.stride,
+                _chk(lib.ammc_pack_conv4_dgrad_weight_f32(_ptr(w), L.cout, L.cin, L.gc, L.rows, L.stride, 2,
                                                           _ptr(slot.wd[i]), s), "pack_dgrad")
         slot.has_dgrad = keep
         oh, ow = slot.out_hw

@@ -1,0 +1,288 @@
+"""`FlowNet2SD` (reference Code/models/flownet2/models.py:9-59 over FlowNetSD.py:7-100, submodules.py:9-45), the frozen
+flow estimator behind the flow-consistency term of the generator loss (train_helper.py:309-316), eval-mode forward on the
+HIP kernels.  Same constructor, `state_dict` keys (45,371,666 parameters) and call: `net(frames [B,3,2,H,W] in 0..255)`
+-> flow `[B,2,H,W]`.  The published checkpoint is not available here; parity is against the reference class itself on
+synthetic parameters (tests/golden/flownet2sd_eval.npz).
+
+Every Conv2d(k 3, stride 1|2, bias) + LeakyReLU(0.1) is one launch of `ammc_conv_gemm_f32` (ntaps 9, x_step = stride);
+every ConvTranspose2d(k 4, s 2, p 1) is four 2x2-tap parity convolutions through doubled output strides (the forward of a
+transposed conv IS the input gradient of a conv: the filters come from `ammc_pack_conv4_dgrad_weight_f32`, pad 1).
+Concatenations (`torch.cat`, models.py:35-52) are channel slices of one buffer; a layer that READS a concatenation runs
+once per part (channel counts 1026 / 770 / 386 / 194 are not what the kernel tiles; their parts 512+512+2 ... are) and
+accumulates through the epilogue's residual input.  Exact fp32 MFMA throughout (flows reach tens of pixels).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import ACT_LRELU, ACT_NONE, AmmcConvDesc
+from .engine import Act, _cin_pad, _kpad, _ptr
+
+SLOPE = 0.1
+
+
+def _chk(rc, what):
+    if rc != 0:
+        _lib.check(rc, what)
+
+
+def _ncols(c: int) -> int:
+    return c if c % 64 == 0 else 32
+
+
+class _Engine:
+    def __init__(self, module: "FlowNet2SD"):
+        self.m = module
+        self.lib = _lib.load()
+        self.ws: Dict[Tuple, dict] = {}
+        self.packs: Optional[dict] = None
+        self.pack_version = None
+
+    # ---- parameters ------------------------------------------------------------------------------------------
+    def _version(self):
+        ps = list(self.m.parameters())
+        return (sum(p._version for p in ps), ps[0].device, ps[0].data_ptr())
+
+    def _pack_conv(self, w: torch.Tensor, b: torch.Tensor, parts: Sequence[int]):
+        """3x3 conv over a (possibly concatenated) input: one packed filter per part, bias padded to the column count"""
+        lib, dev = self.lib, w.device
+        s = torch.cuda.current_stream(dev).cuda_stream
+        co = w.shape[0]
+        n = _ncols(co)
+        out, c0 = [], 0
+        for c in parts:
+            cp = _cin_pad(c)
+            wp = torch.zeros(n, _kpad(9 * cp), device=dev)
+            ws = w.detach()[:, c0:c0 + c].contiguous()
+            _chk(lib.ammc_pack_conv_weight_f32(_ptr(ws), co, c, 3, cp, _ptr(wp), s), "pack_conv")
+            out.append((wp, cp))
+            c0 += c
+        bias = torch.zeros(n, device=dev)
+        bias[:co].copy_(b.detach())
+        return dict(w=out, bias=bias, n=n, co=co)
+
+    def _pack_deconv(self, w: torch.Tensor, b: torch.Tensor, parts: Sequence[int]):
+        """ConvTranspose2d(k 4, s 2, p 1), weight [Cin, Cout, 4, 4]: per input part four parity filters [rows][4*cin_p]"""
+        lib, dev = self.lib, w.device
+        s = torch.cuda.current_stream(dev).cuda_stream
+        co = w.shape[1]
+        rows = _ncols(co)
+        out, c0 = [], 0
+        wd = w.detach().contiguous()
+        for c in parts:
+            cp = _cin_pad(c)
+            kp = _kpad(4 * cp)
+            wp = torch.zeros(4 * rows * kp, device=dev)
+            _chk(lib.ammc_pack_conv4_dgrad_weight_f32(_ptr(wd, c0 * co * 16), c, co, cp, rows, 2, 1, _ptr(wp), s),
+                 "pack_deconv")
+            out.append((wp, cp, rows * kp))
+            c0 += c
+        bias = torch.zeros(rows, device=dev)
+        bias[:co].copy_(b.detach())
+        return dict(w=out, bias=bias, n=rows, co=co)
+
+    def _ensure_packs(self):
+        v = self._version()
+        if self.packs is not None and v == self.pack_version:
+            return
+        m, pk = self.m, {}
+        single = ["conv0", "conv1", "conv1_1", "conv2", "conv2_1", "conv3", "conv3_1", "conv4", "conv4_1", "conv5",
+                  "conv5_1", "conv6", "conv6_1"]
+        for name in single:
+            conv = getattr(m, name)[0]
+            pk[name] = self._pack_conv(conv.weight, conv.bias, [conv.weight.shape[1]])
+        cat = {5: (512, 512, 2), 4: (512, 256, 2), 3: (256, 128, 2), 2: (128, 64, 2)}
+        for lvl, parts in cat.items():
+            ic = getattr(m, f"inter_conv{lvl}")[0]
+            pk[f"inter_conv{lvl}"] = self._pack_conv(ic.weight, ic.bias, parts)
+        pk["deconv5"] = self._pack_deconv(m.deconv5[0].weight, m.deconv5[0].bias, (1024,))
+        for lvl in (4, 3, 2):
+            dc = getattr(m, f"deconv{lvl}")[0]
+            pk[f"deconv{lvl}"] = self._pack_deconv(dc.weight, dc.bias, cat[lvl + 1])
+        for lvl in (6, 5, 4, 3, 2):
+            pf = getattr(m, f"predict_flow{lvl}")
+            pk[f"predict_flow{lvl}"] = self._pack_conv(pf.weight, pf.bias, [pf.weight.shape[1]])
+        for a, b in ((6, 5), (5, 4), (4, 3), (3, 2)):
+            up = getattr(m, f"upsampled_flow{a}_to_{b}")
+            pk[f"up{a}"] = self._pack_deconv(up.weight, up.bias, (2,))
+        self.packs, self.pack_version = pk, v
+
+    # ---- workspace -------------------------------------------------------------------------------------------
+    def _workspace(self, B, H, W, dev) -> dict:
+        key = (B, H, W, dev)
+        ws = self.ws.get(key)
+        if ws is not None:
+            return ws
+
+        def act(div, c):
+            h, w = H // div, W // div
+            return Act(torch.zeros(B, h + 2, w + 2, c, device=dev), B, h, w, c, 0, 1)
+
+        ws = dict(x0=act(1, 8), c0=act(1, 64), t1=act(2, 64), c1=act(2, 128), t2=act(4, 128), t3=act(8, 256),
+                  t4=act(16, 512), t5=act(32, 512), t6=act(64, 1024), c6=act(64, 1024),
+                  cat2=act(4, 196), cat3=act(8, 388), cat4=act(16, 772), cat5=act(32, 1028),
+                  ic5=act(32, 512), ic4=act(16, 256), ic3=act(8, 128), ic2=act(4, 64),
+                  f6=act(64, 4), f5=act(32, 4), f4=act(16, 4), f3=act(8, 4), f2=act(4, 4))
+        self.ws[key] = ws
+        return ws
+
+    # ---- launches --------------------------------------------------------------------------------------------
+    def _conv(self, x: Act, pk: dict, y: Act, stride=1, act=ACT_LRELU, n_store=0):
+        """3x3 conv of `x` (one Act, or the list of parts of a concatenation) into y"""
+        parts = x if isinstance(x, (list, tuple)) else [x]
+        s = torch.cuda.current_stream(y.buf.device).cuda_stream
+        for i, (xp, (wp, cp)) in enumerate(zip(parts, pk["w"])):
+            d = AmmcConvDesc()
+            d.x, d.w, d.y = xp.tap0(), _ptr(wp), y.pix0()
+            d.shift = _ptr(pk["bias"]) if i == 0 else None
+            d.res = y.pix0() if i > 0 else None
+            d.batch, d.height, d.width = y.B, y.H, y.W
+            d.cin, d.ntaps, d.n, d.up, d.cgroup, d.x_step = cp, 9, pk["n"], 1, pk["n"], stride
+            d.act = act if len(parts) == 1 else ACT_NONE
+            d.n_store = n_store if n_store else (pk["co"] if pk["co"] != pk["n"] else 0)
+            d.x_bs, d.x_rs, d.x_ps = xp.strides
+            d.y_bs, d.y_rs, d.y_ps = y.strides
+            d.r_bs, d.r_rs, d.r_ps = y.strides
+            _chk(self.lib.ammc_conv_gemm_f32(C.byref(d), s), "flownet.conv")
+        assert len(parts) == 1 or act == ACT_NONE, "a multi-part conv carries no activation in this network"
+
+    def _deconv(self, x, pk: dict, y: Act, lrelu: bool):
+        """ConvTranspose2d(k 4, s 2, p 1) of x (Act or parts) into y (twice the resolution) [+ LeakyReLU]"""
+        parts = x if isinstance(x, (list, tuple)) else [x]
+        s = torch.cuda.current_stream(y.buf.device).cuda_stream
+        for i, (xp, (wp, cp, per)) in enumerate(zip(parts, pk["w"])):
+            for ph in range(4):
+                py, px = ph >> 1, ph & 1
+                d = AmmcConvDesc()
+                # window origin: input pixel ((py + 1) >> 1) - 1 + q' for output row 2 q' + py
+                d.x = xp.pix0() + 4 * ((((py + 1) >> 1) - 1) * xp.rs + (((px + 1) >> 1) - 1) * xp.ps)
+                d.w = _ptr(wp, ph * per)
+                d.y = y.pix0() + 4 * (py * y.rs + px * y.ps)
+                d.shift = _ptr(pk["bias"]) if i == 0 else None
+                d.res = d.y if i > 0 else None
+                d.batch, d.height, d.width = xp.B, xp.H, xp.W
+                d.cin, d.ntaps, d.n, d.up, d.cgroup, d.x_step = cp, 4, pk["n"], 1, pk["n"], 1
+                d.act = ACT_LRELU if (lrelu and len(parts) == 1) else ACT_NONE
+                d.n_store = pk["co"] if pk["co"] != pk["n"] else 0
+                d.x_bs, d.x_rs, d.x_ps = xp.strides
+                d.y_bs, d.y_rs, d.y_ps = y.bs, 2 * y.rs, 2 * y.ps
+                d.r_bs, d.r_rs, d.r_ps = y.bs, 2 * y.rs, 2 * y.ps
+                _chk(self.lib.ammc_conv_gemm_f32(C.byref(d), s), "flownet.deconv")
+        if lrelu and len(parts) > 1:
+            _chk(self.lib.ammc_lrelu_f32(y.pix0(), *y.strides, y.B, y.H, y.W, y.c, SLOPE, s), "flownet.lrelu")
+
+    def forward(self, inputs: torch.Tensor) -> torch.Tensor:
+        if not inputs.is_cuda:
+            raise _lib.AmmcHipError("FlowNet2SD runs on the HIP kernels only: input must be a GPU tensor")
+        if inputs.dim() != 5 or inputs.shape[1] != 3 or inputs.shape[2] != 2:
+            raise ValueError("expected frame pairs [B, 3, 2, H, W]")
+        B, _, _, H, W = inputs.shape
+        if H % 64 or W % 64:
+            raise ValueError(f"frame size {H}x{W} must be divisible by 64 (six stride-2 levels)")
+        x = inputs.detach().float().contiguous()
+        dev = x.device
+        self._ensure_packs()
+        ws, pk, lib = self._workspace(B, H, W, dev), self.packs, self.lib
+        s = torch.cuda.current_stream(dev).cuda_stream
+        x0 = ws["x0"]
+        _chk(lib.ammc_flownet_prep_f32(_ptr(x), B, H, W, x0.pix0(), *x0.strides, float(self.m.rgb_max), s), "prep")
+        cat2, cat3, cat4, cat5 = ws["cat2"], ws["cat3"], ws["cat4"], ws["cat5"]
+        c2, d2, u3 = cat2.slice(0, 128), cat2.slice(128, 64), cat2.slice(192, 4)
+        c3, d3, u4 = cat3.slice(0, 256), cat3.slice(256, 128), cat3.slice(384, 4)
+        c4, d4, u5 = cat4.slice(0, 512), cat4.slice(512, 256), cat4.slice(768, 4)
+        c5, d5, u6 = cat5.slice(0, 512), cat5.slice(512, 512), cat5.slice(1024, 4)
+        self._conv(x0, pk["conv0"], ws["c0"])
+        self._conv(ws["c0"], pk["conv1"], ws["t1"], stride=2)
+        self._conv(ws["t1"], pk["conv1_1"], ws["c1"])
+        self._conv(ws["c1"], pk["conv2"], ws["t2"], stride=2)
+        self._conv(ws["t2"], pk["conv2_1"], c2)
+        self._conv(c2, pk["conv3"], ws["t3"], stride=2)
+        self._conv(ws["t3"], pk["conv3_1"], c3)
+        self._conv(c3, pk["conv4"], ws["t4"], stride=2)
+        self._conv(ws["t4"], pk["conv4_1"], c4)
+        self._conv(c4, pk["conv5"], ws["t5"], stride=2)
+        self._conv(ws["t5"], pk["conv5_1"], c5)
+        self._conv(c5, pk["conv6"], ws["t6"], stride=2)
+        self._conv(ws["t6"], pk["conv6_1"], ws["c6"])
+        # decoder (models.py:31-54)
+        self._conv(ws["c6"], pk["predict_flow6"], ws["f6"], act=ACT_NONE)
+        self._deconv(ws["f6"], pk["up6"], u6, lrelu=False)
+        self._deconv(ws["c6"], pk["deconv5"], d5, lrelu=True)
+        p5 = [c5, d5, u6]
+        self._conv(p5, pk["inter_conv5"], ws["ic5"], act=ACT_NONE)
+        self._conv(ws["ic5"], pk["predict_flow5"], ws["f5"], act=ACT_NONE)
+        self._deconv(ws["f5"], pk["up5"], u5, lrelu=False)
+        self._deconv(p5, pk["deconv4"], d4, lrelu=True)
+        p4 = [c4, d4, u5]
+        self._conv(p4, pk["inter_conv4"], ws["ic4"], act=ACT_NONE)
+        self._conv(ws["ic4"], pk["predict_flow4"], ws["f4"], act=ACT_NONE)
+        self._deconv(ws["f4"], pk["up4"], u4, lrelu=False)
+        self._deconv(p4, pk["deconv3"], d3, lrelu=True)
+        p3 = [c3, d3, u4]
+        self._conv(p3, pk["inter_conv3"], ws["ic3"], act=ACT_NONE)
+        self._conv(ws["ic3"], pk["predict_flow3"], ws["f3"], act=ACT_NONE)
+        self._deconv(ws["f3"], pk["up3"], u3, lrelu=False)
+        self._deconv(p3, pk["deconv2"], d2, lrelu=True)
+        p2 = [c2, d2, u3]
+        self._conv(p2, pk["inter_conv2"], ws["ic2"], act=ACT_NONE)
+        f2 = ws["f2"]
+        self._conv(ws["ic2"], pk["predict_flow2"], f2, act=ACT_NONE)
+        out = torch.empty(B, 2, H, W, device=dev, dtype=torch.float32)
+        _chk(lib.ammc_upsample4_bilinear_f32(f2.pix0(), *f2.strides, B, f2.H, f2.W, 2, float(self.m.div_flow), _ptr(out), s),
+             "upsample")
+        return out
+
+
+def _conv(cin, cout, stride=1):
+    return nn.Sequential(nn.Conv2d(cin, cout, 3, stride, 1, bias=True), nn.LeakyReLU(SLOPE, inplace=True))
+
+
+def _deconv(cin, cout):
+    return nn.Sequential(nn.ConvTranspose2d(cin, cout, 4, 2, 1, bias=True), nn.LeakyReLU(SLOPE, inplace=True))
+
+
+def _iconv(cin, cout):
+    return nn.Sequential(nn.Conv2d(cin, cout, 3, 1, 1, bias=True))
+
+
+class FlowNet2SD(nn.Module):
+    """parameter holders with the reference's names and shapes; `forward` (eval mode) runs on the HIP kernels"""
+
+    def __init__(self, batchNorm: bool = False, div_flow: float = 20):
+        super().__init__()
+        if batchNorm:
+            raise NotImplementedError("FlowNet2SD(batchNorm=True) is not built; the reference constructs it with "
+                                      "batchNorm=False (models/__init__.py:126, flownet2/models.py:10)")
+        self.batchNorm, self.rgb_max, self.div_flow = False, 255.0, div_flow
+        self.conv0 = _conv(6, 64)
+        self.conv1, self.conv1_1 = _conv(64, 64, 2), _conv(64, 128)
+        self.conv2, self.conv2_1 = _conv(128, 128, 2), _conv(128, 128)
+        self.conv3, self.conv3_1 = _conv(128, 256, 2), _conv(256, 256)
+        self.conv4, self.conv4_1 = _conv(256, 512, 2), _conv(512, 512)
+        self.conv5, self.conv5_1 = _conv(512, 512, 2), _conv(512, 512)
+        self.conv6, self.conv6_1 = _conv(512, 1024, 2), _conv(1024, 1024)
+        self.deconv5, self.deconv4 = _deconv(1024, 512), _deconv(1026, 256)
+        self.deconv3, self.deconv2 = _deconv(770, 128), _deconv(386, 64)
+        self.inter_conv5, self.inter_conv4 = _iconv(1026, 512), _iconv(770, 256)
+        self.inter_conv3, self.inter_conv2 = _iconv(386, 128), _iconv(194, 64)
+        self.predict_flow6, self.predict_flow5 = nn.Conv2d(1024, 2, 3, 1, 1), nn.Conv2d(512, 2, 3, 1, 1)
+        self.predict_flow4, self.predict_flow3 = nn.Conv2d(256, 2, 3, 1, 1), nn.Conv2d(128, 2, 3, 1, 1)
+        self.predict_flow2 = nn.Conv2d(64, 2, 3, 1, 1)
+        self.upsampled_flow6_to_5 = nn.ConvTranspose2d(2, 2, 4, 2, 1)
+        self.upsampled_flow5_to_4 = nn.ConvTranspose2d(2, 2, 4, 2, 1)
+        self.upsampled_flow4_to_3 = nn.ConvTranspose2d(2, 2, 4, 2, 1)
+        self.upsampled_flow3_to_2 = nn.ConvTranspose2d(2, 2, 4, 2, 1)
+        object.__setattr__(self, "_engine", None)
+
+    def forward(self, inputs: torch.Tensor) -> torch.Tensor:
+        if self.training:
+            raise NotImplementedError("FlowNet2SD is a frozen estimator here: call .eval() (train_helper.py:284)")
+        if self._engine is None:
+            object.__setattr__(self, "_engine", _Engine(self))
+        with torch.no_grad():
+            return self._engine.forward(inputs)

@@ -321,3 +321,13 @@ def load_pretrained_branches(model: torch.nn.Module, rgb_ckpt, op_ckpt, map_loca
         own.update({f"{prefix}.{k}": v for k, v in ck.items() if f"{prefix}.{k}" in own})
     model.load_state_dict(own)
     return model, 0
+
+
+def flownet_flow_fn(flownet: torch.nn.Module) -> Callable:
+    """`flow_fn` for `train_step_gan` from a (frozen, eval-mode) FlowNet2-SD: frames in [-1, 1] -> flow / 255, as
+    train_helper.py:309-316 feeds it (`(pair * 0.5 + 0.5) * 255`, then `/ 255`, detached)"""
+    def fn(prev: torch.Tensor, cur: torch.Tensor) -> torch.Tensor:
+        pair = torch.cat([prev.unsqueeze(2), cur.unsqueeze(2)], 2)
+        with torch.no_grad():
+            return flownet((pair * 0.5 + 0.5) * 255.0) / 255.0
+    return fn

@@ -183,6 +183,45 @@ def make_discriminator_state(input_nc=3, num_filters=(128, 256, 512, 512), tag="
     return sd
 
 
+def flownet2sd_schema():
+    """state_dict entries of `FlowNet2SD(batchNorm=False)` (reference models/flownet2/FlowNetSD.py:12-45; 45,371,666
+    parameters): Conv2d k3 with bias inside Sequentials (`.0.`), ConvTranspose2d k4 [in, out, 4, 4]"""
+    convs = [("conv0", 6, 64), ("conv1", 64, 64), ("conv1_1", 64, 128), ("conv2", 128, 128), ("conv2_1", 128, 128),
+             ("conv3", 128, 256), ("conv3_1", 256, 256), ("conv4", 256, 512), ("conv4_1", 512, 512),
+             ("conv5", 512, 512), ("conv5_1", 512, 512), ("conv6", 512, 1024), ("conv6_1", 1024, 1024)]
+    for name, ci, co in convs:
+        yield f"{name}.0.weight", (co, ci, 3, 3)
+        yield f"{name}.0.bias", (co,)
+    for name, ci, co in (("deconv5", 1024, 512), ("deconv4", 1026, 256), ("deconv3", 770, 128), ("deconv2", 386, 64)):
+        yield f"{name}.0.weight", (ci, co, 4, 4)
+        yield f"{name}.0.bias", (co,)
+    for name, ci, co in (("inter_conv5", 1026, 512), ("inter_conv4", 770, 256), ("inter_conv3", 386, 128),
+                         ("inter_conv2", 194, 64)):
+        yield f"{name}.0.weight", (co, ci, 3, 3)
+        yield f"{name}.0.bias", (co,)
+    for lvl, ci in ((6, 1024), (5, 512), (4, 256), (3, 128), (2, 64)):
+        yield f"predict_flow{lvl}.weight", (2, ci, 3, 3)
+        yield f"predict_flow{lvl}.bias", (2,)
+    for name in ("upsampled_flow6_to_5", "upsampled_flow5_to_4", "upsampled_flow4_to_3", "upsampled_flow3_to_2"):
+        yield f"{name}.weight", (2, 2, 4, 4)
+        yield f"{name}.bias", (2,)
+
+
+def make_flownet2sd_state(tag="ammc-flow"):
+    """variance-preserving uniform weights (the published checkpoint is not available), small biases"""
+    sd = OrderedDict()
+    for key, shape in flownet2sd_schema():
+        t = f"{tag}:{key}"
+        if len(shape) == 1:
+            sd[key] = hashed_uniform(t, shape, -0.1, 0.1)
+        else:
+            transposed = key.startswith(("deconv", "upsampled"))
+            fan_in = (shape[0] * 4 if transposed else shape[1] * 9)          # k4 s2: 4 taps reach an output pixel
+            bound = (6.0 / (1.01 * fan_in)) ** 0.5                            # LeakyReLU(0.1) gain
+            sd[key] = hashed_uniform(t, shape, -bound, bound)
+    return sd
+
+
 # ----------------------------------------------------------------------------
 # synthetic clips (SURVEY.md 8(d); reference loader two_stream_dataset.py:72-99)
 # ----------------------------------------------------------------------------

@@ -250,7 +250,20 @@ int ammc_transpose_pad_f32(const float* w, int32_t rows, int32_t cols, int32_t r
  * through doubled y strides.  This packs those filters: stride 1 -> [rows][16*cout_p], stride 2 ->
  * [4][rows][4*cout_p] (phase = py*2+px). */
 int ammc_pack_conv4_dgrad_weight_f32(const float* w_oihw, int32_t cout, int32_t cin, int32_t cout_p, int32_t rows,
-                                     int32_t stride, float* out, void* stream);
+                                     int32_t stride, int32_t pad /* of the convolution: 2 (D) or 1 */, float* out,
+                                     void* stream);
+
+/* FlowNet2-SD forward (Code/models/flownet2/models.py:15-59): the pieces that are not convolutions.  Its Conv2d(k 3,
+ * stride 1|2) + LeakyReLU(0.1) layers are ammc_conv_gemm_f32 (ntaps 9, x_step = stride, AMMC_ACT_LRELU); its
+ * ConvTranspose2d(k 4, s 2, p 1) layers are the four 2x2-tap parity convolutions of ammc_pack_conv4_dgrad_weight_f32
+ * (pad 1); layers whose input is a concatenation run once per part and accumulate through `res`. */
+int ammc_flownet_prep_f32(const float* in /* [B][3][2][H][W], 0..rgb_max */, int32_t batch, int32_t h, int32_t w,
+                          float* y /* NHWC, 8 channels */, int64_t y_bs, int64_t y_rs, int64_t y_ps, float rgb_max,
+                          void* stream);
+int ammc_lrelu_f32(float* y, int64_t y_bs, int64_t y_rs, int64_t y_ps, int32_t batch, int32_t h, int32_t w, int32_t c,
+                   float slope, void* stream);
+int ammc_upsample4_bilinear_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, int32_t batch, int32_t h,
+                                int32_t w, int32_t c, float premul, float* out /* NCHW [B][c][4h][4w] */, void* stream);
 /* g *= (y > 0 ? 1 : slope) in place: autograd of nn.LeakyReLU evaluated on the layer output */
 int ammc_lrelu_bwd_f32(const float* y, int64_t y_bs, int64_t y_rs, int64_t y_ps, float* g, int64_t g_bs, int64_t g_rs,
                        int64_t g_ps, int32_t batch, int32_t h, int32_t w, int32_t c, float slope, void* stream);

@@ -362,3 +362,45 @@ def fwd_flops_per_clip(h: int = 256, w: int = 256, in_channel=(12, 6), out_chann
         total += 2.0 * h * w * 9 * 64 * cout
     total += 2 * dc(512, 512, h // 8, w // 8)
     return total
+
+
+# ---- FlowNet2-SD, the frozen flow estimator of the flow-consistency term -------------------------
+
+def flownet2sd_forward(sd: State, inputs: torch.Tensor, rgb_max: float = 255.0, div_flow: float = 20.0) -> torch.Tensor:
+    """`FlowNet2SD.forward` in eval mode (models/flownet2/models.py:15-59 over FlowNetSD.py:12-58, submodules.py:9-45,
+    batchNorm=False): inputs [B,3,2,H,W] in 0..255 -> flow [B,2,H,W].  conv = Conv2d(k3, pad 1, bias) + LeakyReLU(0.1);
+    deconv = ConvTranspose2d(k4, s2, p1, bias) + LeakyReLU(0.1); i_conv / predict_flow = bare Conv2d(k3);
+    upsampled_flow = ConvTranspose2d(2, 2, 4, 2, 1)."""
+    def conv(name, x, stride=1):
+        return F.leaky_relu(F.conv2d(x, sd[name + ".0.weight"], sd[name + ".0.bias"], stride=stride, padding=1), 0.1)
+
+    def deconv(name, x):
+        return F.leaky_relu(F.conv_transpose2d(x, sd[name + ".0.weight"], sd[name + ".0.bias"], stride=2, padding=1), 0.1)
+
+    def bare(name, x):
+        return F.conv2d(x, sd[name + ".weight"], sd[name + ".bias"], padding=1)
+
+    def up(name, x):
+        return F.conv_transpose2d(x, sd[name + ".weight"], sd[name + ".bias"], stride=2, padding=1)
+
+    b = inputs.shape[0]
+    rgb_mean = inputs.contiguous().view(b, 3, -1).mean(dim=-1).view(b, 3, 1, 1, 1)
+    x = (inputs - rgb_mean) / rgb_max
+    x = torch.cat((x[:, :, 0], x[:, :, 1]), dim=1)
+    c0 = conv("conv0", x)
+    c1 = conv("conv1_1", conv("conv1", c0, 2))
+    c2 = conv("conv2_1", conv("conv2", c1, 2))
+    c3 = conv("conv3_1", conv("conv3", c2, 2))
+    c4 = conv("conv4_1", conv("conv4", c3, 2))
+    c5 = conv("conv5_1", conv("conv5", c4, 2))
+    c6 = conv("conv6_1", conv("conv6", c5, 2))
+    flow6 = bare("predict_flow6", c6)
+    cat5 = torch.cat((c5, deconv("deconv5", c6), up("upsampled_flow6_to_5", flow6)), 1)
+    flow5 = bare("predict_flow5", F.conv2d(cat5, sd["inter_conv5.0.weight"], sd["inter_conv5.0.bias"], padding=1))
+    cat4 = torch.cat((c4, deconv("deconv4", cat5), up("upsampled_flow5_to_4", flow5)), 1)
+    flow4 = bare("predict_flow4", F.conv2d(cat4, sd["inter_conv4.0.weight"], sd["inter_conv4.0.bias"], padding=1))
+    cat3 = torch.cat((c3, deconv("deconv3", cat4), up("upsampled_flow4_to_3", flow4)), 1)
+    flow3 = bare("predict_flow3", F.conv2d(cat3, sd["inter_conv3.0.weight"], sd["inter_conv3.0.bias"], padding=1))
+    cat2 = torch.cat((c2, deconv("deconv2", cat3), up("upsampled_flow3_to_2", flow3)), 1)
+    flow2 = bare("predict_flow2", F.conv2d(cat2, sd["inter_conv2.0.weight"], sd["inter_conv2.0.bias"], padding=1))
+    return F.interpolate(flow2 * div_flow, scale_factor=4, mode="bilinear", align_corners=False)

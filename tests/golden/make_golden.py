@@ -304,6 +304,40 @@ def discriminator_and_losses(name="discriminator_64_b2"):
     print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if not k.startswith(("adv_dW", "dis_dW"))})
 
 
+def load_ref_flownet():
+    """`models/flownet2/*` import each other package-relatively; load them inside a synthetic package (no stubs)"""
+    pkg = types.ModuleType("refflow")
+    pkg.__path__ = [f"{REF}/models/flownet2"]
+    sys.modules["refflow"] = pkg
+    mods = {}
+    for name in ("submodules", "FlowNetSD", "models"):
+        spec = importlib.util.spec_from_file_location(f"refflow.{name}", f"{REF}/models/flownet2/{name}.py")
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[f"refflow.{name}"] = m
+        spec.loader.exec_module(m)
+        mods[name] = m
+    return mods["models"]
+
+
+def flownet2sd_golden(name="flownet2sd_eval"):
+    """FlowNet2-SD (the frozen estimator of the flow-consistency term, train_helper.py:309-316) in eval mode on
+    synthetic parameters: inputs are frame pairs in 0..255, output the x4-upsampled flow."""
+    models = load_ref_flownet()
+    net = models.FlowNet2SD().eval()
+    sd = S.make_flownet2sd_state()
+    net.load_state_dict(sd, strict=True)
+    out = {"param_count": np.int64(sum(p.numel() for p in net.parameters())),
+           "state_keys": np.array(list(net.state_dict().keys()))}
+    for tag, shape in (("a", (2, 3, 2, 64, 64)), ("b", (1, 3, 2, 64, 128))):
+        x = (S.hashed_uniform(f"{name}:{tag}", shape) + 1) * 127.5
+        with torch.no_grad():
+            y = net(x)
+        out["shape_" + tag] = np.array(shape)
+        out["flow_" + tag] = y.numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, {k: getattr(v, "shape", v) for k, v in out.items() if k != "state_keys"})
+
+
 def main():
     torch.set_num_threads(8)
     ref = load_ref_unet()
@@ -317,6 +351,7 @@ def main():
     twostream_train(ref, 64, 2, "twostream_64_b2_train")
     score_fusion_golden()
     discriminator_and_losses()
+    flownet2sd_golden()
 
 
 

@@ -1,0 +1,51 @@
+"""FlowNet2-SD forward on the HIP kernels against vectors recorded from the reference's FlowNet2SD
+class (tests/golden/flownet2sd_eval.npz) and the oracle at another size.  Tolerance 2e-5 of max|flow| (26 fp32 layers,
+multi-part accumulation of the concatenated inputs in a different order than ATen's single convolution)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from ammcnet_aaai2021_amd import _lib, synthetic as S
+from ammcnet_aaai2021_amd.flownet import FlowNet2SD
+from oracle import ammc_oracle as O
+from conftest import GOLDEN, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _net():
+    sd = S.make_flownet2sd_state()
+    net = FlowNet2SD()
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    net.load_state_dict(sd, strict=True)
+    return net.to(DEV).eval(), sd
+
+
+def test_flownet2sd_golden_and_oracle():
+    g = np.load(os.path.join(GOLDEN, "flownet2sd_eval.npz"))
+    net, sd = _net()
+    assert sum(p.numel() for p in net.parameters()) == int(g["param_count"])
+    for tag in ("a", "b"):
+        shape = tuple(int(v) for v in g["shape_" + tag])
+        x = (S.hashed_uniform(f"flownet2sd_eval:{tag}", shape) + 1) * 127.5
+        y = net(x.to(DEV))
+        assert y.shape == (shape[0], 2, shape[3], shape[4])
+        assert rel_err(y.cpu().numpy(), g["flow_" + tag]) <= 2e-5
+    x = (S.hashed_uniform("flow-other", (1, 3, 2, 128, 192)) + 1) * 127.5
+    want = O.flownet2sd_forward(sd, x)
+    assert rel_err(net(x.to(DEV)).cpu(), want) <= 2e-5
+
+
+def test_flownet2sd_interface():
+    net, _ = _net()
+    with pytest.raises(_lib.AmmcHipError):
+        net(torch.zeros(1, 3, 2, 64, 64))                      # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 3, 2, 96, 64, device=DEV))          # six stride-2 levels
+    with pytest.raises(NotImplementedError):
+        net.train()(torch.zeros(1, 3, 2, 64, 64, device=DEV))
+    with pytest.raises(NotImplementedError):
+        FlowNet2SD(batchNorm=True)

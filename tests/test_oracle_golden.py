@@ -216,3 +216,18 @@ def test_discriminator_and_losses_golden():
     for k, v in sdd.items():
         assert abs(v.grad.double().norm().item() - float(g["dis_dWnorm:" + k])) < 1e-4 * float(g["dis_dWnorm:" + k])
     assert abs(O.flow_loss(fake.detach()[:, :2], real[:, :2]).item() - float(g["flow_loss"])) < 1e-6
+
+
+def test_flownet2sd_golden():
+    """the oracle's FlowNet2-SD restatement against outputs recorded from the reference's class"""
+    g = np.load(os.path.join(GOLDEN, "flownet2sd_eval.npz"))
+    sd = S.make_flownet2sd_state()
+    assert list(sd.keys()) == list(g["state_keys"])
+    assert sum(v.numel() for v in sd.values()) == int(g["param_count"]) == 45371666      # FlowNetSD.py:4
+    for tag in ("a", "b"):
+        shape = tuple(int(v) for v in g["shape_" + tag])
+        x = (S.hashed_uniform(f"flownet2sd_eval:{tag}", shape) + 1) * 127.5
+        with torch.no_grad():
+            y = O.flownet2sd_forward(sd, x)
+        assert y.shape == (shape[0], 2, shape[3], shape[4])
+        assert rel_err(y.numpy(), g["flow_" + tag]) < 1e-6
