@@ -217,6 +217,9 @@ __global__ __launch_bounds__(WS_NT, 2) void wgrad_s16_kernel(WgradS16Args a) {
   }
 }
 
+// wgrad_tap_s16.hip: the halo-patch form; -12345 = not its case
+int wgrad_tap_s16_try(const AmmcWgradDesc& d, const float* g_inv_scale, int kpad, hipStream_t stream);
+
 }  // namespace ammc_s16
 using namespace ammc_s16;
 
@@ -236,6 +239,10 @@ extern "C" int ammc_conv_wgrad_s16(const AmmcWgradDesc* desc, const float* g_inv
   a.M = (int)M;
   a.kpad = ((9 * d.cin + 31) / 32) * 32;
   a.cin_log2 = ammc_ilog2(d.cin);
+  {
+    const int rc = wgrad_tap_s16_try(d, g_inv_scale, a.kpad, (hipStream_t)stream);
+    if (rc != -12345) return rc;
+  }
   constexpr size_t lds = (size_t)2 * 32 * (WS_BR + WS_BC) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
