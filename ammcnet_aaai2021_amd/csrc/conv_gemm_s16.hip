@@ -590,7 +590,8 @@ __global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restric
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-  if ((threadIdx.x & 63) == 0 && m > 0.f && m < INFINITY) atomicMax(out_bits, __float_as_int(m));
+  // 256 slots, picked by workgroup: a single address would serialise the atomics of every wave of the launch
+  if ((threadIdx.x & 63) == 0 && m > 0.f && m < INFINITY) atomicMax(out_bits + (blockIdx.x & 255), __float_as_int(m));
 }
 
 __device__ __forceinline__ float pow2_to_1024(int amax_bits) {
@@ -604,7 +605,14 @@ __device__ __forceinline__ float pow2_to_1024(int amax_bits) {
 __global__ __launch_bounds__(256) void split_rows_scaled_kernel(const float* __restrict__ src, int64_t ngroups,
                                                                 float* __restrict__ dst, const int* __restrict__ amax_bits,
                                                                 float* __restrict__ inv_scale, int n) {
-  const float f = pow2_to_1024(amax_bits[0]);
+  __shared__ int red[256];
+  red[threadIdx.x] = amax_bits[threadIdx.x];                  // the maximum over the 256 slots of ammc_absmax_bits_f32
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] = max(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  const float f = pow2_to_1024(red[0]);
   const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (blockIdx.x == 0)
     for (int i = threadIdx.x; i < n; i += 256) inv_scale[i] = 1.f / f;        // a power of two: exact

@@ -51,23 +51,53 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(
     be = *reinterpret_cast<const f32x4*>(beta + tx * 4);
   }
   if (ty < PY) {
-    for (int m = m0 + ty; m < m1; m += PY) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(x + pix_off(m, H, W, xt) + tx * 4);
-      if (MODE == 0) {
+    // four pixels per iteration, all loads first: a single 16-byte load in flight per thread left these kernels at
+    // ~1 TB/s (latency-bound); the pixel coordinates advance incrementally instead of two divisions per load
+    constexpr int U = 4;
+    int px[U], py[U], pb[U];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { s0[i] += v[i]; s1[i] += v[i] * v[i]; }
-      } else if (MODE == 2) {
+    for (int u = 0; u < U; ++u) {
+      const int m = m0 + ty + u * PY;
+      px[u] = m % W;
+      const int q = m / W;
+      py[u] = q % H;
+      pb[u] = q / H;
+    }
+    const int step = U * PY;
+    for (int mb = m0 + ty; mb < m1; mb += step) {
+      f32x4 v[U], g[U];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s0[i] += v[i];
-      } else {
-        const f32x4 g = *reinterpret_cast<const f32x4*>(dy + pix_off(m, H, W, dt) + tx * 4);
+      for (int u = 0; u < U; ++u) {
+        const bool ok = mb + u * PY < m1;
+        const int64_t ox = (int64_t)pb[u] * xt.bs + (int64_t)py[u] * xt.rs + (int64_t)px[u] * xt.ps;
+        v[u] = ok ? *reinterpret_cast<const f32x4*>(x + ox + tx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (MODE == 1) {
+          const int64_t od = (int64_t)pb[u] * dt.bs + (int64_t)py[u] * dt.rs + (int64_t)px[u] * dt.ps;
+          g[u] = ok ? *reinterpret_cast<const f32x4*>(dy + od + tx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float xh = (v[i] - mu[i]) * is[i];
-          const float pre = v[i] * ga[i] + be[i];      // ga = folded scale, be = folded shift: the forward's expression
-          const float gi = (!relu || pre > 0.f) ? g[i] : 0.f;
-          s0[i] += gi;
-          s1[i] += gi * xh;
+      for (int u = 0; u < U; ++u) {
+        if (MODE == 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { s0[i] += v[u][i]; s1[i] += v[u][i] * v[u][i]; }
+        } else if (MODE == 2) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) s0[i] += v[u][i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float xh = (v[u][i] - mu[i]) * is[i];
+            const float pre = v[u][i] * ga[i] + be[i];      // ga = folded scale, be = folded shift: the forward's expression
+            const float gi = (!relu || pre > 0.f) ? g[u][i] : 0.f;
+            s0[i] += gi;
+            s1[i] += gi * xh;
+          }
+        }
+        px[u] += step;                                       // next pixel of this stream
+        while (px[u] >= W) {
+          px[u] -= W;
+          if (++py[u] == H) { py[u] = 0; ++pb[u]; }
         }
       }
     }
@@ -156,7 +186,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ c, Tensor3 ct, const float* __restrict__ dy, Tensor3 dt,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ sums /* [2][C]: dbeta, dgamma */, float inv_count,
-    int relu, float* __restrict__ dc, Tensor3 ot, int M, int H, int W, int C4) {
+    int relu, float* __restrict__ dc, Tensor3 ot, int M, int H, int W, int C4, int* __restrict__ amax_bits) {
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (gid >= (int64_t)M * C4) return;
   const int c4 = (int)(gid % C4);
@@ -179,6 +209,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     o[i] = ga[i] * (gi - sg[i] * inv_count - xh * sgx[i] * inv_count);
   }
   *reinterpret_cast<f32x4*>(dc + pix_off(m, H, W, ot) + c4 * 4) = o;
+  if (amax_bits) {       // largest |dc| of the tensor, for the S16 re-encoding of this gradient (ammc_absmax_bits_f32)
+    float mx = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if ((threadIdx.x & 63) == 0 && mx > 0.f && mx < INFINITY) atomicMax(amax_bits + (blockIdx.x & 255), __float_as_int(mx));
+  }
 }
 
 // MaxPool2d(2) backward (+ the gradient that reaches the same tensor through the skip path):
@@ -490,12 +526,12 @@ int ammc_bn_bwd_apply_f32(const float* c_raw, int64_t c_bs, int64_t c_rs, int64_
                           int64_t d_bs, int64_t d_rs, int64_t d_ps, const float* mean, const float* invstd,
                           const float* gamma, const float* beta, const float* sums, int32_t relu, float* dc,
                           int64_t o_bs, int64_t o_rs, int64_t o_ps, int32_t batch, int32_t h, int32_t w, int32_t c,
-                          void* stream) {
+                          int32_t* amax_bits, void* stream) {
   if (check_nhwc(c_raw, batch, h, w, c) || !dy || !mean || !invstd || !gamma || !beta || !sums || !dc) return AMMC_EINVAL;
   const int M = batch * h * w;
   Tensor3 ct{c_bs, c_rs, c_ps}, dt{d_bs, d_rs, d_ps}, ot{o_bs, o_rs, o_ps};
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk((int64_t)M * (c >> 2))), dim3(256), 0, (hipStream_t)stream,
-                     c_raw, ct, dy, dt, mean, invstd, gamma, beta, sums, 1.f / (float)M, relu, dc, ot, M, h, w, c >> 2);
+                     c_raw, ct, dy, dt, mean, invstd, gamma, beta, sums, 1.f / (float)M, relu, dc, ot, M, h, w, c >> 2, amax_bits);
   return ammc_launch_status();
 }
 

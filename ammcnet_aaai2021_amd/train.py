@@ -70,7 +70,7 @@ class _Ops:
         self.s16 = TRAIN_PRECISION == "s16"
         self._shadows: Dict[int, torch.Tensor] = {}
         self.overflow = ws.buf(1, dtype=torch.int32)
-        self.amax = ws.buf(1, dtype=torch.int32)
+        self.amax = ws.buf(256, dtype=torch.int32)         # slots of ammc_absmax_bits_f32 / bn_bwd_apply
 
     def shadow(self, a: Act) -> Act:
         """the S16 twin of an fp32 NHWC buffer (same geometry, allocated once per underlying buffer)"""
@@ -80,16 +80,18 @@ class _Ops:
             buf = self._shadows[key] = self.ws.buf(*a.buf.shape)
         return Act(buf, a.B, a.H, a.W, a.c, a.c_off, a.halo)
 
-    def to_s16(self, x: Act, rescale: bool = False):
+    def to_s16(self, x: Act, rescale: bool = False, have_amax: bool = False):
         """re-encode the fp32 buffer behind `x` into its S16 twin; `rescale` (gradients): first bring it into the half
-        range by a power of two found on the device.  Returns (twin, inverse scale [1] or None)."""
+        range by a power of two found on the device (`have_amax`: the producer already left max |x| in self.amax).
+        Returns (twin, inverse scale [1] or None)."""
         lib, s = self.lib, self.s
         xs = self.shadow(x)
         inv = None
         if rescale:
-            self.amax.zero_()
             inv = torch.empty(1024, device=self.dev, dtype=torch.float32)
-            _chk(lib.ammc_absmax_bits_f32(_ptr(x.buf), x.buf.numel(), self.amax.data_ptr(), s), "absmax")
+            if not have_amax:
+                self.amax.zero_()
+                _chk(lib.ammc_absmax_bits_f32(_ptr(x.buf), x.buf.numel(), self.amax.data_ptr(), s), "absmax")
             _chk(lib.ammc_split_rows_scaled_f32(_ptr(x.buf), x.buf.numel(), _ptr(xs.buf), self.amax.data_ptr(), _ptr(inv),
                                                 1024, s), "split_rows_scaled(x)")
         else:
@@ -254,12 +256,15 @@ class _ConvBN:
             g = sums.clone()
             o.all_reduce(g)
             sums = g.mul_(1.0 / world)
+        fused_amax = o.s16 and (da is not None or (self.cin_p >= 8 and WGRAD_S16))
+        if fused_amax:
+            o.amax.zero_()                                    # bn_bwd_apply leaves max |dc| there for the S16 re-encoding
         _chk(lib.ammc_bn_bwd_apply_f32(c.pix0(), *c.strides, dy.pix0(), *dy.strides, _ptr(self.mean), _ptr(self.invstd),
                                        _ptr(self.scale), _ptr(self.shift), _ptr(sums), 1, self.dc.pix0(),
-                                       *self.dc.strides, c.B, c.H, c.W, self.cout, s), "bn_bwd_apply")
-        pre = None
-        if o.s16 and self.cin_p >= 8 and WGRAD_S16:
-            pre = o.to_s16(self.dc, rescale=True)             # shared by the weight- and the input-gradient launches
+                                       *self.dc.strides, c.B, c.H, c.W, self.cout,
+                                       o.amax.data_ptr() if fused_amax else None, s), "bn_bwd_apply")
+        pre = o.to_s16(self.dc, rescale=True, have_amax=True) if fused_amax else None   # shared by wgrad and dgrad
+        if pre is not None and self.cin_p >= 8 and WGRAD_S16:
             o.wgrad_s16(pre[0], o.shadow(self.x), self.dwp, pre[1], n=self.cout, cin=self.cin_p,
                         what=self.name + ".wgrad")            # shadow(x): the twin the forward conv left behind
         else:

@@ -175,7 +175,8 @@ int ammc_split_kblk_f32(const float* src, int32_t n, int32_t kpad, float* dst, v
 /* fp32 -> S16, count elements (multiple of 8): packed filters, gathered codebook rows */
 int ammc_split_rows_f32(const float* src, int64_t count, float* dst, void* stream);
 /* Gradient tensors as S16 operands (what autograd derives for the 3x3 convs, train_helper.py:337-339): the largest
- * |v| of the tensor as its fp32 bit pattern (atomicMax into *out_bits, zeroed by the caller), then the split of
+ * |v| of the tensor as its fp32 bit pattern (atomicMax into one of the 256 slots out_bits[0..256), zeroed by the
+ * caller; the consumer takes the maximum of the slots), then the split of
  * v * 2^k with k chosen so that the maximum lands at 2^10; inv_scale[0..n) = 2^-k is the epilogue scale of the
  * convolution that consumes the tensor. */
 int ammc_absmax_bits_f32(const float* src, int64_t count, int32_t* out_bits, void* stream);
@@ -303,6 +304,7 @@ int ammc_bn_bwd_apply_f32(const float* c_raw, int64_t c_bs, int64_t c_rs, int64_
                           int64_t d_bs, int64_t d_rs, int64_t d_ps, const float* mean, const float* invstd,
                           const float* gamma, const float* beta, const float* sums, int32_t relu, float* dc,
                           int64_t o_bs, int64_t o_rs, int64_t o_ps, int32_t batch, int32_t h, int32_t w, int32_t c,
+                          int32_t* amax_bits /* may be NULL: [256] slots, max |dc| as in ammc_absmax_bits_f32 */,
                           void* stream);
 /* per-channel sum over pixels (bias gradients): partial Q=1 */
 int ammc_chan_sum_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, int32_t batch, int32_t h, int32_t w,

@@ -34,7 +34,7 @@ def test_wgrad_s16_vs_fp64(B, H, W, cin, n, gmag):
     A16 = Act(torch.empty_like(A32.buf), B, H, W, cin, 0, 1)
     G16 = Act(torch.empty_like(G32.buf), B, H, W, n, 0, 1)
     _lib.check(lib.ammc_split_rows_f32(_ptr(A32.buf), A32.buf.numel(), _ptr(A16.buf), s), "split a")
-    amax = torch.zeros(1, dtype=torch.int32, device=DEV)
+    amax = torch.zeros(256, dtype=torch.int32, device=DEV)
     inv = torch.empty(8, device=DEV)
     _lib.check(lib.ammc_absmax_bits_f32(_ptr(G32.buf), G32.buf.numel(), amax.data_ptr(), s), "absmax")
     _lib.check(lib.ammc_split_rows_scaled_f32(_ptr(G32.buf), G32.buf.numel(), _ptr(G16.buf), amax.data_ptr(), _ptr(inv),
