@@ -187,8 +187,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ sums /* [2][C]: dbeta, dgamma */, float inv_count,
     int relu, float* __restrict__ dc, Tensor3 ot, int M, int H, int W, int C4, int* __restrict__ amax_bits) {
-  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (int64_t)M * C4) return;
+  int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = gid < (int64_t)M * C4;
+  if (!live) {
+    if (!amax_bits) return;
+    gid = (int64_t)M * C4 - 1;               // (the block-wide max below needs every thread at the barrier)
+  }
   const int c4 = (int)(gid % C4);
   const int m = (int)(gid / C4);
   const int C = C4 * 4;
@@ -208,12 +212,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float gi = (!relu || pre > 0.f) ? g[i] : 0.f;
     o[i] = ga[i] * (gi - sg[i] * inv_count - xh * sgx[i] * inv_count);
   }
-  *reinterpret_cast<f32x4*>(dc + pix_off(m, H, W, ot) + c4 * 4) = o;
+  if (live) *reinterpret_cast<f32x4*>(dc + pix_off(m, H, W, ot) + c4 * 4) = o;
   if (amax_bits) {       // largest |dc| of the tensor, for the S16 re-encoding of this gradient (ammc_absmax_bits_f32)
+    __shared__ float wmax[4];
     float mx = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-    if ((threadIdx.x & 63) == 0 && mx > 0.f && mx < INFINITY) atomicMax(amax_bits + (blockIdx.x & 255), __float_as_int(mx));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {                                   // one atomic per workgroup, 256 slots
+      mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+      if (mx > 0.f && mx < INFINITY) atomicMax(amax_bits + (blockIdx.x & 255), __float_as_int(mx));
+    }
   }
 }
 
