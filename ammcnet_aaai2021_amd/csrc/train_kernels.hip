@@ -118,13 +118,42 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(
 }
 
 // partial[nblk][Q][C] -> out[Q][C], double accumulation, fixed order (deterministic)
+// A workgroup combines 16 columns: 16 slices of the partial rows per column (thread = (slice, column)), then a
+// fixed-order LDS tree - deterministic, and 16x shorter dependent fp64 chains than one thread per column.
+constexpr int RP_COLS = 16, RP_SLICES = 16;
+
+__device__ __forceinline__ void column_sums(const float* __restrict__ partial, int nblk, int64_t row_stride, int col,
+                                            bool valid, int second_off, double (&red)[2][RP_SLICES][RP_COLS], double& s,
+                                            double& ss) {
+  const int cl = threadIdx.x % RP_COLS, sl = threadIdx.x / RP_COLS;
+  double a = 0.0, b = 0.0;
+  if (valid) {
+    for (int r = sl; r < nblk; r += RP_SLICES) {
+      a += (double)partial[(int64_t)r * row_stride + col];
+      if (second_off) b += (double)partial[(int64_t)r * row_stride + second_off + col];
+    }
+  }
+  red[0][sl][cl] = a;
+  red[1][sl][cl] = b;
+  __syncthreads();
+  for (int o = RP_SLICES / 2; o > 0; o >>= 1) {
+    if (sl < o) {
+      red[0][sl][cl] += red[0][sl + o][cl];
+      red[1][sl][cl] += red[1][sl + o][cl];
+    }
+    __syncthreads();
+  }
+  s = red[0][0][cl];
+  ss = red[1][0][cl];
+}
+
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nblk, int QC,
                                                               float scale, float* __restrict__ out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= QC) return;
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)partial[(int64_t)b * QC + i];
-  out[i] = (float)(s * (double)scale);
+  __shared__ double red[2][RP_SLICES][RP_COLS];
+  const int i = blockIdx.x * RP_COLS + threadIdx.x % RP_COLS;
+  double s, ss;
+  column_sums(partial, nblk, QC, i, i < QC, 0, red, s, ss);
+  if (threadIdx.x < RP_COLS && i < QC) out[i] = (float)(s * (double)scale);
 }
 
 // BN training finalize: batch mean / biased var -> invstd, folded scale/shift; running stats.
@@ -133,13 +162,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
     float* __restrict__ running_var, float* __restrict__ mean, float* __restrict__ invstd,
     float* __restrict__ scale, float* __restrict__ shift) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, ss = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    s += (double)partial[(int64_t)b * 2 * C + c];
-    ss += (double)partial[(int64_t)b * 2 * C + C + c];
-  }
+  __shared__ double red[2][RP_SLICES][RP_COLS];
+  const int c = blockIdx.x * RP_COLS + threadIdx.x % RP_COLS;
+  double s, ss;
+  column_sums(partial, nblk, (int64_t)2 * C, c, c < C, C, red, s, ss);
+  if (threadIdx.x >= RP_COLS || c >= C) return;
   const double mu = s / count;
   double var = ss / count - mu * mu;
   var = var > 0.0 ? var : 0.0;
@@ -503,7 +530,7 @@ int ammc_bn_finalize_f32(const float* partial, int32_t nblocks, int32_t c, float
                          float* mean, float* invstd, float* scale, float* shift, void* stream) {
   if (!partial || !gamma || !beta || !running_mean || !running_var || !mean || !invstd || !scale || !shift ||
       nblocks <= 0 || c <= 0 || count <= 0.f) return AMMC_EINVAL;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(nblk(c)), dim3(256), 0, (hipStream_t)stream, partial, nblocks, c,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + RP_COLS - 1) / RP_COLS), dim3(256), 0, (hipStream_t)stream, partial, nblocks, c,
                      count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
   return ammc_launch_status();
 }
@@ -557,7 +584,7 @@ int ammc_chan_sum_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, 
 
 int ammc_reduce_partials_f32(const float* partial, int32_t nblocks, int32_t qc, float scale, float* out, void* stream) {
   if (!partial || !out || nblocks <= 0 || qc <= 0) return AMMC_EINVAL;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(nblk(qc)), dim3(256), 0, (hipStream_t)stream, partial, nblocks, qc,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((qc + RP_COLS - 1) / RP_COLS), dim3(256), 0, (hipStream_t)stream, partial, nblocks, qc,
                      scale, out);
   return ammc_launch_status();
 }
