@@ -348,38 +348,43 @@ __global__ __launch_bounds__(256) void commit_bwd_kernel(const float* __restrict
   *reinterpret_cast<f32x4*>(dz + (int64_t)n * D4 * 4 + d4 * 4) = o;
 }
 
-// EMA codebook update, step 1: one workgroup per slot, thread = feature.  Rows are visited in
-// index order, so the sums are deterministic (no atomics).
+// EMA codebook update, step 1: one workgroup per slot.  Each of the four waves scans its own quarter of the rows
+// (ballot of `nearest slot == mine`), adds the hit rows feature-parallel in row order, and the four partial sums are
+// combined in wave order: deterministic (no atomics) and free of workgroup barriers inside the scan (the first form
+// synchronised three times per 256 rows and took 1.8 ms per launch).
 __global__ __launch_bounds__(256) void ema_accumulate_kernel(const float* __restrict__ x, const int* __restrict__ idx,
                                                              int k, int N, int D, int M, float decay, float omd,
                                                              float* __restrict__ cluster_size,
                                                              float* __restrict__ embed_avg /* [D][M] */, int raw) {
   const int slot = blockIdx.x;
-  __shared__ int hits[256];
+  __shared__ float wsum[4][256];
   __shared__ int wcount[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float sum = 0.f;
-  int count = 0;
-  for (int base = 0; base < N; base += 256) {
-    const int n = base + threadIdx.x;
-    const bool hit = n < N && idx[(int64_t)n * k] == slot;
-    // ordered compaction (row order is kept, so the float sums are deterministic)
-    const unsigned long long bal = __ballot(hit);
-    if (lane == 0) wcount[wave] = __popcll(bal);
-    __syncthreads();
-    int off = 0, nh = 0;
+  const int chunk = ((N + 3) / 4 + 63) / 64 * 64;
+  const int n_lo = wave * chunk, n_hi = min(n_lo + chunk, N);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};                   // features lane, lane + 64, ... (D <= 256)
+  int cnt = 0;
+  for (int base = n_lo; base < n_hi; base += 64) {
+    const int n = base + lane;
+    const bool hit = n < n_hi && idx[(int64_t)n * k] == slot;
+    unsigned long long bal = __ballot(hit);
+    cnt += __popcll(bal);
+    while (bal) {                                        // wave-uniform: rows in increasing order
+      const int b = __ffsll((long long)bal) - 1;
+      bal &= bal - 1;
+      const float* row = x + (int64_t)(base + b) * D;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      if (w < wave) off += wcount[w];
-      nh += wcount[w];
+      for (int j = 0; j < 4; ++j)
+        if (lane + 64 * j < D) acc[j] += row[lane + 64 * j];
     }
-    if (hit) hits[off + __popcll(bal & ((1ull << lane) - 1ull))] = n;
-    __syncthreads();
-    count += nh;
-    for (int d = threadIdx.x; d < D; d += 256)
-      for (int i = 0; i < nh; ++i) sum += x[(int64_t)hits[i] * D + d];
-    __syncthreads();
   }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wsum[wave][lane + 64 * j] = acc[j];
+  if (lane == 0) wcount[wave] = cnt;
+  __syncthreads();
+  const int count = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+  float sum = 0.f;
+  if (threadIdx.x < D) sum = ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
   if (raw) {            // counts[M] / sums[D][M] only: the EMA is applied after a cross-rank all-reduce
     if (threadIdx.x == 0) cluster_size[slot] = (float)count;
     for (int d = threadIdx.x; d < D; d += 256) embed_avg[(int64_t)d * M + slot] = sum;
