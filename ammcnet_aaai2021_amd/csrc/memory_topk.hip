@@ -26,7 +26,7 @@
 
 namespace ammc_impl {
 
-constexpr int BR = 64;      // feature rows per workgroup
+constexpr int BR = 32;      // feature rows per workgroup (32: two workgroups per CU at batch 16, whose MFMA and top-k VALU phases overlap)
 constexpr int RT = BR / 32;
 
 template <int K>

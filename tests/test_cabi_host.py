@@ -37,7 +37,7 @@ def test_argument_errors_are_status_codes_not_aborts():
     assert lib.ammc_conv_gemm_f32(None, None) == -1
     d = _lib.AmmcConvDesc()
     assert lib.ammc_conv_gemm_f32(d, None) == -1                      # null pointers
-    assert lib.ammc_memory_topk_blocks(0) == 0 and lib.ammc_memory_topk_blocks(129) == 3      # 64 rows per workgroup
+    assert lib.ammc_memory_topk_blocks(0) == 0 and lib.ammc_memory_topk_blocks(129) == 5      # 32 rows per workgroup
     assert lib.ammc_maxpool2x2_f32(None, 0, 0, 0, None, 0, 0, 0, 1, 1, 1, 4, None) == -1
     with pytest.raises(_lib.AmmcHipError):
         _lib.check(-2, "x")
