@@ -85,3 +85,38 @@ def test_conv_tap_s16_vs_fp64(B, H, W, cin, n, relu, res, sliced):
     assert err <= 2e-6, err
     assert int(flag.item()) == 0
     assert float(ya.buf[:, 0].abs().max()) == 0.0 and float(ya.buf[:, :, 0].abs().max()) == 0.0     # halo untouched
+
+
+@pytest.mark.parametrize("B,H,W,cin,n", [(12, 64, 64, 64, 64), (6, 64, 64, 64, 128), (16, 64, 64, 32, 256), (24, 32, 32, 64, 128)])
+def test_conv_tap_fp32_output_with_fp32_residual(B, H, W, cin, n):
+    """the form the training path uses (train.py `_Ops.conv_s16`): S16 operands, fp32 NHWC output, per-column scale
+    (the undo of the gradient rescaling), fp32 residual - every conv_tap_s16 variant (4-wave 64x64 and 64x128 with
+    one accumulator set, 8-wave with two)"""
+    lib = _lib.load()
+    tag = f"tapf-{B}-{H}-{W}-{cin}-{n}"
+    x = S.hashed_uniform(tag + "x", (B, cin, H, W)).to(DEV)
+    w = (S.hashed_uniform(tag + "w", (n, cin, 3, 3)) * (2.0 / (9 * cin)) ** 0.5).to(DEV)
+    scale = torch.full((n,), 0.25, device=DEV)
+    xa = _s16_act(x)
+    res = Act(torch.zeros(B, H + 2, W + 2, n, device=DEV), B, H, W, n, 0, 1)
+    res.interior().copy_(S.hashed_uniform(tag + "r", (B, H, W, n)).to(DEV))
+    ya = Act(torch.zeros(B, H + 2, W + 2, n, device=DEV), B, H, W, n, 0, 1)
+    wp = torch.empty(n, 9 * cin, device=DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.ammc_pack_conv_weight_f32(_ptr(w), n, cin, 3, cin, _ptr(wp), s), "pack")
+    ws = torch.empty_like(wp)
+    _lib.check(lib.ammc_split_rows_f32(_ptr(wp), wp.numel(), _ptr(ws), s), "split")
+    d = AmmcConvDesc()
+    d.x, d.w, d.y, d.scale, d.res = xa.tap0(), _ptr(ws), ya.pix0(), _ptr(scale), res.pix0()
+    d.batch, d.height, d.width, d.cin, d.ntaps, d.n, d.up, d.cgroup, d.act, d.y_f32 = B, H, W, cin, 9, n, 1, n, ACT_NONE, 1
+    d.x_bs, d.x_rs, d.x_ps = xa.strides
+    d.y_bs, d.y_rs, d.y_ps = ya.strides
+    d.r_bs, d.r_rs, d.r_ps = res.strides
+    _lib.check(lib.ammc_conv_gemm_s16(C.byref(d), s), "conv_gemm_s16")
+    got = ya.interior().permute(0, 3, 1, 2).double().cpu()
+    wsa = Act(ws.view(1, 1, n, 9 * cin), 1, 1, n, 9 * cin, 0, 0)
+    wr = _s16_read(wsa).view(9 * cin, n).t().reshape(n, 9, cin).permute(0, 2, 1).reshape(n, cin, 3, 3).double().cpu()
+    want = F.conv2d(_s16_read(xa).double().cpu(), wr, padding=1) * 0.25 + res.interior().permute(0, 3, 1, 2).double().cpu()
+    err = float((got - want).abs().max() / want.abs().max())
+    assert err <= 2e-6, err
+    assert float(ya.buf[:, 0].abs().max()) == 0.0 and float(ya.buf[:, :, 0].abs().max()) == 0.0

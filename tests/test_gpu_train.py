@@ -158,3 +158,28 @@ def test_adam_steps_track_the_oracle():
         losses.append(float(loss))
         wlosses.append(float(wl))
     assert np.allclose(losses, wlosses, rtol=2e-4), (losses, wlosses)
+
+
+def test_train_step_at_sizes_the_halo_patch_kernels_take():
+    """batch 4 at 128x128: the 128x128 and 64x64 levels go through conv_tap_s16 (fp32 outputs, fp32 residual of the
+    input-gradient convs) and wgrad_tap_s16, which the 64x64 fixtures above are too small to reach; compared with
+    the oracle's autograd like the first test (same gates)."""
+    sd = S.make_twostream_state()
+    net = A.get_twostream((12, 6), (3, 2), 64, 256, 2)
+    net.load_state_dict(sd)
+    net = net.to(DEV)
+    out, loss, want, wloss, msd = _train_step(net, sd, 4, 128, "train-128")
+    assert rel_err(out[0].detach().cpu(), want[0]) <= 1e-4 and rel_err(out[1].detach().cpu(), want[1]) <= 1e-4
+    assert abs(float(loss) - float(wloss)) <= 1e-4 * abs(float(wloss))
+    errs = []
+    for name, p in net.named_parameters():
+        ref = msd[name].grad
+        if ref is None or float(ref.abs().max()) == 0.0:
+            continue
+        errs.append(_l2rel(p.grad.cpu(), ref))
+    errs = np.array(errs)
+    assert errs.max() <= GTOL and np.median(errs) <= GMED and errs.min() <= 1e-5, (errs.max(), np.median(errs), errs.min())
+    nsd = net.state_dict()
+    for key, v in msd.items():
+        if key not in dict(net.named_parameters()):
+            assert rel_err(nsd[key].cpu().double(), v.double()) <= 1e-4, key
