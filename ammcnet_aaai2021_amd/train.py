@@ -364,14 +364,16 @@ class _Stream:
         self.outc_b = ws.buf(32)
         self.w32 = ws.buf(32, 64, 3, 3)
         # backward buffers
-        self.dpre = ws.act(B, H, W, 32)
+        self.dpre = ws.act(B, H, W, 64)
         self.du = [ws.act(B, H >> lvl, W >> lvl, CHANS[lvl]) for lvl in (2, 1, 0)]      # grads of up outputs
         self.dcat = [ws.act(B, H >> i, W >> i, 2 * CHANS[i]) for i in range(3)]
         self.dbottom = ws.act(B, h, w, 512)
         self.dskip_tot = [ws.act(B, H >> i, W >> i, CHANS[i]) for i in range(3)]
         self.dpooled = [ws.act(B, H >> (i + 1), W >> (i + 1), CHANS[i]) for i in range(3)]
-        self.outc_dwp = ws.buf(32, 576)
-        self.outc_wdp = ws.buf(64, _kpad(9 * 32))
+        # output layer: its gradient buffer is 64 channels wide (3 or 2 real ones) so that the S16 kernels' 64-filter
+        # forms apply to its weight- and input-gradient; the fp32 path uses the first 32
+        self.outc_dwp = ws.buf(64, 576)
+        self.outc_wdp = ws.buf(64, _kpad(9 * 64))
         self.scratch = ws.buf(lib.ammc_chan_reduce_blocks(B * H * W) * 512 + 1024)
 
     # ---- forward pieces -------------------------------------------------------------
@@ -441,12 +443,21 @@ class _Stream:
         out = torch.empty((self.B, self.cout, self.H, self.W), device=o.dev, dtype=torch.float32)
         d = AmmcConvDesc()
         u3 = self.u3
-        d.x, d.w, d.shift, d.y = u3.tap0(), _ptr(self.outc_wp), _ptr(self.outc_b), _ptr(out)
+        d.shift, d.y = _ptr(self.outc_b), _ptr(out)
         d.batch, d.height, d.width = self.B, self.H, self.W
         d.cin, d.ntaps, d.n, d.up, d.cgroup, d.act, d.n_store = 64, 9, 32, 1, 32, ACT_TANH, self.cout
-        d.x_bs, d.x_rs, d.x_ps = u3.strides
         d.y_bs, d.y_rs, d.y_ps, d.y_cs = self.cout * self.H * self.W, self.W, 1, self.H * self.W
-        _chk(lib.ammc_conv_gemm_f32(C.byref(d), s), "outc")
+        if o.s16:
+            u16, _ = o.to_s16(u3)                          # also the A operand of the weight gradient later
+            w16 = torch.empty_like(self.outc_wp)
+            _chk(lib.ammc_split_rows_f32(_ptr(self.outc_wp), self.outc_wp.numel(), _ptr(w16), s), "split_rows(w)")
+            d.x, d.w, d.y_f32 = u16.tap0(), _ptr(w16), 1
+            d.x_bs, d.x_rs, d.x_ps = u16.strides
+            _chk(lib.ammc_conv_gemm_s16(C.byref(d), s), "outc")
+        else:
+            d.x, d.w = u3.tap0(), _ptr(self.outc_wp)
+            d.x_bs, d.x_rs, d.x_ps = u3.strides
+            _chk(lib.ammc_conv_gemm_f32(C.byref(d), s), "outc")
         self.out = out
         return out
 
@@ -459,13 +470,21 @@ class _Stream:
         _chk(lib.ammc_tanh_bwd_nhwc_f32(_ptr(dout), _ptr(self.out), self.B, self.cout, self.H, self.W, dp.pix0(),
                                         *dp.strides, 32, s), "tanh_bwd")
         grads[net.outc.bias] = o.chan_sum(dp, 32, self.scratch)[:self.cout]
-        o.wgrad(dp, self.u3, self.outc_dwp, n=32, cin=64, ntaps=9, what="outc.wgrad")
+        if o.s16 and WGRAD_S16:
+            pre = o.to_s16(dp, rescale=True)
+            o.wgrad_s16(pre[0], o.shadow(self.u3), self.outc_dwp, pre[1], n=64, cin=64, what="outc.wgrad")
+        else:
+            pre = None
+            o.wgrad(dp.slice(0, 32), self.u3, self.outc_dwp, n=32, cin=64, ntaps=9, what="outc.wgrad")
         dw = torch.empty_like(net.outc.weight)
         _chk(lib.ammc_unpack_conv_wgrad_f32(_ptr(self.outc_dwp), self.cout, 64, 3, 64, _ptr(dw), s), "unpack")
         grads[net.outc.weight] = dw
-        _chk(lib.ammc_pack_conv_dgrad_weight_f32(_ptr(net.outc.weight.detach()), self.cout, 64, 32, 64,
+        _chk(lib.ammc_pack_conv_dgrad_weight_f32(_ptr(net.outc.weight.detach()), self.cout, 64, 64, 64,
                                                  _ptr(self.outc_wdp), s), "pack_dgrad")
-        o.conv(dp, self.outc_wdp, self.du[2], ntaps=9, cin=32, n=64, what="outc.dgrad")
+        if o.s16:
+            o.conv_s16(dp, self.outc_wdp, self.du[2], ntaps=9, cin=64, n=64, what="outc.dgrad", rescale=True, pre=pre)
+        else:
+            o.conv(dp, self.outc_wdp, self.du[2], ntaps=9, cin=64, n=64, what="outc.dgrad")
         for j in (2, 1, 0):
             lvl = (2, 1, 0)[j]
             c = CHANS[lvl]
