@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libammc_hip.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU = 0, 1, 2, 3
 
@@ -30,7 +30,7 @@ class AmmcConvDesc(C.Structure):
         ("x_bs", _i64), ("x_rs", _i64), ("x_ps", _i64),
         ("y_bs", _i64), ("y_rs", _i64), ("y_ps", _i64),
         ("r_bs", _i64), ("r_rs", _i64), ("r_ps", _i64),
-        ("y_cs", _i64), ("x_step", _i32), ("y_f32", _i32), ("w_kblk", _i32), ("reserved3", _i32), ("overflow_flag", _p),
+        ("y_cs", _i64), ("x_step", _i32), ("y_f32", _i32), ("reserved2", _i32), ("reserved3", _i32), ("overflow_flag", _p),
         ("splitk_ws", _p), ("splitk_ws_floats", _i64), ("sq_target", _p), ("sq_acc", _p),
         ("pool_y", _p), ("pool_bs", _i64), ("pool_rs", _i64), ("pool_ps", _i64),
     ]
@@ -71,7 +71,6 @@ SIGNATURES = {
     "ammc_split_rows_f32": (C.c_int, [_p, _i64, _p, _p]),
     "ammc_absmax_bits_f32": (C.c_int, [_p, _i64, _p, _p]),
     "ammc_split_rows_scaled_f32": (C.c_int, [_p, _i64, _p, _p, _p, _i32, _p]),
-    "ammc_split_kblk_f32": (C.c_int, [_p, _i32, _i32, _p, _p]),
     "ammc_nchw_to_s16_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _i64, _i64, _i64, _i32, _p]),
     "ammc_s16_to_nchw_f32": (C.c_int, [_p, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _p, _p]),
     "ammc_maxpool2x2_s16": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _p]),

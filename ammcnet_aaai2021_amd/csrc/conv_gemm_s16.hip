@@ -52,13 +52,10 @@ __device__ __forceinline__ void join8(const f16x8& hi, const f16x8& lo, float (&
   for (int i = 0; i < 8; ++i) v[i] = (float)hi[i] + (float)lo[i] * LO_INV;
 }
 
-// BD ("B direct"): the filter fragments bypass LDS.  The filter is then pre-packed k-blocked,
-// [Kpad/8][N][8 hi | 8 lo], so a lane's fragment (8 consecutive k of one output channel) is 32
-// contiguous bytes and a half-wave reads 1 KiB contiguous from L2 straight into VGPRs, one chunk
-// ahead.  With both operands in LDS the kernel is LDS-bandwidth bound (4-byte operands at the
-// 16-bit MFMA rate: DMA writes + fragment reads saturate the 128-256 B/clk LDS port at ~40 % MFMA
-// utilisation); taking B out halves that traffic.
-template <int WGM, int WGN, int TM, int TN, int NS, bool BD>
+// Variants measured and removed: filter fragments straight from L2 (no LDS for B), three LDS
+// stages with counted vmcnt, 16-wave tiles - all within 3 % of this two-stage form, which is bound by its L2 -> LDS
+// operand traffic.  The stride-1 3x3 layers have moved to conv_tap_s16.hip for that reason.
+template <int WGM, int WGN, int TM, int TN>
 __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN >= 1024 ? 1 : 2)) void conv_gemm_s16_kernel(ConvArgs a) {
   constexpr int NT = 64 * WGM * WGN;        // threads: one wave per (wm, wn)
   constexpr int BM = WGM * TM * 32;
@@ -69,12 +66,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN >= 1024 ? 1 : 2)) v
   constexpr int BJ = BN * 8 / NT;
   constexpr int RJ = NT / 8;                // tile rows covered by one round of pieces
   constexpr int JS = NT * 4;                // floats between a thread's consecutive pieces
-  constexpr int STAGES = NS * (A_STAGE + (BD ? 0 : B_STAGE));    // floats; NS = 2 or 3 LDS stages
+  constexpr int STAGES = 2 * (A_STAGE + B_STAGE);                // floats; two LDS stages
   constexpr int TILE = BM * BN;                                  // floats of the parked output tile
   constexpr int REGION = STAGES > TILE ? STAGES : TILE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
-  float* Bs = smem + NS * A_STAGE;
+  float* Bs = smem + 2 * A_STAGE;
   int* tab_out = reinterpret_cast<int*>(smem + REGION);          // [BM]
   int* tab_res = tab_out + BM;
 
@@ -159,7 +156,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN >= 1024 ? 1 : 2)) v
       float* dst_ = adst_ + j * JS;                                                                       \
       __builtin_amdgcn_global_load_lds(src_, dst_, 16, 0, 0);                                             \
     }                                                                                                     \
-    if (!BD) _Pragma("unroll") for (int j = 0; j < BJ; ++j) {                                             \
+    _Pragma("unroll") for (int j = 0; j < BJ; ++j) {                                             \
       const float* src_ = b_src[j] + (c) * 32;                                                            \
       float* dst_ = bdst_ + j * JS;                                                                       \
       __builtin_amdgcn_global_load_lds(src_, dst_, 16, 0, 0);                                             \
@@ -177,53 +174,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN >= 1024 ? 1 : 2)) v
   const int swz = (l31 >> 1) & 7;
   const int a_row = (wm * TM * 32 + l31) * 32;
   const int b_row = (wn * TN * 32 + l31) * 32;
-
-  // leave only the newest chunk's DMA (AJ + BJ instructions of this thread) in flight.  Literal counts:
-  // a template-dependent asm operand makes hipcc drop the kernel's host stub.
-#define S16_WAIT_NEWEST()                                            \
-  {                                                                  \
-    if (AJ + BJ == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      \
-    else if (AJ + BJ == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); \
-    else if (AJ + BJ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   \
-  }
-
-  // Fragment reads as inline asm: hipcc's waitcnt pass treats an in-flight LDS-DMA as a pending LDS write
-  // and puts `s_waitcnt vmcnt(0)` in front of every compiler-visible ds_read, which drains a multi-stage
-  // pipeline every chunk.  The asm reads are invisible to it; ordering is ours: the data of this stage was
-  // retired by the counted vmcnt + s_barrier of the previous iteration; lgkmcnt(0) + sched_barrier keep the
-  // MFMAs behind the reads (guide rule 18).
-#define S16_LDS_ADDR(p) ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(p))
-#define S16_COMPUTE_ASM(stage)                                                                           \
-  {                                                                                                      \
-    const uint32_t abase_ = S16_LDS_ADDR(As + (stage) * A_STAGE + a_row);                                \
-    const uint32_t bbase_ = S16_LDS_ADDR(Bs + (stage) * B_STAGE + b_row);                                \
-    _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                      \
-      const int g = 2 * s + h;                                                                           \
-      const uint32_t so_hi = (uint32_t)(((2 * g) ^ swz) << 4);                                           \
-      const uint32_t so_lo = (uint32_t)(((2 * g + 1) ^ swz) << 4);                                       \
-      f32x4 ahv[TM], alv[TM], bhv[TN], blv[TN];                                                          \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                   \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(ahv[i]) : "v"(abase_ + i * 4096 + so_hi));            \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(alv[i]) : "v"(abase_ + i * 4096 + so_lo));            \
-      }                                                                                                  \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                   \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(bhv[j]) : "v"(bbase_ + j * 4096 + so_hi));            \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(blv[j]) : "v"(bbase_ + j * 4096 + so_lo));            \
-      }                                                                                                  \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
-      __builtin_amdgcn_sched_barrier(0);                                                                 \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) {    \
-        const f16x8 ah_ = __builtin_bit_cast(f16x8, ahv[i]);                                             \
-        const f16x8 al_ = __builtin_bit_cast(f16x8, alv[i]);                                             \
-        const f16x8 bh_ = __builtin_bit_cast(f16x8, bhv[j]);                                             \
-        const f16x8 bl_ = __builtin_bit_cast(f16x8, blv[j]);                                             \
-        hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bh_, hh[i][j], 0, 0, 0);                 \
-        xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bl_, xx[i][j], 0, 0, 0);                 \
-        xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al_, bh_, xx[i][j], 0, 0, 0);                 \
-      }                                                                                                  \
-    }                                                                                                    \
-  }
 
 #define S16_COMPUTE(stage)                                                                               \
   {                                                                                                      \
@@ -250,64 +200,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN >= 1024 ? 1 : 2)) v
     }                                                                                                    \
   }
 
-  if (BD) {
-    // ---- B-direct pipeline: A through two LDS stages, B fragments of the NEXT chunk in registers --------
-    const float* wl[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-      wl[j] = d.w + ((int64_t)h * d.n + n0 + (wn * TN + j) * 32 + l31) * 8;
-    const int64_t kb_stride = (int64_t)d.n * 8;                 // floats between consecutive k-blocks
-    f16x8 b0h[2][TN], b0l[2][TN], b1h[2][TN], b1l[2][TN];
-#define S16_LOADB(c, BH, BL)                                                                   \
-  _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int j = 0; j < TN; ++j) { \
-    const float* p_ = wl[j] + ((int64_t)(c) * 4 + 2 * s) * kb_stride;                          \
-    BH[s][j] = *reinterpret_cast<const f16x8*>(p_);                                            \
-    BL[s][j] = *reinterpret_cast<const f16x8*>(p_ + 4);                                        \
-  }
-#define S16_COMPUTE_BD(stage, BH, BL)                                                                    \
-  {                                                                                                      \
-    const float* Ac = As + (stage) * A_STAGE + a_row;                                                    \
-    _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                      \
-      const int g = 2 * s + h;                                                                           \
-      const int so_hi = ((2 * g) ^ swz) << 2;                                                            \
-      const int so_lo = ((2 * g + 1) ^ swz) << 2;                                                        \
-      f16x8 ah[TM], al[TM];                                                                              \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                   \
-        ah[i] = *reinterpret_cast<const f16x8*>(Ac + i * 1024 + so_hi);                                  \
-        al[i] = *reinterpret_cast<const f16x8*>(Ac + i * 1024 + so_lo);                                  \
-      }                                                                                                  \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) {    \
-        hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], BH[s][j], hh[i][j], 0, 0, 0);          \
-        xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], BL[s][j], xx[i][j], 0, 0, 0);          \
-        xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], BH[s][j], xx[i][j], 0, 0, 0);          \
-      }                                                                                                  \
-    }                                                                                                    \
-  }
-    S16_ISSUE(0, 0);
-    S16_LOADB(0, b0h, b0l);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int c = 0; c < a.nchunks; c += 2) {
-      if (c + 1 < a.nchunks) {
-        S16_ISSUE(c + 1, 1);
-        S16_LOADB(c + 1, b1h, b1l);
-      }
-      S16_COMPUTE_BD(0, b0h, b0l);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (c + 1 < a.nchunks) {
-        if (c + 2 < a.nchunks) {
-          S16_ISSUE(c + 2, 0);
-          S16_LOADB(c + 2, b0h, b0l);
-        }
-        S16_COMPUTE_BD(1, b1h, b1l);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-      }
-    }
-#undef S16_LOADB
-#undef S16_COMPUTE_BD
-  } else if (NS == 2) {
+  {
     // two stages: the DMA of chunk c+1 flies while chunk c is contracted; one full drain per chunk
     if (c_lo < c_hi) S16_ISSUE(c_lo, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -319,28 +212,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN >= 1024 ? 1 : 2)) v
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
-  } else {
-    // three stages: chunks c+1 and c+2 are in flight while chunk c is contracted.  The DMA of a chunk is
-    // AJ+BJ instructions per thread, so `vmcnt(AJ+BJ)` retires everything but the newest chunk; raw
-    // s_barrier (a __syncthreads() would drain vmcnt(0) and serialise the pipeline again).
-    S16_ISSUE(0, 0);
-    if (a.nchunks > 1) S16_ISSUE(1, 1);
-    if (a.nchunks > 1) { S16_WAIT_NEWEST(); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    __builtin_amdgcn_s_barrier();
-    int stage = 0;
-    for (int c = 0; c < a.nchunks; ++c) {
-      const int nxt = stage + 2 >= 3 ? stage - 1 : stage + 2;
-      if (c + 2 < a.nchunks && a.dbg != 1) S16_ISSUE(c + 2, nxt);
-      if (a.dbg != 2) S16_COMPUTE_ASM(stage);
-      if (c + 2 < a.nchunks) { S16_WAIT_NEWEST(); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      stage = stage == 2 ? 0 : stage + 1;
-    }
-    __syncthreads();
   }
 #undef S16_COMPUTE
-#undef S16_COMPUTE_ASM
 #undef S16_ISSUE
 
   const int nstore = d.n_store > 0 ? d.n_store : d.n;
@@ -481,14 +354,14 @@ __global__ void splitk_epilogue_kernel(ConvArgs a);
 // conv_tap_s16.hip: the halo-patch kernel for stride-1 3x3 layers; -12345 = not its case
 int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream);
 
-template <int WGM, int WGN, int TM, int TN, int NS = 2, bool BD = false>
+template <int WGM, int WGN, int TM, int TN>
 int launch(const ConvArgs& a, hipStream_t stream) {
   constexpr int BM = WGM * TM * 32;
   constexpr int BN = WGN * TN * 32;
-  constexpr int STAGES = NS * (BM * 32 + (BD ? 0 : BN * 32));
+  constexpr int STAGES = 2 * (BM * 32 + BN * 32);
   constexpr int TILE = BM * BN;
   constexpr size_t lds = (size_t)((STAGES > TILE ? STAGES : TILE) + 2 * BM) * sizeof(float);
-  auto kern = conv_gemm_s16_kernel<WGM, WGN, TM, TN, NS, BD>;
+  auto kern = conv_gemm_s16_kernel<WGM, WGN, TM, TN>;
   static_assert(lds <= 160 * 1024, "LDS budget");
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -628,26 +501,6 @@ __global__ __launch_bounds__(256) void split_rows_scaled_kernel(const float* __r
   *reinterpret_cast<f16x8*>(dst + g * 8 + 4) = lo;
 }
 
-// packed filter [N][Kpad] fp32 -> k-blocked S16 [Kpad/8][N][8 hi | 8 lo] (the BD kernels' layout)
-__global__ __launch_bounds__(256) void split_kblk_kernel(const float* __restrict__ src, int N, int kpad,
-                                                         float* __restrict__ dst) {
-  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;       // one thread per (n, k-block)
-  const int kblocks = kpad >> 3;
-  if (g >= (int64_t)N * kblocks) return;
-  const int kb = (int)(g % kblocks);
-  const int n = (int)(g / kblocks);
-  const f32x4 a0 = *reinterpret_cast<const f32x4*>(src + (int64_t)n * kpad + kb * 8);
-  const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + (int64_t)n * kpad + kb * 8 + 4);
-  float v[8];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { v[i] = a0[i]; v[4 + i] = a1[i]; }
-  f16x8 hi, lo;
-  split8(v, hi, lo);
-  float* o = dst + ((int64_t)kb * N + n) * 8;
-  *reinterpret_cast<f16x8*>(o) = hi;
-  *reinterpret_cast<f16x8*>(o + 4) = lo;
-}
-
 // NCHW fp32 -> S16 NHWC (explicit strides), channels c..cp-1 zero; one thread per (pixel, group of 8)
 __global__ __launch_bounds__(256) void nchw_to_s16_kernel(const float* __restrict__ x, int B, int C, int H, int W,
                                                           float* __restrict__ y, int64_t y_bs, int64_t y_rs,
@@ -744,6 +597,7 @@ extern "C" int ammc_conv_gemm_s16(const AmmcConvDesc* desc, void* stream) {
   const AmmcConvDesc& d = *desc;
   if (d.batch <= 0 || d.height <= 0 || d.width <= 0) return AMMC_EINVAL;
   if (d.ntaps != 9 && d.ntaps != 1 && d.ntaps != 4) return AMMC_EINVAL;
+  if (d.reserved2) return AMMC_EUNSUP;
   if (d.ntaps != 1 && (d.cin < 8 || (d.cin & (d.cin - 1)))) return AMMC_EUNSUP;    // whole groups of 8
   if (d.x_step < 0 || d.x_step > 2) return AMMC_EINVAL;
   if (d.ntaps == 1 && (d.cin <= 0 || d.cin % 32)) return AMMC_EUNSUP;
@@ -781,7 +635,7 @@ extern "C" int ammc_conv_gemm_s16(const AmmcConvDesc* desc, void* stream) {
   if (d.pool_y) return AMMC_EUNSUP;                 // the fused max-pool output exists in the halo-patch kernel only
   // split-K for layers that cannot fill the chip (small batch: 32x32 / 64x64 levels with K up to 4608): each K
   // slice is its own workgroup writing an fp32 partial tile; a streaming kernel sums the slices and finishes
-  if (d.splitk_ws && !d.y_f32 && !d.w_kblk && d.up == 1 && d.n % 128 == 0 && a.nchunks >= 16) {
+  if (d.splitk_ws && !d.y_f32 && d.up == 1 && d.n % 128 == 0 && a.nchunks >= 16) {
     const int64_t tiles = ((M + 127) / 128) * (d.n / 128);
     if (tiles < 192) {
       int ksp = (int)((512 + tiles - 1) / tiles);
@@ -793,26 +647,14 @@ extern "C" int ammc_conv_gemm_s16(const AmmcConvDesc* desc, void* stream) {
       }
     }
   }
-  if (d.w_kblk) {                                   // k-blocked filter: B fragments bypass LDS
-    if (d.n == 32) return launch<4, 1, 1, 1, 2, true>(a, s);
-    if (d.n % 128 == 0) return launch<2, 2, 2, 2, 2, true>(a, s);
-    // N = 64: a 256 x 64 tile keeps the 64x64 wave tile (A fragment reads per MFMA as in the 128x128 kernel);
-    // with B out of LDS it still fits two workgroups per CU
-    return M >= 4096 ? launch<4, 1, 2, 2, 2, true>(a, s) : launch<4, 1, 1, 2, 2, true>(a, s);
-  }
   if (d.n == 32) return launch<4, 1, 1, 1>(a, s);
   // 256-row tiles (8 waves, one workgroup per CU) move 25 % / 17 % fewer LDS-DMA bytes per FLOP than the
   // 128-row ones; they pay off once there are enough tiles to fill the chip
   // ... and the K loop is long enough to amortise a prologue/epilogue that nothing overlaps (one workgroup per CU);
   // short-K layers (ConvTranspose, K = Cin <= 512) keep the 128-row tiles, three workgroups per CU
   const bool many = M >= (int64_t)256 * 512 / (d.n >= 256 ? d.n / 128 : 1) && a.nchunks > 16;
-  if (d.n % 128 == 0) {
-    if (big == 3 && many) return launch<4, 2, 2, 2, 3>(a, s);
-    if (big == 4 && many) return launch<8, 2, 1, 2>(a, s);     // 16 waves, 32x64 wave tiles
-    return (big && many) ? launch<4, 2, 2, 2>(a, s) : launch<2, 2, 2, 2>(a, s);
-  }
-  if (big == 3 && many) return launch<8, 1, 1, 2, 3>(a, s);
-  return (big == 2 && many) ? launch<8, 1, 1, 2>(a, s) : launch<4, 1, 1, 2>(a, s);
+  if (d.n % 128 == 0) return (big && many) ? launch<4, 2, 2, 2>(a, s) : launch<2, 2, 2, 2>(a, s);
+  return launch<4, 1, 1, 2>(a, s);
 }
 
 extern "C" int ammc_split_rows_f32(const float* src, int64_t count, float* dst, void* stream) {
@@ -836,13 +678,6 @@ extern "C" int ammc_split_rows_scaled_f32(const float* src, int64_t count, float
     return AMMC_EINVAL;
   hipLaunchKernelGGL(split_rows_scaled_kernel, dim3(nblk(count >> 3)), dim3(256), 0, (hipStream_t)stream, src, count >> 3,
                      dst, amax_bits, inv_scale, n);
-  return ammc_launch_status();
-}
-
-extern "C" int ammc_split_kblk_f32(const float* src, int32_t n, int32_t kpad, float* dst, void* stream) {
-  if (!src || !dst || n <= 0 || kpad <= 0 || (kpad & 31) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return AMMC_EINVAL;
-  hipLaunchKernelGGL(split_kblk_kernel, dim3(nblk((int64_t)n * (kpad >> 3))), dim3(256), 0, (hipStream_t)stream, src, n,
-                     kpad, dst);
   return ammc_launch_status();
 }
 

@@ -27,8 +27,6 @@ from . import _lib
 from ._lib import ACT_NONE, ACT_RELU, ACT_TANH, AmmcConvDesc
 
 BN_EPS = 1e-5
-# S16 kernels: filter fragments straight from L2 into registers (k-blocked filter) instead of through LDS
-S16_BDIRECT = os.environ.get("AMMC_S16_BDIRECT", "0") != "0"   # measured: no faster than LDS-staged B
 # AMMC_GRAPH=1: eval forwards replay a captured hipGraph (one host call per forward).  Off by default: measured
 # on MI355X the ~100 launches of a forward are NOT launch-bound (batch 1: 1.58 ms eager vs 1.58 ms replayed; the
 # chain of dependent small kernels is the floor), and a replay costs an extra copy of the inputs into static buffers.
@@ -73,7 +71,7 @@ class Act:
 
 def _tap_eligible(x: "Act", ntaps: int, cin: int, n: int, up: int = 1, y_f32: int = 0) -> bool:
     """does csrc/conv_tap_s16.hip (the halo-patch 3x3 kernel) take this S16 layer?  Mirrors `conv_tap_s16_try`."""
-    if os.environ.get("AMMC_S16_TAP", "1") == "0" or S16_BDIRECT:
+    if os.environ.get("AMMC_S16_TAP", "1") == "0":
         return False
     if ntaps != 9 or up != 1 or cin % 32 or x.W % 32 or x.H % 8:
         return False
@@ -154,15 +152,11 @@ class _Packer:
         self.s16 = s16                  # filters as (hi, lo) half pairs for ammc_conv_gemm_s16
 
     def _split(self, t: torch.Tensor) -> torch.Tensor:
-        """packed filter [N][Kpad] -> S16; k-blocked when the B-direct kernels are used"""
+        """packed filter [N][Kpad] -> S16"""
         if not self.s16:
             return t
         out = torch.empty_like(t)
-        if S16_BDIRECT:
-            _lib.check(self.lib.ammc_split_kblk_f32(_ptr(t), t.shape[0], t.shape[1], _ptr(out), self.stream()),
-                       "split_kblk")
-        else:
-            _lib.check(self.lib.ammc_split_rows_f32(_ptr(t), t.numel(), _ptr(out), self.stream()), "split_rows")
+        _lib.check(self.lib.ammc_split_rows_f32(_ptr(t), t.numel(), _ptr(out), self.stream()), "split_rows")
         return out
 
     def stream(self) -> int:
@@ -294,7 +288,6 @@ class _Builder:
             d.pool_y = pool.pix0()
             d.pool_bs, d.pool_rs, d.pool_ps = pool.strides
         d.y_f32 = 1 if (y_f32 and self.s16) else 0
-        d.w_kblk = 1 if (self.s16 and S16_BDIRECT) else 0
         d.overflow_flag = self.overflow.data_ptr() if self.s16 else None
         if self.s16 and os.environ.get("AMMC_S16_SPLITK", "1") != "0":
             d.splitk_ws, d.splitk_ws_floats = self.splitk.data_ptr(), self.splitk.numel()
@@ -338,7 +331,6 @@ class _Builder:
         d.batch, d.height, d.width = x.B, x.H, x.W
         d.cin, d.ntaps, d.n, d.up, d.cgroup, d.act, d.n_store = x.c, 9, 32, 1, 32, ACT_TANH, cout
         d.y_f32 = 1 if self.s16 else 0
-        d.w_kblk = 1 if (self.s16 and S16_BDIRECT) else 0
         d.x_bs, d.x_rs, d.x_ps = x.strides
         d.y_bs, d.y_rs, d.y_ps, d.y_cs = cout * x.H * x.W, x.W, 1, x.H * x.W
         self.plan.keep.extend([d, w, bias32])

@@ -86,7 +86,7 @@ typedef struct AmmcConvDesc {
   int64_t y_cs;          /* output channel stride: 0/1 = NHWC; H*W (with y_ps=1, y_rs=W) = NCHW    */
   int32_t x_step;        /* 0/1; 2 = the input is at twice the resolution of m (with ntaps=4: the  */
   int32_t y_f32;         /* (2x2 stride-2 gather of the ConvTranspose dgrad).  y_f32: ammc_conv_gemm_s16 only, 1 = fp32 output */
-  int32_t w_kblk;        /* ammc_conv_gemm_s16 only: 1 = w is k-blocked (ammc_split_kblk_f32), fragments bypass LDS */
+  int32_t reserved2;     /* 0 */
   int32_t reserved3;
   int32_t* overflow_flag; /* ammc_conv_gemm_s16 only, may be NULL: set to 1 when an S16 output exceeds the half range */
   float* splitk_ws;      /* ammc_conv_gemm_s16 only, may be NULL: fp32 workspace that lets small-M layers split K    */
@@ -170,8 +170,6 @@ int ammc_sum_partials_f32(const float* partial, int32_t nparts, float inv_count,
  * not).  Replaces the same reference calls as ammc_conv_gemm_f32.
  * ---------------------------------------------------------------------------------------- */
 int ammc_conv_gemm_s16(const AmmcConvDesc* desc, void* stream);
-/* packed filter [n][kpad] fp32 -> k-blocked S16 [kpad/8][n][8 hi | 8 lo] (w_kblk = 1) */
-int ammc_split_kblk_f32(const float* src, int32_t n, int32_t kpad, float* dst, void* stream);
 /* fp32 -> S16, count elements (multiple of 8): packed filters, gathered codebook rows */
 int ammc_split_rows_f32(const float* src, int64_t count, float* dst, void* stream);
 /* Gradient tensors as S16 operands (what autograd derives for the 3x3 convs, train_helper.py:337-339): the largest
