@@ -44,6 +44,9 @@ def parse():
     p.add_argument("--size", type=int, default=256)
     p.add_argument("--precision", choices=("fp32", "s16"), default=os.environ.get("AMMC_PRECISION", "s16"),
                    help="fp32 = exact fp32 MFMA; s16 = split-fp16 MFMA with fp32 accumulation (fp32-equivalent)")
+    p.add_argument("--mode", choices=("infer", "train"), default="infer",
+                   help="infer = the headline metric (BASELINE.json configs[1]); train = configs[2]/[3]: fwd+bwd+Adam, "
+                        "batch 32 per GPU, data parallel with a bucketed RCCL gradient all-reduce when --gpus > 1")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-batch", type=int, default=4)
     p.add_argument("--cpu-iters", type=int, default=10)
@@ -85,6 +88,64 @@ def cpu_baseline(args):
                       f"(host has {ncpu} logical CPUs)"}
 
 
+def train_mode(args, rank, world, dev, dist):
+    """BASELINE.json configs[2] / configs[3]: one optimisation step of the shipped network (256 slots) per "step",
+    batch 32 per GPU (weak scaling), gradients averaged over RCCL inside backward (parallel.BucketedGradReducer)."""
+    import ammcnet_aaai2021_amd as A
+    from ammcnet_aaai2021_amd import harness, parallel, synthetic as S
+    from oracle.ammc_oracle import fwd_flops_per_clip
+    batch = 32 if args.batch == 16 else args.batch
+    net = A.get_twostream((12, 6), (3, 2), 64, 256, 2)
+    net.load_state_dict(S.make_twostream_state())
+    net = net.to(dev).train()
+    if world > 1:
+        parallel.broadcast_state(net)
+        parallel.attach_reducer(net, parallel.BucketedGradReducer())
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    rgb_x, op_x, rgb_t, op_t = (t.to(dev) for t in S.make_clips(batch, args.size, args.size, tag=f"trainbench{rank}"))
+    rgb = torch.cat([rgb_x.view(batch, 4, 3, args.size, args.size), rgb_t[:, None]], 1)
+    op = torch.cat([op_x.view(batch, 3, 2, args.size, args.size), op_t[:, None]], 1)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        loss = harness.train_step(net, opt, rgb, op)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = harness.train_step(net, opt, rgb, op)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert bool(torch.isfinite(loss))
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        value = batch * args.steps * world / elapsed
+        flops = 3.0 * fwd_flops_per_clip(args.size, args.size)
+        from ammcnet_aaai2021_amd import train as T
+        print(json.dumps({
+            "metric": "clips/sec, 256x256x4 dual-stream clips (twostream forward + backward + Adam, training)",
+            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32" if T.TRAIN_PRECISION == "fp32" else "f32-equivalent: (hi,lo) f16 split MFMA for the 3x3 convolutions, f32 elsewhere",
+            "data": "synthetic",
+            "config": {"workload": "Ped2 dual-stream + 256-slot memory, batch 32 per GPU, fwd+bwd+Adam "
+                                   "(BASELINE.json configs[2]; configs[3] with --gpus 8)",
+                       "batch_per_gpu": batch, "frame": f"{args.size}x{args.size}",
+                       "parallelism": f"dp{world} (bucketed RCCL all-reduce of 100 MB of fp32 gradients)"},
+            "whole_path_tflops": round(value * flops / 1e12 / world, 2), "roofline": None, "cpu_baseline": None}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -104,6 +165,9 @@ def main():
 
     import ammcnet_aaai2021_amd as A
     from ammcnet_aaai2021_amd import synthetic as S
+
+    if args.mode == "train":
+        return train_mode(args, rank, world, dev, dist)
 
     sd = S.make_twostream_state(n_embed=args.n_embed)
     net = A.get_twostream((12, 6), (3, 2), 64, args.n_embed, 2)
