@@ -132,3 +132,20 @@ def test_fused_maxpool_matches_pool_kernel(monkeypatch):
     for x, y in ((a[0], b[0]), (a[1], b[1]), (a[3][0], b[3][0]), (a[3][1], b[3][1])):
         assert float((x - y).abs().max() / y.abs().max()) <= 2e-6
     assert abs(float(a[2][0]) - float(b[2][0])) <= 1e-6 * abs(float(b[2][0]))
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 256, 256), (3, 64, 96), (5, 32, 64), (24, 64, 64), (7, 128, 32), (2, 8, 8), (9, 96, 160)])
+def test_s16_dispatch_is_consistent_across_shapes(B, H, W):
+    """which kernel a layer gets (halo-patch variants, implicit GEMM, split-K, fused pooling) depends on batch and frame
+    size; whatever the mix, the S16 model must agree with the exact-fp32 kernels (2e-5 of max|ref|) and the two
+    streams' commit scores to 1e-5"""
+    net, _ = _net()
+    rgb_x, op_x, _, _ = (t.to(DEV) for t in S.make_clips(B, H, W, tag=f"shape-{B}-{H}-{W}"))
+    with torch.no_grad():
+        a = net(rgb_x, op_x)
+        net.precision = "fp32"
+        b = net(rgb_x, op_x)
+    for x, y in ((a[0], b[0]), (a[1], b[1])):
+        assert float((x - y).abs().max() / y.abs().max()) <= 2e-5
+    for x, y in zip(a[2], b[2]):
+        assert abs(float(x) - float(y)) <= 1e-5 * abs(float(y))
