@@ -155,13 +155,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # AMMC_BENCH_SHARE_GPU=1 (tests on a one-GPU box): every rank on cuda:0, gloo instead of RCCL (which needs one
+    # device per rank); everything else is the code the multi-GPU runs execute
+    share = os.environ.get("AMMC_BENCH_SHARE_GPU", "0") != "0"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import ammcnet_aaai2021_amd as A
     from ammcnet_aaai2021_amd import synthetic as S
