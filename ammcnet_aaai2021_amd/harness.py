@@ -40,9 +40,10 @@ def subvideo_batches(n_frames: int, batch: int = EVAL_BATCH, rgb_len_clip: int =
     return [(s, min(s + batch, n_clip)) for s in range(0, max(n_clip, 0), batch)]
 
 
-def score_batch(model: Callable, rgb_frames: torch.Tensor, op_frames: torch.Tensor, s: int, e: int,
-                device=None) -> Dict[str, np.ndarray]:
-    """run clips [s, e) of a sub-video as ONE batch; per-clip PSNR and the batch's commit values"""
+def score_batch_device(model: Callable, rgb_frames: torch.Tensor, op_frames: torch.Tensor, s: int, e: int,
+                       device=None) -> torch.Tensor:
+    """run clips [s, e) of a sub-video as ONE batch; returns [2 b + 2] on the model's device: per-clip rgb PSNR, per-clip
+    flow PSNR, the batch's two commit values - nothing is copied to the host, so batches can be queued back to back"""
     rgb = torch.stack([rgb_frames[i:i + RGB_LEN_CLIP] for i in range(s, e)])
     op = torch.stack([op_frames[i:i + OP_LEN_CLIP] for i in range(s, e)])
     if device is not None:
@@ -57,8 +58,17 @@ def score_batch(model: Callable, rgb_frames: torch.Tensor, op_frames: torch.Tens
         else:
             rgb_out, op_out, (rgb_diff, op_diff), _ = model(rgb_in, op_in)
             rgb_psnr, op_psnr = psnr_per_sample(rgb_out, rgb[:, -1]), psnr_per_sample(op_out, op[:, -1])
-        stats = torch.cat([rgb_psnr, op_psnr, rgb_diff.reshape(1), op_diff.reshape(1)]).cpu().numpy()
+        return torch.cat([rgb_psnr, op_psnr, rgb_diff.reshape(1), op_diff.reshape(1)])
+
+
+def _unpack_scores(stats: np.ndarray, b: int) -> Dict[str, np.ndarray]:
     return {"rgb_psnr": stats[:b], "op_psnr": stats[b:2 * b], "rgb_comm": stats[2 * b], "op_comm": stats[2 * b + 1]}
+
+
+def score_batch(model: Callable, rgb_frames: torch.Tensor, op_frames: torch.Tensor, s: int, e: int,
+                device=None) -> Dict[str, np.ndarray]:
+    """`score_batch_device` + the copy to the host (one sync)"""
+    return _unpack_scores(score_batch_device(model, rgb_frames, op_frames, s, e, device).cpu().numpy(), e - s)
 
 
 def assemble_records(n_frames: int, batches, scores: Sequence[Dict[str, np.ndarray]]) -> Dict[str, np.ndarray]:
@@ -94,14 +104,21 @@ def evaluate_dataset(model: Callable, videos: Sequence, dataset_name: str = "syn
     sharded over `world` ranks; every rank returns the full record dict (test_helper.py:479-484)."""
     plan = [(v, s, e) for v, (rgb, _) in enumerate(videos) for s, e in subvideo_batches(rgb.shape[0])]
     mine = parallel.shard_batches(len(plan), rank, world)
-    local = {}
+    pending = []
     resident = (None, None)                 # one sub-video at a time lives on the device (<= ~150 MB for 180 frames)
     for i in mine:
         v, s, e = plan[i]
         if device is not None and resident[0] != v:
             resident = (v, (videos[v][0].to(device, non_blocking=True), videos[v][1].to(device, non_blocking=True)))
         rgb_v, op_v = resident[1] if device is not None else videos[v]
-        local[i] = score_batch(model, rgb_v, op_v, s, e, None)
+        pending.append((i, e - s, score_batch_device(model, rgb_v, op_v, s, e, None)))      # queued, not awaited
+    local = {}
+    if pending:                              # ONE device-to-host copy for all batches of this rank
+        flat = torch.cat([t for _, _, t in pending]).cpu().numpy()
+        off = 0
+        for i, b, t in pending:
+            local[i] = _unpack_scores(flat[off:off + t.numel()], b)
+            off += t.numel()
     allsc = parallel.gather_records(local, world)
     out = {"dataset": dataset_name, "rgb_img_pred_records": [], "rgb_fea_comm_records": [],
            "op_img_pred_records": [], "op_fea_comm_records": []}
