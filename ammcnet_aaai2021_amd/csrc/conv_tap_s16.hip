@@ -54,18 +54,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
   constexpr int BJ = BN * 8 >= NT ? BN * 8 / NT : 1;       // filter pieces per thread per tap (every wave issues:
   constexpr int B_STAGE = BJ * (NT / 8) * 32;                    // a 32-filter slice is padded to 64 rows; floats)
   // filter-slice stages: 3 = slices t+1 and t+2 fly during step t; the 4-wave 128-filter variant keeps 2 (one slice
-  // ahead) so that two workgroups fit a CU, and parks its output tile in two 64-column halves for the same reason
+  // ahead) so that two workgroups fit a CU
   constexpr int NB = (NT == 256 && BN == 128) ? 2 : 3;
   constexpr int PD = NB - 1;
-  constexpr int EPC = (NT == 256 && BN == 128) ? 64 : BN;
   constexpr int STAGES = AS * T_ASTAGE + NB * B_STAGE;
-  constexpr int TILE = BM * EPC;
-  constexpr int REGION = STAGES > TILE ? STAGES : TILE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
   float* Bs = smem + AS * T_ASTAGE;
-  int* tab_out = reinterpret_cast<int*>(smem + REGION);          // [BM]
-  int* tab_res = tab_out + BM;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -77,6 +72,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
   const AmmcConvDesc& d = a.d;
 
   const int logical = ammc_xcd_remap(blockIdx.x, gridDim.x);
+  // Two workgroups share a CU (AS == 1).  Started together they stay in phase: both stream their patch, both run
+  // their MFMAs and both store their tile at the same moments, so the chip alternates between an idle matrix pipe and
+  // an idle memory system (the stores of one round of 512 tiles alone are 5-9 us at the full HBM rate).  Every other
+  // group of 256 workgroups (the dispatcher fills the 256 CUs once, then a second time) runs at a higher wave priority:
+  // it gets ahead of its CU-mate, finishes first, and from then on one workgroup's epilogue and prologue hide behind
+  // the other's MFMAs.  Measured with the layer launched back to back (same box): 128x128 128->128 169 -> 155 us,
+  // 256x256 64->64 224 -> 212 us; inside the model, where kernels of different shapes follow each other, the dispatch
+  // order is less regular and the step time moves within its noise (AMMC_S16_DBG=-1 turns it off for A/Bs).
+  if (AS == 1 && a.dbg != -1 && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_setprio(1);
   const int n0 = (logical % a.n_tiles) * BN;
   int sp = logical / a.n_tiles;
   const int tx = sp % a.tiles_x;
@@ -107,12 +111,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
     int row = n0 + j * (NT / 8) + (tid >> 3);
     row = row < d.n ? row : d.n - 1;                         // padding rows of a 32-filter slice: any valid address
     b_src[j] = d.w + (int64_t)row * a.kpad + 4 * sl;
-  }
-
-  for (int i = tid; i < BM; i += NT) {
-    const int y = y0 + (i >> 5), x = x0 + (i & 31);
-    tab_out[i] = (int)((int64_t)b * d.y_bs + (int64_t)y * d.y_rs + (int64_t)x * d.y_ps);
-    tab_res[i] = (int)((int64_t)b * d.r_bs + (int64_t)y * d.r_rs + (int64_t)x * d.r_ps);
   }
 
   // (macros, not lambdas / dependent expressions: see the hipcc notes in DESIGN.md section 8)
@@ -149,8 +147,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
       for (int r = 0; r < 16; ++r) xx[i][j][r] = 0.f;
 #define TAP_ACC(i, j, r) (SA ? hh[i][j][r] : hh[i][j][r] + xx[(SA ? 0 : (i))][(SA ? 0 : (j))][r] * T_LO_INV)
 
-  const int swzb = (l31 >> 1) & 7;
-  const int b_row = (wn * TN * 32 + l31) * 32;
+  // filter row of this lane: MFMA row l31 takes filter pi(l31), pi = swap bits 2 and 3, so that a lane's accumulator
+  // registers are runs of eight consecutive output channels (see the epilogue)
+  const int pl31 = (l31 & 19) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+  const int swzb = (pl31 >> 1) & 7;
+  const int b_row = (wn * TN * 32 + pl31) * 32;
   int hpb[TM];                                  // halo pixel of this lane's output pixel for tap (0,0)
 #pragma unroll
   for (int i = 0; i < TM; ++i) hpb[i] = (wm * TM + i) * T_HW + l31;
@@ -194,18 +195,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
         }                                                                                                  \
         TAP_PRIO(1);                                                                                       \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)      \
-          hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], hh[i][j], 0, 0, 0);             \
+          hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], hh[i][j], 0, 0, 0);             \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)      \
-          hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah2_[i], bl[j], hh[i][j], 0, 0, 0);           \
+          hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah2_[i], hh[i][j], 0, 0, 0);           \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)      \
-          hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al2_[i], bh[j], hh[i][j], 0, 0, 0);           \
+          hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al2_[i], hh[i][j], 0, 0, 0);           \
         TAP_PRIO(0);                                                                                       \
       } else {                                                                                             \
         TAP_PRIO(1);                                                                                       \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) {    \
-          hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], hh[i][j], 0, 0, 0);             \
-          xx[SA ? 0 : i][SA ? 0 : j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], xx[SA ? 0 : i][SA ? 0 : j], 0, 0, 0); \
-          xx[SA ? 0 : i][SA ? 0 : j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], xx[SA ? 0 : i][SA ? 0 : j], 0, 0, 0); \
+          hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], hh[i][j], 0, 0, 0);             \
+          xx[SA ? 0 : i][SA ? 0 : j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], xx[SA ? 0 : i][SA ? 0 : j], 0, 0, 0); \
+          xx[SA ? 0 : i][SA ? 0 : j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], xx[SA ? 0 : i][SA ? 0 : j], 0, 0, 0); \
         }                                                                                                  \
         TAP_PRIO(0);                                                                                       \
       }                                                                                                    \
@@ -263,40 +264,71 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
     }
     TAP_STEP(0) TAP_STEP(1) TAP_STEP(2) TAP_STEP(3) TAP_STEP(4) TAP_STEP(5) TAP_STEP(6) TAP_STEP(7) TAP_STEP(8)
   }
-  __syncthreads();
 #undef TAP_WAIT
 #undef TAP_STEP
 #undef TAP_COMPUTE
 #undef TAP_ISSUE_A
 #undef TAP_ISSUE_B
 
+  // ---- epilogue, straight from the accumulators ---------------------------------------------------------------
+  // The MFMAs take the filter fragment as the row operand, so an accumulator tile has PIXELS on lanes (lane l31 =
+  // pixel x0 + l31 of image row wm*TM + i) and CHANNELS on registers: register r of lane half h is MFMA row
+  // (r & 3) + 8 (r >> 2) + 4 h, and the filter fragment presents filter pi(row) there (pi swaps bits 2 and 3, see
+  // b_row), so registers 8 o .. 8 o + 7 of a lane are the EIGHT CONSECUTIVE channels of S16 group 2 o + h: a lane
+  // stores whole 32-byte groups (16 B of hi halves, 16 B of lo halves), the two lane halves write neighbouring groups -
+  // no LDS round trip, no barrier.  (The first form parked the tile in LDS to get 32-byte stores; with everything else
+  // removed that epilogue was 10-35 % of the kernel.)
+  int o_pix[TM], r_pix[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int y = y0 + wm * TM + i, x = x0 + l31;
+    o_pix[i] = (int)((int64_t)b * d.y_bs + (int64_t)y * d.y_rs + (int64_t)x * d.y_ps);
+    r_pix[i] = (int)((int64_t)b * d.r_bs + (int64_t)y * d.r_rs + (int64_t)x * d.r_ps);
+  }
+
   if (d.y_f32) {
-    // ---- direct fp32 store (channels on lanes), NHWC or NCHW through y_cs; tanh and the fused squared error of
-    // `psnr_error` for the output layer (as in conv_gemm_s16_kernel; a patch lies inside one sample) --------------
+    // fp32 output, NHWC (16-byte stores of four channels) or NCHW through y_cs (lanes = consecutive pixels); tanh and
+    // the fused squared error of `psnr_error` for the output layer (a patch lies inside one sample)
     const int nstore = d.n_store > 0 ? d.n_store : d.n;
     const int64_t ycs = d.y_cs > 0 ? d.y_cs : 1;
     float sq0 = 0.f;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int ncol = n0 + (wn * TN + j) * 32 + l31;
-      const float sc = d.scale ? d.scale[ncol] : 1.f;
-      const float sh = d.shift ? d.shift[ncol] : 0.f;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
+      for (int q = 0; q < 4; ++q) {                             // register quad q: channels c0 .. c0 + 3
+        const int c0 = n0 + (wn * TN + j) * 32 + 8 * (2 * (q >> 1) + h) + 4 * (q & 1);
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (d.scale) sc = *reinterpret_cast<const f32x4*>(d.scale + c0);
+        if (d.shift) sh = *reinterpret_cast<const f32x4*>(d.shift + c0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (ncol < nstore) {
-            float v = TAP_ACC(i, j, r) * sc + sh;
-            if (d.act == AMMC_ACT_RELU) v = v > 0.f ? v : 0.f;
-            else if (d.act == AMMC_ACT_TANH) v = tanhf(v);
-            if (d.res) v += d.res[tab_res[row] + ncol];             // fp32 outputs take an fp32 NHWC residual
-            const int64_t addr = tab_out[row] + (int64_t)ncol * ycs;
-            d.y[addr] = v;
-            if (d.sq_target) {
-              const float df = 0.5f * (d.sq_target[addr] - v);
-              sq0 += df * df;
-            }
+        for (int i = 0; i < TM; ++i) {
+          f32x4 v;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float t = TAP_ACC(i, j, 4 * q + k) * sc[k] + sh[k];
+            if (d.act == AMMC_ACT_RELU) t = t > 0.f ? t : 0.f;
+            else if (d.act == AMMC_ACT_TANH) t = tanhf(t);
+            v[k] = t;
+          }
+          if (d.res) {                                          // fp32 outputs take an fp32 NHWC residual
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(d.res + r_pix[i] + c0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += rv[k];
+          }
+          if (ycs == 1 && c0 + 4 <= nstore) {
+            *reinterpret_cast<f32x4*>(d.y + o_pix[i] + c0) = v;
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (c0 + k < nstore) d.y[o_pix[i] + (int64_t)(c0 + k) * ycs] = v[k];
+          }
+          if (d.sq_target) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (c0 + k < nstore) {
+                const float df = 0.5f * (d.sq_target[o_pix[i] + (int64_t)(c0 + k) * ycs] - v[k]);
+                sq0 += df * df;
+              }
           }
         }
       }
@@ -309,117 +341,76 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
     return;
   }
 
-  // ---- epilogue: park the tile in LDS, then 8 channels of one pixel per thread (as conv_gemm_s16_kernel) ------
-  float* T = smem;                                               // [BM][EPC]
-  constexpr int CG = EPC / 8;
-  for (int c0 = 0; c0 < BN; c0 += EPC) {
-    if (c0 > 0) __syncthreads();
+  // S16 output [+ S16 residual] [+ the 2x2 max-pool of it as a second output: rows 2 wm, 2 wm + 1 are this wave's two
+  // row tiles and the horizontal neighbour is the next lane, so the window never leaves the wave]
+  float vmax = 0.f;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = (wn * TN + j) * 32 + l31;
-      if (col >= c0 && col < c0 + EPC) {
+  for (int j = 0; j < TN; ++j) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+    for (int o = 0; o < 2; ++o) {
+      const int c0 = n0 + (wn * TN + j) * 32 + 8 * (2 * o + h);  // this lane's S16 group
+      float sc[8], sh[8];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            T[row * EPC + col - c0] = TAP_ACC(i, j, r);
-          }
-        }
-      }
-    }
-    __syncthreads();
-    for (int item = tid; item < BM * CG; item += NT) {
-      const int row = item / CG;
-      const int cg = item - row * CG;
-      const int ncol0 = n0 + c0 + cg * 8;
-      float v[8];
-      {
-        const f32x4 t0 = *reinterpret_cast<const f32x4*>(T + row * EPC + cg * 8);
-        const f32x4 t1 = *reinterpret_cast<const f32x4*>(T + row * EPC + cg * 8 + 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { v[i] = t0[i]; v[4 + i] = t1[i]; }
-      }
+      for (int k = 0; k < 8; ++k) sc[k] = 1.f, sh[k] = 0.f;
       if (d.scale) {
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.scale + ncol0);
-        const f32x4 s1 = *reinterpret_cast<const f32x4*>(d.scale + ncol0 + 4);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.scale + c0), s1 = *reinterpret_cast<const f32x4*>(d.scale + c0 + 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v[i] *= s0[i]; v[4 + i] *= s1[i]; }
+        for (int k = 0; k < 4; ++k) sc[k] = s0[k], sc[4 + k] = s1[k];
       }
       if (d.shift) {
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.shift + ncol0);
-        const f32x4 s1 = *reinterpret_cast<const f32x4*>(d.shift + ncol0 + 4);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.shift + c0), s1 = *reinterpret_cast<const f32x4*>(d.shift + c0 + 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v[i] += s0[i]; v[4 + i] += s1[i]; }
+        for (int k = 0; k < 4; ++k) sh[k] = s0[k], sh[4 + k] = s1[k];
       }
-      if (d.act == AMMC_ACT_RELU) {
+      float pooled[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
-      }
-      if (d.res) {
-        const float* rp = d.res + tab_res[row] + ncol0;
-        const f16x8t rh = *reinterpret_cast<const f16x8t*>(rp);
-        const f16x8t rl = *reinterpret_cast<const f16x8t*>(rp + 4);
+      for (int i = 0; i < TM; ++i) {
+        float v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] += (float)rh[i] + (float)rl[i] * T_LO_INV;
-      }
-      f16x8t hi, lo;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const _Float16 hv = (_Float16)v[i];
-        hi[i] = hv;
-        lo[i] = (_Float16)((v[i] - (float)hv) * T_LO_SCALE);
-      }
-      if (d.overflow_flag) {
-        bool bad = false;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) bad |= !(fabsf(v[i]) <= 65504.f);
-        if (bad) atomicOr(d.overflow_flag, 1);
-      }
-      float* yp = d.y + tab_out[row] + ncol0;
-      *reinterpret_cast<f16x8t*>(yp) = hi;
-      *reinterpret_cast<f16x8t*>(yp + 4) = lo;
-    }
-    if (d.pool_y) {
-      // fused nn.MaxPool2d(2) (unet.py:36): the patch holds whole 2x2 windows (8 rows x 32 pixels).  Same values as
-      // pooling the stored tensor: the S16 rounding is monotone, so it commutes with max.
-      for (int item = tid; item < (BM / 4) * CG; item += NT) {
-        const int pp = item / CG;
-        const int cg = item - pp * CG;
-        const int py = pp >> 4, px = pp & 15;
-        const int ncol0 = n0 + c0 + cg * 8;
-        float sc[8], sh[8], m[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          sc[i] = d.scale ? d.scale[ncol0 + i] : 1.f;
-          sh[i] = d.shift ? d.shift[ncol0 + i] : 0.f;
+        for (int k = 0; k < 8; ++k) {
+          float t = TAP_ACC(i, j, 8 * o + k) * sc[k] + sh[k];
+          if (d.act == AMMC_ACT_RELU) t = t > 0.f ? t : 0.f;
+          v[k] = t;
         }
+        if (d.res) {
+          const f16x8t* rp = reinterpret_cast<const f16x8t*>(d.res + r_pix[i] + c0);
+          const f16x8t rh = rp[0], rl = rp[1];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int row = (2 * py + (q >> 1)) * 32 + 2 * px + (q & 1);
-          const f32x4 t0 = *reinterpret_cast<const f32x4*>(T + row * EPC + cg * 8);
-          const f32x4 t1 = *reinterpret_cast<const f32x4*>(T + row * EPC + cg * 8 + 4);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            float v = (i < 4 ? t0[i] : t1[i - 4]) * sc[i] + sh[i];
-            if (d.act == AMMC_ACT_RELU) v = v > 0.f ? v : 0.f;
-            m[i] = q == 0 ? v : (v > m[i] ? v : m[i]);
-          }
+          for (int k = 0; k < 8; ++k) v[k] += (float)rh[k] + (float)rl[k] * T_LO_INV;
         }
         f16x8t hi, lo;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const _Float16 hv = (_Float16)m[i];
-          hi[i] = hv;
-          lo[i] = (_Float16)((m[i] - (float)hv) * T_LO_SCALE);
+        for (int k = 0; k < 8; ++k) {
+          const _Float16 hv = (_Float16)v[k];
+          hi[k] = hv;
+          lo[k] = (_Float16)((v[k] - (float)hv) * T_LO_SCALE);
+          vmax = fmaxf(vmax, fabsf(v[k]));
+          if (TM == 2) pooled[k] = i == 0 ? v[k] : fmaxf(pooled[k], v[k]);
         }
-        float* yp = d.pool_y + ((int64_t)b * d.pool_bs + (int64_t)((y0 >> 1) + py) * d.pool_rs +
-                                (int64_t)((x0 >> 1) + px) * d.pool_ps) + ncol0;
-        *reinterpret_cast<f16x8t*>(yp) = hi;
-        *reinterpret_cast<f16x8t*>(yp + 4) = lo;
+        f16x8t* yp = reinterpret_cast<f16x8t*>(d.y + o_pix[i] + c0);
+        yp[0] = hi;
+        yp[1] = lo;
+      }
+      if (TM == 2 && d.pool_y) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pooled[k] = fmaxf(pooled[k], __shfl_xor(pooled[k], 1));
+        if ((l31 & 1) == 0) {
+          f16x8t hi, lo;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const _Float16 hv = (_Float16)pooled[k];
+            hi[k] = hv;
+            lo[k] = (_Float16)((pooled[k] - (float)hv) * T_LO_SCALE);
+          }
+          f16x8t* pp = reinterpret_cast<f16x8t*>(d.pool_y + ((int64_t)b * d.pool_bs + (int64_t)((y0 >> 1) + wm) * d.pool_rs +
+                                                            (int64_t)((x0 >> 1) + (l31 >> 1)) * d.pool_ps) + c0);
+          pp[0] = hi;
+          pp[1] = lo;
+        }
       }
     }
   }
+  if (d.overflow_flag && !(vmax <= 65504.f)) atomicOr(d.overflow_flag, 1);   // |v| beyond the half range (or NaN)
 }
 
 template <int WGM, int WGN, int TM, int TN, int AS = 2>
@@ -429,10 +420,8 @@ static int launch_tap(const TapArgs& a, hipStream_t stream) {
   constexpr int T_ASTAGE = (T_APIECES + NT - 1) / NT * NT * 4;
   constexpr int BJ = BN * 8 >= NT ? BN * 8 / NT : 1;
   constexpr int NB = (NT == 256 && BN == 128) ? 2 : 3;
-  constexpr int EPC = (NT == 256 && BN == 128) ? 64 : BN;
   constexpr int STAGES = AS * T_ASTAGE + NB * BJ * (NT / 8) * 32;
-  constexpr int TILE = 256 * EPC;
-  constexpr size_t lds = (size_t)((STAGES > TILE ? STAGES : TILE) + 2 * 256) * sizeof(float);
+  constexpr size_t lds = (size_t)STAGES * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto kern = conv_tap_s16_kernel<WGM, WGN, TM, TN, AS>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -470,11 +459,7 @@ int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream) {
   a.dbg = dbg;
   a.n_tiles = 0;
   if (d.n == 32) return launch_tap<8, 1, 1, 1, 1>(a, stream);       // the output layer: 2-3 filters, fp32 NCHW + tanh
-  if (d.n == 64) {
-    if (mode == 2) return launch_tap<8, 1, 1, 2, 2>(a, stream);
-    if (mode == 3) return launch_tap<8, 1, 1, 2, 1>(a, stream);
-    return launch_tap<4, 1, 2, 2, 1>(a, stream);       // 4 waves of 64x64 (2 image rows x 64 filters), 2 workgroups per CU
-  }
+  if (d.n == 64) return launch_tap<4, 1, 2, 2, 1>(a, stream);       // 4 waves of 64x64 (2 image rows x 64 filters), 2 workgroups per CU
   // 4 waves of 64x128 (one accumulator set), two workgroups per CU: fewer LDS reads per MFMA and the neighbour's
   // MFMAs behind every prologue / epilogue - once there are two workgroups for every CU (measured: 128x128 layers
   // +10 %, 64x64 +6 %, but 32x32 at batch 16 = one workgroup per CU -19 %)
