@@ -23,7 +23,13 @@ __device__ __forceinline__ int64_t pix_off(int m, int H, int W, const Tensor3& t
   return (int64_t)b * t.bs + (int64_t)y * t.rs + (int64_t)x * t.ps;
 }
 
-constexpr int RED_PIX = 2048;      // pixels per workgroup in the per-channel reductions
+// Pixels per workgroup in the per-channel reductions: about 2048 workgroups whatever the level (a fixed 2048 pixels
+// left the 32x32 level with 16 workgroups on a 256-CU chip and the average of these kernels at 2.2 TB/s).  A function
+// of the pixel count alone, so the partial sums - and the results - are the same on every launch.
+__host__ __device__ inline int red_pix_for(int M) {
+  int p = ((M + 2047) / 2048 + 63) & ~63;
+  return p < 64 ? 64 : (p > 2048 ? 2048 : p);
+}
 
 // ---- per-channel reductions ---------------------------------------------------------
 // MODE 0: sum(x), sum(x^2)                         (BN forward statistics)
@@ -40,8 +46,9 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(
   const int tx = threadIdx.x % C4;
   const int ty = threadIdx.x / C4;
   const int PY = 256 / C4;
-  const int m0 = blockIdx.x * RED_PIX;
-  const int m1 = min(m0 + RED_PIX, M);
+  const int red_pix = red_pix_for(M);
+  const int m0 = blockIdx.x * red_pix;
+  const int m1 = min(m0 + red_pix, M);
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
   f32x4 mu, is, ga, be;
   if (MODE == 1 && ty < PY) {
@@ -118,9 +125,10 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(
 }
 
 // partial[nblk][Q][C] -> out[Q][C], double accumulation, fixed order (deterministic)
-// A workgroup combines 16 columns: 16 slices of the partial rows per column (thread = (slice, column)), then a
-// fixed-order LDS tree - deterministic, and 16x shorter dependent fp64 chains than one thread per column.
-constexpr int RP_COLS = 16, RP_SLICES = 16;
+// A workgroup of 1024 threads combines 8 columns: 128 slices of the partial rows per column (thread = (slice, column)),
+// then a fixed-order LDS tree - deterministic, and short dependent chains: with ~2048 partial rows per layer and only
+// C / 8 workgroups, the rows have to be spread over many threads or these finalizers cost more than the reductions.
+constexpr int RP_COLS = 8, RP_SLICES = 128, RP_THREADS = RP_COLS * RP_SLICES;
 
 __device__ __forceinline__ void column_sums(const float* __restrict__ partial, int nblk, int64_t row_stride, int col,
                                             bool valid, int second_off, double (&red)[2][RP_SLICES][RP_COLS], double& s,
@@ -128,9 +136,22 @@ __device__ __forceinline__ void column_sums(const float* __restrict__ partial, i
   const int cl = threadIdx.x % RP_COLS, sl = threadIdx.x / RP_COLS;
   double a = 0.0, b = 0.0;
   if (valid) {
-    for (int r = sl; r < nblk; r += RP_SLICES) {
-      a += (double)partial[(int64_t)r * row_stride + col];
-      if (second_off) b += (double)partial[(int64_t)r * row_stride + second_off + col];
+    // eight rows per trip, loads first (one dependent load per row left this latency-bound); the sums keep row order
+    constexpr int U = 4;
+    for (int r0 = sl; r0 < nblk; r0 += U * RP_SLICES) {
+      float va[U], vb[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int r = r0 + u * RP_SLICES;
+        const bool ok = r < nblk;
+        va[u] = ok ? partial[(int64_t)r * row_stride + col] : 0.f;
+        vb[u] = ok && second_off ? partial[(int64_t)r * row_stride + second_off + col] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        a += (double)va[u];
+        b += (double)vb[u];
+      }
     }
   }
   red[0][sl][cl] = a;
@@ -147,7 +168,7 @@ __device__ __forceinline__ void column_sums(const float* __restrict__ partial, i
   ss = red[1][0][cl];
 }
 
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nblk, int QC,
+__global__ __launch_bounds__(RP_THREADS) void reduce_partials_kernel(const float* __restrict__ partial, int nblk, int QC,
                                                               float scale, float* __restrict__ out) {
   __shared__ double red[2][RP_SLICES][RP_COLS];
   const int i = blockIdx.x * RP_COLS + threadIdx.x % RP_COLS;
@@ -157,7 +178,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 }
 
 // BN training finalize: batch mean / biased var -> invstd, folded scale/shift; running stats.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(
+__global__ __launch_bounds__(RP_THREADS) void bn_finalize_kernel(
     const float* __restrict__ partial, int nblk, int C, float count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
     float* __restrict__ running_var, float* __restrict__ mean, float* __restrict__ invstd,
@@ -513,7 +534,7 @@ using namespace ammc_impl;
 
 extern "C" {
 
-int ammc_chan_reduce_blocks(int32_t pixels) { return pixels <= 0 ? 0 : (pixels + RED_PIX - 1) / RED_PIX; }
+int ammc_chan_reduce_blocks(int32_t pixels) { return pixels <= 0 ? 0 : (pixels + red_pix_for(pixels) - 1) / red_pix_for(pixels); }
 
 static int check_nhwc(const void* p, int b, int h, int w, int c) {
   if (!p || b <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3) || c > 1024) return AMMC_EINVAL;
@@ -535,7 +556,7 @@ int ammc_bn_finalize_f32(const float* partial, int32_t nblocks, int32_t c, float
                          float* mean, float* invstd, float* scale, float* shift, void* stream) {
   if (!partial || !gamma || !beta || !running_mean || !running_var || !mean || !invstd || !scale || !shift ||
       nblocks <= 0 || c <= 0 || count <= 0.f) return AMMC_EINVAL;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + RP_COLS - 1) / RP_COLS), dim3(256), 0, (hipStream_t)stream, partial, nblocks, c,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + RP_COLS - 1) / RP_COLS), dim3(RP_THREADS), 0, (hipStream_t)stream, partial, nblocks, c,
                      count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
   return ammc_launch_status();
 }
@@ -589,7 +610,7 @@ int ammc_chan_sum_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, 
 
 int ammc_reduce_partials_f32(const float* partial, int32_t nblocks, int32_t qc, float scale, float* out, void* stream) {
   if (!partial || !out || nblocks <= 0 || qc <= 0) return AMMC_EINVAL;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((qc + RP_COLS - 1) / RP_COLS), dim3(256), 0, (hipStream_t)stream, partial, nblocks, qc,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((qc + RP_COLS - 1) / RP_COLS), dim3(RP_THREADS), 0, (hipStream_t)stream, partial, nblocks, qc,
                      scale, out);
   return ammc_launch_status();
 }
