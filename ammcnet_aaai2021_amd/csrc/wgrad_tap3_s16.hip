@@ -1,0 +1,260 @@
+// 3x3 weight gradient, S16 operands, halo patch in LDS (see wgrad_tap_s16.hip), with THREE MFMAs per product block.
+//
+// wgrad_tap_s16.hip feeds an MFMA 16 channels x {hi, lo} per operand: one instruction yields the four plane products
+// of a 16 x 16 channel block, of which lo*lo is wasted, and an accumulator tile covers only 16 x 16 outputs - nine taps
+// x 144 registers hold 16 x 16 x 9 outputs per wave, 20 transposed LDS reads feed 9 MFMAs.
+//
+// Here an MFMA row is ONE plane of a channel and the planes are concatenated along K (K = pixels):
+//     acc += G_hi[16 px]            * A_hi[16 px]
+//          + (G_hi | G_lo')[px 0-7]  * (A_lo' | A_hi)[px 0-7]          (lo' = lo * 2^-11, applied to the fragment)
+//          + (G_hi | G_lo')[px 8-15] * (A_lo' | A_hi)[px 8-15]
+// = hi*hi + 2^-11 (hi*lo + lo*hi) over 16 pixels of a 32 x 32 channel block in 3 MFMAs (4 before), into ONE fp32 tile:
+// a wave holds 32 x 32 x 9 outputs in the same 144 registers, a workgroup 128 gradient channels x 64 input channels,
+// and a k-step of 16 pixels is 60 transposed reads for 27 MFMAs.  The pre-scaled lo halves are exact down to the
+// half-precision subnormals, i.e. an absolute 2^-25 of the operand scale (the same argument as the single-accumulator
+// forward kernel, conv_tap_s16.hip).
+//
+// ds_read_b64_tr_b16 takes a per-lane address: lane 4q+p of a 16-lane group supplies 8 bytes of pixel row q and gets
+// back the four pixels of "column" l16.  Pointing p = 0,1 at the 16 hi (or lo) bytes of one S16 group and p = 2,3 at
+// those of the next gives 16 channels of a single plane per lane group, 32 per wave.
+//
+// LDS: two stages of G [64 px][128 ch] (32 KB) and A [4 x 34 halo px][64 ch] (34.8 KB, padded to whole DMA rounds).
+// The 16-byte slot index s = 2 * group + plane of pixel row m is stored at s ^ ((m & 1) | (m & 2) << 2): a transposed
+// read touches four consecutive rows x four groups of one plane, which that XOR spreads over all sixteen 16-byte bank
+// slots (rows are 512 / 256 B, i.e. bank-aligned), for any start row - conflict free for every tap.
+// One workgroup of 8 waves per CU (147 KB); split over patches, fp32 atomics into the packed gradient.
+// Variants: <4, 2, 1> 128 x 64 channel tiles (N % 128 == 0), <2, 2, 2> 64 x 64 with the two patch rows on different waves
+// (64-filter layers).  Needs H % 2 == 0, W % 32 == 0, N % 64 == 0, Cin % 64 == 0; wgrad_tap_s16_try falls back otherwise.
+#include "ammc_common.h"
+#include <hip/hip_fp16.h>
+#include <stdlib.h>
+
+namespace ammc_s16 {
+
+typedef _Float16 f16x8u __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2u __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4u __attribute__((ext_vector_type(4)));
+
+struct WgradTap3Args {
+  AmmcWgradDesc d;
+  const float* g_inv_scale;
+  int kpad, tiles_x, tiles_y, npatch, patches_per_block, msplit, col_tiles;
+};
+
+constexpr int W3_PH = 2, W3_PW = 32, W3_PX = W3_PH * W3_PW;            // 64 output pixels per patch
+constexpr int W3_HW = W3_PW + 2, W3_HPX = (W3_PH + 2) * W3_HW;         // 136 halo pixels
+constexpr int W3_NT = 512;
+__device__ __forceinline__ int w3_swz(int m) { return (m & 1) | ((m & 2) << 2); }
+
+template <int OFF>
+__device__ __forceinline__ u32x2u w3_read_tr16(uint32_t addr) {
+  u32x2u v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+
+__device__ __forceinline__ f16x8u w3_frag(u32x2u a, u32x2u b) {
+  u32x4u v;
+  v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+  return __builtin_bit_cast(f16x8u, v);
+}
+
+// NG x NA x NP = 8 waves: NG 32-channel blocks of the gradient, NA of the input, NP = 2: the two image rows of a patch
+// go to different waves (64-filter layers: both waves add their halves to the same outputs).
+template <int NG, int NA, int NP>
+__global__ __launch_bounds__(W3_NT, 2) void wgrad_tap3_s16_kernel(WgradTap3Args a) {
+  static_assert(NG * NA * NP == 8 && (NP == 1 || NP == 2), "8 waves");
+  constexpr int W3_TN = 32 * NG, W3_TC = 32 * NA;
+  constexpr int W3_GRB = W3_TN * 4, W3_ARB = W3_TC * 4;                  // row bytes (multiples of 256)
+  constexpr int W3_GSLOTS = W3_TN / 4, W3_ASLOTS = W3_TC / 4;            // 16-byte slots per row
+  constexpr int W3_GJ = W3_PX * W3_GSLOTS / W3_NT;                       // DMA rounds
+  constexpr int W3_AJ = (W3_HPX * W3_ASLOTS + W3_NT - 1) / W3_NT;        // (the last one partly padding)
+  constexpr int W3_GSTAGE = W3_PX * W3_TN;                               // floats
+  constexpr int W3_ASTAGE = W3_AJ * W3_NT * 4;                           // floats
+  static_assert(W3_PX * W3_GSLOTS % W3_NT == 0, "G pieces");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Gs = smem;                                             // [2][64 px][TN]
+  float* As = smem + 2 * W3_GSTAGE;                             // [2][136 px (+pad)][TC]
+
+  const AmmcWgradDesc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wg = wave % NG, wa = (wave / NG) % NA, wp = wave / (NG * NA);   // this wave's blocks of G, of A, its row
+
+  int bid = blockIdx.x;
+  const int ms = bid % a.msplit;
+  bid /= a.msplit;
+  const int c0 = (bid % a.col_tiles) * W3_TC;                   // first input channel of the tile
+  const int row0 = (bid / a.col_tiles) * W3_TN;                 // first gradient channel
+  const int p_begin = ms * a.patches_per_block;
+  const int p_end = min(p_begin + a.patches_per_block, a.npatch);
+  if (p_begin >= p_end) return;
+
+  // DMA pieces: piece p -> image row p / SLOTS, physical slot p % SLOTS, which holds logical slot ps ^ swz(row)
+  int g_off[W3_GJ], a_off[W3_AJ];
+#pragma unroll
+  for (int j = 0; j < W3_GJ; ++j) {
+    const int p = j * W3_NT + tid;
+    const int px = p / W3_GSLOTS, ls = (p % W3_GSLOTS) ^ w3_swz(px & 3);
+    g_off[j] = (int)((int64_t)(px >> 5) * d.g_rs + (int64_t)(px & 31) * d.g_ps) + row0 + 4 * ls;
+  }
+#pragma unroll
+  for (int j = 0; j < W3_AJ; ++j) {
+    int p = j * W3_NT + tid;
+    p = p < W3_HPX * W3_ASLOTS ? p : W3_HPX * W3_ASLOTS - 1;
+    const int hp = p / W3_ASLOTS, ls = (p % W3_ASLOTS) ^ w3_swz(hp & 3);
+    const int hy = hp / W3_HW, hx = hp - hy * W3_HW;
+    a_off[j] = (int)((int64_t)hy * d.a_rs + (int64_t)hx * d.a_ps) + c0 + 4 * ls;
+  }
+
+#define W3_ISSUE(patch, stage)                                                                            \
+  {                                                                                                       \
+    int sp_ = (patch);                                                                                    \
+    const int tx_ = sp_ % a.tiles_x;                                                                      \
+    sp_ /= a.tiles_x;                                                                                     \
+    const int ty_ = sp_ % a.tiles_y, b_ = sp_ / a.tiles_y;                                                \
+    const float* gp_ = d.g + ((int64_t)b_ * d.g_bs + (int64_t)(ty_ * W3_PH) * d.g_rs + (int64_t)(tx_ * W3_PW) * d.g_ps); \
+    const float* ap_ = d.a + ((int64_t)b_ * d.a_bs + (int64_t)(ty_ * W3_PH) * d.a_rs + (int64_t)(tx_ * W3_PW) * d.a_ps); \
+    float* gdst_ = Gs + (stage) * W3_GSTAGE + wave * 256;                                                 \
+    float* adst_ = As + (stage) * W3_ASTAGE + wave * 256;                                                 \
+    _Pragma("unroll") for (int j = 0; j < W3_GJ; ++j) {                                                   \
+      const float* src_ = gp_ + g_off[j];                                                                 \
+      __builtin_amdgcn_global_load_lds(src_, gdst_ + j * (W3_NT * 4), 16, 0, 0);                          \
+    }                                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < W3_AJ; ++j) {                                                   \
+      const float* src_ = ap_ + a_off[j];                                                                 \
+      __builtin_amdgcn_global_load_lds(src_, adst_ + j * (W3_NT * 4), 16, 0, 0);                          \
+    }                                                                                                     \
+  }
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // transposed-read lane roles: lane 4q+p of a 16-lane group supplies pixel row q; p >> 1 picks the S16 group of the
+  // pair, p & 1 the 8-byte half of its 16 plane bytes
+  const int l16 = lane & 15, q = l16 >> 2, p = l16 & 3, gi = l31 >> 4;
+  const int sg = 8 * wg + 4 * gi + 2 * (p >> 1);                // logical slot of this lane's hi bytes in a G row
+  const int sa = 8 * wa + 4 * gi + 2 * (p >> 1);                // ... in an A row
+  // G pixel rows of a read are y*32 + x16 + 4j + q: row & 3 == q, one swizzle per lane.  Fragment roles per lane half:
+  //   F_hi: plane hi, pixels 8h .. 8h+7        F_x1 / F_x2: plane (G: h, A: 1-h), pixels 0-7 / 8-15
+  const uint32_t g_lane_hi = (uint32_t)(((sg + 0) ^ w3_swz(q)) * 16 + (p & 1) * 8 + q * W3_GRB + h * (8 * W3_GRB));
+  const uint32_t g_lane_x = (uint32_t)(((sg + h) ^ w3_swz(q)) * 16 + (p & 1) * 8 + q * W3_GRB);
+  // A rows start anywhere: (row & 3) = (q + 2 (y + r) + s) & 3 for tap (r, s); the four possible swizzled slot offsets,
+  // rotated by q, so that the index below is a compile-time constant
+  uint32_t a_sw_hi[4], a_sw_x[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    a_sw_hi[k] = (uint32_t)(((sa + 0) ^ w3_swz((q + k) & 3)) * 16);
+    a_sw_x[k] = (uint32_t)(((sa + (1 - h)) ^ w3_swz((q + k) & 3)) * 16);
+  }
+  const uint32_t a_lane = (uint32_t)((p & 1) * 8 + q * W3_ARB);
+  const _Float16 c_lo = (_Float16)(1.f / 2048.f), c_one = (_Float16)1.f;
+  const _Float16 cg = h ? c_lo : c_one;                         // G cross fragments: the upper lane half holds lo
+  const _Float16 ca = h ? c_one : c_lo;                         // A cross fragments: the lower lane half holds lo
+  const uint32_t g_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)Gs;
+  const uint32_t a_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)As;
+
+  // one tap of one k-step: 6 transposed reads, 3 MFMAs.  Y (image row of the patch) and T are literals.
+#define W3_TAP(Y, T)                                                                                          \
+  {                                                                                                           \
+    constexpr int off_ = (((Y) + (T) / 3) * W3_HW + (T) % 3) * W3_ARB;                                        \
+    constexpr int k_ = (2 * ((Y) + (T) / 3) + (T) % 3) & 3;                                                   \
+    const uint32_t ahi_ = abase + a_sw_hi[k_] + h * (8 * W3_ARB), ax_ = abase + a_sw_x[k_];                   \
+    const u32x2u h0_ = w3_read_tr16<off_>(ahi_), h1_ = w3_read_tr16<off_ + 4 * W3_ARB>(ahi_);                 \
+    const u32x2u x0_ = w3_read_tr16<off_>(ax_), x1_ = w3_read_tr16<off_ + 4 * W3_ARB>(ax_);                   \
+    const u32x2u x2_ = w3_read_tr16<off_ + 8 * W3_ARB>(ax_), x3_ = w3_read_tr16<off_ + 12 * W3_ARB>(ax_);     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf_hi, w3_frag(h0_, h1_), acc[T], 0, 0, 0);               \
+    acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf_x1, w3_frag(x0_, x1_) * ca, acc[T], 0, 0, 0);          \
+    acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf_x2, w3_frag(x2_, x3_) * ca, acc[T], 0, 0, 0);          \
+  }
+#define W3_ROW(Y)                                                                                             \
+  _Pragma("unroll 1") for (int xh = 0; xh < 2; ++xh) {                                                        \
+    const uint32_t gaddr_hi = gst + g_lane_hi + (uint32_t)(((Y) * 32 + 16 * xh) * W3_GRB);                    \
+    const uint32_t gaddr_x = gst + g_lane_x + (uint32_t)(((Y) * 32 + 16 * xh) * W3_GRB);                      \
+    const u32x2u gh0 = w3_read_tr16<0>(gaddr_hi), gh1 = w3_read_tr16<4 * W3_GRB>(gaddr_hi);                   \
+    const u32x2u gx0 = w3_read_tr16<0>(gaddr_x), gx1 = w3_read_tr16<4 * W3_GRB>(gaddr_x);                     \
+    const u32x2u gx2 = w3_read_tr16<8 * W3_GRB>(gaddr_x), gx3 = w3_read_tr16<12 * W3_GRB>(gaddr_x);           \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    const f16x8u gf_hi = w3_frag(gh0, gh1), gf_x1 = w3_frag(gx0, gx1) * cg, gf_x2 = w3_frag(gx2, gx3) * cg;   \
+    const uint32_t abase = ast + a_lane + (uint32_t)(16 * xh * W3_ARB);                                       \
+    W3_TAP(Y, 0) W3_TAP(Y, 1) W3_TAP(Y, 2) W3_TAP(Y, 3) W3_TAP(Y, 4) W3_TAP(Y, 5) W3_TAP(Y, 6) W3_TAP(Y, 7)   \
+    W3_TAP(Y, 8)                                                                                              \
+  }
+
+  W3_ISSUE(p_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int pt = p_begin; pt < p_end; ++pt) {
+    const int stage = (pt - p_begin) & 1;
+    if (pt + 1 < p_end) W3_ISSUE(pt + 1, stage ^ 1);
+    const uint32_t gst = g_base + (uint32_t)(stage * W3_GSTAGE * 4);
+    const uint32_t ast = a_base + (uint32_t)(stage * W3_ASTAGE * 4);
+    if (NP == 1 || wp == 0) { W3_ROW(0) }
+    if (NP == 1 || wp == 1) { W3_ROW(1) }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+#undef W3_ISSUE
+#undef W3_TAP
+#undef W3_ROW
+
+  // ---- add to the packed gradient: row = gradient channel (registers), column = tap * Cin + c (lanes) -------------
+  const float inv = a.g_inv_scale ? a.g_inv_scale[0] : 1.f;
+  const int c = c0 + 32 * wa + l31;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int col = t * d.cin + c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + 32 * wg + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < d.n) unsafeAtomicAdd(d.dw + (int64_t)row * a.kpad + col, acc[t][r] * inv);
+    }
+  }
+}
+
+template <int NG, int NA, int NP>
+static int launch_wgrad_tap3(WgradTap3Args a, hipStream_t stream) {
+  constexpr int TN = 32 * NG, TC = 32 * NA;
+  constexpr int AJ = (W3_HPX * (TC / 4) + W3_NT - 1) / W3_NT;
+  constexpr size_t lds = (size_t)(2 * W3_PX * TN + 2 * AJ * W3_NT * 4) * sizeof(float);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  auto kern = wgrad_tap3_s16_kernel<NG, NA, NP>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds);
+  if (e != hipSuccess) return (int)e;
+  a.col_tiles = a.d.cin / TC;
+  const int tiles = (a.d.n / TN) * a.col_tiles;
+  int msplit = (256 + tiles - 1) / tiles;                           // one workgroup per CU, at least 8 patches each
+  const int max_split = (a.npatch + 7) / 8;
+  if (msplit > max_split) msplit = max_split;
+  if (msplit < 1) msplit = 1;
+  a.patches_per_block = (a.npatch + msplit - 1) / msplit;
+  a.msplit = (a.npatch + a.patches_per_block - 1) / a.patches_per_block;
+  hipLaunchKernelGGL(kern, dim3(tiles * a.msplit), dim3(W3_NT), lds, stream, a);
+  return ammc_launch_status();
+}
+
+// Called by wgrad_tap_s16_try; -12345 = not this kernel's case.
+int wgrad_tap3_s16_try(const AmmcWgradDesc& d, const float* g_inv_scale, int kpad, hipStream_t stream) {
+  if (d.height % W3_PH || d.width % W3_PW || d.n % 64 || d.cin % 64) return -12345;
+  const int64_t gmax = (int64_t)(W3_PH - 1) * d.g_rs + (int64_t)(W3_PW - 1) * d.g_ps + d.n;
+  const int64_t amax = (int64_t)(W3_PH + 1) * d.a_rs + (int64_t)(W3_PW + 1) * d.a_ps + d.cin;
+  if (gmax >= (1LL << 30) || amax >= (1LL << 30)) return -12345;
+  WgradTap3Args a;
+  a.d = d;
+  a.g_inv_scale = g_inv_scale;
+  a.kpad = kpad;
+  a.tiles_x = d.width / W3_PW;
+  a.tiles_y = d.height / W3_PH;
+  a.npatch = d.batch * a.tiles_x * a.tiles_y;
+  return d.n % 128 == 0 ? launch_wgrad_tap3<4, 2, 1>(a, stream) : launch_wgrad_tap3<2, 2, 2>(a, stream);
+}
+
+}  // namespace ammc_s16

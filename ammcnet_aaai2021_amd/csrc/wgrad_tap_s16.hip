@@ -214,10 +214,17 @@ static int launch_wgrad_tap(WgradTapArgs a, hipStream_t stream) {
   return ammc_launch_status();
 }
 
+// wgrad_tap3_s16.hip: three MFMAs per product block, 128 x 64 channel tiles (N % 128 == 0, Cin % 64 == 0)
+int wgrad_tap3_s16_try(const AmmcWgradDesc& d, const float* g_inv_scale, int kpad, hipStream_t stream);
+
 // Called by ammc_conv_wgrad_s16 after its argument checks; -12345 = not this kernel's case.
 int wgrad_tap_s16_try(const AmmcWgradDesc& d, const float* g_inv_scale, int kpad, hipStream_t stream) {
   static const int mode = getenv("AMMC_WGRAD_TAP") ? atoi(getenv("AMMC_WGRAD_TAP")) : 1;
   if (!mode) return -12345;
+  if (mode != 2) {                                         // AMMC_WGRAD_TAP=2: this file's kernels only (A/Bs)
+    const int rc = wgrad_tap3_s16_try(d, g_inv_scale, kpad, stream);
+    if (rc != -12345) return rc;
+  }
   if (d.height % WT_PH || d.width % WT_PW) return -12345;
   const bool wide = d.n % 128 == 0 && d.cin % 16 == 0;
   const bool narrow = d.n % 64 == 0 && d.cin % 32 == 0;

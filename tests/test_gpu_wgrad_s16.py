@@ -20,7 +20,9 @@ DEV = "cuda:0"
 # (csrc/wgrad_tap_s16.hip), the rest to the im2col one (csrc/wgrad_s16.hip); AMMC_WGRAD_TAP=0 forces the latter
 @pytest.mark.parametrize("B,H,W,cin,n,gmag", [(2, 32, 32, 64, 128, 1.0), (3, 20, 24, 128, 64, 3e-7), (2, 16, 16, 16, 64, 1e-6),
                                                (1, 9, 7, 32, 32, 1.0), (4, 64, 64, 64, 64, 2e-8), (1, 8, 64, 16, 128, 1e-5),
-                                               (2, 16, 32, 128, 64, 1.0), (3, 12, 96, 256, 256, 1e-3)])
+                                               (2, 16, 32, 128, 64, 1.0), (3, 12, 96, 256, 256, 1e-3),
+                                               # the three-MFMA halo-patch kernel (N % 128 == 0, Cin % 64 == 0, H even)
+                                               (1, 2, 32, 64, 128, 1.0), (2, 6, 64, 128, 256, 1e-6), (5, 10, 32, 512, 128, 3e-4)])
 def test_wgrad_s16_vs_fp64(B, H, W, cin, n, gmag):
     lib = _lib.load()
     s = torch.cuda.current_stream().cuda_stream
