@@ -4,15 +4,18 @@
 // of a 16 x 16 channel block, of which lo*lo is wasted, and an accumulator tile covers only 16 x 16 outputs - nine taps
 // x 144 registers hold 16 x 16 x 9 outputs per wave, 20 transposed LDS reads feed 9 MFMAs.
 //
-// Here an MFMA row is ONE plane of a channel and the planes are concatenated along K (K = pixels):
-//     acc += G_hi[16 px]            * A_hi[16 px]
-//          + (G_hi | G_lo')[px 0-7]  * (A_lo' | A_hi)[px 0-7]          (lo' = lo * 2^-11, applied to the fragment)
-//          + (G_hi | G_lo')[px 8-15] * (A_lo' | A_hi)[px 8-15]
+// Here an MFMA row is ONE plane of a channel and the planes are concatenated along K (K = pixels; the 16 K slots of
+// an MFMA are two lane halves of 8):
+//     acc += (GH[0-7]  | GH[8-15])  * (AH[0-7]  | AH[8-15])
+//          + (GL'[0-7] | GH'[0-7])  * (AH[0-7]  | AL[0-7])             (X' = X * 2^-11, applied to the G fragment)
+//          + (GH'[8-15] | GL'[8-15]) * (AL[8-15] | AH[8-15])
 // = hi*hi + 2^-11 (hi*lo + lo*hi) over 16 pixels of a 32 x 32 channel block in 3 MFMAs (4 before), into ONE fp32 tile:
-// a wave holds 32 x 32 x 9 outputs in the same 144 registers, a workgroup 128 gradient channels x 64 input channels,
-// and a k-step of 16 pixels is 60 transposed reads for 27 MFMAs.  The pre-scaled lo halves are exact down to the
-// half-precision subnormals, i.e. an absolute 2^-25 of the operand scale (the same argument as the single-accumulator
-// forward kernel, conv_tap_s16.hip).
+// a wave holds 32 x 32 x 9 outputs in the same 144 registers, a workgroup 128 gradient channels x 64 input channels.
+// The A fragment of the hi*hi MFMA is a lane select of the two cross fragments (their hi halves are exactly AH[0-7] on
+// the lower lanes and AH[8-15] on the upper ones - the K order of an MFMA is free as long as both operands agree), so
+// a tap costs 4 transposed reads and a k-step of 16 pixels 6 + 36 reads for 27 MFMAs.  The pre-scaled G halves are
+// exact down to the half-precision subnormals, i.e. an absolute 2^-25 of the operand scale (the argument of the
+// single-accumulator forward kernel, conv_tap_s16.hip).
 //
 // ds_read_b64_tr_b16 takes a per-lane address: lane 4q+p of a 16-lane group supplies 8 bytes of pixel row q and gets
 // back the four pixels of "column" l16.  Pointing p = 0,1 at the 16 hi (or lo) bytes of one S16 group and p = 2,3 at
@@ -138,51 +141,73 @@ __global__ __launch_bounds__(W3_NT, 2) void wgrad_tap3_s16_kernel(WgradTap3Args 
   const int l16 = lane & 15, q = l16 >> 2, p = l16 & 3, gi = l31 >> 4;
   const int sg = 8 * wg + 4 * gi + 2 * (p >> 1);                // logical slot of this lane's hi bytes in a G row
   const int sa = 8 * wa + 4 * gi + 2 * (p >> 1);                // ... in an A row
-  // G pixel rows of a read are y*32 + x16 + 4j + q: row & 3 == q, one swizzle per lane.  Fragment roles per lane half:
-  //   F_hi: plane hi, pixels 8h .. 8h+7        F_x1 / F_x2: plane (G: h, A: 1-h), pixels 0-7 / 8-15
+  // G pixel rows of a read are y*32 + x16 + 4j + q: row & 3 == q, one swizzle per lane.  Fragments per lane half h:
+  //   G_hi = GH[8h .. 8h+7]                                   A_x1 = (h ? AL : AH)[0-7]      A_x2 = (h ? AH : AL)[8-15]
+  //   G_x1 = 2^-11 (h ? GH : GL)[0-7]                         A_hi = h ? A_x2 : A_x1 = AH[8h .. 8h+7]   (a lane select)
+  //   G_x2 = 2^-11 (h ? GL : GH)[8-15]
+  // K order is free as long as both operands agree: the hi*hi MFMA takes its A fragment from the halves of the two
+  // cross fragments that hold hi, so a tap costs FOUR transposed reads, not six.  The 2^-11 of the cross terms goes on
+  // the whole G cross fragments (hi and lo halves alike), once per k-step.
   const uint32_t g_lane_hi = (uint32_t)(((sg + 0) ^ w3_swz(q)) * 16 + (p & 1) * 8 + q * W3_GRB + h * (8 * W3_GRB));
-  const uint32_t g_lane_x = (uint32_t)(((sg + h) ^ w3_swz(q)) * 16 + (p & 1) * 8 + q * W3_GRB);
+  const uint32_t g_lane_x1 = (uint32_t)(((sg + (1 - h)) ^ w3_swz(q)) * 16 + (p & 1) * 8 + q * W3_GRB);
+  const uint32_t g_lane_x2 = (uint32_t)(((sg + h) ^ w3_swz(q)) * 16 + (p & 1) * 8 + q * W3_GRB);
   // A rows start anywhere: (row & 3) = (q + 2 (y + r) + s) & 3 for tap (r, s); the four possible swizzled slot offsets,
   // rotated by q, so that the index below is a compile-time constant
-  uint32_t a_sw_hi[4], a_sw_x[4];
+  uint32_t a_sw_x1[4], a_sw_x2[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    a_sw_hi[k] = (uint32_t)(((sa + 0) ^ w3_swz((q + k) & 3)) * 16);
-    a_sw_x[k] = (uint32_t)(((sa + (1 - h)) ^ w3_swz((q + k) & 3)) * 16);
+    a_sw_x1[k] = (uint32_t)(((sa + h) ^ w3_swz((q + k) & 3)) * 16);
+    a_sw_x2[k] = (uint32_t)(((sa + (1 - h)) ^ w3_swz((q + k) & 3)) * 16);
   }
   const uint32_t a_lane = (uint32_t)((p & 1) * 8 + q * W3_ARB);
-  const _Float16 c_lo = (_Float16)(1.f / 2048.f), c_one = (_Float16)1.f;
-  const _Float16 cg = h ? c_lo : c_one;                         // G cross fragments: the upper lane half holds lo
-  const _Float16 ca = h ? c_one : c_lo;                         // A cross fragments: the lower lane half holds lo
+  const _Float16 cg = (_Float16)(1.f / 2048.f);
+  const bool upper = h != 0;
   const uint32_t g_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)Gs;
   const uint32_t a_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)As;
 
-  // one tap of one k-step: 6 transposed reads, 3 MFMAs.  Y (image row of the patch) and T are literals.
-#define W3_TAP(Y, T)                                                                                          \
+  // one tap of one k-step: 4 transposed reads, 3 MFMAs; the reads of taps T + 1 and T + 2 are in flight during the
+  // MFMAs of tap T (three register sets, counted lgkmcnt).  Y (image row of the patch), T and S are literals.
+  u32x2u ar[3][4];
+#define W3_AREAD(Y, T, S)                                                                                     \
   {                                                                                                           \
     constexpr int off_ = (((Y) + (T) / 3) * W3_HW + (T) % 3) * W3_ARB;                                        \
     constexpr int k_ = (2 * ((Y) + (T) / 3) + (T) % 3) & 3;                                                   \
-    const uint32_t ahi_ = abase + a_sw_hi[k_] + h * (8 * W3_ARB), ax_ = abase + a_sw_x[k_];                   \
-    const u32x2u h0_ = w3_read_tr16<off_>(ahi_), h1_ = w3_read_tr16<off_ + 4 * W3_ARB>(ahi_);                 \
-    const u32x2u x0_ = w3_read_tr16<off_>(ax_), x1_ = w3_read_tr16<off_ + 4 * W3_ARB>(ax_);                   \
-    const u32x2u x2_ = w3_read_tr16<off_ + 8 * W3_ARB>(ax_), x3_ = w3_read_tr16<off_ + 12 * W3_ARB>(ax_);     \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
+    const uint32_t a1_ = abase + a_sw_x1[k_], a2_ = abase + a_sw_x2[k_];                                      \
+    ar[S][0] = w3_read_tr16<off_>(a1_);                                                                       \
+    ar[S][1] = w3_read_tr16<off_ + 4 * W3_ARB>(a1_);                                                          \
+    ar[S][2] = w3_read_tr16<off_ + 8 * W3_ARB>(a2_);                                                          \
+    ar[S][3] = w3_read_tr16<off_ + 12 * W3_ARB>(a2_);                                                         \
+  }
+#define W3_TAP(Y, T)                                                                                          \
+  {                                                                                                           \
+    if ((T) + 2 <= 8) {                                                                                       \
+      W3_AREAD(Y, ((T) + 2 <= 8 ? (T) + 2 : 0), (((T) + 2) % 3));                                             \
+      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                                      \
+    } else if ((T) == 7) {                                                                                    \
+      asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                                      \
+    } else {                                                                                                  \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+    }                                                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                        \
-    acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf_hi, w3_frag(h0_, h1_), acc[T], 0, 0, 0);               \
-    acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf_x1, w3_frag(x0_, x1_) * ca, acc[T], 0, 0, 0);          \
-    acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf_x2, w3_frag(x2_, x3_) * ca, acc[T], 0, 0, 0);          \
+    const f16x8u ax1_ = w3_frag(ar[(T) % 3][0], ar[(T) % 3][1]), ax2_ = w3_frag(ar[(T) % 3][2], ar[(T) % 3][3]); \
+    const f16x8u ahi_ = upper ? ax2_ : ax1_;                                                                  \
+    acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf_hi, ahi_, acc[T], 0, 0, 0);                            \
+    acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf_x1, ax1_, acc[T], 0, 0, 0);                            \
+    acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf_x2, ax2_, acc[T], 0, 0, 0);                            \
   }
 #define W3_ROW(Y)                                                                                             \
   _Pragma("unroll 1") for (int xh = 0; xh < 2; ++xh) {                                                        \
-    const uint32_t gaddr_hi = gst + g_lane_hi + (uint32_t)(((Y) * 32 + 16 * xh) * W3_GRB);                    \
-    const uint32_t gaddr_x = gst + g_lane_x + (uint32_t)(((Y) * 32 + 16 * xh) * W3_GRB);                      \
-    const u32x2u gh0 = w3_read_tr16<0>(gaddr_hi), gh1 = w3_read_tr16<4 * W3_GRB>(gaddr_hi);                   \
-    const u32x2u gx0 = w3_read_tr16<0>(gaddr_x), gx1 = w3_read_tr16<4 * W3_GRB>(gaddr_x);                     \
-    const u32x2u gx2 = w3_read_tr16<8 * W3_GRB>(gaddr_x), gx3 = w3_read_tr16<12 * W3_GRB>(gaddr_x);           \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
+    const uint32_t gpix_ = (uint32_t)(((Y) * 32 + 16 * xh) * W3_GRB);                                         \
+    const uint32_t ghi_ = gst + g_lane_hi + gpix_, g1_ = gst + g_lane_x1 + gpix_, g2_ = gst + g_lane_x2 + gpix_; \
+    const u32x2u gh0 = w3_read_tr16<0>(ghi_), gh1 = w3_read_tr16<4 * W3_GRB>(ghi_);                           \
+    const u32x2u gx0 = w3_read_tr16<0>(g1_), gx1 = w3_read_tr16<4 * W3_GRB>(g1_);                             \
+    const u32x2u gx2 = w3_read_tr16<8 * W3_GRB>(g2_), gx3 = w3_read_tr16<12 * W3_GRB>(g2_);                   \
+    const uint32_t abase = ast + a_lane + (uint32_t)(16 * xh * W3_ARB);                                       \
+    W3_AREAD(Y, 0, 0)                                                                                         \
+    W3_AREAD(Y, 1, 1)                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                        \
     const f16x8u gf_hi = w3_frag(gh0, gh1), gf_x1 = w3_frag(gx0, gx1) * cg, gf_x2 = w3_frag(gx2, gx3) * cg;   \
-    const uint32_t abase = ast + a_lane + (uint32_t)(16 * xh * W3_ARB);                                       \
     W3_TAP(Y, 0) W3_TAP(Y, 1) W3_TAP(Y, 2) W3_TAP(Y, 3) W3_TAP(Y, 4) W3_TAP(Y, 5) W3_TAP(Y, 6) W3_TAP(Y, 7)   \
     W3_TAP(Y, 8)                                                                                              \
   }
@@ -203,6 +228,7 @@ __global__ __launch_bounds__(W3_NT, 2) void wgrad_tap3_s16_kernel(WgradTap3Args 
   }
 #undef W3_ISSUE
 #undef W3_TAP
+#undef W3_AREAD
 #undef W3_ROW
 
   // ---- add to the packed gradient: row = gradient channel (registers), column = tap * Cin + c (lanes) -------------

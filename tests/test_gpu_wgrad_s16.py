@@ -16,12 +16,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-# W % 32 == 0 and H % 4 == 0 with (n % 128, cin % 16) or (n % 64, cin % 32) go to the halo-patch kernel
-# (csrc/wgrad_tap_s16.hip), the rest to the im2col one (csrc/wgrad_s16.hip); AMMC_WGRAD_TAP=0 forces the latter
+# W % 32 == 0, H even, n % 64 == 0, cin % 64 == 0 go to the three-MFMA halo-patch kernel (csrc/wgrad_tap3_s16.hip);
+# W % 32 == 0 and H % 4 == 0 with (n % 128, cin % 16) or (n % 64, cin % 32) to the four-product one
+# (csrc/wgrad_tap_s16.hip), the rest to the im2col one (csrc/wgrad_s16.hip); AMMC_WGRAD_TAP=2 / =0 force the latter two
 @pytest.mark.parametrize("B,H,W,cin,n,gmag", [(2, 32, 32, 64, 128, 1.0), (3, 20, 24, 128, 64, 3e-7), (2, 16, 16, 16, 64, 1e-6),
                                                (1, 9, 7, 32, 32, 1.0), (4, 64, 64, 64, 64, 2e-8), (1, 8, 64, 16, 128, 1e-5),
                                                (2, 16, 32, 128, 64, 1.0), (3, 12, 96, 256, 256, 1e-3),
-                                               # the three-MFMA halo-patch kernel (N % 128 == 0, Cin % 64 == 0, H even)
+                                               # more shapes of the three-MFMA kernel: one patch row pair, a tiny gradient, five samples
                                                (1, 2, 32, 64, 128, 1.0), (2, 6, 64, 128, 256, 1e-6), (5, 10, 32, 512, 128, 3e-4)])
 def test_wgrad_s16_vs_fp64(B, H, W, cin, n, gmag):
     lib = _lib.load()
