@@ -35,13 +35,14 @@ __host__ __device__ inline int red_pix_for(int M) {
 // MODE 0: sum(x), sum(x^2)                         (BN forward statistics)
 // MODE 1: sum(g), sum(g * xhat), g = dy * [pre>0]  (BN backward), xhat = (c - mean) * invstd
 // MODE 2: sum(x)                                   (bias gradients)
+// MODE 3: MODE 1 + max|g|, max|xhat| per channel    (Q = 4: bounds max|dc| before dc exists, bn_bwd_finalize_kernel)
 // Layout: thread = (channel group of 4, pixel lane); partial[block][q][C].
 template <int MODE>
 __global__ __launch_bounds__(256) void chan_reduce_kernel(
     const float* __restrict__ x, Tensor3 xt, const float* __restrict__ dy, Tensor3 dt,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, int relu, int M, int H, int W, int C, float* __restrict__ partial) {
-  __shared__ f32x4 red[2][256];
+  __shared__ f32x4 red[MODE == 3 ? 4 : 2][256];
   const int C4 = C >> 2;
   const int tx = threadIdx.x % C4;
   const int ty = threadIdx.x / C4;
@@ -49,9 +50,9 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(
   const int red_pix = red_pix_for(M);
   const int m0 = blockIdx.x * red_pix;
   const int m1 = min(m0 + red_pix, M);
-  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f}, m0v = {0.f, 0.f, 0.f, 0.f}, m1v = {0.f, 0.f, 0.f, 0.f};
   f32x4 mu, is, ga, be;
-  if (MODE == 1 && ty < PY) {
+  if ((MODE == 1 || MODE == 3) && ty < PY) {
     mu = *reinterpret_cast<const f32x4*>(mean + tx * 4);
     is = *reinterpret_cast<const f32x4*>(invstd + tx * 4);
     ga = *reinterpret_cast<const f32x4*>(gamma + tx * 4);
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(
         const bool ok = mb + u * PY < m1;
         const int64_t ox = (int64_t)pb[u] * xt.bs + (int64_t)py[u] * xt.rs + (int64_t)px[u] * xt.ps;
         v[u] = ok ? *reinterpret_cast<const f32x4*>(x + ox + tx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        if (MODE == 1) {
+        if (MODE == 1 || MODE == 3) {
           const int64_t od = (int64_t)pb[u] * dt.bs + (int64_t)py[u] * dt.rs + (int64_t)px[u] * dt.ps;
           g[u] = ok ? *reinterpret_cast<const f32x4*>(dy + od + tx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -99,6 +100,10 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(
             const float gi = (!relu || pre > 0.f) ? g[u][i] : 0.f;
             s0[i] += gi;
             s1[i] += gi * xh;
+            if (MODE == 3) {                       // (out-of-range pixels load zeros: xh = -mean * invstd, a real value
+              m0v[i] = fmaxf(m0v[i], fabsf(gi));   //  of the bound's domain only if the channel has such a pixel - it
+              m1v[i] = fmaxf(m1v[i], fabsf(xh));   //  can only loosen the bound)
+            }
           }
         }
         px[u] += step;                                       // next pixel of this stream
@@ -111,16 +116,29 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(
   }
   red[0][threadIdx.x] = s0;
   red[1][threadIdx.x] = s1;
+  if (MODE == 3) {
+    red[2][threadIdx.x] = m0v;
+    red[3][threadIdx.x] = m1v;
+  }
   __syncthreads();
   if (ty == 0) {
     for (int j = 1; j < PY; ++j) {
       const f32x4 a0 = red[0][j * C4 + tx], a1 = red[1][j * C4 + tx];
 #pragma unroll
       for (int i = 0; i < 4; ++i) { s0[i] += a0[i]; s1[i] += a1[i]; }
+      if (MODE == 3) {
+        const f32x4 b0 = red[2][j * C4 + tx], b1 = red[3][j * C4 + tx];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { m0v[i] = fmaxf(m0v[i], b0[i]); m1v[i] = fmaxf(m1v[i], b1[i]); }
+      }
     }
-    float* p = partial + (int64_t)blockIdx.x * (MODE == 2 ? 1 : 2) * C;
+    float* p = partial + (int64_t)blockIdx.x * (MODE == 2 ? 1 : (MODE == 3 ? 4 : 2)) * C;
     *reinterpret_cast<f32x4*>(p + tx * 4) = s0;
     if (MODE != 2) *reinterpret_cast<f32x4*>(p + C + tx * 4) = s1;
+    if (MODE == 3) {
+      *reinterpret_cast<f32x4*>(p + 2 * C + tx * 4) = m0v;
+      *reinterpret_cast<f32x4*>(p + 3 * C + tx * 4) = m1v;
+    }
   }
 }
 
@@ -273,6 +291,116 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
       if (mx > 0.f && mx < INFINITY) atomicMax(amax_bits + (blockIdx.x & 255), __float_as_int(mx));
     }
   }
+}
+
+// BN backward finalize for the fused S16 path: partial[nblk][4][C] of chan_reduce_kernel<3> -> sums[2][C] (dbeta, dgamma)
+// and an upper bound of max |dc| into the 256 amax slots (as ammc_absmax_bits_f32 leaves the exact one):
+//   |dc| = |scale| |g - sum_g / M - xhat sum_gx / M| <= |scale| (max|g| + |sum_g| / M + max|xhat| |sum_gx| / M)
+// The S16 encoding only needs a power of two that brings the tensor into the half range; a bound that is a few times
+// too large moves every value down a bit or two of an exponent range with 2^-24 to spare - and it is known BEFORE
+// dc is written, so bn_bwd_apply_s16_kernel stores the S16 twin directly (no fp32 dc, no re-encoding pass).
+__global__ __launch_bounds__(RP_THREADS) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                                     float inv_count, const float* __restrict__ scale,
+                                                                     float* __restrict__ sums, int* __restrict__ amax_bits) {
+  __shared__ double red[2][RP_SLICES][RP_COLS];
+  __shared__ float redm[2][RP_SLICES][RP_COLS];
+  const int cl = threadIdx.x % RP_COLS, sl = threadIdx.x / RP_COLS;
+  const int c = blockIdx.x * RP_COLS + cl;
+  double s, ss;
+  column_sums(partial, nblk, (int64_t)4 * C, c, c < C, C, red, s, ss);
+  float mg = 0.f, mx = 0.f;
+  if (c < C)
+    for (int r = sl; r < nblk; r += RP_SLICES) {
+      mg = fmaxf(mg, partial[(int64_t)r * 4 * C + 2 * C + c]);
+      mx = fmaxf(mx, partial[(int64_t)r * 4 * C + 3 * C + c]);
+    }
+  redm[0][sl][cl] = mg;
+  redm[1][sl][cl] = mx;
+  __syncthreads();
+  for (int o = RP_SLICES / 2; o > 0; o >>= 1) {
+    if (sl < o) {
+      redm[0][sl][cl] = fmaxf(redm[0][sl][cl], redm[0][sl + o][cl]);
+      redm[1][sl][cl] = fmaxf(redm[1][sl][cl], redm[1][sl + o][cl]);
+    }
+    __syncthreads();
+  }
+  if (sl != 0 || c >= C) return;
+  const float sg = (float)s, sgx = (float)ss;
+  sums[c] = sg;
+  sums[C + c] = sgx;
+  const float bound = fabsf(scale[c]) * (redm[0][0][cl] + fabsf(sg) * inv_count + redm[1][0][cl] * fabsf(sgx) * inv_count);
+  if (bound > 0.f && bound < INFINITY) atomicMax(amax_bits + (blockIdx.x & 255), __float_as_int(bound));
+}
+
+__device__ __forceinline__ float tk_pow2_to_1024(int amax_bits) {      // as pow2_to_1024 of conv_gemm_s16.hip
+  int e = ((amax_bits >> 23) & 255) - 127;
+  if (amax_bits == 0) e = 10;
+  int fe = 10 - e;
+  fe = fe < -60 ? -60 : (fe > 60 ? 60 : fe);
+  return __int_as_float((fe + 127) << 23);
+}
+
+// bn_bwd_apply with the S16 twin as output: one thread per (pixel, group of 8 channels); dc * f with the power of
+// two f from the amax slots (inverse into inv_scale[0..n) for the consumers' epilogues), optionally dc in fp32 too
+__global__ __launch_bounds__(256) void bn_bwd_apply_s16_kernel(
+    const float* __restrict__ c, Tensor3 ct, const float* __restrict__ dy, Tensor3 dt,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ sums, float inv_count, int relu,
+    float* __restrict__ dc16, float* __restrict__ dc32, Tensor3 ot, int M, int H, int W, int C8,
+    const int* __restrict__ amax_bits, float* __restrict__ inv_scale, int n_inv) {
+  __shared__ int red[256];
+  red[threadIdx.x] = amax_bits[threadIdx.x];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] = max(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  const float f = tk_pow2_to_1024(red[0]);
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < n_inv; i += 256) inv_scale[i] = 1.f / f;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (int64_t)M * C8) return;
+  const int c8 = (int)(gid % C8);
+  const int m = (int)(gid / C8);
+  const int C = C8 * 8;
+  const float* cp = c + pix_off(m, H, W, ct) + c8 * 8;
+  const float* gp = dy + pix_off(m, H, W, dt) + c8 * 8;
+  float o[8];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int cc = c8 * 8 + half * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(cp + half * 4);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gp + half * 4);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + cc);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + cc);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + cc);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(beta + cc);
+    const f32x4 sg = *reinterpret_cast<const f32x4*>(sums + cc);
+    const f32x4 sgx = *reinterpret_cast<const f32x4*>(sums + C + cc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float xh = (v[i] - mu[i]) * is[i];
+      const float pre = v[i] * ga[i] + be[i];
+      const float gi = (!relu || pre > 0.f) ? g[i] : 0.f;
+      o[half * 4 + i] = ga[i] * (gi - sg[i] * inv_count - xh * sgx[i] * inv_count);
+    }
+  }
+  const int64_t oo = pix_off(m, H, W, ot) + c8 * 8;
+  if (dc32) {
+    *reinterpret_cast<f32x4*>(dc32 + oo) = f32x4{o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<f32x4*>(dc32 + oo + 4) = f32x4{o[4], o[5], o[6], o[7]};
+  }
+  typedef _Float16 tk_f16x8 __attribute__((ext_vector_type(8)));
+  tk_f16x8 hi, lo;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float v = o[i] * f;
+    const _Float16 hv = (_Float16)v;
+    hi[i] = hv;
+    lo[i] = (_Float16)((v - (float)hv) * 2048.f);
+  }
+  *reinterpret_cast<tk_f16x8*>(dc16 + oo) = hi;
+  *reinterpret_cast<tk_f16x8*>(dc16 + oo + 4) = lo;
 }
 
 // MaxPool2d(2) backward (+ the gradient that reaches the same tensor through the skip path):
@@ -595,6 +723,43 @@ int ammc_bn_bwd_apply_f32(const float* c_raw, int64_t c_bs, int64_t c_rs, int64_
   Tensor3 ct{c_bs, c_rs, c_ps}, dt{d_bs, d_rs, d_ps}, ot{o_bs, o_rs, o_ps};
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk((int64_t)M * (c >> 2))), dim3(256), 0, (hipStream_t)stream,
                      c_raw, ct, dy, dt, mean, invstd, gamma, beta, sums, 1.f / (float)M, relu, dc, ot, M, h, w, c >> 2, amax_bits);
+  return ammc_launch_status();
+}
+
+int ammc_bn_bwd_reduce_bound_f32(const float* c_raw, int64_t c_bs, int64_t c_rs, int64_t c_ps, const float* dy,
+                                 int64_t d_bs, int64_t d_rs, int64_t d_ps, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, int32_t relu, int32_t batch, int32_t h,
+                                 int32_t w, int32_t c, float* partial, void* stream) {
+  if (check_nhwc(c_raw, batch, h, w, c) || !dy || !mean || !invstd || !gamma || !beta || !partial) return AMMC_EINVAL;
+  const int M = batch * h * w;
+  Tensor3 ct{c_bs, c_rs, c_ps}, dt{d_bs, d_rs, d_ps};
+  hipLaunchKernelGGL(chan_reduce_kernel<3>, dim3(ammc_chan_reduce_blocks(M)), dim3(256), 0, (hipStream_t)stream,
+                     c_raw, ct, dy, dt, mean, invstd, gamma, beta, relu, M, h, w, c, partial);
+  return ammc_launch_status();
+}
+
+int ammc_bn_bwd_finalize_f32(const float* partial, int32_t nblocks, int32_t c, int32_t pixels, const float* gamma,
+                             float* sums, int32_t* amax_bits, void* stream) {
+  if (!partial || !gamma || !sums || !amax_bits || nblocks <= 0 || c <= 0 || pixels <= 0) return AMMC_EINVAL;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + RP_COLS - 1) / RP_COLS), dim3(RP_THREADS), 0, (hipStream_t)stream,
+                     partial, nblocks, c, 1.f / (float)pixels, gamma, sums, amax_bits);
+  return ammc_launch_status();
+}
+
+int ammc_bn_bwd_apply_s16_f32(const float* c_raw, int64_t c_bs, int64_t c_rs, int64_t c_ps, const float* dy,
+                              int64_t d_bs, int64_t d_rs, int64_t d_ps, const float* mean, const float* invstd,
+                              const float* gamma, const float* beta, const float* sums, int32_t relu, float* dc16,
+                              float* dc32, int64_t o_bs, int64_t o_rs, int64_t o_ps, int32_t batch, int32_t h,
+                              int32_t w, int32_t c, const int32_t* amax_bits, float* inv_scale, int32_t n_inv,
+                              void* stream) {
+  if (check_nhwc(c_raw, batch, h, w, c) || !dy || !mean || !invstd || !gamma || !beta || !sums || !dc16 || !amax_bits ||
+      !inv_scale || n_inv <= 0 || (c & 7) || ((uintptr_t)dc16 & 31) || ((o_bs | o_rs | o_ps) & 7))
+    return AMMC_EINVAL;
+  const int M = batch * h * w;
+  Tensor3 ct{c_bs, c_rs, c_ps}, dt{d_bs, d_rs, d_ps}, ot{o_bs, o_rs, o_ps};
+  hipLaunchKernelGGL(bn_bwd_apply_s16_kernel, dim3(nblk((int64_t)M * (c >> 3))), dim3(256), 0, (hipStream_t)stream, c_raw,
+                     ct, dy, dt, mean, invstd, gamma, beta, sums, 1.f / (float)M, relu, dc16, dc32, ot, M, h, w, c >> 3,
+                     amax_bits, inv_scale, n_inv);
   return ammc_launch_status();
 }
 

@@ -32,6 +32,7 @@ CHANS = (64, 128, 256, 512)
 # 1x1 / transposed convs - stays on the fp32 kernels), "fp32" = exact fp32 MFMA throughout
 TRAIN_PRECISION = os.environ.get("AMMC_TRAIN_PRECISION", "s16")
 WGRAD_S16 = os.environ.get("AMMC_WGRAD_S16", "1") != "0"          # the 3x3 weight gradients as well (wgrad_s16.hip)
+FUSE_BN_BWD = os.environ.get("AMMC_FUSE_BN_BWD", "1") != "0"      # BN backward writes the S16 twin of dc (one rank)
 
 
 class _WS:
@@ -201,7 +202,7 @@ class _ConvBN:
         self.mean, self.invstd = ws.buf(self.cout), ws.buf(self.cout)
         self.scale, self.shift = ws.buf(self.cout), ws.buf(self.cout)
         self.nblk = ops.lib.ammc_chan_reduce_blocks(x.B * x.H * x.W)
-        self.partial = ws.buf(self.nblk, 2, self.cout)
+        self.partial = ws.buf(self.nblk, 4, self.cout)               # Q = 2 sums (+ 2 maxima in the fused S16 backward)
         # backward
         self.dc = ws.act(x.B, x.H, x.W, self.cout)
         self.dwp = ws.buf(self.cout, self.kpad)
@@ -241,29 +242,51 @@ class _ConvBN:
         stores the parameter gradients in `grads`."""
         o, lib, s = self.ops, self.ops.lib, self.ops.s
         c = self.craw
-        _chk(lib.ammc_bn_bwd_reduce_f32(c.pix0(), *c.strides, dy.pix0(), *dy.strides, _ptr(self.mean), _ptr(self.invstd),
-                                        _ptr(self.scale), _ptr(self.shift), 1, c.B, c.H, c.W, self.cout,
-                                        _ptr(self.partial), s), "bn_bwd_reduce")
-        sums = torch.empty(2 * self.cout, device=o.dev, dtype=torch.float32)
-        _chk(lib.ammc_reduce_partials_f32(_ptr(self.partial), self.nblk, 2 * self.cout, 1.0, _ptr(sums), s), "reduce")
-        grads[self.bn.bias] = sums[:self.cout]
-        grads[self.bn.weight] = sums[self.cout:]
         world = o.sync_world
-        if world > 1:
-            # the input gradient needs the sums over the GLOBAL batch; the kernel divides by the local pixel
-            # count, so hand it global_sums / world (equal batch per rank).  dgamma / dbeta stay local: the
-            # gradient all-reduce averages them like every other parameter.
-            g = sums.clone()
-            o.all_reduce(g)
-            sums = g.mul_(1.0 / world)
-        fused_amax = o.s16 and (da is not None or (self.cin_p >= 8 and WGRAD_S16))
-        if fused_amax:
-            o.amax.zero_()                                    # bn_bwd_apply leaves max |dc| there for the S16 re-encoding
-        _chk(lib.ammc_bn_bwd_apply_f32(c.pix0(), *c.strides, dy.pix0(), *dy.strides, _ptr(self.mean), _ptr(self.invstd),
-                                       _ptr(self.scale), _ptr(self.shift), _ptr(sums), 1, self.dc.pix0(),
-                                       *self.dc.strides, c.B, c.H, c.W, self.cout,
-                                       o.amax.data_ptr() if fused_amax else None, s), "bn_bwd_apply")
-        pre = o.to_s16(self.dc, rescale=True, have_amax=True) if fused_amax else None   # shared by wgrad and dgrad
+        s16_wgrad = o.s16 and self.cin_p >= 8 and WGRAD_S16
+        fused_amax = o.s16 and (da is not None or s16_wgrad)
+        if fused_amax and world == 1 and FUSE_BN_BWD:
+            # one rank, S16 consumers: the reduction also bounds max |dc|, so the apply pass writes the S16 twin of dc
+            # directly (fp32 dc only where the fp32 weight-gradient kernel still reads it)
+            _chk(lib.ammc_bn_bwd_reduce_bound_f32(c.pix0(), *c.strides, dy.pix0(), *dy.strides, _ptr(self.mean),
+                                                  _ptr(self.invstd), _ptr(self.scale), _ptr(self.shift), 1, c.B, c.H, c.W,
+                                                  self.cout, _ptr(self.partial), s), "bn_bwd_reduce_bound")
+            sums = torch.empty(2 * self.cout, device=o.dev, dtype=torch.float32)
+            o.amax.zero_()
+            _chk(lib.ammc_bn_bwd_finalize_f32(_ptr(self.partial), self.nblk, self.cout, c.B * c.H * c.W, _ptr(self.scale),
+                                              _ptr(sums), o.amax.data_ptr(), s), "bn_bwd_finalize")
+            grads[self.bn.bias] = sums[:self.cout]
+            grads[self.bn.weight] = sums[self.cout:]
+            dc16 = o.shadow(self.dc)
+            inv = torch.empty(1024, device=o.dev, dtype=torch.float32)
+            _chk(lib.ammc_bn_bwd_apply_s16_f32(c.pix0(), *c.strides, dy.pix0(), *dy.strides, _ptr(self.mean),
+                                               _ptr(self.invstd), _ptr(self.scale), _ptr(self.shift), _ptr(sums), 1,
+                                               dc16.pix0(), None if s16_wgrad else self.dc.pix0(), *self.dc.strides,
+                                               c.B, c.H, c.W, self.cout, o.amax.data_ptr(), _ptr(inv), 1024, s),
+                 "bn_bwd_apply_s16")
+            pre = (dc16, inv)
+        else:
+            _chk(lib.ammc_bn_bwd_reduce_f32(c.pix0(), *c.strides, dy.pix0(), *dy.strides, _ptr(self.mean), _ptr(self.invstd),
+                                            _ptr(self.scale), _ptr(self.shift), 1, c.B, c.H, c.W, self.cout,
+                                            _ptr(self.partial), s), "bn_bwd_reduce")
+            sums = torch.empty(2 * self.cout, device=o.dev, dtype=torch.float32)
+            _chk(lib.ammc_reduce_partials_f32(_ptr(self.partial), self.nblk, 2 * self.cout, 1.0, _ptr(sums), s), "reduce")
+            grads[self.bn.bias] = sums[:self.cout]
+            grads[self.bn.weight] = sums[self.cout:]
+            if world > 1:
+                # the input gradient needs the sums over the GLOBAL batch; the kernel divides by the local pixel
+                # count, so hand it global_sums / world (equal batch per rank).  dgamma / dbeta stay local: the
+                # gradient all-reduce averages them like every other parameter.
+                g = sums.clone()
+                o.all_reduce(g)
+                sums = g.mul_(1.0 / world)
+            if fused_amax:
+                o.amax.zero_()                                # bn_bwd_apply leaves max |dc| there for the S16 re-encoding
+            _chk(lib.ammc_bn_bwd_apply_f32(c.pix0(), *c.strides, dy.pix0(), *dy.strides, _ptr(self.mean), _ptr(self.invstd),
+                                           _ptr(self.scale), _ptr(self.shift), _ptr(sums), 1, self.dc.pix0(),
+                                           *self.dc.strides, c.B, c.H, c.W, self.cout,
+                                           o.amax.data_ptr() if fused_amax else None, s), "bn_bwd_apply")
+            pre = o.to_s16(self.dc, rescale=True, have_amax=True) if fused_amax else None   # shared by wgrad and dgrad
         if pre is not None and self.cin_p >= 8 and WGRAD_S16:
             o.wgrad_s16(pre[0], o.shadow(self.x), self.dwp, pre[1], n=self.cout, cin=self.cin_p,
                         what=self.name + ".wgrad")            # shadow(x): the twin the forward conv left behind

@@ -304,6 +304,23 @@ int ammc_bn_bwd_apply_f32(const float* c_raw, int64_t c_bs, int64_t c_rs, int64_
                           int64_t o_bs, int64_t o_rs, int64_t o_ps, int32_t batch, int32_t h, int32_t w, int32_t c,
                           int32_t* amax_bits /* may be NULL: [256] slots, max |dc| as in ammc_absmax_bits_f32 */,
                           void* stream);
+/* The same backward with the S16 twin of dc as its output (training on the split-fp16 kernels, one rank):
+ * reduce_bound: partial Q=4 = the two sums + per-channel max|g|, max|xhat|; finalize: sums[2][C] and an upper bound of
+ * max|dc| (|scale| (max|g| + |sum_g|/M + max|xhat| |sum_gx|/M)) into the [256] amax slots (zeroed by the caller) - the
+ * power-of-two rescaling of the gradient is known before dc exists; apply_s16: dc * 2^k as an S16 image (dc16; same
+ * strides for the optional fp32 dc32), 2^-k into inv_scale[0..n_inv) for the consumers' epilogues. */
+int ammc_bn_bwd_reduce_bound_f32(const float* c_raw, int64_t c_bs, int64_t c_rs, int64_t c_ps, const float* dy,
+                                 int64_t d_bs, int64_t d_rs, int64_t d_ps, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, int32_t relu, int32_t batch, int32_t h,
+                                 int32_t w, int32_t c, float* partial, void* stream);
+int ammc_bn_bwd_finalize_f32(const float* partial, int32_t nblocks, int32_t c, int32_t pixels, const float* gamma,
+                             float* sums, int32_t* amax_bits, void* stream);
+int ammc_bn_bwd_apply_s16_f32(const float* c_raw, int64_t c_bs, int64_t c_rs, int64_t c_ps, const float* dy,
+                              int64_t d_bs, int64_t d_rs, int64_t d_ps, const float* mean, const float* invstd,
+                              const float* gamma, const float* beta, const float* sums, int32_t relu, float* dc16,
+                              float* dc32 /* may be NULL */, int64_t o_bs, int64_t o_rs, int64_t o_ps, int32_t batch,
+                              int32_t h, int32_t w, int32_t c, const int32_t* amax_bits, float* inv_scale,
+                              int32_t n_inv, void* stream);
 /* per-channel sum over pixels (bias gradients): partial Q=1 */
 int ammc_chan_sum_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, int32_t batch, int32_t h, int32_t w,
                       int32_t c, float* partial, void* stream);
