@@ -184,3 +184,59 @@ def test_train_step_at_sizes_the_halo_patch_kernels_take():
     for key, v in msd.items():
         if key not in dict(net.named_parameters()):
             assert rel_err(nsd[key].cpu().double(), v.double()) <= 1e-4, key
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 32, 64), (3, 9, 7, 128), (1, 32, 32, 512)])
+def test_fused_bn_backward_writes_the_s16_twin(B, H, W, C):
+    """`ammc_bn_bwd_reduce_bound_f32` -> `ammc_bn_bwd_finalize_f32` -> `ammc_bn_bwd_apply_s16_f32` (the gradient of
+    BatchNorm(batch stats) + ReLU straight into an S16 image, its power-of-two scale taken from a BOUND of max|dc| that
+    the reduction pass yields) against the fp64 formula of `unet.py:11-16`'s backward: dbeta / dgamma 1e-5, dc 2e-6 of
+    max|dc| after decoding the twin, the bound really bounds, and it is not looser than 8x."""
+    from ammcnet_aaai2021_amd import _lib
+    from ammcnet_aaai2021_amd.engine import Act, _ptr
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    tag = f"bnbwd-{B}-{H}-{W}-{C}"
+    craw = Act(torch.zeros(B, H + 2, W + 2, C, device=DEV), B, H, W, C, 0, 1)
+    dy = Act(torch.zeros(B, H + 2, W + 2, C, device=DEV), B, H, W, C, 0, 1)
+    craw.interior().copy_(S.hashed_normal(tag + "c", (B, H, W, C), 1.5).to(DEV))
+    dy.interior().copy_((S.hashed_normal(tag + "g", (B, H, W, C), 1.0) * 3e-6).to(DEV))        # gradient-sized values
+    gamma = (S.hashed_uniform(tag + "ga", (C,)) + 1.5).to(DEV)
+    beta = (S.hashed_uniform(tag + "be", (C,)) * 0.2).to(DEV)
+    x = craw.interior().double()
+    mean, var = x.mean((0, 1, 2)), x.var((0, 1, 2), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale, shift = gamma.double() * invstd, beta.double() - mean * gamma.double() * invstd
+    g = dy.interior().double() * ((x * scale + shift) > 0)
+    xhat = (x - mean) * invstd
+    M = B * H * W
+    sg, sgx = g.sum((0, 1, 2)), (g * xhat).sum((0, 1, 2))
+    want = scale * (g - sg / M - xhat * sgx / M)
+    f32 = lambda t: t.float().contiguous()
+    mean32, invstd32, scale32, shift32 = f32(mean), f32(invstd), f32(scale), f32(shift)
+    nblk = lib.ammc_chan_reduce_blocks(M)
+    partial = torch.zeros(nblk, 4, C, device=DEV)
+    _lib.check(lib.ammc_bn_bwd_reduce_bound_f32(craw.pix0(), *craw.strides, dy.pix0(), *dy.strides, _ptr(mean32),
+                                                _ptr(invstd32), _ptr(scale32), _ptr(shift32), 1, B, H, W, C,
+                                                _ptr(partial), s), "reduce_bound")
+    sums = torch.empty(2 * C, device=DEV)
+    amax = torch.zeros(256, dtype=torch.int32, device=DEV)
+    _lib.check(lib.ammc_bn_bwd_finalize_f32(_ptr(partial), nblk, C, M, _ptr(scale32), _ptr(sums), amax.data_ptr(), s), "fin")
+    assert float((sums[:C].double() - sg).abs().max() / sg.abs().max()) <= 1e-5
+    assert float((sums[C:].double() - sgx).abs().max() / sgx.abs().max()) <= 1e-5
+    bound = float(amax.max().reshape(1).view(torch.float32))                # the slots hold float bit patterns
+    true_max = float(want.abs().max())
+    assert true_max <= bound <= 8.0 * true_max, (true_max, bound)
+    dc16 = Act(torch.zeros(B, H + 2, W + 2, C, device=DEV), B, H, W, C, 0, 1)
+    dc32 = Act(torch.zeros(B, H + 2, W + 2, C, device=DEV), B, H, W, C, 0, 1)
+    inv = torch.empty(16, device=DEV)
+    _lib.check(lib.ammc_bn_bwd_apply_s16_f32(craw.pix0(), *craw.strides, dy.pix0(), *dy.strides, _ptr(mean32), _ptr(invstd32),
+                                             _ptr(scale32), _ptr(shift32), _ptr(sums), 1, dc16.pix0(), dc32.pix0(),
+                                             *dc16.strides, B, H, W, C, amax.data_ptr(), _ptr(inv), 16, s), "apply_s16")
+    back = torch.empty(B, C, H, W, device=DEV)
+    _lib.check(lib.ammc_s16_to_nchw_f32(dc16.pix0(), *dc16.strides, B, C, H, W, _ptr(back), s), "decode")
+    got = back.permute(0, 2, 3, 1).double() * float(inv[0])
+    assert float(inv[0]) == float(inv[15]) and 2.0 ** -12 <= true_max / float(inv[0]) < 2048.0
+    assert float((got - want).abs().max() / true_max) <= 2e-6
+    assert float((dc32.interior().double() - want).abs().max() / true_max) <= 2e-6
+    assert float(dc16.buf[:, 0].abs().max()) == 0.0 and float(dc16.buf[:, :, 0].abs().max()) == 0.0      # halo untouched
