@@ -246,6 +246,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN >= 1024 ? 1 : 2)) v
       const int ncol = n0 + (wn * TN + j) * 32 + l31;
       const float sc = d.scale ? d.scale[ncol] : 1.f;
       const float sh = d.shift ? d.shift[ncol] : 0.f;
+      int64_t coff = (int64_t)ncol * ycs;
+      if (d.up == 2) {                                              // pixel shuffle: column group g -> output pixel (2y + g/2, 2x + g%2)
+        const int g = ncol / d.cgroup;
+        coff = (int64_t)(g >> 1) * d.y_rs + (int64_t)(g & 1) * d.y_ps + (ncol - g * d.cgroup);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN >= 1024 ? 1 : 2)) v
             if (d.act == AMMC_ACT_RELU) v = v > 0.f ? v : 0.f;
             else if (d.act == AMMC_ACT_TANH) v = tanhf(v);
             if (d.res) v += d.res[tab_res[row] + ncol];             // fp32 outputs take an fp32 NHWC residual
-            const int64_t addr = o + (int64_t)ncol * ycs;
+            const int64_t addr = o + coff;
             d.y[addr] = v;
             if (d.sq_target) {
               const float df = 0.5f * (d.sq_target[addr] - v);
@@ -605,7 +610,7 @@ extern "C" int ammc_conv_gemm_s16(const AmmcConvDesc* desc, void* stream) {
   if (d.n_store < 0 || d.n_store > d.n || d.y_cs < 0) return AMMC_EINVAL;
   if (d.up != 1 && d.up != 2) return AMMC_EINVAL;
   if (d.up == 2 && (d.cgroup <= 0 || d.cgroup % 32 || d.n != 4 * d.cgroup)) return AMMC_EINVAL;
-  if (d.y_f32 && d.up != 1) return AMMC_EUNSUP;
+  if (d.y_f32 && d.up != 1 && (d.res || d.y_cs > 1 || d.n_store || d.sq_target)) return AMMC_EUNSUP;
   if (!d.y_f32 && (d.n_store || d.y_cs > 1 || d.act == AMMC_ACT_TANH)) return AMMC_EUNSUP;
   if (((uintptr_t)d.x | (uintptr_t)d.w) & 15) return AMMC_EINVAL;
   if (!d.y_f32 && (((uintptr_t)d.y & 31) || ((d.y_bs | d.y_rs | d.y_ps) & 7))) return AMMC_EINVAL;

@@ -32,6 +32,9 @@ CHANS = (64, 128, 256, 512)
 # 1x1 / transposed convs - stays on the fp32 kernels), "fp32" = exact fp32 MFMA throughout
 TRAIN_PRECISION = os.environ.get("AMMC_TRAIN_PRECISION", "s16")
 WGRAD_S16 = os.environ.get("AMMC_WGRAD_S16", "1") != "0"          # the 3x3 weight gradients as well (wgrad_s16.hip)
+# ConvTranspose forward / input gradient on the S16 kernels too: opt-in - its short-K GEMMs gain less than the operand
+# re-encoding costs (74.9 ms/step without, 75.5 with)
+CONVT_S16 = os.environ.get("AMMC_CONVT_S16", "0") != "0"
 FUSE_BN_BWD = os.environ.get("AMMC_FUSE_BN_BWD", "1") != "0"      # BN backward writes the S16 twin of dc (one rank)
 
 
@@ -111,7 +114,7 @@ class _Ops:
         _chk(self.lib.ammc_conv_wgrad_s16(C.byref(d), _ptr(inv) if inv is not None else None, self.s), what)
 
     def conv_s16(self, x: Act, w: torch.Tensor, y: Act, *, ntaps, cin, n, res: Optional[Act] = None, what="conv",
-                 rescale: bool = False, pre=None):
+                 rescale: bool = False, pre=None, shift=None, up=1, cgroup=None, x_step=1):
         """3x3 conv on the split-fp16 MFMA kernels: x (fp32, any channel slice of its buffer) is re-encoded into its S16
         twin (or `pre` = what `to_s16` returned for it), the packed filter likewise; fp32 output (+ fp32 residual).
         ammc_conv_gemm_s16 picks the kernel."""
@@ -124,8 +127,10 @@ class _Ops:
         d.w, d.y = _ptr(w16), y.pix0()
         d.res = res.pix0() if res is not None else None
         d.scale = _ptr(inv) if inv is not None else None
-        d.batch, d.height, d.width = y.B, y.H, y.W
-        d.cin, d.ntaps, d.n, d.up, d.cgroup, d.act, d.y_f32 = cin, ntaps, n, 1, n, ACT_NONE, 1
+        d.shift = _ptr(shift) if shift is not None else None
+        d.batch, d.height, d.width = y.B, y.H // up, y.W // up
+        d.cin, d.ntaps, d.n, d.up, d.act, d.y_f32, d.x_step = cin, ntaps, n, up, ACT_NONE, 1, x_step
+        d.cgroup = cgroup if cgroup is not None else n
         d.x_bs, d.x_rs, d.x_ps = xs.strides
         d.y_bs, d.y_rs, d.y_ps = y.strides
         if res is not None:
@@ -453,8 +458,8 @@ class _Stream:
             m = self.up_mods[j]
             _chk(lib.ammc_pack_convt_weight_f32(_ptr(m.up.weight.detach()), 2 * c, c, _ptr(self.up_wp[j]), s), "pack")
             self.up_b4[j].copy_(m.up.bias.detach().repeat(4))
-            o.conv(y, self.up_wp[j], self.cat[lvl].slice(c, c), ntaps=1, cin=2 * c, n=4 * c, shift=self.up_b4[j], up=2,
-                   cgroup=c, what=f"up{j + 1}.up")
+            (o.conv_s16 if o.s16 and CONVT_S16 else o.conv)(y, self.up_wp[j], self.cat[lvl].slice(c, c), ntaps=1, cin=2 * c,
+                                                          n=4 * c, shift=self.up_b4[j], up=2, cgroup=c, what=f"up{j + 1}.up")
             self.up_dc[j].forward()
             y = self.up_out[j]
         net = self.net
@@ -522,7 +527,11 @@ class _Stream:
             grads[m.up.weight] = dwt
             _chk(lib.ammc_transpose_pad_f32(_ptr(self.up_wp[j]), 4 * c, 2 * c, 4 * c, _ptr(self.up_wT[j]), s), "transpose")
             dst = self.dbottom if j == 0 else self.du[j - 1]
-            o.conv(dys, self.up_wT[j], dst, ntaps=4, cin=c, n=2 * c, x_step=2, what=f"up{j + 1}.up.dgrad")
+            if o.s16 and CONVT_S16:
+                o.conv_s16(dys, self.up_wT[j], dst, ntaps=4, cin=c, n=2 * c, x_step=2, rescale=True,
+                           what=f"up{j + 1}.up.dgrad")
+            else:
+                o.conv(dys, self.up_wT[j], dst, ntaps=4, cin=c, n=2 * c, x_step=2, what=f"up{j + 1}.up.dgrad")
         return self.dbottom
 
     def memory_backward(self, dq4: Act, ddiff: Optional[torch.Tensor], dq_one: Optional[torch.Tensor], grads) -> Act:

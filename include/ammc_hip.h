@@ -166,8 +166,8 @@ int ammc_sum_partials_f32(const float* partial, int32_t nparts, float inv_count,
  * 32 bytes [8 hi | 8 lo] (4 B/element: strides in ELEMENTS are those of the fp32 layout).
  * ammc_conv_gemm_s16 takes the same descriptor as ammc_conv_gemm_f32 with x, w and res in S16
  * and computes a*b as hi*hi + (hi*lo + lo*hi)*2^-11 with three v_mfma_f32_32x32x16_f16 and fp32
- * accumulation; y is S16 unless y_f32 = 1 (then n_store / y_cs / TANH are available, res/up are
- * not).  Replaces the same reference calls as ammc_conv_gemm_f32.
+ * accumulation; y is S16 unless y_f32 = 1 (then n_store / y_cs / TANH and an fp32 residual are available; up = 2
+ * only without them).  Replaces the same reference calls as ammc_conv_gemm_f32.
  * ---------------------------------------------------------------------------------------- */
 int ammc_conv_gemm_s16(const AmmcConvDesc* desc, void* stream);
 /* fp32 -> S16, count elements (multiple of 8): packed filters, gathered codebook rows */

@@ -240,3 +240,26 @@ def test_fused_bn_backward_writes_the_s16_twin(B, H, W, C):
     assert float((got - want).abs().max() / true_max) <= 2e-6
     assert float((dc32.interior().double() - want).abs().max() / true_max) <= 2e-6
     assert float(dc16.buf[:, 0].abs().max()) == 0.0 and float(dc16.buf[:, :, 0].abs().max()) == 0.0      # halo untouched
+
+
+def test_convtranspose_on_the_s16_kernels_agrees(monkeypatch):
+    """`AMMC_CONVT_S16=1`: the ConvTranspose forward (1x1 GEMM + pixel shuffle, fp32 output: `ammc_conv_gemm_s16` with
+    y_f32 and up = 2) and its input gradient (2x2 stride-2 gather, ntaps 4 / x_step 2) on the split-fp16 kernels give
+    the gradients of the default (exact-fp32 kernels for these layers) to 1e-4 per tensor, outputs to 1e-5."""
+    from ammcnet_aaai2021_amd import train as T
+    sd = S.make_twostream_state()
+    rgb_x, op_x, rgb_t, op_t = (t.to(DEV) for t in S.make_clips(2, 64, 64, tag="convt-s16"))
+    res = []
+    for flag in (False, True):
+        monkeypatch.setattr(T, "CONVT_S16", flag)
+        net = A.get_twostream((12, 6), (3, 2), 64, 256, 2)
+        net.load_state_dict(sd)
+        net = net.to(DEV).train()
+        out = net(rgb_x, op_x)
+        O.generator_loss(out, rgb_t, op_t).backward()
+        res.append((out[0].detach(), {n: p.grad.clone() for n, p in net.named_parameters()}))
+    (ya, ga), (yb, gb) = res
+    assert float((ya - yb).abs().max() / ya.abs().max()) <= 1e-5
+    errs = {n: _l2rel(gb[n], ga[n]) for n in ga}
+    assert max(errs.values()) <= 1e-4, sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+    assert any(float((ga[n] - gb[n]).abs().max()) > 0 for n in ga)            # the switch did switch kernels
