@@ -48,6 +48,22 @@ __device__ __forceinline__ void topk_insert(float (&v)[K], int (&ix)[K], float c
   }
 }
 
+// The same insertion when candidates arrive in increasing slot order (one lane's walk over the slot tiles): a tie then
+// always loses to the entry already held, so strict comparisons implement the (value, index) order - branch-free for
+// the model's K = 2 (the branchy general form was 40 % of the kernel at 2000 slots).
+template <int K>
+__device__ __forceinline__ void topk_insert_ordered(float (&v)[K], int (&ix)[K], float c, int s) {
+  if (K == 2) {
+    const bool lt0 = c < v[0], lt1 = c < v[1];
+    v[1] = lt0 ? v[0] : (lt1 ? c : v[1]);
+    ix[1] = lt0 ? ix[0] : (lt1 ? s : ix[1]);
+    v[0] = lt0 ? c : v[0];
+    ix[0] = lt0 ? s : ix[0];
+  } else {
+    topk_insert<K>(v, ix, c, s);
+  }
+}
+
 template <int K>
 __global__ __launch_bounds__(256, 2) void memory_topk_kernel(
     const float* __restrict__ x, const float* __restrict__ e_dm, const float* __restrict__ e_md,
@@ -100,6 +116,67 @@ __global__ __launch_bounds__(256, 2) void memory_topk_kernel(
 
   const int ntile = (m + 31) >> 5;
   const int ngroup = d >> 3;                          // groups of 8 features (4 MFMAs)
+  // accumulator reg r of this lane = slot s0 + (r&3) + 8*(r>>2) + 4*h, feature row t*32 + l31
+#define TOPK_TILE_EPILOGUE(s0_, EN)                                                   \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                    \
+    const int s = (s0_) + (r & 3) + 8 * (r >> 2) + 4 * h;                             \
+    if (s < m) {                                                                      \
+      const float en = EN;                                                            \
+      _Pragma("unroll") for (int t = 0; t < RT; ++t) {                                \
+        const float dist = (xnorm[t] - 2.f * acc[t][r]) + en;                         \
+        topk_insert_ordered<K>(bv[t], bi[t], dist, s);                                \
+      }                                                                               \
+    }                                                                                 \
+  }
+  if (d == 64) {
+    // The model's embedding width.  A lane needs 32 dwords of E per slot tile (features 8g + 4h + t); they come
+    // straight from L2, and fetching one group of four MFMAs ahead (the generic loop below) hides 256 cycles of a
+    // ~2000-cycle latency: the kernel sat at a quarter of the fp32 MFMA rate waiting for them.  Here the WHOLE next
+    // tile is in flight during the current one (two register sets, swapped by unrolling the tile loop twice).
+    // Same MFMAs in the same order: bit-identical distances.
+    float e0[32], e1[32], n0[16], n1[16];            // ... and its 16 |E_s|^2 (they were 16 exposed loads per tile)
+#define TOPK_LOAD_E(dst, ndst, tile_)                                                     \
+    {                                                                                 \
+      const int slot_ = ((tile_) << 5) + l31;                                         \
+      const bool sv_ = slot_ < m;                                                     \
+      const float* ep_ = e_dm + (sv_ ? slot_ : 0) + (int64_t)(4 * h) * m;             \
+      _Pragma("unroll") for (int i = 0; i < 32; ++i)                                  \
+        dst[i] = sv_ ? ep_[(int64_t)(8 * (i >> 2) + (i & 3)) * m] : 0.f;              \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                \
+        const int s_ = ((tile_) << 5) + (r & 3) + 8 * (r >> 2) + 4 * h;               \
+        ndst[r] = enorm[s_ < m ? s_ : m - 1];                                         \
+      }                                                                               \
+    }
+#define TOPK_TILE64(src, nsrc, tile_)                                                     \
+    {                                                                                 \
+      f32x16 acc[RT];                                                                 \
+      _Pragma("unroll") for (int t = 0; t < RT; ++t)                                  \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;               \
+      _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                 \
+        const int so = ((2 * g + h) ^ (l31 & 15)) << 2;                               \
+        f32x4 xf[RT];                                                                 \
+        _Pragma("unroll") for (int t = 0; t < RT; ++t)                                \
+          xf[t] = *reinterpret_cast<const f32x4*>(xs + (t * 32 + l31) * 64 + so);     \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                 \
+          _Pragma("unroll") for (int t = 0; t < RT; ++t)                              \
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(src[4 * g + q], xf[t][q], acc[t], 0, 0, 0); \
+      }                                                                               \
+      TOPK_TILE_EPILOGUE((tile_) << 5, nsrc[r])                                       \
+    }
+    int tile = wave;
+    if (tile < ntile) TOPK_LOAD_E(e0, n0, tile)
+    while (tile < ntile) {
+      if (tile + 4 < ntile) TOPK_LOAD_E(e1, n1, tile + 4)
+      TOPK_TILE64(e0, n0, tile)
+      tile += 4;
+      if (tile >= ntile) break;
+      if (tile + 4 < ntile) TOPK_LOAD_E(e0, n0, tile + 4)
+      TOPK_TILE64(e1, n1, tile)
+      tile += 4;
+    }
+#undef TOPK_LOAD_E
+#undef TOPK_TILE64
+  } else {
   for (int tile = wave; tile < ntile; tile += 4) {
     const int s0 = tile << 5;
     const int slot = s0 + l31;
@@ -147,20 +224,10 @@ __global__ __launch_bounds__(256, 2) void memory_topk_kernel(
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(eb[q], xf[t][q], acc[t], 0, 0, 0);
       }
     }
-    // accumulator reg r of this lane = slot s0 + (r&3) + 8*(r>>2) + 4*h, feature row t*32 + l31
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int s = s0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (s < m) {
-        const float en = enorm[s];
-#pragma unroll
-        for (int t = 0; t < RT; ++t) {
-          const float dist = (xnorm[t] - 2.f * acc[t][r]) + en;
-          topk_insert<K>(bv[t], bi[t], dist, s);
-        }
-      }
-    }
+    TOPK_TILE_EPILOGUE(s0, enorm[s])
   }
+  }
+#undef TOPK_TILE_EPILOGUE
 
   // ---- merge the 8 partial lists of every row ------------------------------------------
 #pragma unroll
