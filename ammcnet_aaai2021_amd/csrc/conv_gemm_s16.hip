@@ -67,8 +67,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN >= 1024 ? 1 : 2)) v
   constexpr int RJ = NT / 8;                // tile rows covered by one round of pieces
   constexpr int JS = NT * 4;                // floats between a thread's consecutive pieces
   constexpr int STAGES = 2 * (A_STAGE + B_STAGE);                // floats; two LDS stages
-  constexpr int TILE = BM * BN;                                  // floats of the parked output tile
-  constexpr int REGION = STAGES > TILE ? STAGES : TILE;
+  constexpr int REGION = STAGES;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
   float* Bs = smem + 2 * A_STAGE;
@@ -171,9 +170,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN >= 1024 ? 1 : 2)) v
 #pragma unroll
       for (int r = 0; r < 16; ++r) { hh[i][j][r] = 0.f; xx[i][j][r] = 0.f; }
 
+  // The filter fragment is the MFMA ROW operand and the pixel fragment the column operand: an accumulator tile then has
+  // pixels on lanes and channels on registers.  MFMA row l31 takes filter pi(l31) (bits 2 and 3 swapped), which makes
+  // registers 8o .. 8o+7 of lane half h the eight consecutive channels 8 (2o + h) .. +7 of the tile: a lane stores whole
+  // 32-byte S16 groups (or two fp32 quads) straight from its accumulators (as conv_tap_s16.hip; the tile used to be
+  // parked in LDS to get there).
+  const int pl31 = (l31 & 19) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
   const int swz = (l31 >> 1) & 7;
+  const int swzb = (pl31 >> 1) & 7;
   const int a_row = (wm * TM * 32 + l31) * 32;
-  const int b_row = (wn * TN * 32 + l31) * 32;
+  const int b_row = (wn * TN * 32 + pl31) * 32;
 
 #define S16_COMPUTE(stage)                                                                               \
   {                                                                                                      \
@@ -183,19 +189,21 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN >= 1024 ? 1 : 2)) v
       const int g = 2 * s + h; /* channel group of this lane half */                                     \
       const int so_hi = ((2 * g) ^ swz) << 2;                                                            \
       const int so_lo = ((2 * g + 1) ^ swz) << 2;                                                        \
+      const int sb_hi = ((2 * g) ^ swzb) << 2;                                                           \
+      const int sb_lo = ((2 * g + 1) ^ swzb) << 2;                                                       \
       f16x8 ah[TM], al[TM], bh[TN], bl[TN];                                                              \
       _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                   \
         ah[i] = *reinterpret_cast<const f16x8*>(Ac + i * 1024 + so_hi);                                  \
         al[i] = *reinterpret_cast<const f16x8*>(Ac + i * 1024 + so_lo);                                  \
       }                                                                                                  \
       _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                   \
-        bh[j] = *reinterpret_cast<const f16x8*>(Bc + j * 1024 + so_hi);                                  \
-        bl[j] = *reinterpret_cast<const f16x8*>(Bc + j * 1024 + so_lo);                                  \
+        bh[j] = *reinterpret_cast<const f16x8*>(Bc + j * 1024 + sb_hi);                                  \
+        bl[j] = *reinterpret_cast<const f16x8*>(Bc + j * 1024 + sb_lo);                                  \
       }                                                                                                  \
       _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) {    \
-        hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], hh[i][j], 0, 0, 0);             \
-        xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], xx[i][j], 0, 0, 0);             \
-        xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], xx[i][j], 0, 0, 0);             \
+        hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], hh[i][j], 0, 0, 0);             \
+        xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], xx[i][j], 0, 0, 0);             \
+        xx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], xx[i][j], 0, 0, 0);             \
       }                                                                                                  \
     }                                                                                                    \
   }
@@ -217,61 +225,99 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN >= 1024 ? 1 : 2)) v
 #undef S16_ISSUE
 
   const int nstore = d.n_store > 0 ? d.n_store : d.n;
+  // accumulator element (i, j, 8 o + k) of lane (l31, h): tile row (wm TM + i) 32 + l31, channel c0(j, o) + k
+#define S16_ACC(i, j, r) (hh[i][j][r] + xx[i][j][r] * LO_INV)
+#define S16_C0(j, o) (n0 + (wn * TN + (j)) * 32 + 8 * (2 * (o) + h))
 
   if (a.ksplit > 1) {
     // ---- split-K: this slice's partial tile, fp32 [ksplit][M][N]; ammc_s16 splitk_epilogue_kernel finishes ------
     float* slab = d.splitk_ws + (int64_t)ks * a.M * d.n;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int ncol = n0 + (wn * TN + j) * 32 + l31;
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + (wm * TM + i) * 32 + l31;
+      if (m >= a.M) continue;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (m < a.M) slab[(int64_t)m * d.n + ncol] = hh[i][j][r] + xx[i][j][r] * LO_INV;
+        for (int o = 0; o < 2; ++o) {
+          float* sp = slab + (int64_t)m * d.n + S16_C0(j, o);
+          *reinterpret_cast<f32x4*>(sp) = f32x4{S16_ACC(i, j, 8 * o), S16_ACC(i, j, 8 * o + 1), S16_ACC(i, j, 8 * o + 2), S16_ACC(i, j, 8 * o + 3)};
+          *reinterpret_cast<f32x4*>(sp + 4) = f32x4{S16_ACC(i, j, 8 * o + 4), S16_ACC(i, j, 8 * o + 5), S16_ACC(i, j, 8 * o + 6), S16_ACC(i, j, 8 * o + 7)};
         }
-      }
     }
     return;
   }
 
   if (d.y_f32) {
-    // ---- direct fp32 store (channels on lanes), NHWC or NCHW through y_cs ------------------
+    // ---- fp32 output: NHWC (two 16-byte stores per 8 channels), NCHW through y_cs (lanes = consecutive pixels), or the
+    // pixel shuffle of a transposed conv; tanh and the fused squared error for the output layer ------------------------
     const int64_t ycs = d.y_cs > 0 ? d.y_cs : 1;
     const int b_first = (int)((int64_t)m0 / ((int64_t)H * W));     // sample of the tile's first row
     float sq0 = 0.f;                                                 // squared error of this lane, sample b_first
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int ncol = n0 + (wn * TN + j) * 32 + l31;
-      const float sc = d.scale ? d.scale[ncol] : 1.f;
-      const float sh = d.shift ? d.shift[ncol] : 0.f;
-      int64_t coff = (int64_t)ncol * ycs;
-      if (d.up == 2) {                                              // pixel shuffle: column group g -> output pixel (2y + g/2, 2x + g%2)
-        const int g = ncol / d.cgroup;
-        coff = (int64_t)(g >> 1) * d.y_rs + (int64_t)(g & 1) * d.y_ps + (ncol - g * d.cgroup);
-      }
+    for (int i = 0; i < TM; ++i) {
+      const int row = (wm * TM + i) * 32 + l31;
+      const int o_pix = tab_out[row];
+      if (o_pix < 0) continue;
+      float sq_row = 0.f;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int o = tab_out[row];
-          if (o >= 0 && ncol < nstore) {
-            float v = (hh[i][j][r] + xx[i][j][r] * LO_INV) * sc + sh;
-            if (d.act == AMMC_ACT_RELU) v = v > 0.f ? v : 0.f;
-            else if (d.act == AMMC_ACT_TANH) v = tanhf(v);
-            if (d.res) v += d.res[tab_res[row] + ncol];             // fp32 outputs take an fp32 NHWC residual
-            const int64_t addr = o + coff;
-            d.y[addr] = v;
-            if (d.sq_target) {
-              const float df = 0.5f * (d.sq_target[addr] - v);
-              const int bs = (int)(((int64_t)m0 + row) / ((int64_t)H * W));
-              if (bs == b_first) sq0 += df * df;
-              else unsafeAtomicAdd(d.sq_acc + bs, df * df);          // a tile that straddles two samples
-            }
+        for (int o = 0; o < 2; ++o) {
+          const int c0 = S16_C0(j, o);
+          float v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = S16_ACC(i, j, 8 * o + k);
+          if (d.scale) {
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.scale + c0), s1 = *reinterpret_cast<const f32x4*>(d.scale + c0 + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] *= s0[k]; v[4 + k] *= s1[k]; }
+          }
+          if (d.shift) {
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.shift + c0), s1 = *reinterpret_cast<const f32x4*>(d.shift + c0 + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] += s0[k]; v[4 + k] += s1[k]; }
+          }
+          if (d.act == AMMC_ACT_RELU) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+          } else if (d.act == AMMC_ACT_TANH) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = tanhf(v[k]);
+          }
+          if (d.res) {                                              // fp32 outputs take an fp32 NHWC residual
+            const float* rp = d.res + tab_res[row] + c0;
+            const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] += r0[k]; v[4 + k] += r1[k]; }
+          }
+          int64_t coff = c0;                                        // NHWC channel offset
+          if (d.up == 2) {                                          // pixel shuffle: column group g -> pixel (2y + g/2, 2x + g%2)
+            const int g = c0 / d.cgroup;
+            coff = (int64_t)(g >> 1) * d.y_rs + (int64_t)(g & 1) * d.y_ps + (c0 - g * d.cgroup);
+          }
+          if (ycs == 1 && c0 + 8 <= nstore) {
+            float* yp = d.y + o_pix + coff;
+            *reinterpret_cast<f32x4*>(yp) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(yp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+              if (c0 + k < nstore) d.y[o_pix + (ycs == 1 ? coff + k : (int64_t)(c0 + k) * ycs)] = v[k];
+          }
+          if (d.sq_target) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+              if (c0 + k < nstore) {
+                const float df = 0.5f * (d.sq_target[o_pix + (int64_t)(c0 + k) * ycs] - v[k]);
+                sq_row += df * df;
+              }
           }
         }
+      if (d.sq_target) {
+        const int bs = (int)(((int64_t)m0 + row) / ((int64_t)H * W));
+        if (bs == b_first) sq0 += sq_row;
+        else unsafeAtomicAdd(d.sq_acc + bs, sq_row);                 // a tile that straddles two samples
       }
     }
     if (d.sq_target) {
@@ -282,76 +328,60 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN >= 1024 ? 1 : 2)) v
     return;
   }
 
-  // ---- S16 store: park the tile in LDS, then 8 channels of one pixel per thread ---------------
-  float* T = smem;                                               // [BM][BN]
+  // ---- S16 store: a lane holds whole 32-byte groups of its pixel ------------------------------------------------------
+  bool bad = false;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = (wn * TN + j) * 32 + l31;
+  for (int i = 0; i < TM; ++i) {
+    const int row = (wm * TM + i) * 32 + l31;
+    const int o_pix = tab_out[row];
+    if (o_pix < 0) continue;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        T[row * BN + col] = hh[i][j][r] + xx[i][j][r] * LO_INV;
+      for (int o = 0; o < 2; ++o) {
+        const int c0 = S16_C0(j, o);
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = S16_ACC(i, j, 8 * o + k);
+        if (d.scale) {
+          const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.scale + c0), s1 = *reinterpret_cast<const f32x4*>(d.scale + c0 + 4);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { v[k] *= s0[k]; v[4 + k] *= s1[k]; }
+        }
+        if (d.shift) {
+          const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.shift + c0), s1 = *reinterpret_cast<const f32x4*>(d.shift + c0 + 4);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { v[k] += s0[k]; v[4 + k] += s1[k]; }
+        }
+        if (d.act == AMMC_ACT_RELU) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+        }
+        int co = c0, goff = 0;
+        if (d.up == 2) {
+          const int g = c0 / d.cgroup;
+          co = c0 - g * d.cgroup;
+          goff = (int)((g >> 1) * d.y_rs + (g & 1) * d.y_ps);
+        }
+        if (d.res) {
+          const float* rp = d.res + tab_res[row] + co;
+          float rv[8];
+          join8(*reinterpret_cast<const f16x8*>(rp), *reinterpret_cast<const f16x8*>(rp + 4), rv);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] += rv[k];
+        }
+        f16x8 hi, lo;
+        split8(v, hi, lo);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bad |= !(fabsf(v[k]) <= 65504.f);     // beyond the half range: hi is +-inf from here on
+        float* yp = d.y + o_pix + goff + co;
+        *reinterpret_cast<f16x8*>(yp) = hi;
+        *reinterpret_cast<f16x8*>(yp + 4) = lo;
       }
-    }
   }
-  __syncthreads();
-  constexpr int CG = BN / 8;                                     // channel groups per tile row
-  for (int item = tid; item < BM * CG; item += NT) {
-    const int row = item / CG;
-    const int cg = item - row * CG;
-    const int o = tab_out[row];
-    if (o < 0) continue;
-    const int ncol0 = n0 + cg * 8;
-    float v[8];
-    {
-      const f32x4 t0 = *reinterpret_cast<const f32x4*>(T + row * BN + cg * 8);
-      const f32x4 t1 = *reinterpret_cast<const f32x4*>(T + row * BN + cg * 8 + 4);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { v[i] = t0[i]; v[4 + i] = t1[i]; }
-    }
-    if (d.scale) {
-      const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.scale + ncol0);
-      const f32x4 s1 = *reinterpret_cast<const f32x4*>(d.scale + ncol0 + 4);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { v[i] *= s0[i]; v[4 + i] *= s1[i]; }
-    }
-    if (d.shift) {
-      const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.shift + ncol0);
-      const f32x4 s1 = *reinterpret_cast<const f32x4*>(d.shift + ncol0 + 4);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { v[i] += s0[i]; v[4 + i] += s1[i]; }
-    }
-    if (d.act == AMMC_ACT_RELU) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
-    }
-    int co = ncol0, goff = 0;
-    if (d.up == 2) {
-      const int g = ncol0 / d.cgroup;
-      co = ncol0 - g * d.cgroup;
-      goff = (int)((g >> 1) * d.y_rs + (g & 1) * d.y_ps);
-    }
-    if (d.res) {
-      const float* rp = d.res + tab_res[row] + co;
-      float rv[8];
-      join8(*reinterpret_cast<const f16x8*>(rp), *reinterpret_cast<const f16x8*>(rp + 4), rv);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] += rv[i];
-    }
-    f16x8 hi, lo;
-    split8(v, hi, lo);
-    if (d.overflow_flag) {                       // |v| beyond the half range: hi is +-inf from here on
-      bool bad = false;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) bad |= !(fabsf(v[i]) <= 65504.f);
-      if (bad) atomicOr(d.overflow_flag, 1);
-    }
-    float* yp = d.y + o + goff + co;
-    *reinterpret_cast<f16x8*>(yp) = hi;
-    *reinterpret_cast<f16x8*>(yp + 4) = lo;
-  }
+  if (d.overflow_flag && bad) atomicOr(d.overflow_flag, 1);
+#undef S16_ACC
+#undef S16_C0
 }
 
 __global__ void splitk_epilogue_kernel(ConvArgs a);
@@ -364,8 +394,7 @@ int launch(const ConvArgs& a, hipStream_t stream) {
   constexpr int BM = WGM * TM * 32;
   constexpr int BN = WGN * TN * 32;
   constexpr int STAGES = 2 * (BM * 32 + BN * 32);
-  constexpr int TILE = BM * BN;
-  constexpr size_t lds = (size_t)((STAGES > TILE ? STAGES : TILE) + 2 * BM) * sizeof(float);
+  constexpr size_t lds = (size_t)(STAGES + 2 * BM) * sizeof(float);
   auto kern = conv_gemm_s16_kernel<WGM, WGN, TM, TN>;
   static_assert(lds <= 160 * 1024, "LDS budget");
   if (lds > 48 * 1024) {
