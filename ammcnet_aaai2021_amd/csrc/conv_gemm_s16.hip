@@ -15,11 +15,12 @@
 // reads, the MFMAs and the epilogue differ.  A lane's A/B fragment for k-step s is channel
 // group 2s + (lane >> 5): its hi and lo slots are two conflict-free ds_read_b128.
 //
-// Epilogue: the accumulators have channels on lanes, so a direct S16 store would be 2-byte
-// scattered writes.  Instead the wave parks its tile in LDS (the DMA stages are idle by then)
-// and every thread then finishes 8 consecutive channels of one pixel: scale/shift, ReLU,
-// residual (S16), split, one 32-byte store.  fp32 outputs (`y_f32`: the encoder output that
-// feeds the memory kernel, the NCHW `outc` frames) keep the direct per-lane store.
+// Epilogue: an S16 store is 8 channels of one pixel = 32 contiguous bytes.  The filter fragment is the MFMA row
+// operand, with its rows presented permuted (bits 2 and 3 of the row swapped), so that an accumulator tile has PIXELS
+// on lanes and runs of eight consecutive CHANNELS on registers: a lane takes 8 channels of its pixel, applies
+// scale / shift / ReLU / the S16 residual, splits, and stores 32 bytes - no LDS round trip (the first form parked the
+// tile in LDS).  fp32 outputs (`y_f32`: the encoder output that feeds the memory kernel, the NCHW `outc` frames, the
+// training path) store two fp32 quads per 8 channels, or one pixel per lane along an NCHW row.
 #include "ammc_common.h"
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
