@@ -247,6 +247,53 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(
   *reinterpret_cast<f32x4*>(y + pix_off(m, H, W, yt) + c4 * 4) = o;
 }
 
+// The same with the S16 image of y as output (fp32 y optional): one thread per (pixel, 8 channels).  A tensor that only
+// split-fp16 convolutions read - the middle activation of a double_conv - never exists in fp32.
+__global__ __launch_bounds__(256) void scale_shift_act_s16_kernel(
+    const float* __restrict__ x, Tensor3 xt, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ res, Tensor3 rt, float* __restrict__ y32, float* __restrict__ y16, Tensor3 yt, int relu,
+    int M, int H, int W, int C8) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (int64_t)M * C8) return;
+  const int c8 = (int)(gid % C8);
+  const int m = (int)(gid / C8);
+  const float* xp = x + pix_off(m, H, W, xt) + c8 * 8;
+  float o[8];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xp + half * 4);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c8 * 8 + half * 4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c8 * 8 + half * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float t = v[i] * sc[i] + sh[i];
+      if (relu) t = t > 0.f ? t : 0.f;
+      o[half * 4 + i] = t;
+    }
+  }
+  if (res) {
+    const float* rp = res + pix_off(m, H, W, rt) + c8 * 8;
+    const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i] += r0[i]; o[4 + i] += r1[i]; }
+  }
+  const int64_t oo = pix_off(m, H, W, yt) + c8 * 8;
+  if (y32) {
+    *reinterpret_cast<f32x4*>(y32 + oo) = f32x4{o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<f32x4*>(y32 + oo + 4) = f32x4{o[4], o[5], o[6], o[7]};
+  }
+  typedef _Float16 ss_f16x8 __attribute__((ext_vector_type(8)));
+  ss_f16x8 hi, lo;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const _Float16 hv = (_Float16)o[i];
+    hi[i] = hv;
+    lo[i] = (_Float16)((o[i] - (float)hv) * 2048.f);
+  }
+  *reinterpret_cast<ss_f16x8*>(y16 + oo) = hi;
+  *reinterpret_cast<ss_f16x8*>(y16 + oo + 4) = lo;
+}
+
 // dc = gamma * invstd * (g - sum_g / M - xhat * sum_gx / M),  g = dy * [pre > 0]
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ c, Tensor3 ct, const float* __restrict__ dy, Tensor3 dt,
@@ -698,6 +745,20 @@ int ammc_scale_shift_act_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t
   Tensor3 xt{x_bs, x_rs, x_ps}, rt{r_bs, r_rs, r_ps}, yt{y_bs, y_rs, y_ps};
   hipLaunchKernelGGL(scale_shift_act_kernel, dim3(nblk((int64_t)M * (c >> 2))), dim3(256), 0, (hipStream_t)stream,
                      x, xt, scale, shift, res, rt, y, yt, relu, M, h, w, c >> 2);
+  return ammc_launch_status();
+}
+
+int ammc_scale_shift_act_s16_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, const float* scale,
+                                 const float* shift, const float* res, int64_t r_bs, int64_t r_rs, int64_t r_ps,
+                                 float* y32, float* y16, int64_t y_bs, int64_t y_rs, int64_t y_ps, int32_t relu,
+                                 int32_t batch, int32_t h, int32_t w, int32_t c, void* stream) {
+  if (check_nhwc(x, batch, h, w, c) || !scale || !shift || !y16 || (c & 7) || ((uintptr_t)y16 & 31) ||
+      ((y_bs | y_rs | y_ps) & 7))
+    return AMMC_EINVAL;
+  const int M = batch * h * w;
+  Tensor3 xt{x_bs, x_rs, x_ps}, rt{r_bs, r_rs, r_ps}, yt{y_bs, y_rs, y_ps};
+  hipLaunchKernelGGL(scale_shift_act_s16_kernel, dim3(nblk((int64_t)M * (c >> 3))), dim3(256), 0, (hipStream_t)stream,
+                     x, xt, scale, shift, res, rt, y32, y16, yt, relu, M, h, w, c >> 3);
   return ammc_launch_status();
 }
 

@@ -35,6 +35,7 @@ WGRAD_S16 = os.environ.get("AMMC_WGRAD_S16", "1") != "0"          # the 3x3 weig
 # ConvTranspose forward / input gradient on the S16 kernels too: opt-in - its short-K GEMMs gain less than the operand
 # re-encoding costs (74.9 ms/step without, 75.5 with)
 CONVT_S16 = os.environ.get("AMMC_CONVT_S16", "0") != "0"
+MID_S16 = os.environ.get("AMMC_MID_S16", "1") != "0"              # double_conv middle activations exist as S16 only
 FUSE_BN_BWD = os.environ.get("AMMC_FUSE_BN_BWD", "1") != "0"      # BN backward writes the S16 twin of dc (one rank)
 
 
@@ -198,6 +199,8 @@ class _ConvBN:
     def __init__(self, ops: _Ops, conv, bn, x: Act, y: Act, res: Optional[Act], name: str):
         ws = ops.ws
         self.ops, self.conv, self.bn, self.x, self.y, self.res, self.name = ops, conv, bn, x, y, res, name
+        self.y_s16_only = False       # set by _DoubleConv: y is read by split-fp16 convolutions only -> written as S16, never as fp32
+        self.x_is_s16 = False         # ... and its consumer finds the twin of x ready
         self.cout, self.cin = conv.weight.shape[0], conv.weight.shape[1]
         self.cin_p = _cin_pad(self.cin)
         assert x.c == self.cin_p or x.c == self.cin, (name, x.c, self.cin_p)
@@ -218,8 +221,11 @@ class _ConvBN:
         o, lib, s = self.ops, self.ops.lib, self.ops.s
         w = self.conv.weight.detach()
         _chk(lib.ammc_pack_conv_weight_f32(_ptr(w), self.cout, self.cin, 3, self.cin_p, _ptr(self.wp), s), "pack")
-        (o.conv_s16 if o.s16 and self.cin_p >= 8 else o.conv)(self.x, self.wp, self.craw, ntaps=9, cin=self.cin_p,
-                                                              n=self.cout, what=self.name)
+        if o.s16 and self.cin_p >= 8:
+            o.conv_s16(self.x, self.wp, self.craw, ntaps=9, cin=self.cin_p, n=self.cout, what=self.name,
+                       pre=(o.shadow(self.x), None) if self.x_is_s16 else None)
+        else:
+            o.conv(self.x, self.wp, self.craw, ntaps=9, cin=self.cin_p, n=self.cout, what=self.name)
         c = self.craw
         _chk(lib.ammc_bn_stats_f32(c.pix0(), *c.strides, c.B, c.H, c.W, self.cout, _ptr(self.partial), s), "bn_stats")
         bn = self.bn
@@ -238,6 +244,13 @@ class _ConvBN:
                                       _ptr(self.invstd), _ptr(self.scale), _ptr(self.shift), s), "bn_finalize")
         bn.num_batches_tracked += 1
         r = self.res
+        if self.y_s16_only:
+            _chk(lib.ammc_scale_shift_act_s16_f32(c.pix0(), *c.strides, _ptr(self.scale), _ptr(self.shift),
+                                                  r.pix0() if r is not None else None,
+                                                  *(r.strides if r is not None else (0, 0, 0)), None,
+                                                  o.shadow(self.y).pix0(), *self.y.strides, 1, c.B, c.H, c.W, self.cout, s),
+                 "bn_apply_s16")
+            return
         _chk(lib.ammc_scale_shift_act_f32(c.pix0(), *c.strides, _ptr(self.scale), _ptr(self.shift),
                                           r.pix0() if r is not None else None, *(r.strides if r is not None else (0, 0, 0)),
                                           self.y.pix0(), *self.y.strides, 1, c.B, c.H, c.W, self.cout, s), "bn_apply")
@@ -317,6 +330,9 @@ class _DoubleConv:
         self.mid = ops.ws.act(x.B, x.H, x.W, seq[0].weight.shape[0])
         self.u0 = _ConvBN(ops, seq[0], seq[1], x, self.mid, None, name + ".conv0")
         self.u1 = _ConvBN(ops, seq[3], seq[4], self.mid, y, res, name + ".conv1")
+        if ops.s16 and WGRAD_S16 and MID_S16 and self.u1.cin_p >= 8:
+            # `mid` is read by conv1 (forward) and by conv1's weight gradient only, both on the S16 kernels
+            self.u0.y_s16_only = self.u1.x_is_s16 = True
         self.dmid = ops.ws.act(x.B, x.H, x.W, seq[0].weight.shape[0])
 
     def forward(self):

@@ -290,6 +290,12 @@ int ammc_scale_shift_act_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t
                              const float* shift, const float* res, int64_t r_bs, int64_t r_rs, int64_t r_ps,
                              float* y, int64_t y_bs, int64_t y_rs, int64_t y_ps, int32_t relu, int32_t batch,
                              int32_t h, int32_t w, int32_t c, void* stream);
+/* The same apply pass with the S16 image of y as its output (same strides; the fp32 y32 is optional): tensors that only
+ * the split-fp16 convolutions read - the middle activation of a double_conv in training - never exist in fp32. */
+int ammc_scale_shift_act_s16_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, const float* scale,
+                                 const float* shift, const float* res, int64_t r_bs, int64_t r_rs, int64_t r_ps,
+                                 float* y32 /* may be NULL */, float* y16, int64_t y_bs, int64_t y_rs, int64_t y_ps,
+                                 int32_t relu, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream);
 /* BN (+ReLU) backward: partial Q=2: sum g, sum g*xhat with g = dy*[c*scale+shift > 0]; then
  * dc = scale*(g - sums[0]/M - xhat*sums[1]/M); sums[0] = dbeta, sums[1] = dgamma.
  * NOTE: the `gamma`/`beta` arguments take the FOLDED scale (gamma*invstd) and shift produced by
