@@ -263,3 +263,36 @@ def test_convtranspose_on_the_s16_kernels_agrees(monkeypatch):
     errs = {n: _l2rel(gb[n], ga[n]) for n in ga}
     assert max(errs.values()) <= 1e-4, sorted(errs.items(), key=lambda kv: -kv[1])[:3]
     assert any(float((ga[n] - gb[n]).abs().max()) > 0 for n in ga)            # the switch did switch kernels
+
+
+def test_scale_shift_act_with_s16_output():
+    """`ammc_scale_shift_act_s16_f32`: y = relu(x * scale + shift) + res as an S16 image (and optionally fp32) against
+    the fp32 kernel's output: the fp32 copies are bit-identical, the decoded S16 image is within 2^-21 of them."""
+    from ammcnet_aaai2021_amd import _lib
+    from ammcnet_aaai2021_amd.engine import Act, _ptr
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    B, H, W, C = 2, 10, 12, 72
+    mk = lambda: Act(torch.zeros(B, H + 2, W + 2, C, device=DEV), B, H, W, C, 0, 1)
+    x, r, y_ref, y32, y16 = mk(), mk(), mk(), mk(), mk()
+    x.interior().copy_(S.hashed_normal("ssa-x", (B, H, W, C), 2.0).to(DEV))
+    r.interior().copy_(S.hashed_normal("ssa-r", (B, H, W, C), 0.5).to(DEV))
+    scale = (S.hashed_uniform("ssa-s", (C,)) + 1.5).to(DEV)
+    shift = S.hashed_uniform("ssa-b", (C,)).to(DEV)
+    _lib.check(lib.ammc_scale_shift_act_f32(x.pix0(), *x.strides, _ptr(scale), _ptr(shift), r.pix0(), *r.strides,
+                                            y_ref.pix0(), *y_ref.strides, 1, B, H, W, C, s), "ref")
+    _lib.check(lib.ammc_scale_shift_act_s16_f32(x.pix0(), *x.strides, _ptr(scale), _ptr(shift), r.pix0(), *r.strides,
+                                                y32.pix0(), y16.pix0(), *y16.strides, 1, B, H, W, C, s), "s16")
+    assert torch.equal(y32.buf, y_ref.buf)
+    back = torch.empty(B, C, H, W, device=DEV)
+    _lib.check(lib.ammc_s16_to_nchw_f32(y16.pix0(), *y16.strides, B, C, H, W, _ptr(back), s), "decode")
+    want = y_ref.interior().permute(0, 3, 1, 2)
+    assert bool(((back - want).abs() <= 2.0 ** -21 * want.abs() + 2e-11).all())
+    assert float(y16.buf[:, 0].abs().max()) == 0.0 and float(y16.buf[:, :, 0].abs().max()) == 0.0
+    # without the fp32 copy
+    y16b = mk()
+    _lib.check(lib.ammc_scale_shift_act_s16_f32(x.pix0(), *x.strides, _ptr(scale), _ptr(shift), None, 0, 0, 0,
+                                                None, y16b.pix0(), *y16b.strides, 0, B, H, W, C, s), "s16 only")
+    _lib.check(lib.ammc_s16_to_nchw_f32(y16b.pix0(), *y16b.strides, B, C, H, W, _ptr(back), s), "decode")
+    want = (x.interior() * scale + shift).permute(0, 3, 1, 2)
+    assert float((back - want).abs().max()) <= 1e-6 * float(want.abs().max())
