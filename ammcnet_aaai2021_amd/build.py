@@ -1,6 +1,7 @@
 """Build libammc_hip.so (hipcc, gfx950 only) in-tree, next to this file.
 
     python -m ammcnet_aaai2021_amd.build [--force]
+    AMMC_HIPCC_FLAGS="-DAMMC_TAP_DEBUG" python -m ammcnet_aaai2021_amd.build --force     # profiling build (AMMC_S16_DBG)
 
 hipcc cross-compiles without a GPU, so this runs in the authoring container; the
 built .so travels to the GPU box with the repo snapshot (it is git-ignored).
@@ -27,6 +28,7 @@ def _digest() -> str:
     h = hashlib.sha256()
     files = sources() + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
     files.append(os.path.join(os.path.dirname(HERE), "include", "ammc_hip.h"))
+    h.update(os.environ.get("AMMC_HIPCC_FLAGS", "").encode())
     for f in files:
         with open(f, "rb") as fp:
             h.update(f.encode())
@@ -53,7 +55,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     procs = []
     for src in sources():
         obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
-        cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-c", src, "-o", obj]
+        cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math"]
+        cmd += os.environ.get("AMMC_HIPCC_FLAGS", "").split() + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -224,25 +224,32 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
     else if ((n) == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");          \
     else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                        \
   }
+// the ablation switches of AMMC_S16_DBG (2 = no MFMA, 3 = no DMA, 4 = no DMA and no barriers) cost ~12 scalar branches
+// per tap, which also cut the loop into small scheduling regions: compiled in only with -DAMMC_TAP_DEBUG
+#ifdef AMMC_TAP_DEBUG
+#define TAP_DBG a.dbg
+#else
+#define TAP_DBG 0
+#endif
 #define TAP_STEP(tap)                                                                                      \
   {                                                                                                        \
-    if (AS == 2 && (tap) < T_AROUNDS && !lastcc && a.dbg < 3) { TAP_ISSUE_A((tap) < T_AROUNDS ? (tap) : 0, cc + 1, (cc + 1) & 1); } \
+    if (AS == 2 && (tap) < T_AROUNDS && !lastcc && TAP_DBG < 3) { TAP_ISSUE_A((tap) < T_AROUNDS ? (tap) : 0, cc + 1, (cc + 1) & 1); } \
     const int bsp_ = bs + PD >= NB ? bs + PD - NB : bs + PD;                                               \
-    if (a.dbg >= 3) {                                                                                      \
+    if (TAP_DBG >= 3) {                                                                                    \
     } else if ((tap) + PD < 9) {                                                                           \
       TAP_ISSUE_B(((tap) + PD) * a.ncc + cc, bsp_);                                                        \
     } else if (!lastcc) {                                                                                  \
       TAP_ISSUE_B(((tap) + PD - 9) * a.ncc + cc + 1, bsp_);                                                \
     }                                                                                                      \
-    if (a.dbg != 2) TAP_COMPUTE(tap, (AS == 2 ? (cc & 1) : 0), bs);                                        \
-    if (a.dbg >= 3) {                                                                                      \
+    if (TAP_DBG != 2) TAP_COMPUTE(tap, (AS == 2 ? (cc & 1) : 0), bs);                                        \
+    if (TAP_DBG >= 3) {                                                                                    \
       TAP_WAIT(0);                                                                                         \
     } else if (!lastcc) {                                                                                  \
       TAP_WAIT((PD - 1) * BJ + (AS == 2 && (tap) < T_AROUNDS ? 1 : 0));                                    \
     } else {                                                                                               \
       TAP_WAIT(((PD - 1) < (7 - (tap)) ? (PD - 1) : ((7 - (tap)) > 0 ? (7 - (tap)) : 0)) * BJ);            \
     }                                                                                                      \
-    if (a.dbg != 4) __builtin_amdgcn_s_barrier();                                                          \
+    if (TAP_DBG != 4) __builtin_amdgcn_s_barrier();                                                        \
     asm volatile("" ::: "memory");                                                                         \
     bs = bs + 1 == NB ? 0 : bs + 1;                                                                        \
   }
