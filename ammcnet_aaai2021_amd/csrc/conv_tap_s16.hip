@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
     int arow_[TM], aswz_[TM];                                                                              \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                       \
       int hp_ = hpb[i] + ((tap) / 3) * T_HW + ((tap) % 3);                                                 \
-      if (AS == 1) asm volatile("" : "+v"(hp_)); /* keep the per-tap addresses out of loop-invariant registers */ \
+      asm volatile("" : "+v"(hp_)); /* keep the per-tap addresses out of loop-invariant registers (else spills) */ \
       arow_[i] = hp_ * 32;                                                                                 \
       aswz_[i] = (hp_ >> 1) & 7;                                                                           \
     }                                                                                                      \
