@@ -238,7 +238,7 @@ def main():
         # (tools/profile_bench.sh -> profiles/rNN_pmc_traffic.json) of this same command
         traffic = None
         import glob
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1:]:
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{args.precision}_pmc_traffic.json")))[-1:]:
             with open(path) as fp:
                 traffic = json.load(fp)["kernels"].get(dom[0], {}).get("traffic_bytes_per_launch")
         s16 = args.precision == "s16"
