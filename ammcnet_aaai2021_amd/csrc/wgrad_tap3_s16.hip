@@ -21,13 +21,15 @@
 // back the four pixels of "column" l16.  Pointing p = 0,1 at the 16 hi (or lo) bytes of one S16 group and p = 2,3 at
 // those of the next gives 16 channels of a single plane per lane group, 32 per wave.
 //
-// LDS: two stages of G [64 px][128 ch] (32 KB) and A [4 x 34 halo px][64 ch] (34.8 KB, padded to whole DMA rounds).
-// The 16-byte slot index s = 2 * group + plane of pixel row m is stored at s ^ ((m & 1) | (m & 2) << 2): a transposed
-// read touches four consecutive rows x four groups of one plane, which that XOR spreads over all sixteen 16-byte bank
-// slots (rows are 512 / 256 B, i.e. bank-aligned), for any start row - conflict free for every tap.
-// One workgroup of 8 waves per CU (147 KB); split over patches, fp32 atomics into the packed gradient.
-// Variants: <4, 2, 1> 128 x 64 channel tiles (N % 128 == 0), <2, 2, 2> 64 x 64 with the two patch rows on different waves
-// (64-filter layers).  Needs H % 2 == 0, W % 32 == 0, N % 64 == 0, Cin % 64 == 0; wgrad_tap_s16_try falls back otherwise.
+// LDS: two stages of G [patch px][TN ch] and A [halo px][TC ch] (padded to whole DMA rounds).
+// The 16-byte slot index s = 2 * group + plane of pixel row m is stored XOR-swizzled by m & 3 (w3_swz): a transposed
+// read touches four consecutive rows x four groups of one plane, which the swizzle spreads over all sixteen 16-byte
+// bank slots for any start row - conflict free for every tap.
+// One workgroup of 8 waves per CU; split over patches, fp32 atomics into the packed gradient.
+// Variants <NG, NA, NP, PH> (32-channel blocks of the gradient / of the input, row groups, patch rows):
+//   <4, 2, 1, 2> 128 x 64 channel tiles (N % 128 == 0)          <2, 2, 2, 2> 64 x 64, the two patch rows on different waves
+//   <1, 2, 4, 4> 32 gradient channels (the output layer)        <2, 1, 4, 4> Cin <= 32 (first layers, zero-padded block)
+// Needs W % 32 == 0, H % 2 == 0 (% 4 for the 4-row patches); wgrad_tap_s16_try falls back otherwise.
 #include "ammc_common.h"
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
@@ -44,10 +46,13 @@ struct WgradTap3Args {
   int kpad, tiles_x, tiles_y, npatch, patches_per_block, msplit, col_tiles;
 };
 
-constexpr int W3_PH = 2, W3_PW = 32, W3_PX = W3_PH * W3_PW;            // 64 output pixels per patch
-constexpr int W3_HW = W3_PW + 2, W3_HPX = (W3_PH + 2) * W3_HW;         // 136 halo pixels
+constexpr int W3_PW = 32, W3_HW = W3_PW + 2;                           // patch width, halo width
 constexpr int W3_NT = 512;
-__device__ __forceinline__ int w3_swz(int m) { return (m & 1) | ((m & 2) << 2); }
+// slot swizzle by pixel row m & 3: rows of 256 / 512 bytes are bank aligned (16 slots of 16 B = all banks) - toggle the
+// plane bit for odd rows and the next 128 B for rows 2, 3; rows of 128 bytes alternate bank halves by themselves, so
+// only rows two apart have to part: toggle the plane bit by bit 1 of the row
+template <int ROWB>
+__device__ __forceinline__ int w3_swz(int m) { return ROWB >= 256 ? ((m & 1) | ((m & 2) << 2)) : ((m >> 1) & 1); }
 
 template <int OFF>
 __device__ __forceinline__ u32x2u w3_read_tr16(uint32_t addr) {
@@ -62,13 +67,16 @@ __device__ __forceinline__ f16x8u w3_frag(u32x2u a, u32x2u b) {
   return __builtin_bit_cast(f16x8u, v);
 }
 
-// NG x NA x NP = 8 waves: NG 32-channel blocks of the gradient, NA of the input, NP = 2: the two image rows of a patch
-// go to different waves (64-filter layers: both waves add their halves to the same outputs).
-template <int NG, int NA, int NP>
+// NG x NA x NP = 8 waves: NG 32-channel blocks of the gradient, NA of the input, NP groups of image rows of the PH-row
+// patch (waves of different groups add their parts to the same outputs).  PH = 4 with one row per wave serves the thin
+// operands: 32 gradient channels (the output layer) or 16 / 8 input channels (the first layers; channels beyond Cin
+// are read from the caller's zero buffer).
+template <int NG, int NA, int NP, int PH>
 __global__ __launch_bounds__(W3_NT, 2) void wgrad_tap3_s16_kernel(WgradTap3Args a) {
-  static_assert(NG * NA * NP == 8 && (NP == 1 || NP == 2), "8 waves");
+  static_assert(NG * NA * NP == 8 && (PH == 2 || PH == 4) && PH % NP == 0, "8 waves");
+  constexpr int W3_PH = PH, W3_PX = PH * W3_PW, W3_HPX = (PH + 2) * W3_HW, RPW = PH / NP;
   constexpr int W3_TN = 32 * NG, W3_TC = 32 * NA;
-  constexpr int W3_GRB = W3_TN * 4, W3_ARB = W3_TC * 4;                  // row bytes (multiples of 256)
+  constexpr int W3_GRB = W3_TN * 4, W3_ARB = W3_TC * 4;                  // row bytes
   constexpr int W3_GSLOTS = W3_TN / 4, W3_ASLOTS = W3_TC / 4;            // 16-byte slots per row
   constexpr int W3_GJ = W3_PX * W3_GSLOTS / W3_NT;                       // DMA rounds
   constexpr int W3_AJ = (W3_HPX * W3_ASLOTS + W3_NT - 1) / W3_NT;        // (the last one partly padding)
@@ -95,19 +103,21 @@ __global__ __launch_bounds__(W3_NT, 2) void wgrad_tap3_s16_kernel(WgradTap3Args 
 
   // DMA pieces: piece p -> image row p / SLOTS, physical slot p % SLOTS, which holds logical slot ps ^ swz(row)
   int g_off[W3_GJ], a_off[W3_AJ];
+  bool a_pad[W3_AJ];                                            // this piece lies beyond the layer's input channels
 #pragma unroll
   for (int j = 0; j < W3_GJ; ++j) {
     const int p = j * W3_NT + tid;
-    const int px = p / W3_GSLOTS, ls = (p % W3_GSLOTS) ^ w3_swz(px & 3);
+    const int px = p / W3_GSLOTS, ls = (p % W3_GSLOTS) ^ w3_swz<W3_GRB>(px & 3);
     g_off[j] = (int)((int64_t)(px >> 5) * d.g_rs + (int64_t)(px & 31) * d.g_ps) + row0 + 4 * ls;
   }
 #pragma unroll
   for (int j = 0; j < W3_AJ; ++j) {
     int p = j * W3_NT + tid;
     p = p < W3_HPX * W3_ASLOTS ? p : W3_HPX * W3_ASLOTS - 1;
-    const int hp = p / W3_ASLOTS, ls = (p % W3_ASLOTS) ^ w3_swz(hp & 3);
+    const int hp = p / W3_ASLOTS, ls = (p % W3_ASLOTS) ^ w3_swz<W3_ARB>(hp & 3);
     const int hy = hp / W3_HW, hx = hp - hy * W3_HW;
     a_off[j] = (int)((int64_t)hy * d.a_rs + (int64_t)hx * d.a_ps) + c0 + 4 * ls;
+    a_pad[j] = c0 + 4 * ls >= d.cin;                           // (slot = 4 elements: hi | lo halves of 8 channels per 2 slots)
   }
 
 #define W3_ISSUE(patch, stage)                                                                            \
@@ -125,7 +135,7 @@ __global__ __launch_bounds__(W3_NT, 2) void wgrad_tap3_s16_kernel(WgradTap3Args 
       __builtin_amdgcn_global_load_lds(src_, gdst_ + j * (W3_NT * 4), 16, 0, 0);                          \
     }                                                                                                     \
     _Pragma("unroll") for (int j = 0; j < W3_AJ; ++j) {                                                   \
-      const float* src_ = ap_ + a_off[j];                                                                 \
+      const float* src_ = a_pad[j] ? d.zeros : ap_ + a_off[j];                                            \
       __builtin_amdgcn_global_load_lds(src_, adst_ + j * (W3_NT * 4), 16, 0, 0);                          \
     }                                                                                                     \
   }
@@ -148,16 +158,16 @@ __global__ __launch_bounds__(W3_NT, 2) void wgrad_tap3_s16_kernel(WgradTap3Args 
   // K order is free as long as both operands agree: the hi*hi MFMA takes its A fragment from the halves of the two
   // cross fragments that hold hi, so a tap costs FOUR transposed reads, not six.  The 2^-11 of the cross terms goes on
   // the whole G cross fragments (hi and lo halves alike), once per k-step.
-  const uint32_t g_lane_hi = (uint32_t)(((sg + 0) ^ w3_swz(q)) * 16 + (p & 1) * 8 + q * W3_GRB + h * (8 * W3_GRB));
-  const uint32_t g_lane_x1 = (uint32_t)(((sg + (1 - h)) ^ w3_swz(q)) * 16 + (p & 1) * 8 + q * W3_GRB);
-  const uint32_t g_lane_x2 = (uint32_t)(((sg + h) ^ w3_swz(q)) * 16 + (p & 1) * 8 + q * W3_GRB);
+  const uint32_t g_lane_hi = (uint32_t)(((sg + 0) ^ w3_swz<W3_GRB>(q)) * 16 + (p & 1) * 8 + q * W3_GRB + h * (8 * W3_GRB));
+  const uint32_t g_lane_x1 = (uint32_t)(((sg + (1 - h)) ^ w3_swz<W3_GRB>(q)) * 16 + (p & 1) * 8 + q * W3_GRB);
+  const uint32_t g_lane_x2 = (uint32_t)(((sg + h) ^ w3_swz<W3_GRB>(q)) * 16 + (p & 1) * 8 + q * W3_GRB);
   // A rows start anywhere: (row & 3) = (q + 2 (y + r) + s) & 3 for tap (r, s); the four possible swizzled slot offsets,
   // rotated by q, so that the index below is a compile-time constant
   uint32_t a_sw_x1[4], a_sw_x2[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    a_sw_x1[k] = (uint32_t)(((sa + h) ^ w3_swz((q + k) & 3)) * 16);
-    a_sw_x2[k] = (uint32_t)(((sa + (1 - h)) ^ w3_swz((q + k) & 3)) * 16);
+    a_sw_x1[k] = (uint32_t)(((sa + h) ^ w3_swz<W3_ARB>((q + k) & 3)) * 16);
+    a_sw_x2[k] = (uint32_t)(((sa + (1 - h)) ^ w3_swz<W3_ARB>((q + k) & 3)) * 16);
   }
   const uint32_t a_lane = (uint32_t)((p & 1) * 8 + q * W3_ARB);
   const _Float16 cg = (_Float16)(1.f / 2048.f);
@@ -221,8 +231,12 @@ __global__ __launch_bounds__(W3_NT, 2) void wgrad_tap3_s16_kernel(WgradTap3Args 
     if (pt + 1 < p_end) W3_ISSUE(pt + 1, stage ^ 1);
     const uint32_t gst = g_base + (uint32_t)(stage * W3_GSTAGE * 4);
     const uint32_t ast = a_base + (uint32_t)(stage * W3_ASTAGE * 4);
-    if (NP == 1 || wp == 0) { W3_ROW(0) }
-    if (NP == 1 || wp == 1) { W3_ROW(1) }
+    if (0 / RPW == wp) { W3_ROW(0) }                     // (uniform per wave; the row is a literal in the offsets)
+    if (1 / RPW == wp) { W3_ROW(1) }
+    if (PH == 4) {
+      if (2 / RPW == wp) { W3_ROW(2) }
+      if (3 / RPW == wp) { W3_ROW(3) }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -240,22 +254,24 @@ __global__ __launch_bounds__(W3_NT, 2) void wgrad_tap3_s16_kernel(WgradTap3Args 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = row0 + 32 * wg + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (row < d.n) unsafeAtomicAdd(d.dw + (int64_t)row * a.kpad + col, acc[t][r] * inv);
+      if (row < d.n && c < d.cin) unsafeAtomicAdd(d.dw + (int64_t)row * a.kpad + col, acc[t][r] * inv);
     }
   }
 }
 
-template <int NG, int NA, int NP>
+template <int NG, int NA, int NP, int PH>
 static int launch_wgrad_tap3(WgradTap3Args a, hipStream_t stream) {
   constexpr int TN = 32 * NG, TC = 32 * NA;
-  constexpr int AJ = (W3_HPX * (TC / 4) + W3_NT - 1) / W3_NT;
-  constexpr size_t lds = (size_t)(2 * W3_PX * TN + 2 * AJ * W3_NT * 4) * sizeof(float);
+  constexpr int AJ = ((PH + 2) * W3_HW * (TC / 4) + W3_NT - 1) / W3_NT;
+  constexpr size_t lds = (size_t)(2 * PH * W3_PW * TN + 2 * AJ * W3_NT * 4) * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = wgrad_tap3_s16_kernel<NG, NA, NP>;
+  auto kern = wgrad_tap3_s16_kernel<NG, NA, NP, PH>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) return (int)e;
-  a.col_tiles = a.d.cin / TC;
+  a.col_tiles = (a.d.cin + TC - 1) / TC;
+  a.tiles_y = a.d.height / PH;
+  a.npatch = a.d.batch * a.tiles_x * a.tiles_y;
   const int tiles = (a.d.n / TN) * a.col_tiles;
   int msplit = (256 + tiles - 1) / tiles;                           // one workgroup per CU, at least 8 patches each
   const int max_split = (a.npatch + 7) / 8;
@@ -269,18 +285,25 @@ static int launch_wgrad_tap3(WgradTap3Args a, hipStream_t stream) {
 
 // Called by wgrad_tap_s16_try; -12345 = not this kernel's case.
 int wgrad_tap3_s16_try(const AmmcWgradDesc& d, const float* g_inv_scale, int kpad, hipStream_t stream) {
-  if (d.height % W3_PH || d.width % W3_PW || d.n % 64 || d.cin % 64) return -12345;
-  const int64_t gmax = (int64_t)(W3_PH - 1) * d.g_rs + (int64_t)(W3_PW - 1) * d.g_ps + d.n;
-  const int64_t amax = (int64_t)(W3_PH + 1) * d.a_rs + (int64_t)(W3_PW + 1) * d.a_ps + d.cin;
+  if (d.height % 2 || d.width % W3_PW) return -12345;
+  const int64_t gmax = (int64_t)3 * d.g_rs + (int64_t)(W3_PW - 1) * d.g_ps + d.n;
+  const int64_t amax = (int64_t)5 * d.a_rs + (int64_t)(W3_PW + 1) * d.a_ps + d.cin;
   if (gmax >= (1LL << 30) || amax >= (1LL << 30)) return -12345;
   WgradTap3Args a;
   a.d = d;
   a.g_inv_scale = g_inv_scale;
   a.kpad = kpad;
   a.tiles_x = d.width / W3_PW;
-  a.tiles_y = d.height / W3_PH;
-  a.npatch = d.batch * a.tiles_x * a.tiles_y;
-  return d.n % 128 == 0 ? launch_wgrad_tap3<4, 2, 1>(a, stream) : launch_wgrad_tap3<2, 2, 2>(a, stream);
+  a.tiles_y = a.npatch = 0;                                       // set by the launcher (patch height)
+  if (d.cin % 64 == 0) {
+    if (d.n % 128 == 0) return launch_wgrad_tap3<4, 2, 1, 2>(a, stream);
+    if (d.n % 64 == 0) return launch_wgrad_tap3<2, 2, 2, 2>(a, stream);
+    if (d.n == 32 && d.height % 4 == 0) return launch_wgrad_tap3<1, 2, 4, 4>(a, stream);    // the output layer
+    return -12345;
+  }
+  // first layers: 8 / 16 / 32 input channels (one zero-padded 32-channel block)
+  if (d.cin <= 32 && d.n % 64 == 0 && d.height % 4 == 0) return launch_wgrad_tap3<2, 1, 4, 4>(a, stream);
+  return -12345;
 }
 
 }  // namespace ammc_s16

@@ -408,7 +408,7 @@ class _Stream:
         self.outc_b = ws.buf(32)
         self.w32 = ws.buf(32, 64, 3, 3)
         # backward buffers
-        self.dpre = ws.act(B, H, W, 64)
+        self.dpre = ws.act(B, H, W, 32)                    # gradient at the output layer: 3 / 2 real channels of 32
         self.du = [ws.act(B, H >> lvl, W >> lvl, CHANS[lvl]) for lvl in (2, 1, 0)]      # grads of up outputs
         self.dcat = [ws.act(B, H >> i, W >> i, 2 * CHANS[i]) for i in range(3)]
         self.dbottom = ws.act(B, h, w, 512)
@@ -516,19 +516,19 @@ class _Stream:
         grads[net.outc.bias] = o.chan_sum(dp, 32, self.scratch)[:self.cout]
         if o.s16 and WGRAD_S16:
             pre = o.to_s16(dp, rescale=True)
-            o.wgrad_s16(pre[0], o.shadow(self.u3), self.outc_dwp, pre[1], n=64, cin=64, what="outc.wgrad")
+            o.wgrad_s16(pre[0], o.shadow(self.u3), self.outc_dwp, pre[1], n=32, cin=64, what="outc.wgrad")
         else:
             pre = None
             o.wgrad(dp.slice(0, 32), self.u3, self.outc_dwp, n=32, cin=64, ntaps=9, what="outc.wgrad")
         dw = torch.empty_like(net.outc.weight)
         _chk(lib.ammc_unpack_conv_wgrad_f32(_ptr(self.outc_dwp), self.cout, 64, 3, 64, _ptr(dw), s), "unpack")
         grads[net.outc.weight] = dw
-        _chk(lib.ammc_pack_conv_dgrad_weight_f32(_ptr(net.outc.weight.detach()), self.cout, 64, 64, 64,
+        _chk(lib.ammc_pack_conv_dgrad_weight_f32(_ptr(net.outc.weight.detach()), self.cout, 64, 32, 64,
                                                  _ptr(self.outc_wdp), s), "pack_dgrad")
         if o.s16:
-            o.conv_s16(dp, self.outc_wdp, self.du[2], ntaps=9, cin=64, n=64, what="outc.dgrad", rescale=True, pre=pre)
+            o.conv_s16(dp, self.outc_wdp, self.du[2], ntaps=9, cin=32, n=64, what="outc.dgrad", rescale=True, pre=pre)
         else:
-            o.conv(dp, self.outc_wdp, self.du[2], ntaps=9, cin=64, n=64, what="outc.dgrad")
+            o.conv(dp, self.outc_wdp, self.du[2], ntaps=9, cin=32, n=64, what="outc.dgrad")
         for j in (2, 1, 0):
             lvl = (2, 1, 0)[j]
             c = CHANS[lvl]

@@ -23,7 +23,11 @@ DEV = "cuda:0"
                                                (1, 9, 7, 32, 32, 1.0), (4, 64, 64, 64, 64, 2e-8), (1, 8, 64, 16, 128, 1e-5),
                                                (2, 16, 32, 128, 64, 1.0), (3, 12, 96, 256, 256, 1e-3),
                                                # more shapes of the three-MFMA kernel: one patch row pair, a tiny gradient, five samples
-                                               (1, 2, 32, 64, 128, 1.0), (2, 6, 64, 128, 256, 1e-6), (5, 10, 32, 512, 128, 3e-4)])
+                                               (1, 2, 32, 64, 128, 1.0), (2, 6, 64, 128, 256, 1e-6), (5, 10, 32, 512, 128, 3e-4),
+                                               # its 4-row-patch forms: 32 gradient channels (output layer), 8 / 16 / 32 input
+                                               # channels (first layers; the missing channels come from the zero buffer)
+                                               (2, 16, 32, 64, 32, 1e-5), (2, 8, 64, 16, 64, 1.0), (1, 4, 32, 8, 128, 1e-3),
+                                               (3, 12, 32, 32, 64, 1.0), (1, 20, 96, 128, 32, 1.0)])
 def test_wgrad_s16_vs_fp64(B, H, W, cin, n, gmag):
     lib = _lib.load()
     s = torch.cuda.current_stream().cuda_stream
