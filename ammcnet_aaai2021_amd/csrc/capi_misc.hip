@@ -1,7 +1,7 @@
 // Library identification and error strings of libammc_hip.so.
 #include "ammc_common.h"
 
-extern "C" int ammc_abi_version(void) { return 21; }
+extern "C" int ammc_abi_version(void) { return 22; }
 
 extern "C" const char* ammc_build_info(void) {
   return "libammc_hip gfx950 (CDNA4) fp32-MFMA build, HIP " __VERSION__;

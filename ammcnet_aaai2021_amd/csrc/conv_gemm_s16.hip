@@ -23,6 +23,7 @@
 // training path) store two fp32 quads per 8 channels, or one pixel per lane along an NCHW row.
 #include "ammc_common.h"
 #include <hip/hip_fp16.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace ammc_s16 {
@@ -388,12 +389,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN >= 1024 ? 1 : 2)) v
 __global__ void splitk_epilogue_kernel(ConvArgs a);
 
 // conv_tap_s16.hip: the halo-patch kernel for stride-1 3x3 layers; -12345 = not its case
-int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream);
+// `label` non-null: nothing is launched, the kernel's name goes to label[0..label_len) (ammc_conv_gemm_s16_variant)
+int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream, char* label, int label_len);
 
 template <int WGM, int WGN, int TM, int TN>
-int launch(const ConvArgs& a, hipStream_t stream) {
+int launch(const ConvArgs& a, hipStream_t stream, char* label, int label_len) {
   constexpr int BM = WGM * TM * 32;
   constexpr int BN = WGN * TN * 32;
+  if (label) {
+    if (a.ksplit > 1) snprintf(label, label_len, "conv_gemm_s16<%dx%d>+splitk%d", BM, BN, a.ksplit);
+    else snprintf(label, label_len, "conv_gemm_s16<%dx%d>", BM, BN);
+    return AMMC_OK;
+  }
   constexpr int STAGES = 2 * (BM * 32 + BN * 32);
   constexpr size_t lds = (size_t)(STAGES + 2 * BM) * sizeof(float);
   auto kern = conv_gemm_s16_kernel<WGM, WGN, TM, TN>;
@@ -627,7 +634,7 @@ inline unsigned nblk(int64_t total) { return (unsigned)((total + 255) / 256); }
 }  // namespace ammc_s16
 using namespace ammc_s16;
 
-extern "C" int ammc_conv_gemm_s16(const AmmcConvDesc* desc, void* stream) {
+static int conv_gemm_s16_dispatch(const AmmcConvDesc* desc, void* stream, char* label, int label_len) {
   if (!desc || !desc->x || !desc->w || !desc->y) return AMMC_EINVAL;
   const AmmcConvDesc& d = *desc;
   if (d.batch <= 0 || d.height <= 0 || d.width <= 0) return AMMC_EINVAL;
@@ -664,7 +671,7 @@ extern "C" int ammc_conv_gemm_s16(const AmmcConvDesc* desc, void* stream) {
   a.ksplit = 1;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (d.ntaps == 9) {
-    const int rc = conv_tap_s16_try(d, a.kpad, s);
+    const int rc = conv_tap_s16_try(d, a.kpad, s, label, label_len);
     if (rc != -12345) return rc;
   }
   if (d.pool_y) return AMMC_EUNSUP;                 // the fused max-pool output exists in the halo-patch kernel only
@@ -678,18 +685,28 @@ extern "C" int ammc_conv_gemm_s16(const AmmcConvDesc* desc, void* stream) {
       while (ksp > 1 && (int64_t)ksp * M * d.n > d.splitk_ws_floats) --ksp;
       if (ksp > 1) {
         a.ksplit = ksp;
-        return launch<2, 2, 2, 2>(a, s);
+        return launch<2, 2, 2, 2>(a, s, label, label_len);
       }
     }
   }
-  if (d.n == 32) return launch<4, 1, 1, 1>(a, s);
+  if (d.n == 32) return launch<4, 1, 1, 1>(a, s, label, label_len);
   // 256-row tiles (8 waves, one workgroup per CU) move 25 % / 17 % fewer LDS-DMA bytes per FLOP than the
   // 128-row ones; they pay off once there are enough tiles to fill the chip
   // ... and the K loop is long enough to amortise a prologue/epilogue that nothing overlaps (one workgroup per CU);
   // short-K layers (ConvTranspose, K = Cin <= 512) keep the 128-row tiles, three workgroups per CU
   const bool many = M >= (int64_t)256 * 512 / (d.n >= 256 ? d.n / 128 : 1) && a.nchunks > 16;
-  if (d.n % 128 == 0) return (big && many) ? launch<4, 2, 2, 2>(a, s) : launch<2, 2, 2, 2>(a, s);
-  return launch<4, 1, 1, 2>(a, s);
+  if (d.n % 128 == 0) return (big && many) ? launch<4, 2, 2, 2>(a, s, label, label_len) : launch<2, 2, 2, 2>(a, s, label, label_len);
+  return launch<4, 1, 1, 2>(a, s, label, label_len);
+}
+
+extern "C" int ammc_conv_gemm_s16(const AmmcConvDesc* desc, void* stream) {
+  return conv_gemm_s16_dispatch(desc, stream, nullptr, 0);
+}
+
+extern "C" int ammc_conv_gemm_s16_variant(const AmmcConvDesc* desc, char* out, int32_t out_len) {
+  if (!out || out_len < 48) return AMMC_EINVAL;
+  out[0] = 0;
+  return conv_gemm_s16_dispatch(desc, nullptr, out, out_len);
 }
 
 extern "C" int ammc_split_rows_f32(const float* src, int64_t count, float* dst, void* stream) {

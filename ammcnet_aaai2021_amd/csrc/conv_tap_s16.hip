@@ -20,6 +20,7 @@
 // conv_gemm_s16_kernel; ammc_conv_gemm_s16 dispatches.
 #include "ammc_common.h"
 #include <hip/hip_fp16.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace ammc_s16 {
@@ -421,7 +422,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
 }
 
 template <int WGM, int WGN, int TM, int TN, int AS = 2>
-static int launch_tap(const TapArgs& a, hipStream_t stream) {
+static int launch_tap(const TapArgs& a, hipStream_t stream, char* label, int label_len) {
+  if (label) {                                     // the name rocprofv3 prints for this instance
+    snprintf(label, label_len, "conv_tap_s16<%d, %d, %d, %d, %d>", WGM, WGN, TM, TN, AS);
+    return AMMC_OK;
+  }
   constexpr int BN = WGN * TN * 32;
   constexpr int NT = 64 * WGM * WGN;
   constexpr int T_ASTAGE = (T_APIECES + NT - 1) / NT * NT * 4;
@@ -443,7 +448,7 @@ static int launch_tap(const TapArgs& a, hipStream_t stream) {
 
 // Called by ammc_conv_gemm_s16 (conv_gemm_s16.hip) after its argument checks.  Returns TAP_SKIP when the descriptor is
 // not this kernel's case (the caller then runs the implicit-GEMM kernel), else the launch status.
-int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream) {
+int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream, char* label, int label_len) {
   static const int mode = getenv("AMMC_S16_TAP") ? atoi(getenv("AMMC_S16_TAP")) : 1;
   static const int dbg = getenv("AMMC_S16_DBG") ? atoi(getenv("AMMC_S16_DBG")) : 0;
   constexpr int TAP_SKIP = -12345;
@@ -465,13 +470,13 @@ int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream) {
   a.kpad = kpad;
   a.dbg = dbg;
   a.n_tiles = 0;
-  if (d.n == 32) return launch_tap<8, 1, 1, 1, 1>(a, stream);       // the output layer: 2-3 filters, fp32 NCHW + tanh
-  if (d.n == 64) return launch_tap<4, 1, 2, 2, 1>(a, stream);       // 4 waves of 64x64 (2 image rows x 64 filters), 2 workgroups per CU
+  if (d.n == 32) return launch_tap<8, 1, 1, 1, 1>(a, stream, label, label_len);       // the output layer: 2-3 filters, fp32 NCHW + tanh
+  if (d.n == 64) return launch_tap<4, 1, 2, 2, 1>(a, stream, label, label_len);       // 4 waves of 64x64 (2 image rows x 64 filters), 2 workgroups per CU
   // 4 waves of 64x128 (one accumulator set), two workgroups per CU: fewer LDS reads per MFMA and the neighbour's
   // MFMAs behind every prologue / epilogue - once there are two workgroups for every CU (measured: 128x128 layers
   // +10 %, 64x64 +6 %, but 32x32 at batch 16 = one workgroup per CU -19 %)
-  if (mode == 4 || (mode == 1 && tiles >= 512)) return launch_tap<4, 1, 2, 4, 1>(a, stream);
-  return launch_tap<4, 2, 2, 2>(a, stream);
+  if (mode == 4 || (mode == 1 && tiles >= 512)) return launch_tap<4, 1, 2, 4, 1>(a, stream, label, label_len);
+  return launch_tap<4, 2, 2, 2>(a, stream, label, label_len);
 }
 
 }  // namespace ammc_s16

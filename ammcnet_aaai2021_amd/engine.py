@@ -69,32 +69,13 @@ class Act:
         return self.buf[:, h:h + self.H, h:h + self.W, self.c_off:self.c_off + self.c]
 
 
-def _tap_eligible(x: "Act", ntaps: int, cin: int, n: int, up: int = 1, y_f32: int = 0) -> bool:
-    """does csrc/conv_tap_s16.hip (the halo-patch 3x3 kernel) take this S16 layer?  Mirrors `conv_tap_s16_try`."""
-    if os.environ.get("AMMC_S16_TAP", "1") == "0":
-        return False
-    if ntaps != 9 or up != 1 or cin % 32 or x.W % 32 or x.H % 8:
-        return False
-    if n == 32:
-        if not y_f32:
-            return False
-    elif n != 64 and n % 128:
-        return False
-    return _tap_tiles(x, n) >= 192
-
-
-def _tap_tiles(x: "Act", n: int) -> int:
-    return x.B * (x.H // 8) * (x.W // 32) * (1 if n <= 64 else n // 128)
-
-
-def _tap_variant(x: "Act", n: int) -> str:
-    """template arguments <WGM, WGN, TM, TN, AS> of the conv_tap_s16_kernel instance `conv_tap_s16_try` launches
-    (the bench's kernel labels must name rocprof's kernels one to one)"""
-    if n == 32:
-        return "8, 1, 1, 1, 1"
-    if n == 64:
-        return "4, 1, 2, 2, 1"
-    return "4, 1, 2, 4, 1" if _tap_tiles(x, n) >= 512 else "4, 2, 2, 2, 2"
+def s16_variant(d: AmmcConvDesc) -> str:
+    """the kernel `ammc_conv_gemm_s16` launches for this descriptor, by the name rocprofv3 reports
+    (`ammc_conv_gemm_s16_variant`: the library's own dispatch code with the launch replaced by the label, so
+    bench labels and test coverage cannot drift from what runs).  Needs no GPU."""
+    buf = C.create_string_buffer(96)
+    _lib.check(_lib.load().ammc_conv_gemm_s16_variant(C.byref(d), buf, 96), "conv_gemm_s16_variant")
+    return buf.value.decode()
 
 
 def _kpad(k: int) -> int:
@@ -177,13 +158,6 @@ class _Packer:
         w = w.detach().contiguous()
         _lib.check(self.lib.ammc_pack_convt_weight_f32(_ptr(w), cin, co, _ptr(out), self.stream()), "pack_convt")
         return self._split(out)
-
-    def outc(self, w: torch.Tensor) -> torch.Tensor:
-        cout, cin = w.shape[0], w.shape[1]
-        out = torch.empty((9, cin, 4), device=self.device, dtype=torch.float32)
-        w = w.detach().contiguous()
-        _lib.check(self.lib.ammc_pack_outc_weight_f32(_ptr(w), cout, cin, _ptr(out), self.stream()), "pack_outc")
-        return out
 
     def bn(self, bn: torch.nn.BatchNorm2d) -> Tuple[torch.Tensor, torch.Tensor]:
         c = bn.num_features
@@ -284,9 +258,6 @@ class _Builder:
              act=ACT_NONE, res: Optional[Act] = None, up: int = 1, cgroup: Optional[int] = None, name="conv",
              cin_true: Optional[int] = None, y_f32: bool = False, pool: Optional[Act] = None):
         d = AmmcConvDesc()
-        if pool is not None:                 # fused 2x2 max-pool output (the halo-patch kernel only; the caller checked)
-            d.pool_y = pool.pix0()
-            d.pool_bs, d.pool_rs, d.pool_ps = pool.strides
         d.y_f32 = 1 if (y_f32 and self.s16) else 0
         d.overflow_flag = self.overflow.data_ptr() if self.s16 else None
         if self.s16 and os.environ.get("AMMC_S16_SPLITK", "1") != "0":
@@ -313,15 +284,14 @@ class _Builder:
         ct = cin_true if cin_true is not None else cin
         flops = 2.0 * m_pix * n * ntaps * ct
         nbytes = 4.0 * m_pix * (ct + n + (n if res is not None else 0))
-        tile = "128x32" if n == 32 else "128x128" if n % 128 == 0 else "128x64"
-        kname = self.kname
-        # the labels mirror the dispatch in ammc_conv_gemm_s16 / conv_tap_s16_try (they must match rocprof's kernels)
-        if self.s16 and n % 128 == 0 and m_pix >= 256 * 512 // (n // 128 if n >= 256 else 1) and ntaps * cin > 512:
-            tile = "256x128"
-        if self.s16 and _tap_eligible(x, ntaps, cin, n, up, d.y_f32):
-            kname, tile = "conv_tap_s16", _tap_variant(x, n)
-        self.plan.add(self.conv_fn, C.byref(d), name=name, flops=flops, nbytes=nbytes,
-                      kernel=f"{kname}<{tile}>")
+        if self.s16:
+            kernel = s16_variant(d)                     # asked BEFORE a fused-pool output is attached (see double_conv)
+        else:
+            kernel = "conv_gemm_f32<%s>" % ("128x32" if n == 32 else "128x128" if n % 128 == 0 else "128x64")
+        if pool is not None:                 # fused 2x2 max-pool output (the halo-patch kernel only; the caller checked)
+            d.pool_y = pool.pix0()
+            d.pool_bs, d.pool_rs, d.pool_ps = pool.strides
+        self.plan.add(self.conv_fn, C.byref(d), name=name, flops=flops, nbytes=nbytes, kernel=kernel)
         return d
 
     def outc_desc(self, x: Act, w: torch.Tensor, bias32: torch.Tensor, cout: int) -> AmmcConvDesc:
@@ -334,6 +304,12 @@ class _Builder:
         d.x_bs, d.x_rs, d.x_ps = x.strides
         d.y_bs, d.y_rs, d.y_ps, d.y_cs = cout * x.H * x.W, x.W, 1, x.H * x.W
         self.plan.keep.extend([d, w, bias32])
+        if self.s16:
+            d.y = d.x                          # any aligned non-null address: the label query launches nothing
+            self.outc_kernel = s16_variant(d)
+            d.y = None
+        else:
+            self.outc_kernel = "conv_gemm_f32<128x32>"
         return d
 
     def double_conv(self, x: Act, p: _DoubleConvPack, mid: Act, y: Act, res: Optional[Act] = None, name="dc",
@@ -341,8 +317,16 @@ class _Builder:
         """`pool`: where the 2x2 max-pool of the output goes; returns True when the second conv stored it itself"""
         self.conv(x, p.w0, mid, ntaps=9, cin=p.cin_p, n=p.cout, scale=p.s0, shift=p.b0, act=ACT_RELU,
                   name=f"{name}.conv0", cin_true=p.cin)
-        fused = pool is not None and res is None and self.s16 and _tap_eligible(mid, 9, p.cout, p.cout) and \
-            os.environ.get("AMMC_FUSE_POOL", "1") != "0"
+        fused = False
+        if pool is not None and res is None and self.s16 and os.environ.get("AMMC_FUSE_POOL", "1") != "0":
+            # the second output exists in the halo-patch kernel only: ask the library whether this layer gets it
+            probe = AmmcConvDesc()
+            probe.x, probe.w, probe.y = mid.tap0(), _ptr(p.w1), y.pix0()
+            probe.batch, probe.height, probe.width = mid.B, mid.H, mid.W
+            probe.cin, probe.ntaps, probe.n, probe.up, probe.cgroup = p.cout, 9, p.cout, 1, p.cout
+            probe.x_bs, probe.x_rs, probe.x_ps = mid.strides
+            probe.y_bs, probe.y_rs, probe.y_ps = y.strides
+            fused = s16_variant(probe).startswith("conv_tap_s16")
         self.conv(mid, p.w1, y, ntaps=9, cin=p.cout, n=p.cout, scale=p.s1, shift=p.b1, act=ACT_RELU, res=res,
                   name=f"{name}.conv1", pool=pool if fused else None)
         return fused
@@ -444,6 +428,7 @@ class StreamGraph:
             y = out
         self.u3 = y
         self.outc = bld.outc_desc(y, sp.outc_w, sp.outc_b, sp.cout)
+        self.outc_kernel = bld.outc_kernel
 
 
 class EvalEngine:
@@ -557,6 +542,16 @@ class EvalEngine:
             flag.zero_()
         return hit
 
+    def take_overflow(self) -> Optional[torch.Tensor]:
+        """the overflow flag of the last forward as a [1] float tensor on the device, and the sticky flag cleared -
+        both queued on the stream, nothing waits (for harness loops that read many batches' flags at once)"""
+        flag = self._last.get("overflow")
+        if flag is None:
+            return None
+        out = flag.to(torch.float32)
+        flag.zero_()
+        return out
+
     def act_nchw(self, a: Act) -> torch.Tensor:
         """an activation of the workspace as an NCHW fp32 tensor (a view for fp32 plans, a decoded copy
         for S16 plans); halo-free activations (z, qk) are fp32 in both"""
@@ -587,8 +582,7 @@ class EvalEngine:
             else:
                 s.outc.sq_target, s.outc.sq_acc = None, None
             launch(lib.ammc_conv_gemm_s16 if self.s16 else lib.ammc_conv_gemm_f32, (C.byref(s.outc),),
-                   dict(name="outc_tanh", kernel=("conv_tap_s16<8, 1, 1, 1, 1>" if self.s16 and _tap_eligible(s.x_in, 9, 64, 32, 1, 1)
-                                                  else ("conv_gemm_s16" if self.s16 else "conv_gemm_f32") + "<128x32>"),
+                   dict(name="outc_tanh", kernel=s.outc_kernel,
                         flops=2.0 * B * H * W * 9 * 64 * s.sp.cout, bytes=4.0 * B * H * W * (64 + s.sp.cout)))
 
     def _graph_for(self, st, B, H, W, device, tflags):

@@ -41,9 +41,11 @@ def subvideo_batches(n_frames: int, batch: int = EVAL_BATCH, rgb_len_clip: int =
 
 
 def score_batch_device(model: Callable, rgb_frames: torch.Tensor, op_frames: torch.Tensor, s: int, e: int,
-                       device=None) -> torch.Tensor:
-    """run clips [s, e) of a sub-video as ONE batch; returns [2 b + 2] on the model's device: per-clip rgb PSNR, per-clip
-    flow PSNR, the batch's two commit values - nothing is copied to the host, so batches can be queued back to back"""
+                       device=None, exact: bool = False) -> torch.Tensor:
+    """run clips [s, e) of a sub-video as ONE batch; returns [2 b + 3] on the model's device: per-clip rgb PSNR, per-clip
+    flow PSNR, the batch's two commit values and the S16 range flag of the batch (0 / 1; always 0 for models without
+    one) - nothing is copied to the host, so batches can be queued back to back.  `exact`: run the HIP model's
+    exact-fp32 kernels (the re-run of a flagged batch)."""
     rgb = torch.stack([rgb_frames[i:i + RGB_LEN_CLIP] for i in range(s, e)])
     op = torch.stack([op_frames[i:i + OP_LEN_CLIP] for i in range(s, e)])
     if device is not None:
@@ -52,23 +54,39 @@ def score_batch_device(model: Callable, rgb_frames: torch.Tensor, op_frames: tor
     rgb_in = rgb[:, :-1].reshape(b, -1, *rgb.shape[-2:])
     op_in = op[:, :-1].reshape(b, -1, *op.shape[-2:])
     with torch.no_grad():
+        flag = None
         if hasattr(model, "forward_scored") and rgb_in.is_cuda:
             # the HIP model accumulates the squared errors inside the `outc` kernel
-            (_, _, (rgb_diff, op_diff), _), rgb_psnr, op_psnr = model.forward_scored(rgb_in, op_in, rgb[:, -1], op[:, -1])
+            (_, _, (rgb_diff, op_diff), _), rgb_psnr, op_psnr = model.forward_scored(
+                rgb_in, op_in, rgb[:, -1], op[:, -1], defer_guard=True, exact=exact)
+            flag = getattr(model, "last_overflow", None)
         else:
             rgb_out, op_out, (rgb_diff, op_diff), _ = model(rgb_in, op_in)
             rgb_psnr, op_psnr = psnr_per_sample(rgb_out, rgb[:, -1]), psnr_per_sample(op_out, op[:, -1])
-        return torch.cat([rgb_psnr, op_psnr, rgb_diff.reshape(1), op_diff.reshape(1)])
+        if flag is None:
+            flag = torch.zeros(1, device=rgb_psnr.device, dtype=rgb_psnr.dtype)
+        return torch.cat([rgb_psnr, op_psnr, rgb_diff.reshape(1), op_diff.reshape(1), flag.reshape(1).to(rgb_psnr.dtype)])
 
 
 def _unpack_scores(stats: np.ndarray, b: int) -> Dict[str, np.ndarray]:
-    return {"rgb_psnr": stats[:b], "op_psnr": stats[b:2 * b], "rgb_comm": stats[2 * b], "op_comm": stats[2 * b + 1]}
+    return {"rgb_psnr": stats[:b], "op_psnr": stats[b:2 * b], "rgb_comm": stats[2 * b], "op_comm": stats[2 * b + 1],
+            "overflow": bool(stats[2 * b + 2] != 0)}
 
 
 def score_batch(model: Callable, rgb_frames: torch.Tensor, op_frames: torch.Tensor, s: int, e: int,
                 device=None) -> Dict[str, np.ndarray]:
-    """`score_batch_device` + the copy to the host (one sync)"""
-    return _unpack_scores(score_batch_device(model, rgb_frames, op_frames, s, e, device).cpu().numpy(), e - s)
+    """`score_batch_device` + the copy to the host (one sync); a batch whose S16 range flag is set is re-run on the
+    exact-fp32 kernels"""
+    sc = _unpack_scores(score_batch_device(model, rgb_frames, op_frames, s, e, device).cpu().numpy(), e - s)
+    if sc["overflow"]:
+        sc = _unpack_scores(score_batch_device(model, rgb_frames, op_frames, s, e, device, exact=True).cpu().numpy(), e - s)
+        _count_fallback(model)
+    return sc
+
+
+def _count_fallback(model) -> None:
+    if isinstance(model, torch.nn.Module):
+        object.__setattr__(model, "s16_fallbacks", getattr(model, "s16_fallbacks", 0) + 1)
 
 
 def assemble_records(n_frames: int, batches, scores: Sequence[Dict[str, np.ndarray]]) -> Dict[str, np.ndarray]:
@@ -119,6 +137,13 @@ def evaluate_dataset(model: Callable, videos: Sequence, dataset_name: str = "syn
         for i, b, t in pending:
             local[i] = _unpack_scores(flat[off:off + t.numel()], b)
             off += t.numel()
+        # S16 range guard (zero syncs in the loop above): the per-batch flags came back with the scores; batches
+        # whose activations left the half range are re-run on the exact-fp32 kernels, the rest stand
+        for i in [i for i in local if local[i]["overflow"]]:
+            v, s, e = plan[i]
+            rgb_v, op_v = videos[v]
+            local[i] = _unpack_scores(score_batch_device(model, rgb_v, op_v, s, e, device, exact=True).cpu().numpy(), e - s)
+            _count_fallback(model)
     allsc = parallel.gather_records(local, world)
     out = {"dataset": dataset_name, "rgb_img_pred_records": [], "rgb_fea_comm_records": [],
            "op_img_pred_records": [], "op_fea_comm_records": []}
@@ -219,7 +244,9 @@ def train_step_gan(generator: torch.nn.Module, discriminator: torch.nn.Module, o
     flow_pred = flow_gt = None
     if flow_fn is not None:
         with torch.no_grad():
-            flow_pred, flow_gt = flow_fn(rgb[:, -2], out[0].detach()), flow_fn(rgb[:, -2], rgb_t)
+            # the reference pairs BOTH frames with `rgb_input_last = rgb[:, -1]`, i.e. with the target frame itself
+            # (train_helper.py:299, 309-312), not with the frame before it: followed as written
+            flow_pred, flow_gt = flow_fn(rgb[:, -1], out[0].detach()), flow_fn(rgb[:, -1], rgb_t)
     d_params = [p for p in discriminator.parameters() if p.requires_grad]
     for p in d_params:                 # the G step needs dL/d(frame) through D, not D's weight gradients
         p.requires_grad_(False)

@@ -75,7 +75,6 @@ def main(argv=None):
         model.load_state_dict(synthetic.make_twostream_state(embed_dim=a.embed_dim, n_embed=a.n_embed, k=a.k))
     model = model.to(dev).eval()
     model.precision = a.precision
-    model.s16_guard = True
     staged = None
     if a.data:
         blob = torch.load(a.data, map_location="cpu")

@@ -23,7 +23,7 @@ import torch
 
 from . import _lib
 from ._lib import ACT_NONE, ACT_TANH, AmmcConvDesc, AmmcWgradDesc
-from .engine import Act, _cin_pad, _kpad, _ptr
+from .engine import Act, _cin_pad, _kpad, _ptr, s16_variant
 
 BN_MOMENTUM = 0.1
 CHANS = (64, 128, 256, 512)
@@ -74,8 +74,20 @@ class _Ops:
         self.sync_group = None          # set per step by TrainEngine: a process group, or False for "no sync"
         self.s16 = TRAIN_PRECISION == "s16"
         self._shadows: Dict[int, torch.Tensor] = {}
-        self.overflow = ws.buf(1, dtype=torch.int32)
         self.amax = ws.buf(256, dtype=torch.int32)         # slots of ammc_absmax_bits_f32 / bn_bwd_apply
+        # bench.py: a list here brackets every MFMA launch of the 3x3 layers with HIP events on the launch stream and
+        # collects (kernel label, algorithmic flops, start event, end event)
+        self.timing: Optional[list] = None
+
+    def _mfma_launch(self, label, flops: float, call, what: str):
+        if self.timing is None:
+            _chk(call(), what)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _chk(call(), what)
+        e1.record()
+        self.timing.append((label() if callable(label) else label, flops, e0, e1))
 
     def shadow(self, a: Act) -> Act:
         """the S16 twin of an fp32 NHWC buffer (same geometry, allocated once per underlying buffer)"""
@@ -103,7 +115,7 @@ class _Ops:
             _chk(lib.ammc_split_rows_f32(_ptr(x.buf), x.buf.numel(), _ptr(xs.buf), s), "split_rows(x)")
         return xs, inv
 
-    def wgrad_s16(self, g16: Act, a16: Act, dw: torch.Tensor, inv, *, n, cin, what="wgrad"):
+    def wgrad_s16(self, g16: Act, a16: Act, dw: torch.Tensor, inv, *, n, cin, what="wgrad", true_nc=None):
         """3x3 weight gradient from the S16 twins of the output gradient and of the layer input"""
         dw.zero_()
         d = AmmcWgradDesc()
@@ -112,7 +124,10 @@ class _Ops:
         d.n, d.cin, d.ntaps, d.a_step = n, cin, 9, 1
         d.g_bs, d.g_rs, d.g_ps = g16.strides
         d.a_bs, d.a_rs, d.a_ps = a16.strides
-        _chk(self.lib.ammc_conv_wgrad_s16(C.byref(d), _ptr(inv) if inv is not None else None, self.s), what)
+        self._mfma_launch("conv_wgrad_s16 (3x3 weight gradients: wgrad_tap3_s16 / wgrad_tap_s16 instances)",
+                          2.0 * g16.B * g16.H * g16.W * 9 * (true_nc if true_nc is not None else n * cin),   # unpadded channels
+                          lambda: self.lib.ammc_conv_wgrad_s16(C.byref(d), _ptr(inv) if inv is not None else None, self.s),
+                          what)
 
     def conv_s16(self, x: Act, w: torch.Tensor, y: Act, *, ntaps, cin, n, res: Optional[Act] = None, what="conv",
                  rescale: bool = False, pre=None, shift=None, up=1, cgroup=None, x_step=1):
@@ -136,8 +151,10 @@ class _Ops:
         d.y_bs, d.y_rs, d.y_ps = y.strides
         if res is not None:
             d.r_bs, d.r_rs, d.r_ps = res.strides
-        d.overflow_flag = self.overflow.data_ptr()
-        _chk(lib.ammc_conv_gemm_s16(C.byref(d), s), what)
+        # (fp32 outputs: no S16 range flag here - an operand beyond the half range becomes inf in `to_s16` and the
+        # loss turns non-finite, which the training loop sees)
+        self._mfma_launch(lambda: s16_variant(d), 2.0 * d.batch * d.height * d.width * ntaps * cin * n,
+                          lambda: lib.ammc_conv_gemm_s16(C.byref(d), s), what)
 
     @property
     def sync_world(self) -> int:
@@ -307,7 +324,7 @@ class _ConvBN:
             pre = o.to_s16(self.dc, rescale=True, have_amax=True) if fused_amax else None   # shared by wgrad and dgrad
         if pre is not None and self.cin_p >= 8 and WGRAD_S16:
             o.wgrad_s16(pre[0], o.shadow(self.x), self.dwp, pre[1], n=self.cout, cin=self.cin_p,
-                        what=self.name + ".wgrad")            # shadow(x): the twin the forward conv left behind
+                        what=self.name + ".wgrad", true_nc=self.cout * self.cin)            # shadow(x): the twin the forward conv left behind
         else:
             o.wgrad(self.dc, self.x, self.dwp, n=self.cout, cin=self.cin_p, ntaps=9, what=self.name + ".wgrad")
         dw = torch.empty_like(self.conv.weight)
@@ -516,7 +533,8 @@ class _Stream:
         grads[net.outc.bias] = o.chan_sum(dp, 32, self.scratch)[:self.cout]
         if o.s16 and WGRAD_S16:
             pre = o.to_s16(dp, rescale=True)
-            o.wgrad_s16(pre[0], o.shadow(self.u3), self.outc_dwp, pre[1], n=32, cin=64, what="outc.wgrad")
+            o.wgrad_s16(pre[0], o.shadow(self.u3), self.outc_dwp, pre[1], n=32, cin=64, what="outc.wgrad",
+                        true_nc=self.cout * 64)
         else:
             pre = None
             o.wgrad(dp.slice(0, 32), self.u3, self.outc_dwp, n=32, cin=64, ntaps=9, what="outc.wgrad")

@@ -27,9 +27,13 @@ from .engine import EvalEngine
 from .train import HipPathFunction, TrainEngine
 
 
-# Inference arithmetic: "fp32" = exact fp32 MFMA (v_mfma_f32_32x32x2_f32); "s16" = split-fp16 MFMA with
-# fp32 accumulation, fp32-equivalent (conv_gemm_s16.hip).  Per model: `model.precision = "..."`.
-DEFAULT_PRECISION = os.environ.get("AMMC_PRECISION", "fp32")
+# Inference arithmetic: "s16" (default) = split-fp16 MFMA with fp32 accumulation: 22 significant bits per operand,
+# as accurate against fp64 as native fp32, at 3x the speed of "fp32" = exact fp32 MFMA
+# (v_mfma_f32_32x32x2_f32).  Per model: `model.precision = "..."`; process-wide: AMMC_PRECISION.
+# The one thing S16 does not share with fp32 is the RANGE of the hi half (|v| <= 65504): every S16 epilogue raises a
+# device flag beyond it and the guard below (on by default, `model.s16_guard = False` turns it off) recomputes the
+# batch on the exact-fp32 kernels, so the default mode never returns frames computed from a saturated activation.
+DEFAULT_PRECISION = os.environ.get("AMMC_PRECISION", "s16")
 
 
 def _no_training(mod):
@@ -40,6 +44,13 @@ def _no_training(mod):
             "own; call .eval() for a stand-alone block - there is no ATen fallback")
 
 
+def _fp32_engine(mod, kind: str) -> EvalEngine:
+    """the exact-fp32 plans of a model whose default engine is S16 (built on first use: the overflow fallback)"""
+    if getattr(mod, "_engine_fp32", None) is None:
+        object.__setattr__(mod, "_engine_fp32", EvalEngine(mod, kind, "fp32"))
+    return mod._engine_fp32
+
+
 def _run(mod, kind: str, n_inputs: int, *inputs):
     """dispatch a model-boundary forward to the eval plan or to the training Function"""
     if not mod.training:
@@ -47,14 +58,12 @@ def _run(mod, kind: str, n_inputs: int, *inputs):
         if mod._engine is None or mod._engine.precision != prec:
             object.__setattr__(mod, "_engine", EvalEngine(mod, kind, prec))
         out = mod._engine.forward(*inputs)
-        if prec == "s16" and getattr(mod, "s16_guard", False):
-            # S16 carries |v| <= 65504 in the hi half; the conv epilogues raise a device flag beyond that.  Reading
-            # it costs one device sync per forward, so the guard is opt-in (`model.s16_guard = True`): on overflow
-            # the batch is recomputed on the exact-fp32 kernels.
+        if prec == "s16" and getattr(mod, "s16_guard", True):
+            # Reading the flag is one 4-byte device-to-host copy per forward (the host runs ~100 launches ahead of the
+            # device, so the wait costs the launch latency of the next forward's first kernel: < 1 % at batch 16,
+            # measured in DESIGN.md section 5; the harness loop avoids even that, see `forward_scored(defer_guard=True)`).
             if mod._engine.overflowed():
-                if getattr(mod, "_engine_fp32", None) is None:
-                    object.__setattr__(mod, "_engine_fp32", EvalEngine(mod, kind, "fp32"))
-                out = mod._engine_fp32.forward(*inputs)
+                out = _fp32_engine(mod, kind).forward(*inputs)
                 object.__setattr__(mod, "s16_fallbacks", getattr(mod, "s16_fallbacks", 0) + 1)
         return out
     if mod._train_engine is None:
@@ -230,20 +239,38 @@ class twostream(nn.Module):
             self._quant_src = (self._engine, st.x4, st.x4q)
         return out
 
-    def forward_scored(self, rgb_x, op_x, rgb_target, op_target=None):
+    def forward_scored(self, rgb_x, op_x, rgb_target, op_target=None, defer_guard: bool = False, exact: bool = False):
         """eval forward + per-sample PSNR of the predicted frames against `rgb_target` (and `op_target`), with the
         squared error accumulated inside the `outc` kernel (the scoring tail of
         run_helper/test_helper.py:445-454 without re-reading the frames).  Returns (forward's 4-tuple,
-        rgb_psnr [B], op_psnr [B] or None)."""
+        rgb_psnr [B], op_psnr [B] or None).
+
+        S16 range guard: by default as in `forward` (one flag read, fp32 recomputation on overflow).  With
+        `defer_guard=True` nothing is read back: `self.last_overflow` is a [1] float tensor ON THE DEVICE (1 = an
+        activation of this batch left the half range; the sticky flag is cleared by a queued kernel), so a harness
+        can queue batches back to back, copy scores and flags to the host once, and re-run only the flagged batches
+        with `exact=True` (the fp32 kernels) - `harness.evaluate_dataset` does exactly that."""
         if self.training:
             raise NotImplementedError("forward_scored is an evaluation entry: call .eval() first")
-        prec = getattr(self, "precision", None) or DEFAULT_PRECISION
-        if self._engine is None or self._engine.precision != prec:
-            object.__setattr__(self, "_engine", EvalEngine(self, "twostream", prec))
-        out = self._engine.forward(rgb_x, op_x, targets=(rgb_target, op_target))
-        st = self._engine._last["streams"][0]
-        self._quant_src = (self._engine, st.x4, st.x4q)
-        return out, self._engine.last_psnr[0], self._engine.last_psnr[1]
+        prec = "fp32" if exact else (getattr(self, "precision", None) or DEFAULT_PRECISION)
+        if exact and (getattr(self, "precision", None) or DEFAULT_PRECISION) != "fp32":
+            eng = _fp32_engine(self, "twostream")
+        else:
+            if self._engine is None or self._engine.precision != prec:
+                object.__setattr__(self, "_engine", EvalEngine(self, "twostream", prec))
+            eng = self._engine
+        out = eng.forward(rgb_x, op_x, targets=(rgb_target, op_target))
+        self.last_overflow = None
+        if prec == "s16" and getattr(self, "s16_guard", True):
+            if defer_guard:
+                self.last_overflow = eng.take_overflow()
+            elif eng.overflowed():
+                eng = _fp32_engine(self, "twostream")
+                out = eng.forward(rgb_x, op_x, targets=(rgb_target, op_target))
+                object.__setattr__(self, "s16_fallbacks", getattr(self, "s16_fallbacks", 0) + 1)
+        st = eng._last["streams"][0]
+        self._quant_src = (eng, st.x4, st.x4q)
+        return out, eng.last_psnr[0], eng.last_psnr[1]
 
     # reference side effects (unet.py:986, 988): `quant_befor` / `quant_after`, which nothing reads.
     # Served lazily as NCHW tensors of the workspace (valid until the next forward of that shape).

@@ -56,8 +56,7 @@ const char* ammc_error_string(int code);
  *                      `out += x` (unet.py:386) through `res`
  *   ntaps=9, n=32, n_store=cout, act=TANH, NCHW strides
  *                      `outc` + torch.tanh (unet.py:920, 998-1007): the 2-3 output channels
- *                      ride in a 32-wide MFMA column tile (the VALU form, kept below as
- *                      ammc_conv3x3_out_tanh_f32, is L1-line-bound and 7x slower)
+ *                      ride in a 32-wide MFMA column tile
  *   ntaps=4, x_step=2  gradient of that ConvTranspose2d w.r.t. its input (autograd of unet.py:51)
  *   ntaps=9 on dY with the flipped/transposed filter: gradient of the 3x3 conv w.r.t. its input
  *   ntaps=1, up=2      nn.ConvTranspose2d(C, C/2, 2, stride 2) + bias (unet.py:47,51):
@@ -101,16 +100,6 @@ typedef struct AmmcConvDesc {
 } AmmcConvDesc;
 
 int ammc_conv_gemm_f32(const AmmcConvDesc* desc, void* stream);
-
-/* 3x3 conv with 1..4 output channels + bias + tanh, NCHW output:
- * `outc` followed by torch.tanh (unet.py:920, 998-1007).  x is halo-padded NHWC
- * (offset to tap (0,0) of pixel (0,0,0)); w_packed comes from ammc_pack_outc_weight_f32
- * (OIHW [cout][cin][3][3] -> [9][cin][4]). */
-int ammc_pack_outc_weight_f32(const float* w_oihw, int32_t cout, int32_t cin, float* out, void* stream);
-int ammc_conv3x3_out_tanh_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps,
-                              const float* w_packed, const float* bias,
-                              int32_t batch, int32_t height, int32_t width,
-                              int32_t cin, int32_t cout, float* y_nchw, void* stream);
 
 /* nn.MaxPool2d(2) (unet.py:36) on NHWC; input strides explicit (the skip tensor lives in
  * the concat buffer), output strides explicit (halo-padded). h,w are OUTPUT sizes. */
@@ -170,6 +159,11 @@ int ammc_sum_partials_f32(const float* partial, int32_t nparts, float inv_count,
  * only without them).  Replaces the same reference calls as ammc_conv_gemm_f32.
  * ---------------------------------------------------------------------------------------- */
 int ammc_conv_gemm_s16(const AmmcConvDesc* desc, void* stream);
+/* Which kernel ammc_conv_gemm_s16 launches for this descriptor, as the NUL-terminated name rocprofv3 reports for it
+ * (e.g. "conv_tap_s16<4, 1, 2, 4, 1>", "conv_gemm_s16<128x128>", "...+splitk4"), without launching anything: the same
+ * argument checks and the same dispatch code run with the launch replaced by the label.  Tests pin kernel coverage on
+ * it and bench.py labels its per-kernel timings with it. */
+int ammc_conv_gemm_s16_variant(const AmmcConvDesc* desc, char* out, int32_t out_len);
 /* fp32 -> S16, count elements (multiple of 8): packed filters, gathered codebook rows */
 int ammc_split_rows_f32(const float* src, int64_t count, float* dst, void* stream);
 /* Gradient tensors as S16 operands (what autograd derives for the 3x3 convs, train_helper.py:337-339): the largest

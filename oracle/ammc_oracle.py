@@ -343,27 +343,6 @@ def clone_state(sd: State, requires_grad: bool = False) -> State:
     return out
 
 
-def fwd_flops_per_clip(h: int = 256, w: int = 256, in_channel=(12, 6), out_channel=(3, 2),
-                       embed_dim: int = 64, n_embed: int = 256, k: int = 2) -> float:
-    """Algorithmic forward FLOPs (2*MAC) of one dual-stream clip: convs, ConvT,
-    1x1, distance GEMM (168.10 GFLOP at the shipped config)."""
-    def dc(cin, cout, hh, ww):
-        return 2.0 * hh * ww * 9 * (cin * cout + cout * cout)
-    total = 0.0
-    for cin, cout in zip(in_channel, out_channel):
-        total += dc(cin, 64, h, w) + dc(64, 128, h // 2, w // 2) + dc(128, 256, h // 4, w // 4)
-        total += dc(256, 512, h // 8, w // 8)
-        n = (h // 8) * (w // 8)
-        total += 2.0 * n * (512 * embed_dim + embed_dim * n_embed + k * embed_dim * 512)
-        for c, s in ((512, 4), (256, 2), (128, 1)):
-            hh, ww = h // s, w // s                     # output resolution of this up block
-            total += 2.0 * (hh // 2) * (ww // 2) * c * (c // 2) * 4     # ConvT
-            total += dc(c, c // 2, hh, ww)
-        total += 2.0 * h * w * 9 * 64 * cout
-    total += 2 * dc(512, 512, h // 8, w // 8)
-    return total
-
-
 # ---- SURVEY.md 8(f)4: FlowNet2-SD, the frozen flow estimator of the flow-consistency term -------------------------
 
 def flownet2sd_forward(sd: State, inputs: torch.Tensor, rgb_max: float = 255.0, div_flow: float = 20.0) -> torch.Tensor:

@@ -66,7 +66,9 @@ STAGES = ["rgb.inc", "rgb.down1", "rgb.down2", "rgb.down3", "rgb.vq_down3", "rgb
           "rgb.up1", "rgb.up2", "rgb.up3", "op.up1", "op.up2", "op.up3"]
 
 
-def twostream_eval(ref, hw, batch, n_embed, name, full):
+def twostream_eval(ref, hw, batch, n_embed, name, full, rows=None, q_step=1, grid=16):
+    """`rows`: batch rows kept in the per-stage samples (all when None); `q_step`: spatial stride of the stored
+    quantised maps; `grid`: samples per side of the per-stage subsample - all three only to keep the batch-16 fixture of the benchmark's own shape a few MB"""
     cfg = dict(in_channel=(12, 6), out_channel=(3, 2), embed_dim=64, n_embed=n_embed, k=2)
     sd = S.make_twostream_state(**cfg)
     net = ref.get_twostream(cfg["in_channel"], cfg["out_channel"], 64, n_embed, 2)
@@ -79,8 +81,13 @@ def twostream_eval(ref, hw, batch, n_embed, name, full):
     for h in handles:
         h.remove()
     out = {"rgb_diff": rd.numpy(), "op_diff": od.numpy(),
-           "rgb_q": rq.numpy(), "op_q": oq.numpy(),
+           "rgb_q": rq[:, ::q_step, ::q_step].contiguous().numpy(), "op_q": oq[:, ::q_step, ::q_step].contiguous().numpy(),
            "rgb_moments": moments(rgb), "op_moments": moments(op)}
+    if q_step != 1:
+        out["q_step"] = np.int64(q_step)
+    if rows is not None:
+        out["st_rows"] = np.array(rows, dtype=np.int64)
+    pick = (lambda t: t[list(rows)]) if rows is not None else (lambda t: t)
     step = 1 if full else 4
     out["rgb"] = sub(rgb, step)
     out["op"] = sub(op, step)
@@ -92,16 +99,16 @@ def twostream_eval(ref, hw, batch, n_embed, name, full):
     for st in STAGES:
         o = got[st]
         if st == "bridge":
-            bs = max(1, o[0].shape[-1] // 16)
-            out["st.rgb.bridge"], out["st.op.bridge"] = sub(o[0], bs), sub(o[1], bs)
+            bs = max(1, o[0].shape[-1] // grid)
+            out["st.rgb.bridge"], out["st.op.bridge"] = sub(pick(o[0]), bs), sub(pick(o[1]), bs)
             out["mo.rgb.bridge"], out["mo.op.bridge"] = moments(o[0]), moments(o[1])
         elif st.endswith("quantize"):
-            out[f"st.{st}"] = o[0].numpy() if full else o[0][:, ::2, ::2].contiguous().numpy()
+            out[f"st.{st}"] = o[0].numpy() if full else pick(o[0])[:, ::2, ::2].contiguous().numpy()
         elif st.endswith("vq_down3"):
-            out[f"st.{st}"] = sub(o[0], max(1, o[0].shape[-1] // 16))
+            out[f"st.{st}"] = sub(pick(o[0]), max(1, o[0].shape[-1] // grid))
             out[f"mo.{st}"] = moments(o[0])
         else:
-            out[f"st.{st}"] = sub(o, max(1, o.shape[-1] // 16))    # <=16x16 samples per channel
+            out[f"st.{st}"] = sub(pick(o), max(1, o.shape[-1] // grid))    # <=16x16 samples per channel
             out[f"mo.{st}"] = moments(o)
     out["cfg"] = np.array(json.dumps(dict(hw=hw, batch=batch, tag=name, **cfg)))
     np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
@@ -348,6 +355,8 @@ def main():
     twostream_eval(ref, 64, 2, 256, "twostream_64_b2_eval", full=True)
     twostream_eval(ref, 64, 2, 2000, "twostream_64_b2_m2000_eval", full=True)
     twostream_eval(ref, 256, 2, 256, "twostream_256_b2_eval", full=False)
+    # the benchmark's own workload (BASELINE.json configs[1]): batch 16, 256x256, 2000 slots
+    twostream_eval(ref, 256, 16, 2000, "twostream_256_b16_m2000_eval", full=False, rows=(0, 7, 15), q_step=4, grid=8)
     twostream_train(ref, 64, 2, "twostream_64_b2_train")
     score_fusion_golden()
     discriminator_and_losses()

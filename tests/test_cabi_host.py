@@ -80,3 +80,50 @@ def test_synthetic_data_is_deterministic():
     rgb, op, rt, ot = S.make_clips(2, 16, 16)
     assert rgb.shape == (2, 12, 16, 16) and op.shape == (2, 6, 16, 16) and ot.shape == (2, 2, 16, 16)
     assert torch.allclose(op[:, 1::2], op[:, 0::2] / 256.0)
+
+
+def _fake_desc(B, H, W, cin, n, ntaps=9, up=1, y_f32=0):
+    """descriptor with fake (aligned, never dereferenced) addresses: `ammc_conv_gemm_s16_variant` runs the argument
+    checks and the dispatch of `ammc_conv_gemm_s16` and launches nothing, so it needs no GPU"""
+    d = _lib.AmmcConvDesc()
+    d.x, d.w, d.y = 0x100000, 0x200000, 0x300000
+    d.batch, d.height, d.width, d.cin, d.ntaps, d.n, d.up = B, H, W, cin, ntaps, n, up
+    d.cgroup = n // 4 if up == 2 else n
+    d.y_f32 = y_f32
+    d.x_ps, d.x_rs = cin, (W + 2) * cin
+    d.x_bs = (H + 2) * d.x_rs
+    d.y_ps, d.y_rs = n, (W * up + 2) * n
+    d.y_bs = (H * up + 2) * d.y_rs
+    return d
+
+
+def test_s16_dispatch_of_the_benchmark_shapes():
+    """which kernel each layer of the benchmark's workload (batch 16, 256x256: BASELINE.json configs[1]) gets - the
+    variants named here are the ones tests/test_gpu_conv_tap.py and the batch-16 golden test must reach"""
+    from ammcnet_aaai2021_amd.engine import s16_variant
+    B = 16
+    want = {
+        (256, 64, 64): "conv_tap_s16<4, 1, 2, 2, 1>",          # inc.1, up3.1
+        (256, 128, 64): "conv_tap_s16<4, 1, 2, 2, 1>",         # up3.0
+        (128, 64, 128): "conv_tap_s16<4, 1, 2, 4, 1>",         # down1.0 ... the dominant variant (>= 512 tiles)
+        (128, 128, 128): "conv_tap_s16<4, 1, 2, 4, 1>",
+        (128, 256, 128): "conv_tap_s16<4, 1, 2, 4, 1>",
+        (64, 128, 256): "conv_tap_s16<4, 1, 2, 4, 1>",
+        (64, 256, 256): "conv_tap_s16<4, 1, 2, 4, 1>",
+        (64, 512, 256): "conv_tap_s16<4, 1, 2, 4, 1>",
+        (32, 256, 512): "conv_tap_s16<4, 2, 2, 2, 2>",         # 256 tiles: the 8-wave variant
+        (32, 512, 512): "conv_tap_s16<4, 2, 2, 2, 2>",
+    }
+    for (hw, cin, n), label in want.items():
+        assert s16_variant(_fake_desc(B, hw, hw, cin, n)) == label, (hw, cin, n)
+    assert s16_variant(_fake_desc(B, 256, 256, 64, 32, y_f32=1)) == "conv_tap_s16<8, 1, 1, 1, 1>"      # outc
+    assert s16_variant(_fake_desc(B, 256, 256, 16, 64)).startswith("conv_gemm_s16<")                   # inc.0 (12 -> 16 channels)
+    assert s16_variant(_fake_desc(B, 32, 32, 512, 1024, ntaps=1, up=2)).startswith("conv_gemm_s16<")   # ConvTranspose
+    # small batches fall back to the implicit GEMM (split-K below 192 tiles)
+    d = _fake_desc(1, 32, 32, 512, 512)
+    assert s16_variant(d) == "conv_gemm_s16<128x128>"
+    d.splitk_ws, d.splitk_ws_floats = 0x400000, 8 << 20
+    assert s16_variant(d).startswith("conv_gemm_s16<128x128>+splitk")
+    bad = _fake_desc(1, 32, 32, 24, 64)                                      # cin not a power of two
+    with pytest.raises(_lib.AmmcHipError):
+        s16_variant(bad)

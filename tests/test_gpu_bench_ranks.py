@@ -1,6 +1,7 @@
-"""bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), on the one GPU of the
-test box: both ranks share cuda:0 and talk over gloo (AMMC_BENCH_SHARE_GPU=1).  Checks the single JSON line, the
-whole-job aggregation and both modes."""
+"""bench.py for N > 1 on the one GPU of the test box, both ways it gets started: as the driver launches it
+(torch.distributed.run, one process per rank) and as a plain `python bench.py --gpus 2` (bench.py starts its own
+ranks).  Both ranks share cuda:0 and talk over gloo (AMMC_BENCH_SHARE_GPU=1).  Checks the single JSON line, the
+whole-job aggregation and all three modes."""
 import json
 import os
 import socket
@@ -22,20 +23,38 @@ def _free_port():
     return p
 
 
+UNITS = {"infer": 4, "train": 2, "stress": 2 * 1024}
+
+
+@pytest.mark.parametrize("launcher", ["torchrun", "self"])
 @pytest.mark.parametrize("mode,extra", [("infer", ["--batch", "4", "--size", "64", "--no-cpu-baseline"]),
-                                         ("train", ["--batch", "2", "--size", "64"])])
-def test_bench_two_ranks(mode, extra):
+                                         ("train", ["--batch", "2", "--size", "64"]),
+                                         ("stress", ["--batch", "2"])])
+def test_bench_two_ranks(mode, extra, launcher):
     env = dict(os.environ, AMMC_BENCH_SHARE_GPU="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--mode", mode] + extra
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--mode", mode] + extra
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port())] + tail
+    else:
+        cmd = [sys.executable] + tail                                # bench.py spawns the two ranks itself
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]                      # rank 0 prints ONE line
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak" and rec["higher_is_better"] is True
-    per_step = 2 * (4 if mode == "infer" else 2)                    # whole-job units per step = sum over ranks
+    assert rec["rccl_ranks"] == 2                                   # read back from dist.get_world_size()
+    per_step = 2 * UNITS[mode]                                      # whole-job units per step = sum over ranks
     assert abs(rec["value"] - per_step / (rec["ms_per_step"] * 1e-3)) <= 0.02 * rec["value"]
     if mode == "infer":
         assert rec["roofline"]["bound"] == "mfma" and rec["roofline"]["frac"] > 0
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "AMMC_BENCH_SHARE_GPU")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "GPU(s) visible" in out.stderr

@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 from ammcnet_aaai2021_amd import _lib, synthetic as S
 from ammcnet_aaai2021_amd._lib import ACT_NONE, ACT_RELU, AmmcConvDesc
-from ammcnet_aaai2021_amd.engine import Act, _ptr
+from ammcnet_aaai2021_amd.engine import Act, _ptr, s16_variant
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -35,14 +35,22 @@ def _s16_read(a: Act) -> torch.Tensor:
     return y
 
 
-@pytest.mark.parametrize("B,H,W,cin,n,relu,res,sliced", [
-    (12, 64, 64, 64, 64, True, False, False),        # N = 64: 8 waves x (32 x 64)
-    (6, 64, 64, 32, 256, False, False, False),       # two N tiles, a single channel block
-    (6, 128, 64, 128, 128, True, True, False),       # four channel blocks, residual epilogue
-    (24, 32, 32, 64, 128, True, False, True),        # one tile per image, input = slice of a 128-channel buffer
-    (1, 256, 256, 64, 64, True, False, False),       # the 256x256 level of the network
+V64, V128, V8W = "conv_tap_s16<4, 1, 2, 2, 1>", "conv_tap_s16<4, 1, 2, 4, 1>", "conv_tap_s16<4, 2, 2, 2, 2>"
+
+
+@pytest.mark.parametrize("B,H,W,cin,n,relu,res,sliced,variant", [
+    (12, 64, 64, 64, 64, True, False, False, V64),        # N = 64: 4 waves x (2 rows x 64 filters)
+    (6, 64, 64, 32, 256, False, False, False, V8W),       # 192 tiles: the 8-wave variant, two N tiles, one channel block
+    (6, 128, 64, 128, 128, True, True, False, V8W),       # four channel blocks, residual epilogue
+    (48, 32, 32, 64, 128, True, False, True, V8W),        # one tile per image, input = slice of a 128-channel buffer
+    (1, 256, 256, 64, 64, True, False, False, V64),       # the 256x256 level of the network
+    # the benchmark's dominant variant (>= 512 tiles, 128-filter tiles, one accumulator set, two workgroups per CU)
+    (16, 64, 64, 32, 256, False, False, False, V128),     # 512 tiles, two N tiles
+    (8, 128, 128, 128, 128, True, True, False, V128),     # 512 tiles, residual
+    (32, 64, 64, 128, 128, True, False, True, V128),      # sliced input (the decoder's concat buffer)
+    (16, 128, 128, 64, 128, True, False, False, V128),    # down1.0 of the benchmark
 ])
-def test_conv_tap_s16_vs_fp64(B, H, W, cin, n, relu, res, sliced):
+def test_conv_tap_s16_vs_fp64(B, H, W, cin, n, relu, res, sliced, variant):
     lib = _lib.load()
     tag = f"tap-{B}-{H}-{W}-{cin}-{n}"
     x = S.hashed_uniform(tag + "x", (B, cin, H, W)).to(DEV)
@@ -69,6 +77,12 @@ def test_conv_tap_s16_vs_fp64(B, H, W, cin, n, relu, res, sliced):
     if res:
         d.r_bs, d.r_rs, d.r_ps = ra.strides
     d.overflow_flag = flag.data_ptr()
+    pa = None
+    if not res:                                        # second output: the 2x2 max-pool of y (the `down` blocks)
+        pa = Act(torch.zeros(B, H // 2 + 2, W // 2 + 2, n, device=DEV), B, H // 2, W // 2, n, 0, 1)
+        d.pool_y = pa.pix0()
+        d.pool_bs, d.pool_rs, d.pool_ps = pa.strides
+    assert s16_variant(d) == variant                   # the library's own dispatch: this case reaches that kernel
     _lib.check(lib.ammc_conv_gemm_s16(C.byref(d), s), "conv_gemm_s16")
     got = _s16_read(ya).double().cpu()
     # reference on the operands as the kernel sees them (S16 round trip of x, w and the residual)
@@ -85,10 +99,15 @@ def test_conv_tap_s16_vs_fp64(B, H, W, cin, n, relu, res, sliced):
     assert err <= 2e-6, err
     assert int(flag.item()) == 0
     assert float(ya.buf[:, 0].abs().max()) == 0.0 and float(ya.buf[:, :, 0].abs().max()) == 0.0     # halo untouched
+    if pa is not None:
+        # S16 rounding is monotone, so the pooled output is EXACTLY the max-pool of the stored (fp64-checked) output
+        assert torch.equal(_s16_read(pa), F.max_pool2d(_s16_read(ya), 2))
+        assert float(pa.buf[:, 0].abs().max()) == 0.0 and float(pa.buf[:, :, 0].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("B,H,W,cin,n", [(12, 64, 64, 64, 64), (6, 64, 64, 64, 128), (16, 64, 64, 32, 256), (24, 32, 32, 64, 128)])
-def test_conv_tap_fp32_output_with_fp32_residual(B, H, W, cin, n):
+@pytest.mark.parametrize("B,H,W,cin,n,variant", [(12, 64, 64, 64, 64, V64), (12, 64, 64, 64, 128, V8W), (16, 64, 64, 32, 256, V128),
+                                                 (48, 32, 32, 64, 128, V8W)])
+def test_conv_tap_fp32_output_with_fp32_residual(B, H, W, cin, n, variant):
     """the form the training path uses (train.py `_Ops.conv_s16`): S16 operands, fp32 NHWC output, per-column scale
     (the undo of the gradient rescaling), fp32 residual - every conv_tap_s16 variant (4-wave 64x64 and 64x128 with
     one accumulator set, 8-wave with two)"""
@@ -112,6 +131,7 @@ def test_conv_tap_fp32_output_with_fp32_residual(B, H, W, cin, n):
     d.x_bs, d.x_rs, d.x_ps = xa.strides
     d.y_bs, d.y_rs, d.y_ps = ya.strides
     d.r_bs, d.r_rs, d.r_ps = res.strides
+    assert s16_variant(d) == variant
     _lib.check(lib.ammc_conv_gemm_s16(C.byref(d), s), "conv_gemm_s16")
     got = ya.interior().permute(0, 3, 1, 2).double().cpu()
     wsa = Act(ws.view(1, 1, n, 9 * cin), 1, 1, n, 9 * cin, 0, 0)

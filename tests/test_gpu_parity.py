@@ -1,6 +1,9 @@
 """Parity of the HIP path (through the C ABI) with the CPU oracle and the golden vectors
 recorded from the reference.  Needs an MI355X: run with `-m gpu`.
 
+Whole-model tests here pin `precision = "fp32"` (the exact-fp32 MFMA kernels); the package default, S16, has the same
+gates in tests/test_gpu_s16.py.
+
 Tolerances (BASELINE.json north_star):
   predicted frames / activations   max|d| / max|ref| <= 1e-4   (fp32 MFMA, exact-fp32 products)
   commit scalars                   rel <= 1e-4
@@ -32,6 +35,7 @@ def _twostream(n_embed=256, k=2, tag="ammc"):
     sd = S.make_twostream_state(n_embed=n_embed, k=k, tag=tag)
     net = A.get_twostream((12, 6), (3, 2), 64, n_embed, k)
     net.load_state_dict(sd, strict=True)
+    net.precision = "fp32"                 # this file pins the exact-fp32 kernels; tests/test_gpu_s16.py the default (S16)
     return net.to(DEV).eval(), sd
 
 
@@ -238,12 +242,14 @@ def test_unet_config1_and_unetmem():
     net = A.get_unet(12, 3)
     net.load_state_dict(S.make_unet_state(12, 3))
     net = net.to(DEV).eval()
+    net.precision = "fp32"
     x = S.make_clips(cfg["batch"], cfg["hw"], cfg["hw"], tag=cfg["tag"])[0]
     assert rel_err(net(x.to(DEV)).cpu(), d["y"]) <= TOL
     sd = {k[4:]: v for k, v in S.make_twostream_state().items() if k.startswith("rgb.")}
     one = A.get_unet_vq_topk_res(12, 3, 64, 256, 2)
     one.load_state_dict(sd)
     one = one.to(DEV).eval()
+    one.precision = "fp32"
     y, diff, q1 = one(x.to(DEV))
     with torch.no_grad():
         wy, wd, wq = O.unetmem_forward(O.clone_state(sd), x, 2)

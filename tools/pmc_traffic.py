@@ -1,19 +1,28 @@
 """HBM-side bytes per launch of every conv kernel from the FETCH_SIZE / WRITE_SIZE passes of tools/profile_bench.sh
 (separate rocprofv3 --pmc runs), keyed by the labels bench.py uses:
 
-    python tools/pmc_traffic.py gpurun_out/prof_<tag> <precision> > profiles/rNN_<precision>_pmc_traffic.json
+    python tools/pmc_traffic.py gpurun_out/prof_<tag> <precision> [batch size n_embed commit] > profiles/rNN_<precision>_pmc_traffic.json
 
 FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B: MI355X_MICROARCH.md, HBM section); rocprofv3 reports KB."""
 import csv, glob, json, re, sys
 from collections import defaultdict
 
 root, prec = sys.argv[1], sys.argv[2]
+extra = sys.argv[3:]
+workload = {"batch": int(extra[0]) if len(extra) > 0 else 16, "size": int(extra[1]) if len(extra) > 1 else 256,
+            "n_embed": int(extra[2]) if len(extra) > 2 else 2000}
+commit = extra[3] if len(extra) > 3 else None
+try:
+    command = open(f"{root}/command.txt").read().strip()
+except OSError:
+    command = "python3 bench.py --steps 5 --warmup 2"
 
 
 def label(name):
     m = re.search(r"(conv_gemm_s16|conv_gemm_f32|conv_tap_s16)_kernel<([^>]*)>", name)
     if not m:
-        return None
+        m2 = re.search(r"(memory_topk_f16|memory_topk|wgrad_tap3_s16|wgrad_tap_s16|wgrad_s16|wgrad_f32)\w*_kernel(<[^>]*>)?", name)
+        return (m2.group(1) + (m2.group(2) or "")) if m2 else None
     if m.group(1) == "conv_tap_s16":                   # labelled by its template arguments <WGM, WGN, TM, TN, AS>
         return "conv_tap_s16<" + ", ".join(v.strip() for v in m.group(2).split(",")) + ">"
     t = [int(v) if v.strip().lstrip("-").isdigit() else 0 for v in m.group(2).split(",")]
@@ -31,7 +40,8 @@ for path in glob.glob(f"{root}/pmc_fetch/**/*counter_collection.csv", recursive=
                 a[0] += float(row["Counter_Value"])
                 a[1] += 1
 out = {"source": f"tools/profile_bench.sh (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes) of "
-                 f"`python3 bench.py --steps 5 --warmup 2` (precision {prec}); tools/pmc_traffic.py", "kernels": {}}
+                 f"`{command}` (precision {prec}); tools/pmc_traffic.py",
+       "workload": workload, "commit": commit, "kernels": {}}
 for lb, c in acc.items():
     f, w = c["FETCH_SIZE"], c["WRITE_SIZE"]
     if not f[1] or not w[1]:
