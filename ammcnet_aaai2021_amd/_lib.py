@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libammc_hip.so")
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU = 0, 1, 2, 3
 
@@ -53,6 +53,7 @@ SIGNATURES = {
     "ammc_abi_version": (C.c_int, []),
     "ammc_build_info": (C.c_char_p, []),
     "ammc_error_string": (C.c_char_p, [C.c_int]),
+    "ammc_set_option": (C.c_int, [C.c_char_p, _i32]),
     "ammc_conv_gemm_f32": (C.c_int, [C.POINTER(AmmcConvDesc), _p]),
     "ammc_maxpool2x2_f32": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _p]),
     "ammc_nchw_to_nhwc_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _i64, _i64, _i64, _i32, _p]),

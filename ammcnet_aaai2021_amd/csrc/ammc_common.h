@@ -22,6 +22,10 @@ __device__ __forceinline__ int ammc_xcd_remap(int bid, int nblk) {
   return start + (bid >> 3);
 }
 
+// dispatch option "s16_mf" (capi_misc.hip): MFMA shape of the halo-patch kernel, -1 = per variant (the measured
+// faster one, default), 1 = v_mfma_f32_16x16x32_f16, 0 = v_mfma_f32_32x32x16_f16; AMMC_S16_MF / ammc_set_option
+int ammc_opt_s16_mf();
+
 static inline int ammc_ilog2(int v) {
   int l = 0;
   while ((1 << l) < v) ++l;

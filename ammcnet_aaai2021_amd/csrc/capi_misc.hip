@@ -1,7 +1,31 @@
 // Library identification and error strings of libammc_hip.so.
 #include "ammc_common.h"
 
-extern "C" int ammc_abi_version(void) { return 22; }
+#include <stdlib.h>
+#include <string.h>
+
+extern "C" int ammc_abi_version(void) { return 23; }
+
+// dispatch options (ammc_common.h): initialised from the environment once, changed by ammc_set_option
+int g_ammc_s16_mf = -2;              // -2 = not read yet; -1 = auto (per variant); 0 / 1 = forced
+
+int ammc_opt_s16_mf() {
+  if (g_ammc_s16_mf == -2) {
+    const char* e = getenv("AMMC_S16_MF");
+    g_ammc_s16_mf = e ? (atoi(e) < 0 ? -1 : atoi(e) != 0) : -1;
+  }
+  return g_ammc_s16_mf;
+}
+
+extern "C" int ammc_set_option(const char* key, int32_t value) {
+  if (!key) return AMMC_EINVAL;
+  if (!strcmp(key, "s16_mf")) {
+    if (value < -1 || value > 1) return AMMC_EINVAL;
+    g_ammc_s16_mf = value;
+    return AMMC_OK;
+  }
+  return AMMC_EUNSUP;
+}
 
 extern "C" const char* ammc_build_info(void) {
   return "libammc_hip gfx950 (CDNA4) fp32-MFMA build, HIP " __VERSION__;

@@ -42,7 +42,18 @@ constexpr int T_APIECES = T_HP * 8;                                             
 // AS = halo-patch stages.  2: the next channel block's patch is prefetched during the current one (one workgroup per
 // CU).  1: the patch is reloaded at every channel-block boundary and TWO workgroups share a CU (<= 80 KB of LDS,
 // <= 128 VGPRs), so one's loads and epilogue overlap the other's MFMAs - for layers with little work per patch.
-template <int WGM, int WGN, int TM, int TN, int AS>
+//
+// MF = the MFMA shape.  0: v_mfma_f32_32x32x16_f16 (an MFMA row tile = one image row of 32 pixels, two k-steps per
+// 32-channel block).  1: v_mfma_f32_16x16x32_f16 (16-pixel x 16-filter tiles, ONE MFMA per 32-channel block): the same
+// LDS bytes, MFMA cycles and accumulator registers per wave tile, but the chip holds a higher clock on this shape
+// under load (MI355X_MICROARCH.md, DVFS give-back item 7), and the 3-filter output layer wastes 13 of 16 MFMA rows
+// instead of 29 of 32.  MF = 1 lays the 128-byte LDS rows out differently: lane l of a fragment read takes row l & 15,
+// S16 group l >> 4, so the 16-byte slot of (group g, hi / lo) in row R is (2 g + (g & 1) ^ lo) ^ (R & 7) - found by
+// exhaustive search: conflict free in all four 16-lane groups of ds_read_b128 for ANY 16 consecutive rows - and the
+// filter rows of a stage are stored tile by tile, tile t row r = filter 32 (t >> 1) + 8 (r >> 2) + 4 (t & 1) + (r & 3),
+// so that the four registers of filter tiles 2 u and 2 u + 1 of a lane are EIGHT CONSECUTIVE channels of one pixel:
+// the 32-byte S16 store of the MF = 0 epilogue, unchanged.
+template <int WGM, int WGN, int TM, int TN, int AS, int MF>
 // (hipcc: the second __launch_bounds__ argument is the minimum number of WAVES PER SIMD, i.e. 512 / it VGPRs)
 __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)) void conv_tap_s16_kernel(TapArgs a) {
   static_assert((WGM * WGN == 8 || WGM * WGN == 4) && WGM * TM == T_TH, "4 or 8 waves, 8 image rows");
@@ -70,6 +81,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
   const int wn = wave % WGN;
   const int h = lane >> 5;
   const int l31 = lane & 31;
+  const int l15 = lane & 15;           // MF = 1: pixel / filter row of a 16x16 tile
+  const int g4 = lane >> 4;            //         S16 group of the 32-channel block (MFMA k = 8 g4 .. 8 g4 + 7)
   const AmmcConvDesc& d = a.d;
 
   const int logical = ammc_xcd_remap(blockIdx.x, gridDim.x);
@@ -100,16 +113,26 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
     int p = j * NT + tid;
     p = p < T_APIECES ? p : T_APIECES - 1;
     const int hp = p >> 3;
-    const int ls = (p & 7) ^ ((hp >> 1) & 7);
+    int ls = (p & 7) ^ ((hp >> 1) & 7);
+    if (MF) {                                       // physical slot q of row R holds source piece pi(q ^ (R & 7)),
+      ls = (p & 7) ^ (hp & 7);                      // pi = swap 2 <-> 3 and 6 <-> 7 (an involution)
+      ls ^= (ls >> 1) & 1;
+    }
     const int hy = hp / T_HW;
     const int hx = hp - hy * T_HW;
     a_off[j] = (int)((int64_t)hy * d.x_rs + (int64_t)hx * d.x_ps) + 4 * ls;
   }
-  const int sl = (tid & 7) ^ ((tid >> 4) & 7);
+  int sl = (tid & 7) ^ ((tid >> 4) & 7);
+  if (MF) {
+    sl = (tid & 7) ^ ((tid >> 3) & 7);
+    sl ^= (sl >> 1) & 1;
+  }
   const float* b_src[BJ];
 #pragma unroll
   for (int j = 0; j < BJ; ++j) {
-    int row = n0 + j * (NT / 8) + (tid >> 3);
+    int row = j * (NT / 8) + (tid >> 3);                     // LDS row of the stage
+    if (MF) row = (row & ~31) | (((row >> 2) & 3) << 3) | (((row >> 4) & 1) << 2) | (row & 3);   // tile-ordered rows
+    row += n0;
     row = row < d.n ? row : d.n - 1;                         // padding rows of a 32-filter slice: any valid address
     b_src[j] = d.w + (int64_t)row * a.kpad + 4 * sl;
   }
@@ -133,17 +156,30 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
   // below, i.e. far under the fp32 rounding of the sum), which halves the accumulator registers.
   constexpr bool SA = AS == 1;
   constexpr int XM = SA ? 1 : TM, XN = SA ? 1 : TN;
-  f32x16 hh[TM][TN], xx[XM][XN];
+  constexpr int PT = 2 * TM, FT = (WGN * TN * 32 == 32) ? 1 : 2 * TN;     // MF = 1: 16-pixel / 16-filter tiles of a wave
+  constexpr int FC = FT > 4 ? 4 : (AS == 2 && FT > 2 ? 2 : FT);                                      //         filter tiles whose fragments are live at once
+  f32x4 acc[MF ? PT : 1][MF ? FT : 1];                                     //         (the output layer uses ONE filter tile)
+  f32x4 acx[MF && !SA ? PT : 1][MF && !SA ? FT : 1];                       //         cross terms (two-accumulator variants)
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < (MF ? PT : 1); ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < (MF ? FT : 1); ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < (MF && !SA ? PT : 1); ++i)
+#pragma unroll
+    for (int j = 0; j < (MF && !SA ? FT : 1); ++j) acx[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define TAP_ACC16(pt, j, k) (SA ? acc[pt][j][k] : acc[pt][j][k] + acx[SA ? 0 : (pt)][SA ? 0 : (j)][k] * T_LO_INV)
+  f32x16 hh[MF ? 1 : TM][MF ? 1 : TN], xx[MF ? 1 : XM][MF ? 1 : XN];
+#pragma unroll
+  for (int i = 0; i < (MF ? 1 : TM); ++i)
+#pragma unroll
+    for (int j = 0; j < (MF ? 1 : TN); ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) hh[i][j][r] = 0.f;
 #pragma unroll
-  for (int i = 0; i < XM; ++i)
+  for (int i = 0; i < (MF ? 1 : XM); ++i)
 #pragma unroll
-    for (int j = 0; j < XN; ++j)
+    for (int j = 0; j < (MF ? 1 : XN); ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) xx[i][j][r] = 0.f;
 #define TAP_ACC(i, j, r) (SA ? hh[i][j][r] : hh[i][j][r] + xx[(SA ? 0 : (i))][(SA ? 0 : (j))][r] * T_LO_INV)
@@ -155,7 +191,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
   const int b_row = (wn * TN * 32 + pl31) * 32;
   int hpb[TM];                                  // halo pixel of this lane's output pixel for tap (0,0)
 #pragma unroll
-  for (int i = 0; i < TM; ++i) hpb[i] = (wm * TM + i) * T_HW + l31;
+  for (int i = 0; i < TM; ++i) hpb[i] = (wm * TM + i) * T_HW + (MF ? l15 : l31);
+  // MF = 1: logical slots of this lane's S16 group (hi, lo) and its filter row of a 16-row tile
+  const int slot_hi = 2 * g4 + (g4 & 1), slot_lo = slot_hi ^ 1;
+  const int b_row16 = (wn * TN * 32 + l15) * 32;
+  const int swzb16 = l15 & 7;
 
 #ifndef AMMC_TAP_SETPRIO
 #define AMMC_TAP_SETPRIO 0
@@ -165,7 +205,52 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
 #else
 #define TAP_PRIO(v)
 #endif
+#define TAP_COMPUTE16(tap, astage, bstage)                                                                 \
+  {                                                                                                        \
+    /* pixel fragments of all PT tiles stay resident (SA: hi, hi 2^-11, lo 2^-11; else hi, lo); filter fragments in  \
+       chunks of FC tiles */                                                                               \
+    const float* Ac = As + (astage) * T_ASTAGE;                                                            \
+    const float* Bc = Bs + (bstage) * B_STAGE + b_row16;                                                   \
+    f16x8t ah[PT], ax_[PT], al2_[PT];      /* ax_: SA ? hi 2^-11 : lo */                                   \
+    _Pragma("unroll") for (int pt = 0; pt < PT; ++pt) {                                                    \
+      int hp_ = hpb[pt >> 1] + 16 * (pt & 1) + ((tap) / 3) * T_HW + ((tap) % 3);                           \
+      asm volatile("" : "+v"(hp_));                                                                        \
+      const float* ap_ = Ac + hp_ * 32;                                                                    \
+      const int sw_ = hp_ & 7;                                                                             \
+      ah[pt] = *reinterpret_cast<const f16x8t*>(ap_ + ((slot_hi ^ sw_) << 2));                             \
+      const f16x8t al_ = *reinterpret_cast<const f16x8t*>(ap_ + ((slot_lo ^ sw_) << 2));                   \
+      if (SA) {                                                                                            \
+        ax_[pt] = ah[pt] * (_Float16)T_LO_INV;                                                             \
+        al2_[pt] = al_ * (_Float16)T_LO_INV;                                                               \
+      } else {                                                                                             \
+        ax_[pt] = al_;                                                                                     \
+      }                                                                                                    \
+    }                                                                                                      \
+    _Pragma("unroll") for (int f0 = 0; f0 < FT; f0 += FC) {                                                \
+      f16x8t bh[FC], bl[FC];                                                                               \
+      _Pragma("unroll") for (int j = 0; j < FC; ++j) {                                                     \
+        bh[j] = *reinterpret_cast<const f16x8t*>(Bc + (f0 + j) * 512 + ((slot_hi ^ swzb16) << 2));         \
+        bl[j] = *reinterpret_cast<const f16x8t*>(Bc + (f0 + j) * 512 + ((slot_lo ^ swzb16) << 2));         \
+      }                                                                                                    \
+      if (SA) {                                                                                            \
+        _Pragma("unroll") for (int pt = 0; pt < PT; ++pt) _Pragma("unroll") for (int j = 0; j < FC; ++j)   \
+          acc[pt][f0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[pt], acc[pt][f0 + j], 0, 0, 0);   \
+        _Pragma("unroll") for (int pt = 0; pt < PT; ++pt) _Pragma("unroll") for (int j = 0; j < FC; ++j)   \
+          acc[pt][f0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ax_[pt], acc[pt][f0 + j], 0, 0, 0);  \
+        _Pragma("unroll") for (int pt = 0; pt < PT; ++pt) _Pragma("unroll") for (int j = 0; j < FC; ++j)   \
+          acc[pt][f0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al2_[pt], acc[pt][f0 + j], 0, 0, 0); \
+      } else {                                                                                             \
+        _Pragma("unroll") for (int pt = 0; pt < PT; ++pt) _Pragma("unroll") for (int j = 0; j < FC; ++j)   \
+          acc[pt][f0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[pt], acc[pt][f0 + j], 0, 0, 0);   \
+        _Pragma("unroll") for (int pt = 0; pt < PT; ++pt) _Pragma("unroll") for (int j = 0; j < FC; ++j)   \
+          acx[SA ? 0 : pt][SA ? 0 : f0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[pt], acx[SA ? 0 : pt][SA ? 0 : f0 + j], 0, 0, 0); \
+        _Pragma("unroll") for (int pt = 0; pt < PT; ++pt) _Pragma("unroll") for (int j = 0; j < FC; ++j)   \
+          acx[SA ? 0 : pt][SA ? 0 : f0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ax_[pt], acx[SA ? 0 : pt][SA ? 0 : f0 + j], 0, 0, 0); \
+      }                                                                                                    \
+    }                                                                                                      \
+  }
 #define TAP_COMPUTE(tap, astage, bstage)                                                                   \
+  if constexpr (MF != 0) TAP_COMPUTE16(tap, astage, bstage) else                                           \
   {                                                                                                        \
     const float* Ac = As + (astage) * T_ASTAGE;                                                            \
     const float* Bc = Bs + (bstage) * B_STAGE + b_row;                                                     \
@@ -242,7 +327,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
     } else if (!lastcc) {                                                                                  \
       TAP_ISSUE_B(((tap) + PD - 9) * a.ncc + cc + 1, bsp_);                                                \
     }                                                                                                      \
-    if (TAP_DBG != 2) TAP_COMPUTE(tap, (AS == 2 ? (cc & 1) : 0), bs);                                        \
+    if (TAP_DBG != 2) { TAP_COMPUTE(tap, (AS == 2 ? (cc & 1) : 0), bs); }                                    \
     if (TAP_DBG >= 3) {                                                                                    \
       TAP_WAIT(0);                                                                                         \
     } else if (!lastcc) {                                                                                  \
@@ -275,6 +360,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
 #undef TAP_WAIT
 #undef TAP_STEP
 #undef TAP_COMPUTE
+#undef TAP_COMPUTE16
 #undef TAP_ISSUE_A
 #undef TAP_ISSUE_B
 
@@ -286,6 +372,133 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
   // stores whole 32-byte groups (16 B of hi halves, 16 B of lo halves), the two lane halves write neighbouring groups -
   // no LDS round trip, no barrier.  (The first form parked the tile in LDS to get 32-byte stores; with everything else
   // removed that epilogue was 10-35 % of the kernel.)
+  if constexpr (MF != 0) {
+    // ---- epilogue of the 16x16x32 form: lane = pixel l15 of a 16-pixel tile, registers = 4 filters of tile j; tiles
+    // 2 u and 2 u + 1 together give the lane channels cb + 8 g4 .. + 7 (see the row order of the filter stage above)
+    const int cbase = n0 + wn * TN * 32 + 8 * g4;
+    if (d.y_f32) {
+      const int nstore = d.n_store > 0 ? d.n_store : d.n;
+      const int64_t ycs = d.y_cs > 0 ? d.y_cs : 1;
+      float sq0 = 0.f;
+#pragma unroll
+      for (int j = 0; j < FT; ++j) {
+        const int c0 = cbase + 32 * (j >> 1) + 4 * (j & 1);
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (d.scale) sc = *reinterpret_cast<const f32x4*>(d.scale + c0);
+        if (d.shift) sh = *reinterpret_cast<const f32x4*>(d.shift + c0);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          const int y = y0 + wm * TM + (pt >> 1), x = x0 + 16 * (pt & 1) + l15;
+          const int64_t op = (int64_t)b * d.y_bs + (int64_t)y * d.y_rs + (int64_t)x * d.y_ps;
+          f32x4 v;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float t = TAP_ACC16(pt, j, k) * sc[k] + sh[k];
+            if (d.act == AMMC_ACT_RELU) t = t > 0.f ? t : 0.f;
+            else if (d.act == AMMC_ACT_TANH) t = tanhf(t);
+            v[k] = t;
+          }
+          if (d.res) {                                          // fp32 outputs take an fp32 NHWC residual
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(d.res + ((int64_t)b * d.r_bs + (int64_t)y * d.r_rs + (int64_t)x * d.r_ps) + c0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += rv[k];
+          }
+          if (ycs == 1 && c0 + 4 <= nstore) {
+            *reinterpret_cast<f32x4*>(d.y + op + c0) = v;
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (c0 + k < nstore) d.y[op + (int64_t)(c0 + k) * ycs] = v[k];
+          }
+          if (d.sq_target) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (c0 + k < nstore) {
+                const float df = 0.5f * (d.sq_target[op + (int64_t)(c0 + k) * ycs] - v[k]);
+                sq0 += df * df;
+              }
+          }
+        }
+      }
+      if (d.sq_target) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq0 += __shfl_xor(sq0, off);
+        if (lane == 0) unsafeAtomicAdd(d.sq_acc + b, sq0);
+      }
+      return;
+    }
+    float vmax = 0.f;
+#pragma unroll
+    for (int u = 0; u < FT / 2; ++u) {
+      const int c0 = cbase + 32 * u;                            // this lane's S16 group
+      float sc[8], sh[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sc[k] = 1.f, sh[k] = 0.f;
+      if (d.scale) {
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.scale + c0), s1 = *reinterpret_cast<const f32x4*>(d.scale + c0 + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sc[k] = s0[k], sc[4 + k] = s1[k];
+      }
+      if (d.shift) {
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.shift + c0), s1 = *reinterpret_cast<const f32x4*>(d.shift + c0 + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sh[k] = s0[k], sh[4 + k] = s1[k];
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float pooled[8];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int pt = 2 * i + c;
+          const int y = y0 + wm * TM + i, x = x0 + 16 * c + l15;
+          float v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            float t = TAP_ACC16(pt, 2 * u + (k >> 2), k & 3) * sc[k] + sh[k];
+            if (d.act == AMMC_ACT_RELU) t = t > 0.f ? t : 0.f;
+            v[k] = t;
+          }
+          if (d.res) {
+            const f16x8t* rp = reinterpret_cast<const f16x8t*>(d.res + ((int64_t)b * d.r_bs + (int64_t)y * d.r_rs + (int64_t)x * d.r_ps) + c0);
+            const f16x8t rh = rp[0], rl = rp[1];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += (float)rh[k] + (float)rl[k] * T_LO_INV;
+          }
+          f16x8t hi, lo;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const _Float16 hv = (_Float16)v[k];
+            hi[k] = hv;
+            lo[k] = (_Float16)((v[k] - (float)hv) * T_LO_SCALE);
+            vmax = fmaxf(vmax, fabsf(v[k]));
+            if (TM == 2) pooled[k] = i == 0 ? v[k] : fmaxf(pooled[k], v[k]);
+          }
+          f16x8t* yp = reinterpret_cast<f16x8t*>(d.y + ((int64_t)b * d.y_bs + (int64_t)y * d.y_rs + (int64_t)x * d.y_ps) + c0);
+          yp[0] = hi;
+          yp[1] = lo;
+        }
+        if (TM == 2 && d.pool_y) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) pooled[k] = fmaxf(pooled[k], __shfl_xor(pooled[k], 1));
+          if ((l15 & 1) == 0) {
+            f16x8t hi, lo;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const _Float16 hv = (_Float16)pooled[k];
+              hi[k] = hv;
+              lo[k] = (_Float16)((pooled[k] - (float)hv) * T_LO_SCALE);
+            }
+            f16x8t* pp = reinterpret_cast<f16x8t*>(d.pool_y + ((int64_t)b * d.pool_bs + (int64_t)((y0 >> 1) + wm) * d.pool_rs +
+                                                              (int64_t)((x0 >> 1) + 8 * c + (l15 >> 1)) * d.pool_ps) + c0);
+            pp[0] = hi;
+            pp[1] = lo;
+          }
+        }
+      }
+    }
+    if (d.overflow_flag && !(vmax <= 65504.f)) atomicOr(d.overflow_flag, 1);   // |v| beyond the half range (or NaN)
+    return;
+  }
   int o_pix[TM], r_pix[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -421,10 +634,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
   if (d.overflow_flag && !(vmax <= 65504.f)) atomicOr(d.overflow_flag, 1);   // |v| beyond the half range (or NaN)
 }
 
-template <int WGM, int WGN, int TM, int TN, int AS = 2>
+template <int WGM, int WGN, int TM, int TN, int AS = 2, int MF = 0>
 static int launch_tap(const TapArgs& a, hipStream_t stream, char* label, int label_len) {
   if (label) {                                     // the name rocprofv3 prints for this instance
-    snprintf(label, label_len, "conv_tap_s16<%d, %d, %d, %d, %d>", WGM, WGN, TM, TN, AS);
+    snprintf(label, label_len, "conv_tap_s16<%d, %d, %d, %d, %d, %d>", WGM, WGN, TM, TN, AS, MF);
     return AMMC_OK;
   }
   constexpr int BN = WGN * TN * 32;
@@ -435,7 +648,7 @@ static int launch_tap(const TapArgs& a, hipStream_t stream, char* label, int lab
   constexpr int STAGES = AS * T_ASTAGE + NB * BJ * (NT / 8) * 32;
   constexpr size_t lds = (size_t)STAGES * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = conv_tap_s16_kernel<WGM, WGN, TM, TN, AS>;
+  auto kern = conv_tap_s16_kernel<WGM, WGN, TM, TN, AS, MF>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) return (int)e;
@@ -470,13 +683,24 @@ int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream, char* 
   a.kpad = kpad;
   a.dbg = dbg;
   a.n_tiles = 0;
-  if (d.n == 32) return launch_tap<8, 1, 1, 1, 1>(a, stream, label, label_len);       // the output layer: 2-3 filters, fp32 NCHW + tanh
-  if (d.n == 64) return launch_tap<4, 1, 2, 2, 1>(a, stream, label, label_len);       // 4 waves of 64x64 (2 image rows x 64 filters), 2 workgroups per CU
+  // the MFMA shape per variant (option "s16_mf": -1 = the measured faster one, 0 / 1 = forced for A/Bs).  Measured at
+  // batch 16, 256x256 on one MI355X: output layer 147 -> 123 us and 64-filter layers 306 -> 293 us
+  // with 16x16x32, 128-filter layers 213 -> 220 us (twice the MFMA instructions leave the fragment reads and the
+  // 2^-11 scaling half the issue slots), the 8-wave two-accumulator variant 165 -> 158 us
+  const int mfo = ammc_opt_s16_mf();
+  const int64_t ntiles = (int64_t)d.batch * (d.height / T_TH) * (d.width / T_TW) * (d.n <= 64 ? 1 : d.n / 128);
+  const bool wide4 = d.n > 64 && (mode == 4 || (mode == 1 && ntiles >= 512));          // the 4-wave 128-filter variant
+  const int mf = mfo < 0 ? (wide4 ? 0 : 1) : mfo;
+  if (d.n == 32) return mf ? launch_tap<8, 1, 1, 1, 1, 1>(a, stream, label, label_len)     // the output layer: 2-3 filters, fp32 NCHW + tanh
+                           : launch_tap<8, 1, 1, 1, 1, 0>(a, stream, label, label_len);
+  if (d.n == 64) return mf ? launch_tap<4, 1, 2, 2, 1, 1>(a, stream, label, label_len)     // 4 waves of 64x64 (2 image rows x 64 filters), 2 workgroups per CU
+                           : launch_tap<4, 1, 2, 2, 1, 0>(a, stream, label, label_len);
   // 4 waves of 64x128 (one accumulator set), two workgroups per CU: fewer LDS reads per MFMA and the neighbour's
   // MFMAs behind every prologue / epilogue - once there are two workgroups for every CU (measured: 128x128 layers
   // +10 %, 64x64 +6 %, but 32x32 at batch 16 = one workgroup per CU -19 %)
-  if (mode == 4 || (mode == 1 && tiles >= 512)) return launch_tap<4, 1, 2, 4, 1>(a, stream, label, label_len);
-  return launch_tap<4, 2, 2, 2>(a, stream, label, label_len);
+  if (mode == 4 || (mode == 1 && tiles >= 512))
+    return mf ? launch_tap<4, 1, 2, 4, 1, 1>(a, stream, label, label_len) : launch_tap<4, 1, 2, 4, 1, 0>(a, stream, label, label_len);
+  return mf ? launch_tap<4, 2, 2, 2, 2, 1>(a, stream, label, label_len) : launch_tap<4, 2, 2, 2, 2, 0>(a, stream, label, label_len);
 }
 
 }  // namespace ammc_s16

@@ -30,6 +30,7 @@ CHANS = (64, 128, 256, 512)
 # 3x3 convolutions of the training path (forward and input-gradient): "s16" = the fp32-equivalent split-fp16 kernels
 # of the inference path (operands converted per launch, fp32 outputs; everything else - statistics, weight gradients,
 # 1x1 / transposed convs - stays on the fp32 kernels), "fp32" = exact fp32 MFMA throughout
+# Process-wide default; per model: `model.train_precision = "fp32" | "s16"` (read when the engine is built / rebuilt)
 TRAIN_PRECISION = os.environ.get("AMMC_TRAIN_PRECISION", "s16")
 WGRAD_S16 = os.environ.get("AMMC_WGRAD_S16", "1") != "0"          # the 3x3 weight gradients as well (wgrad_s16.hip)
 # ConvTranspose forward / input gradient on the S16 kernels too: opt-in - its short-K GEMMs gain less than the operand
@@ -42,15 +43,40 @@ FUSE_BN_BWD = os.environ.get("AMMC_FUSE_BN_BWD", "1") != "0"      # BN backward 
 class _WS:
     """workspace allocator: zero-initialised once (kernels only write interiors)"""
 
+    ZCHUNK = 16 << 20          # floats per chunk of the per-step-zeroed slab (64 MB)
+
     def __init__(self, device):
         self.device = device
         self.lib = _lib.load()
         self.bytes = 0
+        self._zchunks: List[torch.Tensor] = []
+        self._zfree = 0
 
     def buf(self, *shape, dtype=torch.float32) -> torch.Tensor:
         t = torch.zeros(shape, device=self.device, dtype=dtype)
         self.bytes += t.numel() * t.element_size()
         return t
+
+    def zbuf(self, *shape, dtype=torch.float32) -> torch.Tensor:
+        """a buffer that must be ZERO at the start of every backward (weight-gradient accumulators, the slots of the
+        max-|g| reductions): carved out of a few large chunks that `zero_step` clears with one memset each, instead
+        of one fill kernel per buffer per step (there are ~180 of them)"""
+        n = 1
+        for d in shape:
+            n *= d
+        n_al = (n + 63) // 64 * 64                            # 256-byte granules
+        if not self._zchunks or self._zfree + n_al > self._zchunks[-1].numel():
+            self._zchunks.append(self.buf(max(self.ZCHUNK, n_al)))
+            self._zfree = 0
+        flat = self._zchunks[-1][self._zfree:self._zfree + n]
+        self._zfree += n_al
+        t = flat.view(dtype).view(*shape) if dtype != torch.float32 else flat.view(*shape)
+        t._ammc_zslab = True
+        return t
+
+    def zero_step(self) -> None:
+        for c in self._zchunks:
+            c.zero_()
 
     def act(self, B, H, W, c, halo=1) -> Act:
         return Act(self.buf(B, H + 2 * halo, W + 2 * halo, c), B, H, W, c, 0, halo)
@@ -68,11 +94,11 @@ def _chk(rc, what):
 class _Ops:
     """immediate-mode launches of the C ABI on the current stream"""
 
-    def __init__(self, ws: _WS):
+    def __init__(self, ws: _WS, precision: Optional[str] = None):
         self.ws, self.lib, self.dev = ws, ws.lib, ws.device
         self.zeros = ws.buf(1024)
         self.sync_group = None          # set per step by TrainEngine: a process group, or False for "no sync"
-        self.s16 = TRAIN_PRECISION == "s16"
+        self.s16 = (precision or TRAIN_PRECISION) == "s16"
         self._shadows: Dict[int, torch.Tensor] = {}
         self.amax = ws.buf(256, dtype=torch.int32)         # slots of ammc_absmax_bits_f32 / bn_bwd_apply
         # bench.py: a list here brackets every MFMA launch of the 3x3 layers with HIP events on the launch stream and
@@ -97,19 +123,23 @@ class _Ops:
             buf = self._shadows[key] = self.ws.buf(*a.buf.shape)
         return Act(buf, a.B, a.H, a.W, a.c, a.c_off, a.halo)
 
-    def to_s16(self, x: Act, rescale: bool = False, have_amax: bool = False):
+    def to_s16(self, x: Act, rescale: bool = False, have_amax: bool = False, amax: Optional[torch.Tensor] = None):
         """re-encode the fp32 buffer behind `x` into its S16 twin; `rescale` (gradients): first bring it into the half
-        range by a power of two found on the device (`have_amax`: the producer already left max |x| in self.amax).
+        range by a power of two found on the device (`have_amax`: the producer already left max |x| in the slots;
+        `amax`: the caller's own slots, zero at the start of the backward pass - else the shared ones, cleared here).
         Returns (twin, inverse scale [1] or None)."""
         lib, s = self.lib, self.s
         xs = self.shadow(x)
         inv = None
         if rescale:
             inv = torch.empty(1024, device=self.dev, dtype=torch.float32)
+            if amax is None:
+                amax = self.amax
+                if not have_amax:
+                    amax.zero_()
             if not have_amax:
-                self.amax.zero_()
-                _chk(lib.ammc_absmax_bits_f32(_ptr(x.buf), x.buf.numel(), self.amax.data_ptr(), s), "absmax")
-            _chk(lib.ammc_split_rows_scaled_f32(_ptr(x.buf), x.buf.numel(), _ptr(xs.buf), self.amax.data_ptr(), _ptr(inv),
+                _chk(lib.ammc_absmax_bits_f32(_ptr(x.buf), x.buf.numel(), amax.data_ptr(), s), "absmax")
+            _chk(lib.ammc_split_rows_scaled_f32(_ptr(x.buf), x.buf.numel(), _ptr(xs.buf), amax.data_ptr(), _ptr(inv),
                                                 1024, s), "split_rows_scaled(x)")
         else:
             _chk(lib.ammc_split_rows_f32(_ptr(x.buf), x.buf.numel(), _ptr(xs.buf), s), "split_rows(x)")
@@ -117,7 +147,8 @@ class _Ops:
 
     def wgrad_s16(self, g16: Act, a16: Act, dw: torch.Tensor, inv, *, n, cin, what="wgrad", true_nc=None):
         """3x3 weight gradient from the S16 twins of the output gradient and of the layer input"""
-        dw.zero_()
+        if not getattr(dw, "_ammc_zslab", False):          # slab buffers were cleared by `_WS.zero_step` (backward start)
+            dw.zero_()
         d = AmmcWgradDesc()
         d.g, d.a, d.dw, d.zeros = g16.pix0(), a16.tap0(), _ptr(dw), _ptr(self.zeros)
         d.batch, d.height, d.width = g16.B, g16.H, g16.W
@@ -190,7 +221,8 @@ class _Ops:
         _chk(self.lib.ammc_conv_gemm_f32(C.byref(d), self.s), what)
 
     def wgrad(self, g: Act, a: Act, dw: torch.Tensor, *, n, cin, ntaps, a_step=1, what="wgrad"):
-        dw.zero_()
+        if not getattr(dw, "_ammc_zslab", False):
+            dw.zero_()
         d = AmmcWgradDesc()
         d.g = g.pix0()
         d.a = a.tap0() if ntaps == 9 else a.pix0()
@@ -230,7 +262,8 @@ class _ConvBN:
         self.partial = ws.buf(self.nblk, 4, self.cout)               # Q = 2 sums (+ 2 maxima in the fused S16 backward)
         # backward
         self.dc = ws.act(x.B, x.H, x.W, self.cout)
-        self.dwp = ws.buf(self.cout, self.kpad)
+        self.dwp = ws.zbuf(self.cout, self.kpad)
+        self.amax = ws.zbuf(256, dtype=torch.int32)                  # max |dc| slots of this unit (see _Ops.to_s16)
         self.rows = max(64, (self.cin + 63) // 64 * 64) if self.cin >= 32 else 0   # dgrad filter rows
         self.wdp = ws.buf(self.rows, _kpad(9 * self.cout)) if self.rows else None
 
@@ -287,9 +320,8 @@ class _ConvBN:
                                                   _ptr(self.invstd), _ptr(self.scale), _ptr(self.shift), 1, c.B, c.H, c.W,
                                                   self.cout, _ptr(self.partial), s), "bn_bwd_reduce_bound")
             sums = torch.empty(2 * self.cout, device=o.dev, dtype=torch.float32)
-            o.amax.zero_()
             _chk(lib.ammc_bn_bwd_finalize_f32(_ptr(self.partial), self.nblk, self.cout, c.B * c.H * c.W, _ptr(self.scale),
-                                              _ptr(sums), o.amax.data_ptr(), s), "bn_bwd_finalize")
+                                              _ptr(sums), self.amax.data_ptr(), s), "bn_bwd_finalize")
             grads[self.bn.bias] = sums[:self.cout]
             grads[self.bn.weight] = sums[self.cout:]
             dc16 = o.shadow(self.dc)
@@ -297,7 +329,7 @@ class _ConvBN:
             _chk(lib.ammc_bn_bwd_apply_s16_f32(c.pix0(), *c.strides, dy.pix0(), *dy.strides, _ptr(self.mean),
                                                _ptr(self.invstd), _ptr(self.scale), _ptr(self.shift), _ptr(sums), 1,
                                                dc16.pix0(), None if s16_wgrad else self.dc.pix0(), *self.dc.strides,
-                                               c.B, c.H, c.W, self.cout, o.amax.data_ptr(), _ptr(inv), 1024, s),
+                                               c.B, c.H, c.W, self.cout, self.amax.data_ptr(), _ptr(inv), 1024, s),
                  "bn_bwd_apply_s16")
             pre = (dc16, inv)
         else:
@@ -315,13 +347,12 @@ class _ConvBN:
                 g = sums.clone()
                 o.all_reduce(g)
                 sums = g.mul_(1.0 / world)
-            if fused_amax:
-                o.amax.zero_()                                # bn_bwd_apply leaves max |dc| there for the S16 re-encoding
+            # (bn_bwd_apply leaves max |dc| in this unit's slots for the S16 re-encoding)
             _chk(lib.ammc_bn_bwd_apply_f32(c.pix0(), *c.strides, dy.pix0(), *dy.strides, _ptr(self.mean), _ptr(self.invstd),
                                            _ptr(self.scale), _ptr(self.shift), _ptr(sums), 1, self.dc.pix0(),
                                            *self.dc.strides, c.B, c.H, c.W, self.cout,
-                                           o.amax.data_ptr() if fused_amax else None, s), "bn_bwd_apply")
-            pre = o.to_s16(self.dc, rescale=True, have_amax=True) if fused_amax else None   # shared by wgrad and dgrad
+                                           self.amax.data_ptr() if fused_amax else None, s), "bn_bwd_apply")
+            pre = o.to_s16(self.dc, rescale=True, have_amax=True, amax=self.amax) if fused_amax else None   # shared by wgrad and dgrad
         if pre is not None and self.cin_p >= 8 and WGRAD_S16:
             o.wgrad_s16(pre[0], o.shadow(self.x), self.dwp, pre[1], n=self.cout, cin=self.cin_p,
                         what=self.name + ".wgrad", true_nc=self.cout * self.cin)            # shadow(x): the twin the forward conv left behind
@@ -402,8 +433,8 @@ class _Stream:
             self.x4q = ws.act(B, h, w, 512)
             self.bottom = self.x4q
             self.dz = ws.act(B, h, w, self.d, halo=0)
-            self.enc_dwp = ws.buf(max(self.d, 32), 512)
-            self.dec_dwp = ws.buf(512, _kpad(self.k * self.d))
+            self.enc_dwp = ws.zbuf(max(self.d, 32), 512)
+            self.dec_dwp = ws.zbuf(512, _kpad(self.k * self.d))
             self.enc_wT = ws.buf(512, _kpad(self.d))
             self.dx4 = ws.act(B, h, w, 512)
         # decoder (inputs are set by the owner: `bottom` may be replaced by the bridge output)
@@ -418,7 +449,7 @@ class _Stream:
             self.up_dc.append(_DoubleConv(ops, self.up_mods[j].conv, self.cat[lvl], out, None, f"up{j + 1}"))
             self.up_wp.append(ws.buf(4 * c, 2 * c))
             self.up_b4.append(ws.buf(4 * c))
-            self.up_dwp.append(ws.buf(2 * c, 4 * c))
+            self.up_dwp.append(ws.zbuf(2 * c, 4 * c))
             self.up_wT.append(ws.buf(2 * c, 4 * c))
         self.u3 = self.up_out[2]
         self.outc_wp = ws.buf(32, 576)
@@ -433,7 +464,8 @@ class _Stream:
         self.dpooled = [ws.act(B, H >> (i + 1), W >> (i + 1), CHANS[i]) for i in range(3)]
         # output layer: its gradient buffer is 64 channels wide (3 or 2 real ones) so that the S16 kernels' 64-filter
         # forms apply to its weight- and input-gradient; the fp32 path uses the first 32
-        self.outc_dwp = ws.buf(64, 576)
+        self.outc_dwp = ws.zbuf(64, 576)
+        self.outc_amax = ws.zbuf(256, dtype=torch.int32)
         self.outc_wdp = ws.buf(64, _kpad(9 * 64))
         self.scratch = ws.buf(lib.ammc_chan_reduce_blocks(B * H * W) * 512 + 1024)
 
@@ -496,10 +528,8 @@ class _Stream:
             self.up_dc[j].forward()
             y = self.up_out[j]
         net = self.net
-        self.w32.zero_()
-        self.w32[:self.cout].copy_(net.outc.weight.detach())
+        self.w32[:self.cout].copy_(net.outc.weight.detach())          # rows >= cout stay zero from allocation
         _chk(lib.ammc_pack_conv_weight_f32(_ptr(self.w32), 32, 64, 3, 64, _ptr(self.outc_wp), s), "pack")
-        self.outc_b.zero_()
         self.outc_b[:self.cout].copy_(net.outc.bias.detach())
         out = torch.empty((self.B, self.cout, self.H, self.W), device=o.dev, dtype=torch.float32)
         d = AmmcConvDesc()
@@ -532,7 +562,7 @@ class _Stream:
                                         *dp.strides, 32, s), "tanh_bwd")
         grads[net.outc.bias] = o.chan_sum(dp, 32, self.scratch)[:self.cout]
         if o.s16 and WGRAD_S16:
-            pre = o.to_s16(dp, rescale=True)
+            pre = o.to_s16(dp, rescale=True, amax=self.outc_amax)
             o.wgrad_s16(pre[0], o.shadow(self.u3), self.outc_dwp, pre[1], n=32, cin=64, what="outc.wgrad",
                         true_nc=self.cout * 64)
         else:
@@ -605,8 +635,11 @@ class _Stream:
 class TrainEngine:
     """training-mode forward/backward of `UNet`, `UNetMem_v7` or `twostream`"""
 
-    def __init__(self, module, kind: str):
-        self.module, self.kind = module, kind
+    def __init__(self, module, kind: str, precision: Optional[str] = None):
+        precision = precision or TRAIN_PRECISION
+        if precision not in ("fp32", "s16"):
+            raise ValueError("train precision must be 'fp32' (exact fp32 MFMA) or 's16' (split-fp16 MFMA 3x3 layers)")
+        self.module, self.kind, self.precision = module, kind, precision
         self._ws: Dict = {}
         self.generation = 0
 
@@ -615,7 +648,7 @@ class TrainEngine:
         st = self._ws.get(key)
         if st is None:
             ws = _WS(device)
-            ops = _Ops(ws)
+            ops = _Ops(ws, self.precision)
             m = self.module
             if self.kind == "twostream":
                 r = _Stream(ops, m.rgb, B, H, W, True)
@@ -678,6 +711,7 @@ class TrainEngine:
                                "by a later forward of the same shape (one forward per backward is supported)")
         streams: List[_Stream] = st["streams"]
         grads: Dict = {}
+        st["ops"].ws.zero_step()            # weight-gradient accumulators and max-|g| slots: one memset per 64-MB chunk
         reducer = getattr(self.module, "_grad_reducer", None)     # parallel.BucketedGradReducer or None
         sent = set()
 

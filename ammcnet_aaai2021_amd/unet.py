@@ -66,8 +66,9 @@ def _run(mod, kind: str, n_inputs: int, *inputs):
                 out = _fp32_engine(mod, kind).forward(*inputs)
                 object.__setattr__(mod, "s16_fallbacks", getattr(mod, "s16_fallbacks", 0) + 1)
         return out
-    if mod._train_engine is None:
-        object.__setattr__(mod, "_train_engine", TrainEngine(mod, kind))
+    tprec = getattr(mod, "train_precision", None)            # None: train.TRAIN_PRECISION (AMMC_TRAIN_PRECISION, "s16")
+    if mod._train_engine is None or (tprec is not None and mod._train_engine.precision != tprec):
+        object.__setattr__(mod, "_train_engine", TrainEngine(mod, kind, tprec))
     return HipPathFunction.apply(mod._train_engine, n_inputs, *inputs, *mod.parameters())
 
 

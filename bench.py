@@ -40,7 +40,7 @@ PEAK_F16_MFMA_TFLOPS = 2500.0     # dense fp16/bf16 MFMA
 PEAK_HBM_GBS = 8000.0
 PARITY_TOL = 1e-4                 # BASELINE.json north_star: 1e-4 relative fp32
 PARITY_FIXTURE = os.path.join(ROOT, "tests", "golden", "twostream_256_b16_m2000_eval.npz")
-S16_DTYPE = "f32-equivalent: (hi,lo) f16 split, 3x v_mfma_f32_32x32x16_f16, f32 accumulate"
+S16_DTYPE = "f32-equivalent: (hi,lo) f16 split, 3x v_mfma_f32_16x16x32_f16 (32x32x16 in the 8-wave variants), f32 accumulate"
 
 
 def parse():
@@ -240,7 +240,7 @@ def run_train(args, rank, world, dev, dist, steps, warmup, with_cpu):
     """one optimisation step of the shipped network (256 slots) per "step", batch 32 per GPU (weak scaling), gradients
     averaged over RCCL inside backward (parallel.BucketedGradReducer).  Returns the JSON object (rank 0) or None."""
     import ammcnet_aaai2021_amd as A
-    from ammcnet_aaai2021_amd import harness, parallel, synthetic as S, train as T
+    from ammcnet_aaai2021_amd import harness, parallel, synthetic as S
     from ammcnet_aaai2021_amd.workload import fwd_flops_per_clip
     batch = args.batch if (args.batch and args.mode == "train") else 32
     net = A.get_twostream((12, 6), (3, 2), 64, 256, 2)
@@ -267,11 +267,12 @@ def run_train(args, rank, world, dev, dist, steps, warmup, with_cpu):
     # per-kernel durations of the 3x3 layers' MFMA launches: one more step with every such launch bracketed by HIP
     # events on the launch stream (outside the timed region)
     roof, fams = None, {}
+    ops = net._train_engine._last["ops"]
     if rank == 0:
-        ops = net._train_engine._last["ops"]
         ops.timing = []
-        step()
-        torch.cuda.synchronize()
+    step()                                   # every rank takes the step (its gradient all-reduce is a collective)
+    torch.cuda.synchronize()
+    if rank == 0:
         for label, flops, e0, e1 in ops.timing:
             f = fams.setdefault(label, dict(ms=0.0, flops=0.0, launches=0))
             f["ms"] += e0.elapsed_time(e1)
@@ -280,7 +281,7 @@ def run_train(args, rank, world, dev, dist, steps, warmup, with_cpu):
         ops.timing = None
         if fams:
             name, f = max(fams.items(), key=lambda kv: kv[1]["ms"])
-            s16 = T.TRAIN_PRECISION == "s16"
+            s16 = net._train_engine.precision == "s16"
             peak = PEAK_F16_MFMA_TFLOPS if s16 else PEAK_F32_MFMA_TFLOPS
             ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
             roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
@@ -295,7 +296,7 @@ def run_train(args, rank, world, dev, dist, steps, warmup, with_cpu):
         "metric": "clips/sec, 256x256x4 dual-stream clips (twostream forward + backward + Adam, training)",
         "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": steps, "warmup": max(warmup, 1),
         "ms_per_step": round(1e3 * elapsed / steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if T.TRAIN_PRECISION == "fp32" else "f32-equivalent: (hi,lo) f16 split MFMA for the 3x3 convolutions, f32 elsewhere",
+        "dtype": "f32" if net._train_engine.precision == "fp32" else "f32-equivalent: (hi,lo) f16 split MFMA for the 3x3 convolutions, f32 elsewhere",
         "data": "synthetic",
         "config": {"workload": "Ped2 dual-stream + 256-slot memory + AMFT, batch 32 per GPU, fwd+bwd+Adam "
                                "(BASELINE.json configs[2]; configs[3] with --gpus 8)",

@@ -41,6 +41,12 @@ extern "C" {
 int ammc_abi_version(void);                    /* bumps on any signature change */
 const char* ammc_build_info(void);             /* "gfx950 ..." */
 const char* ammc_error_string(int code);
+/* Dispatch options, for A/B measurements and for tests that must reach every kernel instance:
+ *   "s16_mf"  MFMA shape of the halo-patch kernel (conv_tap_s16<..., MF>): -1 = the measured faster one per
+ *             variant (default), 1 = v_mfma_f32_16x16x32_f16, 0 = v_mfma_f32_32x32x16_f16.  Initial value: AMMC_S16_MF.
+ * Returns AMMC_EUNSUP for an unknown key, AMMC_EINVAL for a value out of range.  Not thread safe against
+ * concurrent launches. */
+int ammc_set_option(const char* key, int32_t value);
 
 /*
  * Implicit-GEMM convolution on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32):

@@ -103,20 +103,20 @@ def test_s16_dispatch_of_the_benchmark_shapes():
     from ammcnet_aaai2021_amd.engine import s16_variant
     B = 16
     want = {
-        (256, 64, 64): "conv_tap_s16<4, 1, 2, 2, 1>",          # inc.1, up3.1
-        (256, 128, 64): "conv_tap_s16<4, 1, 2, 2, 1>",         # up3.0
-        (128, 64, 128): "conv_tap_s16<4, 1, 2, 4, 1>",         # down1.0 ... the dominant variant (>= 512 tiles)
-        (128, 128, 128): "conv_tap_s16<4, 1, 2, 4, 1>",
-        (128, 256, 128): "conv_tap_s16<4, 1, 2, 4, 1>",
-        (64, 128, 256): "conv_tap_s16<4, 1, 2, 4, 1>",
-        (64, 256, 256): "conv_tap_s16<4, 1, 2, 4, 1>",
-        (64, 512, 256): "conv_tap_s16<4, 1, 2, 4, 1>",
-        (32, 256, 512): "conv_tap_s16<4, 2, 2, 2, 2>",         # 256 tiles: the 8-wave variant
-        (32, 512, 512): "conv_tap_s16<4, 2, 2, 2, 2>",
+        (256, 64, 64): "conv_tap_s16<4, 1, 2, 2, 1, 1>",          # inc.1, up3.1
+        (256, 128, 64): "conv_tap_s16<4, 1, 2, 2, 1, 1>",         # up3.0
+        (128, 64, 128): "conv_tap_s16<4, 1, 2, 4, 1, 0>",         # down1.0 ... the dominant variant (>= 512 tiles)
+        (128, 128, 128): "conv_tap_s16<4, 1, 2, 4, 1, 0>",
+        (128, 256, 128): "conv_tap_s16<4, 1, 2, 4, 1, 0>",
+        (64, 128, 256): "conv_tap_s16<4, 1, 2, 4, 1, 0>",
+        (64, 256, 256): "conv_tap_s16<4, 1, 2, 4, 1, 0>",
+        (64, 512, 256): "conv_tap_s16<4, 1, 2, 4, 1, 0>",
+        (32, 256, 512): "conv_tap_s16<4, 2, 2, 2, 2, 1>",         # 256 tiles: the 8-wave variant
+        (32, 512, 512): "conv_tap_s16<4, 2, 2, 2, 2, 1>",
     }
     for (hw, cin, n), label in want.items():
         assert s16_variant(_fake_desc(B, hw, hw, cin, n)) == label, (hw, cin, n)
-    assert s16_variant(_fake_desc(B, 256, 256, 64, 32, y_f32=1)) == "conv_tap_s16<8, 1, 1, 1, 1>"      # outc
+    assert s16_variant(_fake_desc(B, 256, 256, 64, 32, y_f32=1)) == "conv_tap_s16<8, 1, 1, 1, 1, 1>"      # outc
     assert s16_variant(_fake_desc(B, 256, 256, 16, 64)).startswith("conv_gemm_s16<")                   # inc.0 (12 -> 16 channels)
     assert s16_variant(_fake_desc(B, 32, 32, 512, 1024, ntaps=1, up=2)).startswith("conv_gemm_s16<")   # ConvTranspose
     # small batches fall back to the implicit GEMM (split-K below 192 tiles)
@@ -124,6 +124,13 @@ def test_s16_dispatch_of_the_benchmark_shapes():
     assert s16_variant(d) == "conv_gemm_s16<128x128>"
     d.splitk_ws, d.splitk_ws_floats = 0x400000, 8 << 20
     assert s16_variant(d).startswith("conv_gemm_s16<128x128>+splitk")
+    lib = _lib.load()                                                        # the A/B switch of the MFMA shape
+    assert lib.ammc_set_option(b"s16_mf", 1) == 0
+    assert s16_variant(_fake_desc(B, 128, 128, 128, 128)) == "conv_tap_s16<4, 1, 2, 4, 1, 1>"
+    assert lib.ammc_set_option(b"s16_mf", 0) == 0
+    assert s16_variant(_fake_desc(B, 256, 256, 64, 64)) == "conv_tap_s16<4, 1, 2, 2, 1, 0>"
+    assert lib.ammc_set_option(b"s16_mf", -1) == 0 and lib.ammc_set_option(b"s16_mf", 2) == -1
+    assert lib.ammc_set_option(b"no_such_option", 1) == -2
     bad = _fake_desc(1, 32, 32, 24, 64)                                      # cin not a power of two
     with pytest.raises(_lib.AmmcHipError):
         s16_variant(bad)

@@ -35,7 +35,16 @@ def _s16_read(a: Act) -> torch.Tensor:
     return y
 
 
-V64, V128, V8W = "conv_tap_s16<4, 1, 2, 2, 1>", "conv_tap_s16<4, 1, 2, 4, 1>", "conv_tap_s16<4, 2, 2, 2, 2>"
+# <WGM, WGN, TM, TN, AS, MF>; every variant exists for both MFMA shapes (MF: 1 = 16x16x32, the default; 0 = 32x32x16)
+V64, V128, V8W = "conv_tap_s16<4, 1, 2, 2, 1, %d>", "conv_tap_s16<4, 1, 2, 4, 1, %d>", "conv_tap_s16<4, 2, 2, 2, 2, %d>"
+
+
+@pytest.fixture(params=[1, 0], ids=["mfma16x16x32", "mfma32x32x16"])
+def mf(request):
+    lib = _lib.load()
+    _lib.check(lib.ammc_set_option(b"s16_mf", request.param), "set_option")
+    yield request.param
+    _lib.check(lib.ammc_set_option(b"s16_mf", -1), "set_option")          # back to the per-variant default
 
 
 @pytest.mark.parametrize("B,H,W,cin,n,relu,res,sliced,variant", [
@@ -50,7 +59,7 @@ V64, V128, V8W = "conv_tap_s16<4, 1, 2, 2, 1>", "conv_tap_s16<4, 1, 2, 4, 1>", "
     (32, 64, 64, 128, 128, True, False, True, V128),      # sliced input (the decoder's concat buffer)
     (16, 128, 128, 64, 128, True, False, False, V128),    # down1.0 of the benchmark
 ])
-def test_conv_tap_s16_vs_fp64(B, H, W, cin, n, relu, res, sliced, variant):
+def test_conv_tap_s16_vs_fp64(B, H, W, cin, n, relu, res, sliced, variant, mf):
     lib = _lib.load()
     tag = f"tap-{B}-{H}-{W}-{cin}-{n}"
     x = S.hashed_uniform(tag + "x", (B, cin, H, W)).to(DEV)
@@ -82,7 +91,7 @@ def test_conv_tap_s16_vs_fp64(B, H, W, cin, n, relu, res, sliced, variant):
         pa = Act(torch.zeros(B, H // 2 + 2, W // 2 + 2, n, device=DEV), B, H // 2, W // 2, n, 0, 1)
         d.pool_y = pa.pix0()
         d.pool_bs, d.pool_rs, d.pool_ps = pa.strides
-    assert s16_variant(d) == variant                   # the library's own dispatch: this case reaches that kernel
+    assert s16_variant(d) == (variant % mf if "%d" in variant else variant)                   # the library's own dispatch: this case reaches that kernel
     _lib.check(lib.ammc_conv_gemm_s16(C.byref(d), s), "conv_gemm_s16")
     got = _s16_read(ya).double().cpu()
     # reference on the operands as the kernel sees them (S16 round trip of x, w and the residual)
@@ -107,7 +116,7 @@ def test_conv_tap_s16_vs_fp64(B, H, W, cin, n, relu, res, sliced, variant):
 
 @pytest.mark.parametrize("B,H,W,cin,n,variant", [(12, 64, 64, 64, 64, V64), (12, 64, 64, 64, 128, V8W), (16, 64, 64, 32, 256, V128),
                                                  (48, 32, 32, 64, 128, V8W)])
-def test_conv_tap_fp32_output_with_fp32_residual(B, H, W, cin, n, variant):
+def test_conv_tap_fp32_output_with_fp32_residual(B, H, W, cin, n, variant, mf):
     """the form the training path uses (train.py `_Ops.conv_s16`): S16 operands, fp32 NHWC output, per-column scale
     (the undo of the gradient rescaling), fp32 residual - every conv_tap_s16 variant (4-wave 64x64 and 64x128 with
     one accumulator set, 8-wave with two)"""
@@ -131,7 +140,7 @@ def test_conv_tap_fp32_output_with_fp32_residual(B, H, W, cin, n, variant):
     d.x_bs, d.x_rs, d.x_ps = xa.strides
     d.y_bs, d.y_rs, d.y_ps = ya.strides
     d.r_bs, d.r_rs, d.r_ps = res.strides
-    assert s16_variant(d) == variant
+    assert s16_variant(d) == (variant % mf if "%d" in variant else variant)
     _lib.check(lib.ammc_conv_gemm_s16(C.byref(d), s), "conv_gemm_s16")
     got = ya.interior().permute(0, 3, 1, 2).double().cpu()
     wsa = Act(ws.view(1, 1, n, 9 * cin), 1, 1, n, 9 * cin, 0, 0)

@@ -143,9 +143,10 @@ def test_s16_overflow_in_a_middle_layer_at_256_through_the_harness():
     ref.load_state_dict(big)
     ref.precision = "fp32"
     want = harness.evaluate_dataset(ref, vids, "synthetic", device=DEV)
+    # (equal up to the order of the float atomics that accumulate the squared errors inside the `outc` kernel)
     for key in ("rgb_img_pred_records", "rgb_fea_comm_records", "op_img_pred_records", "op_fea_comm_records"):
         for a, b in zip(got[key], want[key]):
-            assert np.array_equal(a, b), key
+            assert np.allclose(a, b, rtol=2e-6, atol=0), key
     assert all(np.isfinite(r).all() for r in got["rgb_img_pred_records"])
     # and with clean parameters nothing falls back
     net2, _ = _net()
@@ -191,8 +192,8 @@ def test_s16_dispatch_is_consistent_across_shapes(B, H, W):
         assert abs(float(x) - float(y)) <= 1e-5 * abs(float(y))
 
 
-@pytest.mark.parametrize("prec", ["s16", "fp32"])
-def test_benchmark_workload_b16_256_m2000_vs_reference_vectors(prec):
+@pytest.mark.parametrize("prec,mf", [("s16", 1), ("s16", 0), ("fp32", 1)])
+def test_benchmark_workload_b16_256_m2000_vs_reference_vectors(prec, mf):
     """BASELINE.json configs[1] exactly as bench.py runs it (batch 16, 256x256, 2000 slots) against vectors recorded
     from the reference (`twostream.forward`, unet.py:981-1007): frames, commit scalars, quantised maps, per-sample
     PSNR and per-stage activations; the S16 run must be made of the kernel variants the benchmark reports."""
@@ -202,8 +203,14 @@ def test_benchmark_workload_b16_256_m2000_vs_reference_vectors(prec):
     net, sd = _net(cfg["n_embed"], cfg["k"])
     net.precision = prec
     rgb_x, op_x, rgb_t, _ = S.make_clips(cfg["batch"], cfg["hw"], cfg["hw"], tag=cfg["tag"])
-    with torch.no_grad():
-        (rgb, op, (rd, od), (rq, oq)), psnr, _ = net.forward_scored(rgb_x.to(DEV), op_x.to(DEV), rgb_t.to(DEV))
+    lib = _lib.load()
+    _lib.check(lib.ammc_set_option(b"s16_mf", mf), "set_option")       # MFMA shape of the halo-patch kernel (A/B switch)
+    try:
+        with torch.no_grad():
+            (rgb, op, (rd, od), (rq, oq)), psnr, _ = net.forward_scored(rgb_x.to(DEV), op_x.to(DEV), rgb_t.to(DEV))
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(lib.ammc_set_option(b"s16_mf", -1), "set_option")
     eng, st = net._engine, net._engine._last
     assert eng.precision == prec
     step, qs, rows = int(d["out_step"]), int(d["q_step"]), list(d["st_rows"])
@@ -222,6 +229,6 @@ def test_benchmark_workload_b16_256_m2000_vs_reference_vectors(prec):
     assert max(errs.values()) <= TOL, errs
     if prec == "s16":
         kernels = {m["kernel"] for m in st["plan"].meta} | {s.outc_kernel for s in st["streams"]}
-        assert {"conv_tap_s16<4, 1, 2, 4, 1>", "conv_tap_s16<4, 1, 2, 2, 1>", "conv_tap_s16<4, 2, 2, 2, 2>",
-                "conv_tap_s16<8, 1, 1, 1, 1>", "conv_gemm_s16<128x128>", "conv_gemm_s16<128x64>"} <= kernels, kernels
+        assert {f"conv_tap_s16<4, 1, 2, 4, 1, {mf}>", f"conv_tap_s16<4, 1, 2, 2, 1, {mf}>", f"conv_tap_s16<4, 2, 2, 2, 2, {mf}>",
+                f"conv_tap_s16<8, 1, 1, 1, 1, {mf}>", "conv_gemm_s16<128x128>", "conv_gemm_s16<128x64>"} <= kernels, kernels
         assert not eng.overflowed()

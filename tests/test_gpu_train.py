@@ -2,12 +2,15 @@
 parameter gradient and the in-place buffer updates (BatchNorm running statistics, EMA
 codebook), against the CPU oracle with autograd and the vectors recorded from the reference.
 
-Tolerances: outputs 1e-4 of max|ref|; buffers 1e-4; gradients per tensor, L2-relative:
-  max over tensors <= 1e-2, median <= 2e-3, and the tensors downstream of no ReLU-kink flip
-  agree to ~1e-5.  SURVEY.md 8(d) guessed 1e-3; the fixture itself is noisier than that: the
-  reference's OWN fp32 and fp64 gradients differ by 2e-3 on the rgb decoder / bridge.O2F
-  tensors (a pre-activation within fp32 noise of 0 flips its ReLU mask, which moves a whole
-  dbeta entry), measured with the oracle in both precisions."""
+Two kinds of gradient gates (L2-relative per tensor):
+  * TIGHT, on a fixture without ReLU flips (`test_gradients_without_relu_flips_match_the_fp64_oracle`): 1e-4 against
+    the oracle in float64 (measured: 3.6e-6 max for the default S16 training kernels);
+  * ENVELOPE, on the reference-recorded fixture: a pre-activation within rounding noise of 0 flips its ReLU mask and
+    moves a whole dbeta entry, so the reference's OWN fp32 and fp64 gradients differ by 2.4e-3 max / 2.2e-4 median
+    there (tools/grad_envelope.py prints all three columns).  Gates = 1.5x what the kernels measure against float64
+    on this fixture: S16 6.5e-3 / 3.3e-4, exact fp32 5.4e-3 / 1.7e-3 (its sequential fp32 accumulation flips more
+    masks than the S16 kernels' tree sums).  SURVEY.md 8(d)'s 1e-3 guess is below the fixture's own noise.
+Outputs 1e-4 of max|ref|; buffers 1e-4."""
 import json
 import os
 
@@ -22,8 +25,11 @@ from conftest import GOLDEN, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-GTOL = 1e-2          # per-tensor ceiling (see the module docstring)
-GMED = 2e-3          # median over tensors
+GTOL = 1e-2          # per-tensor ceiling of the envelope gates (see the module docstring)
+GMED = {"s16": 5e-4, "fp32": 2.5e-3}          # median over tensors, per training precision
+# parameters whose gradient passes through a max-pool backward: a near-tie inside a 2x2 window (|a - b| ~ 1e-6 |a|) picks
+# another element when the forward value moves in its last bits - the one discontinuity left on the mask-free fixture
+POOL_UPSTREAM = ("rgb.inc.", "rgb.down1.", "rgb.down2.", "op.inc.", "op.down1.", "op.down2.")
 
 
 def _l2rel(a, b):
@@ -31,9 +37,10 @@ def _l2rel(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
-def _train_step(net, sd, batch, hw, tag, k=2):
+def _train_step(net, sd, batch, hw, tag, k=2, train_precision="s16"):
     rgb_x, op_x, rgb_t, op_t = S.make_clips(batch, hw, hw, tag=tag)
     net.train()
+    net.train_precision = train_precision
     out = net(rgb_x.to(DEV), op_x.to(DEV))
     loss = O.generator_loss(out, rgb_t.to(DEV), op_t.to(DEV))
     loss.backward()
@@ -44,22 +51,26 @@ def _train_step(net, sd, batch, hw, tag, k=2):
     return out, loss, want, wloss, msd
 
 
-def test_twostream_train_step_vs_oracle_and_golden():
+@pytest.mark.parametrize("train_precision", ["s16", "fp32"])
+def test_twostream_train_step_vs_oracle_and_golden(train_precision):
     d = np.load(os.path.join(GOLDEN, "twostream_64_b2_train.npz"))
     cfg = json.loads(str(d["cfg"]))
     sd = S.make_twostream_state()
     net = A.get_twostream((12, 6), (3, 2), 64, 256, 2)
     net.load_state_dict(sd)
     net = net.to(DEV)
-    out, loss, want, wloss, msd = _train_step(net, sd, cfg["batch"], cfg["hw"], cfg["tag"])
+    out, loss, want, wloss, msd = _train_step(net, sd, cfg["batch"], cfg["hw"], cfg["tag"], train_precision=train_precision)
+    assert net._train_engine.precision == train_precision
     assert rel_err(out[0].detach().cpu(), want[0]) <= 1e-4 and rel_err(out[1].detach().cpu(), want[1]) <= 1e-4
     assert rel_err(out[0].detach().cpu(), d["rgb"]) <= 1e-4 and rel_err(out[1].detach().cpu(), d["op"]) <= 1e-4
     assert rel_err(out[2][0].detach().cpu(), want[2][0]) <= 1e-4 and rel_err(out[2][1].detach().cpu(), want[2][1]) <= 1e-4
     assert abs(float(loss) - float(d["loss"])) <= 1e-4 * abs(float(d["loss"]))
+    # gradients against the oracle in FLOAT64 (the envelope gates of the module docstring)
+    _, g64, _ = _oracle_grads(sd, S.make_clips(cfg["batch"], cfg["hw"], cfg["hw"], tag=cfg["tag"]), torch.float64)
     bad, errs = [], []
     for name, p in net.named_parameters():
         assert p.grad is not None, name
-        e = _l2rel(p.grad.cpu(), msd[name].grad)
+        e = _l2rel(p.grad.cpu(), g64[name])
         errs.append(e)
         if e > GTOL:
             bad.append((name, e))
@@ -67,7 +78,7 @@ def test_twostream_train_step_vs_oracle_and_golden():
         gn = float(d[f"gn.{name}"])
         assert abs(float(p.grad.double().norm()) - gn) <= 2e-3 * gn + 1e-10, name
     assert not bad, bad
-    assert float(np.median(errs)) <= GMED and min(errs) <= 1e-5, (np.median(errs), min(errs))
+    assert float(np.median(errs)) <= GMED[train_precision] and min(errs) <= 1e-5, (np.median(errs), min(errs))
     # buffers updated inside forward: BN running stats, num_batches_tracked, EMA codebook
     nsd = net.state_dict()
     for key, v in msd.items():
@@ -77,6 +88,69 @@ def test_twostream_train_step_vs_oracle_and_golden():
     for key in d.files:
         if key.startswith("buf."):
             assert rel_err(nsd[key[4:]].cpu().double(), d[key].astype(np.float64)) <= 1e-4, key
+
+
+def _mask_free_state(tag="ammc"):
+    """the synthetic parameters with every BatchNorm affine set to gamma = +-0.2, beta = 2: relu(gamma * xhat + beta)
+    never clips, so no ReLU mask can flip between two evaluations of the step - what is left of the network (batch
+    statistics, the memory block, max-pool, tanh, every conv / ConvTranspose) is a smooth function of the weights"""
+    sd = S.make_twostream_state(tag=tag)
+    out = {}
+    for k, v in sd.items():
+        leaf = k.rsplit(".", 1)[-1]
+        if leaf in ("weight", "bias") and v.dim() == 1 and (k[:-len(leaf)] + "running_mean") in sd:
+            out[k] = 0.2 * torch.sign(v) if leaf == "weight" else torch.full_like(v, 2.0)
+        else:
+            out[k] = v.clone()
+    return out
+
+
+def _oracle_grads(sd, clips, dtype):
+    rgb_x, op_x, rgb_t, op_t = (t.to(dtype) for t in clips)
+    m = O.clone_state({k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}, requires_grad=True)
+    out = O.twostream_forward(m, rgb_x, op_x, 2, training=True)
+    loss = O.generator_loss(out, rgb_t, op_t)
+    loss.backward()
+    return float(loss.detach()), {k: v.grad.double() for k, v in m.items() if v.requires_grad}, [o.detach() for o in out[:2]]
+
+
+@pytest.mark.parametrize("train_precision", ["s16", "fp32"])
+def test_gradients_without_relu_flips_match_the_fp64_oracle(train_precision):
+    """The tight gradient gate.  On the ordinary fixtures a pre-activation within rounding noise of 0 flips its ReLU
+    mask and moves whole gradient entries (the reference's own fp32 and fp64 gradients differ by 2e-3 there), so those
+    gates cannot be tight.  Here no mask can flip (`_mask_free_state`), the truth is the oracle in FLOAT64, and every
+    gradient tensor of both training precisions must agree with it to 1e-4 L2-relative - or, for the few tensors where
+    the oracle's own fp32 evaluation is noisier than 3e-5 against fp64 (ill-conditioned sums), to 3x that noise.
+    One discontinuity is left, max-pool near-ties: the exact-fp32 kernels (an fmaf chain over K up to 4608 per output)
+    move forward values in the 6th digit, which re-routes ~0.01 % of the pooling windows (tools/train_fp32_debug.py:
+    the inputs of `maxpool2x2_bwd` agree to 6e-6, its outputs to 1.7e-2); the S16 kernels' tree sums stay below the
+    tie gaps of this fixture.  For `train_precision = "fp32"` the tensors upstream of a max-pool are therefore held
+    to 8e-3 only; everything else, and every tensor of the default S16 path, to the tight gate."""
+    sd = _mask_free_state()
+    clips = S.make_clips(2, 64, 64, tag="maskfree")
+    loss64, g64, out64 = _oracle_grads(sd, clips, torch.float64)
+    _, g32, _ = _oracle_grads(sd, clips, torch.float32)
+    net = A.get_twostream((12, 6), (3, 2), 64, 256, 2)
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    net.train_precision = train_precision
+    rgb_x, op_x, rgb_t, op_t = (t.to(DEV) for t in clips)
+    out = net(rgb_x, op_x)
+    assert net._train_engine.precision == train_precision
+    loss = O.generator_loss(out, rgb_t, op_t)
+    loss.backward()
+    assert abs(float(loss) - loss64) <= 2e-6 * abs(loss64)
+    assert rel_err(out[0].detach().cpu(), out64[0]) <= 1e-5 and rel_err(out[1].detach().cpu(), out64[1]) <= 1e-5
+    bad, errs = [], []
+    for name, p in net.named_parameters():
+        e = _l2rel(p.grad.cpu(), g64[name])
+        noise = _l2rel(g32[name], g64[name])
+        errs.append(e)
+        loose = train_precision == "fp32" and name.startswith(POOL_UPSTREAM)
+        if e > (8e-3 if loose else max(1e-4, 3.0 * noise)):
+            bad.append((name, e, noise))
+    assert not bad, bad
+    assert float(np.median(errs)) <= 2e-5, float(np.median(errs))
 
 
 def test_eval_after_train_uses_updated_buffers():
@@ -179,7 +253,7 @@ def test_train_step_at_sizes_the_halo_patch_kernels_take():
         errs.append(_l2rel(p.grad.cpu(), ref))
     errs = np.array(errs)
     # (ReLU-kink noise as above; on this fixture the exact-fp32 kernels land at 7e-3 / 2.7e-3, the S16 ones at 5e-3 / 1.5e-3)
-    assert errs.max() <= GTOL and np.median(errs) <= 2 * GMED and errs.min() <= 1e-5, (errs.max(), np.median(errs), errs.min())
+    assert errs.max() <= GTOL and np.median(errs) <= 4e-3 and errs.min() <= 1e-5, (errs.max(), np.median(errs), errs.min())
     nsd = net.state_dict()
     for key, v in msd.items():
         if key not in dict(net.named_parameters()):
