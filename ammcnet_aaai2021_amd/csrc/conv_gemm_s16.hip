@@ -694,7 +694,8 @@ static int conv_gemm_s16_dispatch(const AmmcConvDesc* desc, void* stream, char* 
   // 128-row ones; they pay off once there are enough tiles to fill the chip
   // ... and the K loop is long enough to amortise a prologue/epilogue that nothing overlaps (one workgroup per CU);
   // short-K layers (ConvTranspose, K = Cin <= 512) keep the 128-row tiles, three workgroups per CU
-  const bool many = M >= (int64_t)256 * 512 / (d.n >= 256 ? d.n / 128 : 1) && a.nchunks > 16;
+  static const int bigk = getenv("AMMC_S16_BIGK") ? atoi(getenv("AMMC_S16_BIGK")) : 16;      // (experiments)
+  const bool many = M >= (int64_t)256 * 512 / (d.n >= 256 ? d.n / 128 : 1) && a.nchunks > bigk;
   if (d.n % 128 == 0) return (big && many) ? launch<4, 2, 2, 2>(a, s, label, label_len) : launch<2, 2, 2, 2>(a, s, label, label_len);
   return launch<4, 1, 1, 2>(a, s, label, label_len);
 }

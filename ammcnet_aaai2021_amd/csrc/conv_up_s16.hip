@@ -1,0 +1,439 @@
+// `up.forward` of the decoder (reference models/unet.py:50-59) as ONE kernel in inference:
+//     y = relu(bn(conv3x3(cat([skip, ConvTranspose2d(x, k 2, s 2) + b]))))            (the first conv of `up.conv`)
+//
+// Why: at batch 16 the three ConvTranspose launches per stream take 0.3 ms at 1.4-3 TB/s, and their outputs
+// (67-268 MB) are written once and read once more by the 3x3 conv that follows.  Both operators are linear, so the
+// up half of the 3x3 conv is composed with the transposed conv ONCE, at weight-packing time
+// (ammc_pack_up_conv_f32): output pixel (2 y + py, 2 x + px) sees the 2 x 2 source pixels (y + sy + py - 1,
+// x + sx + px - 1) of x through filters that depend on its parity class (py, px) only,
+//     W'[py][px][sy][sx][co][ci] = sum over the taps (r, s) whose up-pixel has that source pixel of
+//                                  W3[co][c + cu][r][s] * Wt[ci][cu][dy][dx]       (summed over cu, in double),
+// 8 c instead of 9 c multiply-adds per output and filter, no intermediate tensor, no ConvTranspose launch.  Zero padding
+// composes exactly (a tap outside the image reads a source pixel outside the image: the halo, zero); the transposed
+// conv's bias passes through the taps that are inside the image, i.e. it becomes a shift that depends on the border
+// class of the output pixel: shift9[3][3][n] = shift + scale * (sum of the inside taps' W3 . b).
+//
+// Structure: the halo-patch kernel (conv_tap_s16.hip, 16x16x32 MFMA form) with the output pixels of a workgroup's
+// 8 x 32 patch owned by PARITY CLASS: wave (py, px) holds the 4 x 16 pixels (2 y' + py, 2 x' + px) as four 16-pixel
+// MFMA tiles.  Phase A = the skip half: ordinary 3x3 taps over the skip patch, whose columns are stored even / odd
+// de-interleaved in LDS so that a tile's 16 stride-2 pixels are 16 consecutive LDS rows (conflict-free fragment reads
+// as in the tap kernel); one filter slice per tap, shared by the four waves.  Phase B = the composed half: per
+// 32-channel block of x a 6 x 18 source patch, per 2x2 tap one stage of four class slices (64 filters each), every wave
+// reading ITS class - the same fragment reads per MFMA as phase A.  The LDS regions of the two phases overlay:
+// 80 KB per workgroup, two workgroups per CU.
+#include "ammc_common.h"
+#include <hip/hip_fp16.h>
+#include <stdio.h>
+
+namespace ammc_s16 {
+
+typedef _Float16 f16x8u __attribute__((ext_vector_type(8)));
+
+struct UpArgs {
+  AmmcConvDesc d;        // the 3x3 conv over the SKIP tensor: x (halo corner), cin = c, w = full filter [n][kpad], scale, y ...
+  const float* x2;       // the tensor the transposed conv reads (half resolution, halo 1, S16): its halo corner
+  int64_t x2_bs, x2_rs, x2_ps;
+  const float* w2;       // composed filters, S16 [n][kpad2], k = (tap2 * 4 + class) * cin2 + ch
+  const float* shift9;   // [3][3][n]
+  int cin2, ncc1, ncc2, ncc_full, kpad, kpad2, tiles_x, tiles_y, n_tiles;
+};
+
+constexpr float U_LO_SCALE = 2048.f;
+constexpr float U_LO_INV = 1.f / 2048.f;
+constexpr int U_TH = 8, U_TW = 32, U_HW = U_TW + 2;
+constexpr int U_NT = 256;
+constexpr int U_APIECES = (U_TH + 2) * U_HW * 8;                       // 2720 16-byte pieces of the skip patch
+constexpr int U_AROUNDS = (U_APIECES + U_NT - 1) / U_NT;               // 11
+constexpr int U_ASTAGE = U_AROUNDS * U_NT * 4;                         // floats (45056 B)
+constexpr int U_SH = U_TH / 2 + 2, U_SW = U_TW / 2 + 2;                // 6 x 18 source pixels
+constexpr int U_SPIECES = U_SH * U_SW * 8;                             // 864
+constexpr int U_SROUNDS = (U_SPIECES + U_NT - 1) / U_NT;               // 4
+constexpr int U_SSTAGE = U_SROUNDS * U_NT * 4;                         // floats (16 KB)
+constexpr int U_B2STAGE = 4 * 64 * 32;                                 // four class slices of 64 filters (32 KB)
+constexpr int U_B2J = U_B2STAGE / 4 / U_NT;                            // 8 pieces per thread per stage
+
+template <int TN>      // BN = 32 TN filters per workgroup: 64 (TN 2) or 128 (TN 4)
+__global__ __launch_bounds__(U_NT, 2) void conv_up_s16_kernel(UpArgs a) {
+  constexpr int BN = 32 * TN;
+  constexpr int FT = 2 * TN;                   // 16-filter tiles
+  constexpr int FC = 4;                        // filter tiles whose fragments are live at once (= one phase-B slice)
+  constexpr int BJ = BN * 8 / U_NT;            // phase A: filter pieces per thread per tap
+  constexpr int B_STAGE = BN * 32;             // floats
+  constexpr int NH = BN / 64;                  // phase B: 64-filter halves
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                            // phase A: skip patch, then two filter stages
+  float* Bs = smem + U_ASTAGE;
+  float* Ss = smem;                            // phase B (overlays phase A): source patch, then two stages of class slices
+  float* B2 = smem + U_SSTAGE;
+  static_assert(U_ASTAGE + 2 * B_STAGE <= U_SSTAGE + 2 * U_B2STAGE, "phase A fits the phase B footprint");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;                   // = parity class of this wave's output pixels
+  const int py = wave >> 1, px = wave & 1;
+  const int l15 = lane & 15, g4 = lane >> 4;
+  const AmmcConvDesc& d = a.d;
+
+  const int logical = ammc_xcd_remap(blockIdx.x, gridDim.x);
+  if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(1);     // see conv_tap_s16.hip: de-phase the two workgroups of a CU
+  const int n0 = (logical % a.n_tiles) * BN;
+  int sp = logical / a.n_tiles;
+  const int tx = sp % a.tiles_x;
+  sp /= a.tiles_x;
+  const int ty = sp % a.tiles_y;
+  const int b = sp / a.tiles_y;
+  const int y0 = ty * U_TH, x0 = tx * U_TW;
+
+  const float* xpatch = d.x + ((int64_t)b * d.x_bs + (int64_t)y0 * d.x_rs + (int64_t)x0 * d.x_ps);
+  const float* spatch = a.x2 + ((int64_t)b * a.x2_bs + (int64_t)(y0 >> 1) * a.x2_rs + (int64_t)(x0 >> 1) * a.x2_ps);
+
+  // DMA pieces: piece p -> LDS row R = p >> 3, physical slot p & 7, which holds source piece pi((p & 7) ^ (R & 7))
+  // (pi swaps 2 <-> 3 and 6 <-> 7; conv_tap_s16.hip, MF = 1).  Skip patch: LDS row R = hy * 34 + pos holds column
+  // hx = 2 pos (pos < 17) or 2 (pos - 17) + 1: even columns first, then the odd ones.
+  int a_off[U_AROUNDS];
+#pragma unroll
+  for (int j = 0; j < U_AROUNDS; ++j) {
+    int p = j * U_NT + tid;
+    p = p < U_APIECES ? p : U_APIECES - 1;
+    const int R = p >> 3;
+    int ls = (p & 7) ^ (R & 7);
+    ls ^= (ls >> 1) & 1;
+    const int hy = R / U_HW, pos = R - hy * U_HW;
+    const int hx = pos < 17 ? 2 * pos : 2 * (pos - 17) + 1;
+    a_off[j] = (int)((int64_t)hy * d.x_rs + (int64_t)hx * d.x_ps) + 4 * ls;
+  }
+  int s_off[U_SROUNDS];
+#pragma unroll
+  for (int j = 0; j < U_SROUNDS; ++j) {
+    int p = j * U_NT + tid;
+    p = p < U_SPIECES ? p : U_SPIECES - 1;
+    const int R = p >> 3;
+    int ls = (p & 7) ^ (R & 7);
+    ls ^= (ls >> 1) & 1;
+    const int sy = R / U_SW, sx = R - sy * U_SW;
+    s_off[j] = (int)((int64_t)sy * a.x2_rs + (int64_t)sx * a.x2_ps) + 4 * ls;
+  }
+  // filter rows of a stage are stored tile by tile: LDS row 16 t + r holds filter 32 (t >> 1) + 8 (r >> 2) + 4 (t & 1) + (r & 3)
+  int sl = (tid & 7) ^ ((tid >> 3) & 7);
+  sl ^= (sl >> 1) & 1;
+  const float* b_src[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    int row = j * (U_NT / 8) + (tid >> 3);
+    row = (row & ~31) | (((row >> 2) & 3) << 3) | (((row >> 4) & 1) << 2) | (row & 3);
+    b_src[j] = d.w + (int64_t)(n0 + row) * a.kpad + 4 * sl;
+  }
+  // phase B stage: piece p = j * 256 + tid -> class slice p >> 9 (64 rows x 8 pieces), row (p >> 3) & 63 of the slice
+  int b2_off[U_B2J];
+#pragma unroll
+  for (int j = 0; j < U_B2J; ++j) {
+    const int p = j * U_NT + tid;
+    const int cls = p >> 9;
+    int row = (p >> 3) & 63;
+    row = (row & ~31) | (((row >> 2) & 3) << 3) | (((row >> 4) & 1) << 2) | (row & 3);
+    b2_off[j] = row * a.kpad2 + cls * a.cin2 + 4 * sl;           // (+ n0 + 64 half, + (tap2 * 4) * cin2 + 32 cb: per step)
+  }
+  const float* w2base = a.w2 + (int64_t)n0 * a.kpad2;
+
+#define UP_ISSUE_A(cc)                                                                \
+  _Pragma("unroll") for (int j_ = 0; j_ < U_AROUNDS; ++j_) {                          \
+    const float* src_ = xpatch + a_off[j_] + (cc) * 32;                               \
+    float* dst_ = As + (j_ * U_NT + wave * 64) * 4;                                   \
+    __builtin_amdgcn_global_load_lds(src_, dst_, 16, 0, 0);                           \
+  }
+#define UP_ISSUE_S(cb)                                                                \
+  _Pragma("unroll") for (int j_ = 0; j_ < U_SROUNDS; ++j_) {                          \
+    const float* src_ = spatch + s_off[j_] + (cb) * 32;                               \
+    float* dst_ = Ss + (j_ * U_NT + wave * 64) * 4;                                   \
+    __builtin_amdgcn_global_load_lds(src_, dst_, 16, 0, 0);                           \
+  }
+#define UP_ISSUE_B(chunk, stage)                                                      \
+  _Pragma("unroll") for (int j_ = 0; j_ < BJ; ++j_) {                                 \
+    const float* src_ = b_src[j_] + (chunk) * 32;                                     \
+    float* dst_ = Bs + (stage) * B_STAGE + (j_ * U_NT + wave * 64) * 4;               \
+    __builtin_amdgcn_global_load_lds(src_, dst_, 16, 0, 0);                           \
+  }
+#define UP_ISSUE_B2(tap2, half, cb, stage)                                            \
+  _Pragma("unroll") for (int j_ = 0; j_ < U_B2J; ++j_) {                              \
+    const float* src_ = w2base + (int64_t)(half) * 64 * a.kpad2 + b2_off[j_] + (tap2) * 4 * a.cin2 + (cb) * 32; \
+    float* dst_ = B2 + (stage) * U_B2STAGE + (j_ * U_NT + wave * 64) * 4;             \
+    __builtin_amdgcn_global_load_lds(src_, dst_, 16, 0, 0);                           \
+  }
+#define UP_WAIT_ALL()                                  \
+  {                                                    \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   \
+    __builtin_amdgcn_s_barrier();                      \
+    asm volatile("" ::: "memory");                     \
+  }
+
+  f32x4 acc[4][FT];                           // [pixel tile y'][filter tile]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < FT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int slot_hi = 2 * g4 + (g4 & 1), slot_lo = slot_hi ^ 1;
+  const int swzb = l15 & 7;
+
+  // one MFMA group: the four pixel tiles (fragments ah / ax / al2 resident) against filter tiles [f0, f0 + FC) read at Bc
+#define UP_MFMAS(Bc, f0)                                                                                   \
+  {                                                                                                        \
+    f16x8u bh[FC], bl[FC];                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < FC; ++j) {                                                       \
+      bh[j] = *reinterpret_cast<const f16x8u*>((Bc) + (j * 16 + l15) * 32 + ((slot_hi ^ swzb) << 2));      \
+      bl[j] = *reinterpret_cast<const f16x8u*>((Bc) + (j * 16 + l15) * 32 + ((slot_lo ^ swzb) << 2));      \
+    }                                                                                                      \
+    _Pragma("unroll") for (int pt = 0; pt < 4; ++pt) _Pragma("unroll") for (int j = 0; j < FC; ++j)        \
+      acc[pt][(f0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[pt], acc[pt][(f0) + j], 0, 0, 0);   \
+    _Pragma("unroll") for (int pt = 0; pt < 4; ++pt) _Pragma("unroll") for (int j = 0; j < FC; ++j)        \
+      acc[pt][(f0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ax[pt], acc[pt][(f0) + j], 0, 0, 0);   \
+    _Pragma("unroll") for (int pt = 0; pt < 4; ++pt) _Pragma("unroll") for (int j = 0; j < FC; ++j)        \
+      acc[pt][(f0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al2[pt], acc[pt][(f0) + j], 0, 0, 0);  \
+  }
+  // pixel fragments of the four tiles from LDS rows rbase + pt * rstep + l15 of patch image P
+#define UP_AFRAGS(P, rbase, rstep)                                                                         \
+  f16x8u ah[4], ax[4], al2[4];                                                                             \
+  _Pragma("unroll") for (int pt = 0; pt < 4; ++pt) {                                                       \
+    int R_ = (rbase) + pt * (rstep) + l15;                                                                 \
+    asm volatile("" : "+v"(R_));                                                                           \
+    const float* ap_ = (P) + R_ * 32;                                                                      \
+    const int sw_ = R_ & 7;                                                                                \
+    ah[pt] = *reinterpret_cast<const f16x8u*>(ap_ + ((slot_hi ^ sw_) << 2));                               \
+    const f16x8u al_ = *reinterpret_cast<const f16x8u*>(ap_ + ((slot_lo ^ sw_) << 2));                     \
+    ax[pt] = ah[pt] * (_Float16)U_LO_INV;                                                                  \
+    al2[pt] = al_ * (_Float16)U_LO_INV;                                                                    \
+  }
+
+  // ---- phase A: 3x3 taps over the skip patch -------------------------------------------------------------------------
+  // tile y' of this wave, tap (r, s): halo row 2 y' + py + r, columns 2 l15 + px + s: parity (px + s) & 1, index
+  // l15 + ((px + s) >> 1) -> LDS row (2 y' + py + r) * 34 + parity * 17 + index
+  UP_ISSUE_A(0)
+  UP_ISSUE_B(0, 0)
+  UP_WAIT_ALL()
+  int bs = 0;
+  for (int cc = 0; cc < a.ncc1; ++cc) {
+    if (cc > 0) {
+      UP_ISSUE_A(cc)
+      UP_WAIT_ALL()
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap < 8) {
+        UP_ISSUE_B((tap + 1) * a.ncc_full + cc, bs ^ 1)
+      } else if (cc + 1 < a.ncc1) {
+        UP_ISSUE_B(cc + 1, bs ^ 1)
+      }
+      {
+        const int r = tap / 3, s = tap % 3;
+        const int rb = (py + r) * U_HW + ((px + s) & 1) * 17 + ((px + s) >> 1);
+        UP_AFRAGS(As, rb, 2 * U_HW)
+        const float* Bc = Bs + bs * B_STAGE;
+#pragma unroll
+        for (int f0 = 0; f0 < FT; f0 += FC) UP_MFMAS(Bc + f0 * 512, f0)
+      }
+      UP_WAIT_ALL()
+      bs ^= 1;
+    }
+  }
+
+  // ---- phase B: 2x2 taps over the source patch, class filters ---------------------------------------------------------
+  // tile y' of this wave, tap (sy, sx): source patch row y' + sy + py, columns l15 + sx + px (patch origin = source
+  // pixel (y0 / 2 - 1, x0 / 2 - 1))
+  UP_ISSUE_S(0)
+  UP_ISSUE_B2(0, 0, 0, 0)
+  UP_WAIT_ALL()
+  bs = 0;
+  for (int cb = 0; cb < a.ncc2; ++cb) {
+    if (cb > 0) {
+      UP_ISSUE_S(cb)
+      UP_WAIT_ALL()
+    }
+#pragma unroll
+    for (int st = 0; st < 4 * NH; ++st) {
+      const int tap2 = st / NH, half = st % NH;
+      if (st + 1 < 4 * NH) {
+        UP_ISSUE_B2((st + 1) / NH, (st + 1) % NH, cb, bs ^ 1)
+      } else if (cb + 1 < a.ncc2) {
+        UP_ISSUE_B2(0, 0, cb + 1, bs ^ 1)
+      }
+      {
+        const int sy = tap2 >> 1, sx = tap2 & 1;
+        const int rb = (sy + py) * U_SW + sx + px;
+        UP_AFRAGS(Ss, rb, U_SW)
+        const float* Bc = B2 + bs * U_B2STAGE + wave * (64 * 32);          // this wave's class slice
+        UP_MFMAS(Bc, half * 4)
+      }
+      UP_WAIT_ALL()
+      bs ^= 1;
+    }
+  }
+#undef UP_ISSUE_A
+#undef UP_ISSUE_S
+#undef UP_ISSUE_B
+#undef UP_ISSUE_B2
+#undef UP_WAIT_ALL
+#undef UP_MFMAS
+#undef UP_AFRAGS
+
+  // ---- epilogue: lane = pixel (y0 + 2 y' + py, x0 + 2 l15 + px); filter tiles 2 u, 2 u + 1 give it channels
+  // n0 + 32 u + 8 g4 .. + 7 (one S16 group, 32 bytes); the shift depends on the border class of the pixel
+  float vmax = 0.f;
+  const int xg = x0 + 2 * l15 + px;
+  const int rx = xg == 0 ? 0 : (xg == d.width - 1 ? 2 : 1);
+#pragma unroll
+  for (int u = 0; u < FT / 2; ++u) {
+    const int c0 = n0 + 32 * u + 8 * g4;
+    float sc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sc[k] = 1.f;
+    if (d.scale) {
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.scale + c0), s1 = *reinterpret_cast<const f32x4*>(d.scale + c0 + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sc[k] = s0[k], sc[4 + k] = s1[k];
+    }
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+      const int yg = y0 + 2 * pt + py;
+      const int ry = yg == 0 ? 0 : (yg == d.height - 1 ? 2 : 1);
+      const float* shp = a.shift9 + (int64_t)(ry * 3 + rx) * d.n + c0;
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(shp), h1 = *reinterpret_cast<const f32x4*>(shp + 4);
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float t = acc[pt][2 * u + (k >> 2)][k & 3] * sc[k] + (k < 4 ? h0[k & 3] : h1[k & 3]);
+        if (d.act == AMMC_ACT_RELU) t = t > 0.f ? t : 0.f;
+        v[k] = t;
+      }
+      f16x8u hi, lo;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const _Float16 hv = (_Float16)v[k];
+        hi[k] = hv;
+        lo[k] = (_Float16)((v[k] - (float)hv) * U_LO_SCALE);
+        vmax = fmaxf(vmax, fabsf(v[k]));
+      }
+      f16x8u* yp = reinterpret_cast<f16x8u*>(d.y + ((int64_t)b * d.y_bs + (int64_t)yg * d.y_rs + (int64_t)xg * d.y_ps) + c0);
+      yp[0] = hi;
+      yp[1] = lo;
+    }
+  }
+  if (d.overflow_flag && !(vmax <= 65504.f)) atomicOr(d.overflow_flag, 1);
+}
+
+// composed filters: out[co][(tap2 * 4 + cls) * cin2 + ci], fp32 (the caller splits them into S16)
+__global__ __launch_bounds__(256) void up_compose_kernel(const float* __restrict__ w3, const float* __restrict__ wt,
+                                                         int n, int c, float* __restrict__ out) {
+  const int cin2 = 2 * c;
+  const int64_t total = (int64_t)n * 16 * cin2;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int ci = (int)(gid % cin2);
+  const int q = (int)((gid / cin2) % 16);
+  const int co = (int)(gid / ((int64_t)16 * cin2));
+  const int tap2 = q >> 2, cls = q & 3;
+  const int sy = tap2 >> 1, sx = tap2 & 1, py = cls >> 1, px = cls & 1;
+  // taps r of the 3x3 window whose up-row 2 y + py + r - 1 lies in source row y + sy + py - 1, with its dy:
+  // py 0: sy 0 <- r 0 (dy 1); sy 1 <- r 1 (dy 0), r 2 (dy 1).  py 1: sy 0 <- r 0 (dy 0), r 1 (dy 1); sy 1 <- r 2 (dy 0)
+  double sum = 0.0;
+  for (int r = 0; r < 3; ++r) {
+    const int ur = py + r - 1;                              // up-row relative to 2 y
+    const int srow = ur < 0 ? -1 : (ur >> 1);               // source row relative to y
+    if (srow != sy + py - 1) continue;
+    const int dy = ur & 1;
+    for (int s = 0; s < 3; ++s) {
+      const int uc = px + s - 1;
+      const int scol = uc < 0 ? -1 : (uc >> 1);
+      if (scol != sx + px - 1) continue;
+      const int dx = uc & 1;
+      const float* w3p = w3 + (((int64_t)co * cin2 + c) * 3 + r) * 3 + s;       // + cu * 9
+      const float* wtp = wt + ((int64_t)ci * c * 2 + dy) * 2 + dx;              // + cu * 4
+      for (int cu = 0; cu < c; ++cu) sum += (double)w3p[(int64_t)cu * 9] * (double)wtp[(int64_t)cu * 4];
+    }
+  }
+  out[gid] = (float)sum;
+}
+
+// shift9[ry][rx][co] = shift[co] + scale[co] * sum over the taps inside the image of W3[co][c + cu][r][s] * bt[cu]
+__global__ __launch_bounds__(256) void up_shift9_kernel(const float* __restrict__ w3, const float* __restrict__ bt,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        int n, int c, float* __restrict__ out) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (gid >= 9 * n) return;
+  const int co = gid % n, cls = gid / n;
+  const int ry = cls / 3, rx = cls % 3;
+  double sum = 0.0;
+  for (int r = 0; r < 3; ++r) {
+    if ((ry == 0 && r == 0) || (ry == 2 && r == 2)) continue;
+    for (int s = 0; s < 3; ++s) {
+      if ((rx == 0 && s == 0) || (rx == 2 && s == 2)) continue;
+      const float* w3p = w3 + (((int64_t)co * 2 * c + c) * 3 + r) * 3 + s;
+      for (int cu = 0; cu < c; ++cu) sum += (double)w3p[(int64_t)cu * 9] * (double)bt[cu];
+    }
+  }
+  const double sc = scale ? (double)scale[co] : 1.0, sh = shift ? (double)shift[co] : 0.0;
+  out[gid] = (float)(sh + sc * sum);
+}
+
+template <int TN>
+static int launch_up(const UpArgs& a, hipStream_t stream) {
+  constexpr size_t lds = (size_t)(U_SSTAGE + 2 * U_B2STAGE) * sizeof(float);
+  static_assert(lds <= 80 * 1024, "two workgroups per CU");
+  auto kern = conv_up_s16_kernel<TN>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  UpArgs b = a;
+  b.n_tiles = a.d.n / (32 * TN);
+  const int grid = a.d.batch * a.tiles_y * a.tiles_x * b.n_tiles;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(U_NT), lds, stream, b);
+  return ammc_launch_status();
+}
+
+}  // namespace ammc_s16
+using namespace ammc_s16;
+
+extern "C" int ammc_pack_up_conv_f32(const float* w3_oihw, const float* wt_iohw, const float* bt, const float* scale,
+                                     const float* shift, int32_t n, int32_t c, float* w2_out, float* shift9_out,
+                                     void* stream) {
+  if (!w3_oihw || !wt_iohw || !bt || !w2_out || !shift9_out || n <= 0 || c <= 0) return AMMC_EINVAL;
+  const int64_t total = (int64_t)n * 16 * 2 * c;
+  hipLaunchKernelGGL(up_compose_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w3_oihw,
+                     wt_iohw, n, c, w2_out);
+  hipLaunchKernelGGL(up_shift9_kernel, dim3((9 * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w3_oihw, bt, scale,
+                     shift, n, c, shift9_out);
+  return ammc_launch_status();
+}
+
+extern "C" int ammc_conv_up_s16(const AmmcConvDesc* desc, const float* up_x, int64_t up_bs, int64_t up_rs, int64_t up_ps,
+                                int32_t up_cin, const float* up_w, const float* shift9, void* stream) {
+  if (!desc || !desc->x || !desc->w || !desc->y || !up_x || !up_w || !shift9) return AMMC_EINVAL;
+  const AmmcConvDesc& d = *desc;
+  if (d.batch <= 0 || d.height <= 0 || d.width <= 0) return AMMC_EINVAL;
+  if (d.ntaps != 9 || d.up != 1 || d.x_step > 1 || d.y_f32 || d.res || d.pool_y || d.n_store || d.y_cs > 1) return AMMC_EUNSUP;
+  if (d.cin <= 0 || d.cin % 32 || up_cin != 2 * d.cin) return AMMC_EUNSUP;      // skip half c, source 2 c channels
+  if (d.width % U_TW || d.height % U_TH) return AMMC_EUNSUP;
+  if (d.n != 64 && d.n % 128) return AMMC_EUNSUP;
+  if (((uintptr_t)d.x | (uintptr_t)d.w | (uintptr_t)up_x | (uintptr_t)up_w | (uintptr_t)shift9) & 15) return AMMC_EINVAL;
+  if (((uintptr_t)d.y & 31) || ((d.y_bs | d.y_rs | d.y_ps) & 7)) return AMMC_EINVAL;
+  if ((d.x_bs | d.x_rs | d.x_ps | up_bs | up_rs | up_ps) & 7) return AMMC_EINVAL;
+  const int64_t patch = (int64_t)(U_TH + 1) * d.x_rs + (int64_t)(U_TW + 1) * d.x_ps;
+  const int64_t spatch = (int64_t)(U_SH - 1) * up_rs + (int64_t)(U_SW - 1) * up_ps;
+  const int64_t ymax = (int64_t)d.batch * d.y_bs;
+  if (patch >= (1LL << 30) || spatch >= (1LL << 30) || ymax >= (1LL << 31)) return AMMC_EUNSUP;
+  UpArgs a;
+  a.d = d;
+  a.x2 = up_x;
+  a.x2_bs = up_bs, a.x2_rs = up_rs, a.x2_ps = up_ps;
+  a.w2 = up_w;
+  a.shift9 = shift9;
+  a.cin2 = up_cin;
+  a.ncc1 = d.cin / 32;
+  a.ncc2 = up_cin / 32;
+  a.ncc_full = 2 * d.cin / 32;                   // the packed 3x3 filter covers both halves of the concatenation
+  a.kpad = 9 * 2 * d.cin;
+  a.kpad2 = 16 * up_cin;
+  a.tiles_x = d.width / U_TW;
+  a.tiles_y = d.height / U_TH;
+  a.n_tiles = 0;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return d.n == 64 ? launch_up<2>(a, s) : launch_up<4>(a, s);
+}

@@ -159,6 +159,19 @@ class _Packer:
         _lib.check(self.lib.ammc_pack_convt_weight_f32(_ptr(w), cin, co, _ptr(out), self.stream()), "pack_convt")
         return self._split(out)
 
+    def up_conv(self, conv0: torch.nn.Conv2d, convt: torch.nn.ConvTranspose2d, scale: torch.Tensor,
+                shift: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """composed filters + border-class shifts of `ammc_conv_up_s16` (csrc/conv_up_s16.hip): the transposed conv of an
+        `up` block folded into the up half of the 3x3 conv that follows it"""
+        n, c2 = conv0.weight.shape[0], conv0.weight.shape[1]
+        c = c2 // 2
+        w2 = torch.empty((n, 16 * c2), device=self.device, dtype=torch.float32)
+        shift9 = torch.empty((9, n), device=self.device, dtype=torch.float32)
+        w3, wt, bt = conv0.weight.detach().contiguous(), convt.weight.detach().contiguous(), convt.bias.detach().contiguous()
+        _lib.check(self.lib.ammc_pack_up_conv_f32(_ptr(w3), _ptr(wt), _ptr(bt), _ptr(scale), _ptr(shift), n, c, _ptr(w2),
+                                                  _ptr(shift9), self.stream()), "pack_up_conv")
+        return self._split(w2), shift9
+
     def bn(self, bn: torch.nn.BatchNorm2d) -> Tuple[torch.Tensor, torch.Tensor]:
         c = bn.num_features
         scale = torch.empty(c, device=self.device, dtype=torch.float32)
@@ -195,8 +208,11 @@ class _StreamPack:
         self.inc = _DoubleConvPack(pk, net.inc.conv)
         self.down = [_DoubleConvPack(pk, d.mpconv[1]) for d in (net.down1, net.down2, net.down3)]
         self.up = []
+        self.up_fused = []        # S16 plans: (composed filters, border-class shifts) of ammc_conv_up_s16 per decoder level
         for u in (net.up1, net.up2, net.up3):
-            self.up.append((pk.convt(u.up.weight), u.up.bias.detach(), _DoubleConvPack(pk, u.conv)))
+            dcp = _DoubleConvPack(pk, u.conv)
+            self.up.append((pk.convt(u.up.weight), u.up.bias.detach(), dcp))
+            self.up_fused.append(pk.up_conv(u.conv.conv[0], u.up, dcp.s0, dcp.b0) if pk.s16 else None)
         # `outc` rides in a 32-column MFMA tile: pad the 2-3 filters (and the bias) to 32 rows
         self.cout = net.outc.weight.shape[0]
         w32 = torch.zeros((32,) + tuple(net.outc.weight.shape[1:]), device=pk.device, dtype=torch.float32)
@@ -331,6 +347,31 @@ class _Builder:
                   name=f"{name}.conv1", pool=pool if fused else None)
         return fused
 
+    def up_conv_eligible(self, skip: Act, n: int) -> bool:
+        """does csrc/conv_up_s16.hip take this decoder level?  (mirrors the checks of `ammc_conv_up_s16`)"""
+        return (self.s16 and os.environ.get("AMMC_UP_FUSED", "1") != "0" and skip.W % 32 == 0 and skip.H % 8 == 0
+                and skip.c % 32 == 0 and (n == 64 or n % 128 == 0))
+
+    def up_conv(self, x2: Act, skip: Act, p: _DoubleConvPack, fused, y: Act, name="up"):
+        """ConvTranspose2d(x2) + cat([skip, .]) + conv3x3 + BN + ReLU as ONE launch (reference unet.py:50-59, first conv
+        of `up.conv`): the transposed conv is folded into the filters of the up half (`_Packer.up_conv`)"""
+        w2, shift9 = fused
+        d = AmmcConvDesc()
+        d.x, d.w, d.y = skip.tap0(), _ptr(p.w0), y.pix0()
+        d.scale = _ptr(p.s0)
+        d.batch, d.height, d.width = skip.B, skip.H, skip.W
+        d.cin, d.ntaps, d.n, d.up, d.cgroup, d.act = skip.c, 9, p.cout, 1, p.cout, ACT_RELU
+        d.x_bs, d.x_rs, d.x_ps = skip.strides
+        d.y_bs, d.y_rs, d.y_ps = y.strides
+        d.overflow_flag = self.overflow.data_ptr()
+        self.plan.keep.extend([d, p.w0, p.s0, w2, shift9])
+        m_pix = skip.B * skip.H * skip.W
+        # algorithmic work of what this launch REPLACES (SURVEY.md 8(d)): the transposed conv + the 3x3 conv over 2c channels
+        flops = 2.0 * m_pix * p.cout * 9 * 2 * skip.c + 2.0 * (m_pix // 4) * x2.c * 4 * skip.c
+        nbytes = 4.0 * (m_pix * (skip.c + p.cout) + (m_pix // 4) * x2.c)
+        self.plan.add(self.lib.ammc_conv_up_s16, C.byref(d), x2.tap0(), *x2.strides, x2.c, _ptr(w2), _ptr(shift9),
+                      name=name, flops=flops, nbytes=nbytes, kernel="conv_up_s16<%d>" % (2 if p.cout == 64 else 4))
+
     def maxpool(self, x: Act, y: Act, name="pool"):
         self.plan.add(self.lib.ammc_maxpool2x2_s16 if self.s16 else self.lib.ammc_maxpool2x2_f32,
                       x.pix0(), *x.strides, y.pix0(), *y.strides,
@@ -420,11 +461,16 @@ class StreamGraph:
         for j, lvl in enumerate((2, 1, 0)):            # up1 -> level 2 (H/4), up2 -> level 1, up3 -> level 0
             wt, bias, dc = sp.up[j]
             c = chans[lvl]
-            bld.convt(y, wt, bias, self.cat[lvl].slice(c, c), name=f"up{j + 1}.up")
             h, w = H >> lvl, W >> lvl
             mid = bld.act(B, h, w, c)
             out = bld.act(B, h, w, c)
-            bld.double_conv(self.cat[lvl], dc, mid, out, name=f"up{j + 1}")
+            if sp.up_fused[j] is not None and bld.up_conv_eligible(self.skip[lvl], c):
+                # transposed conv + concat + first conv as one launch; the up half of the concat buffer stays unused
+                bld.up_conv(y, self.skip[lvl], dc, sp.up_fused[j], mid, name=f"up{j + 1}.up+conv0")
+                bld.conv(mid, dc.w1, out, ntaps=9, cin=c, n=c, scale=dc.s1, shift=dc.b1, act=ACT_RELU, name=f"up{j + 1}.conv1")
+            else:
+                bld.convt(y, wt, bias, self.cat[lvl].slice(c, c), name=f"up{j + 1}.up")
+                bld.double_conv(self.cat[lvl], dc, mid, out, name=f"up{j + 1}")
             y = out
         self.u3 = y
         self.outc = bld.outc_desc(y, sp.outc_w, sp.outc_b, sp.cout)

@@ -165,6 +165,19 @@ int ammc_sum_partials_f32(const float* partial, int32_t nparts, float inv_count,
  * only without them).  Replaces the same reference calls as ammc_conv_gemm_f32.
  * ---------------------------------------------------------------------------------------- */
 int ammc_conv_gemm_s16(const AmmcConvDesc* desc, void* stream);
+/* `up.forward` of the decoder in inference (models/unet.py:50-59) as one launch: y = act(scale * conv3x3(cat([skip,
+ * ConvTranspose2d(x2, k 2, s 2) + b])) + shift).  desc describes the 3x3 conv over the SKIP half only: x = the skip
+ * tensor (S16, halo corner), cin = c skip channels, w = the S16 filter of the whole conv ([n][9 * 2c], k = tap * 2c +
+ * ch: ammc_pack_conv_weight_f32 + ammc_split_rows_f32), scale, act, y (S16); desc->shift is ignored.  The other half
+ * comes from x2 (S16, half resolution, halo 1, up_cin = 2c channels: what the transposed conv reads) through the
+ * COMPOSED filters of ammc_pack_up_conv_f32 (the transposed conv folded into the 3x3 taps per output-pixel parity,
+ * summed in double: no intermediate tensor; then ammc_split_rows_f32) and its border-class shifts shift9[3][3][n].
+ * Needs W % 32 == 0, H % 8 == 0, c % 32 == 0, n = 64 or a multiple of 128; AMMC_EUNSUP otherwise (callers then run
+ * the transposed conv and the 3x3 conv separately). */
+int ammc_pack_up_conv_f32(const float* w3_oihw, const float* wt_iohw, const float* bt, const float* scale,
+                          const float* shift, int32_t n, int32_t c, float* w2_out, float* shift9_out, void* stream);
+int ammc_conv_up_s16(const AmmcConvDesc* desc, const float* up_x, int64_t up_bs, int64_t up_rs, int64_t up_ps,
+                     int32_t up_cin, const float* up_w, const float* shift9, void* stream);
 /* Which kernel ammc_conv_gemm_s16 launches for this descriptor, as the NUL-terminated name rocprofv3 reports for it
  * (e.g. "conv_tap_s16<4, 1, 2, 4, 1>", "conv_gemm_s16<128x128>", "...+splitk4"), without launching anything: the same
  * argument checks and the same dispatch code run with the launch replaced by the label.  Tests pin kernel coverage on
