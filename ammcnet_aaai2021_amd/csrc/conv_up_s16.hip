@@ -56,7 +56,7 @@ template <int TN>      // BN = 32 TN filters per workgroup: 64 (TN 2) or 128 (TN
 __global__ __launch_bounds__(U_NT, 2) void conv_up_s16_kernel(UpArgs a) {
   constexpr int BN = 32 * TN;
   constexpr int FT = 2 * TN;                   // 16-filter tiles
-  constexpr int FC = 4;                        // filter tiles whose fragments are live at once (= one phase-B slice)
+  constexpr int FC = 2;                        // filter tiles whose fragments are live at once
   constexpr int BJ = BN * 8 / U_NT;            // phase A: filter pieces per thread per tap
   constexpr int B_STAGE = BN * 32;             // floats
   constexpr int NH = BN / 64;                  // phase B: 64-filter halves
@@ -116,23 +116,16 @@ __global__ __launch_bounds__(U_NT, 2) void conv_up_s16_kernel(UpArgs a) {
   // filter rows of a stage are stored tile by tile: LDS row 16 t + r holds filter 32 (t >> 1) + 8 (r >> 2) + 4 (t & 1) + (r & 3)
   int sl = (tid & 7) ^ ((tid >> 3) & 7);
   sl ^= (sl >> 1) & 1;
-  const float* b_src[BJ];
-#pragma unroll
-  for (int j = 0; j < BJ; ++j) {
-    int row = j * (U_NT / 8) + (tid >> 3);
-    row = (row & ~31) | (((row >> 2) & 3) << 3) | (((row >> 4) & 1) << 2) | (row & 3);
-    b_src[j] = d.w + (int64_t)(n0 + row) * a.kpad + 4 * sl;
-  }
-  // phase B stage: piece p = j * 256 + tid -> class slice p >> 9 (64 rows x 8 pieces), row (p >> 3) & 63 of the slice
-  int b2_off[U_B2J];
-#pragma unroll
-  for (int j = 0; j < U_B2J; ++j) {
-    const int p = j * U_NT + tid;
-    const int cls = p >> 9;
-    int row = (p >> 3) & 63;
-    row = (row & ~31) | (((row >> 2) & 3) << 3) | (((row >> 4) & 1) << 2) | (row & 3);
-    b2_off[j] = row * a.kpad2 + cls * a.cin2 + 4 * sl;           // (+ n0 + 64 half, + (tap2 * 4) * cin2 + 32 cb: per step)
-  }
+  // (thread tid serves LDS rows 32 j + (tid >> 3): the permutation stays inside a block of 32 rows, so round j is a
+  // uniform offset from round 0 - one address register instead of BJ)
+  int row0 = tid >> 3;
+  row0 = (((row0 >> 2) & 3) << 3) | (((row0 >> 4) & 1) << 2) | (row0 & 3);
+  const float* b_src0 = d.w + (int64_t)(n0 + row0) * a.kpad + 4 * sl;
+  // phase B stage: every wave streams ITS class slice (64 filter rows x 8 pieces = 8 per lane) and nobody else reads it:
+  // the slices need no workgroup barrier, only the issuing wave's own vmcnt.  Piece p = j * 64 + lane -> row p >> 3
+  // (row = 8 j + (lane >> 3): after the tile-order permutation 32 (j >> 2) + 16 (j & 1) + 4 ((j >> 1) & 1) + a lane part)
+  const int sl2 = ((lane & 7) ^ ((lane >> 3) & 7)) ^ ((((lane & 7) ^ ((lane >> 3) & 7)) >> 1) & 1);
+  const int b2_lane = ((((lane >> 3) >> 2) & 1) * 8 + ((lane >> 3) & 3)) * a.kpad2 + wave * a.cin2 + 4 * sl2;
   const float* w2base = a.w2 + (int64_t)n0 * a.kpad2;
 
 #define UP_ISSUE_A(cc)                                                                \
@@ -149,14 +142,15 @@ __global__ __launch_bounds__(U_NT, 2) void conv_up_s16_kernel(UpArgs a) {
   }
 #define UP_ISSUE_B(chunk, stage)                                                      \
   _Pragma("unroll") for (int j_ = 0; j_ < BJ; ++j_) {                                 \
-    const float* src_ = b_src[j_] + (chunk) * 32;                                     \
+    const float* src_ = b_src0 + (int64_t)j_ * 32 * a.kpad + (chunk) * 32;            \
     float* dst_ = Bs + (stage) * B_STAGE + (j_ * U_NT + wave * 64) * 4;               \
     __builtin_amdgcn_global_load_lds(src_, dst_, 16, 0, 0);                           \
   }
 #define UP_ISSUE_B2(tap2, half, cb, stage)                                            \
   _Pragma("unroll") for (int j_ = 0; j_ < U_B2J; ++j_) {                              \
-    const float* src_ = w2base + (int64_t)(half) * 64 * a.kpad2 + b2_off[j_] + (tap2) * 4 * a.cin2 + (cb) * 32; \
-    float* dst_ = B2 + (stage) * U_B2STAGE + (j_ * U_NT + wave * 64) * 4;             \
+    const float* src_ = w2base + (int64_t)((half) * 64 + 32 * (j_ >> 2) + 16 * (j_ & 1) + 4 * ((j_ >> 1) & 1)) * a.kpad2 + \
+                        b2_lane + (tap2) * 4 * a.cin2 + (cb) * 32;                    \
+    float* dst_ = B2 + (stage) * U_B2STAGE + wave * (64 * 32) + j_ * 64 * 4;          \
     __builtin_amdgcn_global_load_lds(src_, dst_, 16, 0, 0);                           \
   }
 #define UP_WAIT_ALL()                                  \
@@ -164,6 +158,11 @@ __global__ __launch_bounds__(U_NT, 2) void conv_up_s16_kernel(UpArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   \
     __builtin_amdgcn_s_barrier();                      \
     asm volatile("" ::: "memory");                     \
+  }
+#define UP_WAIT_OWN()                                  \
+  {                                                    \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   \
+    __builtin_amdgcn_sched_barrier(0);                 \
   }
 
   f32x4 acc[4][FT];                           // [pixel tile y'][filter tile]
@@ -245,6 +244,8 @@ __global__ __launch_bounds__(U_NT, 2) void conv_up_s16_kernel(UpArgs a) {
   bs = 0;
   for (int cb = 0; cb < a.ncc2; ++cb) {
     if (cb > 0) {
+      __builtin_amdgcn_s_barrier();            // everyone is past the last tap of the previous block: the patch is free
+      asm volatile("" ::: "memory");
       UP_ISSUE_S(cb)
       UP_WAIT_ALL()
     }
@@ -261,9 +262,10 @@ __global__ __launch_bounds__(U_NT, 2) void conv_up_s16_kernel(UpArgs a) {
         const int rb = (sy + py) * U_SW + sx + px;
         UP_AFRAGS(Ss, rb, U_SW)
         const float* Bc = B2 + bs * U_B2STAGE + wave * (64 * 32);          // this wave's class slice
-        UP_MFMAS(Bc, half * 4)
+#pragma unroll
+        for (int f0 = 0; f0 < 4; f0 += FC) UP_MFMAS(Bc + f0 * 512, half * 4 + f0)
       }
-      UP_WAIT_ALL()
+      UP_WAIT_OWN()                            // this wave's next slice has landed (its own DMA: no barrier needed)
       bs ^= 1;
     }
   }
@@ -272,6 +274,7 @@ __global__ __launch_bounds__(U_NT, 2) void conv_up_s16_kernel(UpArgs a) {
 #undef UP_ISSUE_B
 #undef UP_ISSUE_B2
 #undef UP_WAIT_ALL
+#undef UP_WAIT_OWN
 #undef UP_MFMAS
 #undef UP_AFRAGS
 
