@@ -49,8 +49,9 @@ constexpr int U_SH = U_TH / 2 + 2, U_SW = U_TW / 2 + 2;                // 6 x 18
 constexpr int U_SPIECES = U_SH * U_SW * 8;                             // 864
 constexpr int U_SROUNDS = (U_SPIECES + U_NT - 1) / U_NT;               // 4
 constexpr int U_SSTAGE = U_SROUNDS * U_NT * 4;                         // floats (16 KB)
-constexpr int U_B2STAGE = 4 * 64 * 32;                                 // four class slices of 64 filters (32 KB)
-constexpr int U_B2J = U_B2STAGE / 4 / U_NT;                            // 8 pieces per thread per stage
+constexpr int U_B2SLOT = 4 * 32 * 32;                                  // ring slot: four class slices of 32 filters (16 KB)
+constexpr int U_B2RING = 4;                                            // slots: three stages in flight behind the one in use
+constexpr int U_B2J = 4;                                               // DMA instructions per lane per stage (32 rows x 8 pieces)
 
 template <int TN>      // BN = 32 TN filters per workgroup: 64 (TN 2) or 128 (TN 4)
 __global__ __launch_bounds__(U_NT, 2) void conv_up_s16_kernel(UpArgs a) {
@@ -59,13 +60,14 @@ __global__ __launch_bounds__(U_NT, 2) void conv_up_s16_kernel(UpArgs a) {
   constexpr int FC = 2;                        // filter tiles whose fragments are live at once
   constexpr int BJ = BN * 8 / U_NT;            // phase A: filter pieces per thread per tap
   constexpr int B_STAGE = BN * 32;             // floats
-  constexpr int NH = BN / 64;                  // phase B: 64-filter halves
+  constexpr int SPT = BN / 32;                 // phase B: stages (32 filters) per 2x2 tap
+  constexpr int SPC = 4 * SPT;                 //          stages per 32-channel block of x
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                            // phase A: skip patch, then two filter stages
   float* Bs = smem + U_ASTAGE;
   float* Ss = smem;                            // phase B (overlays phase A): source patch, then two stages of class slices
   float* B2 = smem + U_SSTAGE;
-  static_assert(U_ASTAGE + 2 * B_STAGE <= U_SSTAGE + 2 * U_B2STAGE, "phase A fits the phase B footprint");
+  static_assert(U_ASTAGE + 2 * B_STAGE <= U_SSTAGE + U_B2RING * U_B2SLOT, "phase A fits the phase B footprint");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -121,9 +123,10 @@ __global__ __launch_bounds__(U_NT, 2) void conv_up_s16_kernel(UpArgs a) {
   int row0 = tid >> 3;
   row0 = (((row0 >> 2) & 3) << 3) | (((row0 >> 4) & 1) << 2) | (row0 & 3);
   const float* b_src0 = d.w + (int64_t)(n0 + row0) * a.kpad + 4 * sl;
-  // phase B stage: every wave streams ITS class slice (64 filter rows x 8 pieces = 8 per lane) and nobody else reads it:
-  // the slices need no workgroup barrier, only the issuing wave's own vmcnt.  Piece p = j * 64 + lane -> row p >> 3
-  // (row = 8 j + (lane >> 3): after the tile-order permutation 32 (j >> 2) + 16 (j & 1) + 4 ((j >> 1) & 1) + a lane part)
+  // phase B stage: every wave streams ITS class slice (32 filter rows x 8 pieces = 4 per lane) and nobody else reads it:
+  // the slices need no workgroup barrier, only the issuing wave's own COUNTED vmcnt (a ring of four slots, three stages
+  // in flight).  Piece p = j * 64 + lane -> row p >> 3 = 8 j + (lane >> 3), after the tile-order permutation
+  // 16 (j & 1) + 4 (j >> 1) + a lane part
   const int sl2 = ((lane & 7) ^ ((lane >> 3) & 7)) ^ ((((lane & 7) ^ ((lane >> 3) & 7)) >> 1) & 1);
   const int b2_lane = ((((lane >> 3) >> 2) & 1) * 8 + ((lane >> 3) & 3)) * a.kpad2 + wave * a.cin2 + 4 * sl2;
   const float* w2base = a.w2 + (int64_t)n0 * a.kpad2;
@@ -146,11 +149,11 @@ __global__ __launch_bounds__(U_NT, 2) void conv_up_s16_kernel(UpArgs a) {
     float* dst_ = Bs + (stage) * B_STAGE + (j_ * U_NT + wave * 64) * 4;               \
     __builtin_amdgcn_global_load_lds(src_, dst_, 16, 0, 0);                           \
   }
-#define UP_ISSUE_B2(tap2, half, cb, stage)                                            \
+#define UP_ISSUE_B2(tap2, fblk, cb, slot)                                             \
   _Pragma("unroll") for (int j_ = 0; j_ < U_B2J; ++j_) {                              \
-    const float* src_ = w2base + (int64_t)((half) * 64 + 32 * (j_ >> 2) + 16 * (j_ & 1) + 4 * ((j_ >> 1) & 1)) * a.kpad2 + \
-                        b2_lane + (tap2) * 4 * a.cin2 + (cb) * 32;                    \
-    float* dst_ = B2 + (stage) * U_B2STAGE + wave * (64 * 32) + j_ * 64 * 4;          \
+    const float* src_ = w2base + (int64_t)((fblk) * 32 + 16 * (j_ & 1) + 4 * (j_ >> 1)) * a.kpad2 + b2_lane + \
+                        (tap2) * 4 * a.cin2 + (cb) * 32;                              \
+    float* dst_ = B2 + (slot) * U_B2SLOT + wave * (32 * 32) + j_ * 64 * 4;            \
     __builtin_amdgcn_global_load_lds(src_, dst_, 16, 0, 0);                           \
   }
 #define UP_WAIT_ALL()                                  \
@@ -159,10 +162,12 @@ __global__ __launch_bounds__(U_NT, 2) void conv_up_s16_kernel(UpArgs a) {
     __builtin_amdgcn_s_barrier();                      \
     asm volatile("" ::: "memory");                     \
   }
-#define UP_WAIT_OWN()                                  \
-  {                                                    \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   \
-    __builtin_amdgcn_sched_barrier(0);                 \
+#define UP_WAIT_OWN(n)                                                               \
+  {                                                                                  \
+    if ((n) >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                   \
+    else if ((n) == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");              \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            \
+    __builtin_amdgcn_sched_barrier(0);                                               \
   }
 
   f32x4 acc[4][FT];                           // [pixel tile y'][filter tile]
@@ -238,35 +243,44 @@ __global__ __launch_bounds__(U_NT, 2) void conv_up_s16_kernel(UpArgs a) {
   // ---- phase B: 2x2 taps over the source patch, class filters ---------------------------------------------------------
   // tile y' of this wave, tap (sy, sx): source patch row y' + sy + py, columns l15 + sx + px (patch origin = source
   // pixel (y0 / 2 - 1, x0 / 2 - 1))
+  // Stage g = (cb, st): 2x2 tap st / SPT, filter block st % SPT.  While stage g is contracted, stages g + 1 .. g + 3 are
+  // in flight; after it, `vmcnt(8)` (two stages of four DMA instructions may stay outstanding) retires stage g + 1.
+  const int G = a.ncc2 * SPC;
   UP_ISSUE_S(0)
-  UP_ISSUE_B2(0, 0, 0, 0)
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    if (g < G) { UP_ISSUE_B2(g / SPT, g % SPT, 0, g) }            // (SPC >= 8 > 3: the first stages are all in block 0)
+  }
   UP_WAIT_ALL()
-  bs = 0;
-  for (int cb = 0; cb < a.ncc2; ++cb) {
+  int slot = 0, gbase = 0;
+  for (int cb = 0; cb < a.ncc2; ++cb, gbase += SPC) {
     if (cb > 0) {
       __builtin_amdgcn_s_barrier();            // everyone is past the last tap of the previous block: the patch is free
       asm volatile("" ::: "memory");
       UP_ISSUE_S(cb)
-      UP_WAIT_ALL()
+      UP_WAIT_ALL()                            // (also lands the class slices already in flight)
     }
 #pragma unroll
-    for (int st = 0; st < 4 * NH; ++st) {
-      const int tap2 = st / NH, half = st % NH;
-      if (st + 1 < 4 * NH) {
-        UP_ISSUE_B2((st + 1) / NH, (st + 1) % NH, cb, bs ^ 1)
-      } else if (cb + 1 < a.ncc2) {
-        UP_ISSUE_B2(0, 0, cb + 1, bs ^ 1)
-      }
-      {
-        const int sy = tap2 >> 1, sx = tap2 & 1;
-        const int rb = (sy + py) * U_SW + sx + px;
-        UP_AFRAGS(Ss, rb, U_SW)
-        const float* Bc = B2 + bs * U_B2STAGE + wave * (64 * 32);          // this wave's class slice
+    for (int tap2 = 0; tap2 < 4; ++tap2) {
+      // the pixel fragments of a 2x2 tap serve all its filter stages
+      const int sy = tap2 >> 1, sx = tap2 & 1;
+      const int rb = (sy + py) * U_SW + sx + px;
+      UP_AFRAGS(Ss, rb, U_SW)
 #pragma unroll
-        for (int f0 = 0; f0 < 4; f0 += FC) UP_MFMAS(Bc + f0 * 512, half * 4 + f0)
+      for (int fblk = 0; fblk < SPT; ++fblk) {
+        const int st = tap2 * SPT + fblk;
+        const int left = G - (gbase + st) - 1;                          // stages after this one
+        if (left >= 3) {
+          if (st + 3 < SPC) { UP_ISSUE_B2((st + 3) / SPT, (st + 3) % SPT, cb, (slot + 3) & 3) }
+          else { UP_ISSUE_B2((st + 3 - SPC) / SPT, (st + 3 - SPC) % SPT, cb + 1, (slot + 3) & 3) }
+        }
+        {
+          const float* Bc = B2 + slot * U_B2SLOT + wave * (32 * 32);          // this wave's class slice
+          UP_MFMAS(Bc, fblk * 2)
+        }
+        UP_WAIT_OWN(left >= 3 ? 2 : left - 1)    // stage g + 1 has landed (this wave's own DMA: no barrier needed)
+        slot = (slot + 1) & 3;
       }
-      UP_WAIT_OWN()                            // this wave's next slice has landed (its own DMA: no barrier needed)
-      bs ^= 1;
     }
   }
 #undef UP_ISSUE_A
@@ -379,7 +393,7 @@ __global__ __launch_bounds__(256) void up_shift9_kernel(const float* __restrict_
 
 template <int TN>
 static int launch_up(const UpArgs& a, hipStream_t stream) {
-  constexpr size_t lds = (size_t)(U_SSTAGE + 2 * U_B2STAGE) * sizeof(float);
+  constexpr size_t lds = (size_t)(U_SSTAGE + U_B2RING * U_B2SLOT) * sizeof(float);
   static_assert(lds <= 80 * 1024, "two workgroups per CU");
   auto kern = conv_up_s16_kernel<TN>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
