@@ -104,6 +104,7 @@ class _Ops:
         # bench.py: a list here brackets every MFMA launch of the 3x3 layers with HIP events on the launch stream and
         # collects (kernel label, algorithmic flops, start event, end event)
         self.timing: Optional[list] = None
+        self.collectives = 0            # statistics all-reduces issued (tests: the streams share them)
 
     def _mfma_launch(self, label, flops: float, call, what: str):
         if self.timing is None:
@@ -242,6 +243,36 @@ class _Ops:
         return out
 
 
+def _lockstep(ops: "_Ops", *gens) -> None:
+    """Advance the generators together.  A unit that needs statistics summed over the ranks (`parallel.sync_statistics`)
+    yields the tensor(s) right where the reference-order code would all-reduce them; whatever the generators yield in
+    the same round - the same layer of the rgb and of the flow stream, the two halves of the bridge, the four EMA
+    tensors of the two memories - travels as ONE flat collective and is written back in place.  (Within one stream
+    consecutive layers cannot share a collective: BatchNorm's statistics are needed before the next conv can run.)
+    Without synchronised statistics nothing yields and the generators just run to completion, one after the other."""
+    live = list(gens)
+    while live:
+        pend, nxt = [], []
+        for g in live:
+            try:
+                t = next(g)
+            except StopIteration:
+                continue
+            pend.extend(t if isinstance(t, (list, tuple)) else [t])
+            nxt.append(g)
+        if len(pend) == 1:
+            ops.all_reduce(pend[0])
+        elif pend:
+            flat = torch.cat([t.reshape(-1) for t in pend])
+            ops.all_reduce(flat)
+            off = 0
+            for t in pend:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+        ops.collectives += 1 if pend else 0
+        live = nxt
+
+
 class _ConvBN:
     """conv3x3 (no bias) + BatchNorm2d (batch statistics) + ReLU [+ residual]"""
 
@@ -268,6 +299,10 @@ class _ConvBN:
         self.wdp = ws.buf(self.rows, _kpad(9 * self.cout)) if self.rows else None
 
     def forward(self):
+        for _ in self.forward_gen():
+            raise RuntimeError("synchronised statistics need the lockstep driver (TrainEngine.forward)")
+
+    def forward_gen(self):
         o, lib, s = self.ops, self.ops.lib, self.ops.s
         w = self.conv.weight.detach()
         _chk(lib.ammc_pack_conv_weight_f32(_ptr(w), self.cout, self.cin, 3, self.cin_p, _ptr(self.wp), s), "pack")
@@ -285,7 +320,7 @@ class _ConvBN:
             # synchronised statistics: [2C] sums of every rank are added, the finalizer sees the global batch
             tot = torch.empty(2 * self.cout, device=o.dev, dtype=torch.float32)
             _chk(lib.ammc_reduce_partials_f32(_ptr(self.partial), self.nblk, 2 * self.cout, 1.0, _ptr(tot), s), "reduce")
-            o.all_reduce(tot)
+            yield tot                                           # summed over the ranks by `_lockstep`
             part, nblk, count = tot, 1, count * world
         _chk(lib.ammc_bn_finalize_f32(_ptr(part), nblk, self.cout, count,
                                       _ptr(bn.weight.detach()), _ptr(bn.bias.detach()), float(bn.eps),
@@ -306,6 +341,10 @@ class _ConvBN:
                                           self.y.pix0(), *self.y.strides, 1, c.B, c.H, c.W, self.cout, s), "bn_apply")
 
     def backward(self, dy: Act, da: Optional[Act], da_res: Optional[Act], grads: Dict):
+        for _ in self.backward_gen(dy, da, da_res, grads):
+            raise RuntimeError("synchronised statistics need the lockstep driver (TrainEngine.backward)")
+
+    def backward_gen(self, dy: Act, da: Optional[Act], da_res: Optional[Act], grads: Dict):
         """dy: gradient w.r.t. this unit's output.  Writes da = dgrad (+ da_res) if asked;
         stores the parameter gradients in `grads`."""
         o, lib, s = self.ops, self.ops.lib, self.ops.s
@@ -345,7 +384,7 @@ class _ConvBN:
                 # count, so hand it global_sums / world (equal batch per rank).  dgamma / dbeta stay local: the
                 # gradient all-reduce averages them like every other parameter.
                 g = sums.clone()
-                o.all_reduce(g)
+                yield g
                 sums = g.mul_(1.0 / world)
             # (bn_bwd_apply leaves max |dc| in this unit's slots for the S16 re-encoding)
             _chk(lib.ammc_bn_bwd_apply_f32(c.pix0(), *c.strides, dy.pix0(), *dy.strides, _ptr(self.mean), _ptr(self.invstd),
@@ -383,13 +422,13 @@ class _DoubleConv:
             self.u0.y_s16_only = self.u1.x_is_s16 = True
         self.dmid = ops.ws.act(x.B, x.H, x.W, seq[0].weight.shape[0])
 
-    def forward(self):
-        self.u0.forward()
-        self.u1.forward()
+    def forward_gen(self):
+        yield from self.u0.forward_gen()
+        yield from self.u1.forward_gen()
 
-    def backward(self, dy: Act, da: Optional[Act], da_res: Optional[Act], grads):
-        self.u1.backward(dy, self.dmid, None, grads)
-        self.u0.backward(self.dmid, da, da_res, grads)
+    def backward_gen(self, dy: Act, da: Optional[Act], da_res: Optional[Act], grads):
+        yield from self.u1.backward_gen(dy, self.dmid, None, grads)
+        yield from self.u0.backward_gen(self.dmid, da, da_res, grads)
 
 
 class _Stream:
@@ -470,17 +509,18 @@ class _Stream:
         self.scratch = ws.buf(lib.ammc_chan_reduce_blocks(B * H * W) * 512 + 1024)
 
     # ---- forward pieces -------------------------------------------------------------
-    def encode(self, x: torch.Tensor):
+    def encode_gen(self, x: torch.Tensor):
         o, lib, s = self.ops, self.ops.lib, self.ops.s
         _chk(lib.ammc_nchw_to_nhwc_f32(_ptr(x), self.B, self.cin, self.H, self.W, self.x_in.pix0(),
                                        *self.x_in.strides, self.x_in.c, s), "nchw_to_nhwc")
-        self.inc.forward()
+        yield from self.inc.forward_gen()
         for i in range(3):
             p, sk = self.pooled[i], self.skip[i]
             _chk(lib.ammc_maxpool2x2_f32(sk.pix0(), *sk.strides, p.pix0(), *p.strides, p.B, p.H, p.W, p.c, s), "pool")
-            self.down[i].forward()
+            yield from self.down[i].forward_gen()
 
-    def memory(self):
+    def memory_gen(self):
+        """leaves (diff, q_one) in self.mem_out"""
         o, lib, s, q = self.ops, self.ops.lib, self.ops.s, self.q
         qz = q.quantize
         _chk(lib.ammc_pack_conv_weight_f32(_ptr(q.enc.weight.detach()), self.d, 512, 1, 512, _ptr(self.enc_wp), s), "pack")
@@ -501,8 +541,7 @@ class _Stream:
             sums = torch.empty((self.d, self.m), device=o.dev, dtype=torch.float32)
             _chk(lib.ammc_codebook_count_f32(_ptr(self.z.buf), self.idx.data_ptr(), self.k, self.n, self.d, self.m,
                                              _ptr(counts), _ptr(sums), s), "codebook_count")
-            o.all_reduce(counts)
-            o.all_reduce(sums)
+            yield [counts, sums]
             _chk(lib.ammc_codebook_ema_apply_f32(_ptr(counts), _ptr(sums), self.d, self.m, float(qz.decay),
                                                  float(1 - qz.decay), float(qz.eps), _ptr(qz.cluster_size),
                                                  _ptr(qz.embed_avg), _ptr(qz.embed), s), "codebook_ema_apply")
@@ -512,9 +551,10 @@ class _Stream:
                                            _ptr(qz.embed_avg), _ptr(qz.embed), s), "codebook_ema")
         o.conv(self.qk, self.dec_wp, self.x4q, ntaps=1, cin=self.k * self.d, n=512, shift=q.dec.bias.detach(),
                res=self.x4, what="vq.dec")
-        return diff, self.q_one.clone()
+        self.mem_out = (diff, self.q_one.clone())
 
-    def decode(self, bottom: Act):
+    def decode_gen(self, bottom: Act):
+        """leaves the predicted frame in self.out"""
         o, lib, s = self.ops, self.ops.lib, self.ops.s
         self.dec_in = bottom
         y = bottom
@@ -525,7 +565,7 @@ class _Stream:
             self.up_b4[j].copy_(m.up.bias.detach().repeat(4))
             (o.conv_s16 if o.s16 and CONVT_S16 else o.conv)(y, self.up_wp[j], self.cat[lvl].slice(c, c), ntaps=1, cin=2 * c,
                                                           n=4 * c, shift=self.up_b4[j], up=2, cgroup=c, what=f"up{j + 1}.up")
-            self.up_dc[j].forward()
+            yield from self.up_dc[j].forward_gen()
             y = self.up_out[j]
         net = self.net
         self.w32[:self.cout].copy_(net.outc.weight.detach())          # rows >= cout stay zero from allocation
@@ -550,11 +590,10 @@ class _Stream:
             d.x_bs, d.x_rs, d.x_ps = u3.strides
             _chk(lib.ammc_conv_gemm_f32(C.byref(d), s), "outc")
         self.out = out
-        return out
 
     # ---- backward pieces ------------------------------------------------------------
-    def decode_backward(self, dout: torch.Tensor, grads) -> Act:
-        """from d(tanh output) down to the gradient of the decoder's bottom input; fills dcat[*]"""
+    def decode_backward_gen(self, dout: torch.Tensor, grads):
+        """from d(tanh output) down to the gradient of the decoder's bottom input (self.dbottom); fills dcat[*]"""
         o, lib, s, net = self.ops, self.ops.lib, self.ops.s, self.net
         dout = dout.contiguous()
         dp = self.dpre
@@ -581,7 +620,7 @@ class _Stream:
             lvl = (2, 1, 0)[j]
             c = CHANS[lvl]
             m = self.up_mods[j]
-            self.up_dc[j].backward(self.du[j], self.dcat[lvl], None, grads)
+            yield from self.up_dc[j].backward_gen(self.du[j], self.dcat[lvl], None, grads)
             dys = self.dcat[lvl].slice(c, c)                         # gradient of the ConvTranspose output
             grads[m.up.bias] = o.chan_sum(dys, c, self.scratch)
             x_in = self.dec_in if j == 0 else self.up_out[j - 1]
@@ -596,7 +635,6 @@ class _Stream:
                            what=f"up{j + 1}.up.dgrad")
             else:
                 o.conv(dys, self.up_wT[j], dst, ntaps=4, cin=c, n=2 * c, x_step=2, what=f"up{j + 1}.up.dgrad")
-        return self.dbottom
 
     def memory_backward(self, dq4: Act, ddiff: Optional[torch.Tensor], dq_one: Optional[torch.Tensor], grads) -> Act:
         """gradient through dec / commit term / enc / residual; returns d(x4)"""
@@ -620,16 +658,16 @@ class _Stream:
         o.conv(self.dz, self.enc_wT, self.dx4, ntaps=1, cin=_kpad(self.d), n=512, res=dq4, what="vq.enc.dgrad")
         return self.dx4
 
-    def encode_backward(self, dx4: Act, grads):
+    def encode_backward_gen(self, dx4: Act, grads):
         o, lib, s = self.ops, self.ops.lib, self.ops.s
         dy = dx4
         for i in (2, 1, 0):
-            self.down[i].backward(dy, self.dpooled[i], None, grads)
+            yield from self.down[i].backward_gen(dy, self.dpooled[i], None, grads)
             sk, dpo, add, out = self.skip[i], self.dpooled[i], self.dcat[i].slice(0, CHANS[i]), self.dskip_tot[i]
             _chk(lib.ammc_maxpool2x2_bwd_f32(sk.pix0(), *sk.strides, dpo.pix0(), *dpo.strides, add.pix0(), *add.strides,
                                              out.pix0(), *out.strides, dpo.B, dpo.H, dpo.W, dpo.c, s), "maxpool_bwd")
             dy = out
-        self.inc.backward(dy, None, None, grads)
+        yield from self.inc.backward_gen(dy, None, None, grads)
 
 
 class TrainEngine:
@@ -681,20 +719,22 @@ class TrainEngine:
         diffs, qs, outs = [], [], []
         # same order as the reference's forward (unet.py:981-1007): it fixes the order of the
         # in-place buffer updates
-        for s, x in zip(streams, xs):
-            s.encode(x)
-            if s.has_vq:
-                d, q = s.memory()
-                diffs.append(d)
-                qs.append(q)
+        # (with synchronised statistics the two streams advance layer by layer and share each collective, `_lockstep`;
+        # their buffers are disjoint, so the order between the streams does not matter - within a stream it is kept)
+        ops = st["ops"]
+        _lockstep(ops, *[s.encode_gen(x) for s, x in zip(streams, xs)])
+        vq = [s for s in streams if s.has_vq]
+        _lockstep(ops, *[s.memory_gen() for s in vq])
+        for s in vq:
+            diffs.append(s.mem_out[0])
+            qs.append(s.mem_out[1])
         if self.kind == "twostream":
-            st["o2f"].forward()
-            st["f2o"].forward()
+            _lockstep(ops, st["o2f"].forward_gen(), st["f2o"].forward_gen())
             bottoms = [st["xb"], st["yb"]]
         else:
             bottoms = [streams[0].bottom]
-        for s, b in zip(streams, bottoms):
-            outs.append(s.decode(b))
+        _lockstep(ops, *[s.decode_gen(b) for s, b in zip(streams, bottoms)])
+        outs = [s.out for s in streams]
         self._last = st
         if hasattr(self.module, "_param_epoch"):
             self.module._param_epoch += 1          # buffers changed through raw pointers: invalidate eval packs
@@ -728,27 +768,35 @@ class TrainEngine:
         if self.kind == "twostream":
             d_rgb, d_op, dd_r, dd_o, dq_r, dq_o = gouts
             r, o = streams
-            for s, dout in ((r, d_rgb), (o, d_op)):
-                if dout is None:
-                    dout = torch.zeros_like(s.out)
-                s.decode_backward(dout, grads)
+            ops = st["ops"]
+            douts = [dout if dout is not None else torch.zeros_like(s.out) for s, dout in ((r, d_rgb), (o, d_op))]
+            if ops.sync_world > 1:
+                _lockstep(ops, r.decode_backward_gen(douts[0], grads), o.decode_backward_gen(douts[1], grads))
                 stage_done()
+            else:                                   # one stream after the other: its gradients leave for the all-reduce early
+                for s, dout in zip((r, o), douts):
+                    _lockstep(ops, s.decode_backward_gen(dout, grads))
+                    stage_done()
             # x = zx + O2F(zy); y = zy + F20(zx): dzy = dyb + dgrad_O2F(dxb), dzx = dxb + dgrad_F20(dyb)
-            st["o2f"].backward(r.dbottom, st["dzy"], o.dbottom, grads)
-            st["f2o"].backward(o.dbottom, st["dzx"], r.dbottom, grads)
+            _lockstep(ops, st["o2f"].backward_gen(r.dbottom, st["dzy"], o.dbottom, grads),
+                      st["f2o"].backward_gen(o.dbottom, st["dzx"], r.dbottom, grads))
             stage_done()
             dx4r = r.memory_backward(st["dzx"], g(dd_r), g(dq_r), grads)
             dx4o = o.memory_backward(st["dzy"], g(dd_o), g(dq_o), grads)
-            r.encode_backward(dx4r, grads)
-            stage_done()
-            o.encode_backward(dx4o, grads)
+            if ops.sync_world > 1:
+                _lockstep(ops, r.encode_backward_gen(dx4r, grads), o.encode_backward_gen(dx4o, grads))
+            else:
+                _lockstep(ops, r.encode_backward_gen(dx4r, grads))
+                stage_done()
+                _lockstep(ops, o.encode_backward_gen(dx4o, grads))
         else:
             s = streams[0]
             dout = gouts[0] if gouts[0] is not None else torch.zeros_like(s.out)
-            db = s.decode_backward(dout, grads)
+            _lockstep(st["ops"], s.decode_backward_gen(dout, grads))
+            db = s.dbottom
             if self.kind == "unetmem":
                 db = s.memory_backward(db, g(gouts[1]), g(gouts[2]), grads)
-            s.encode_backward(db, grads)
+            _lockstep(st["ops"], s.encode_backward_gen(db, grads))
         stage_done()
         if reducer is not None:
             reducer.finish()

@@ -101,7 +101,13 @@ def _worker_sync(rank, world, port, q):
     Hn.generator_loss(out, rgb_t[sl].to(dev), op_t[sl].to(dev)).backward()
     torch.cuda.synchronize()
     ok, detail = True, ""
-    if rank == 0:
+    # the rgb and the flow stream (and the two halves of the bridge) share each statistics collective: 17 rounds in the
+    # forward pass (8 encoder units, the memories' EMA tensors, 2 bridge units, 6 decoder units) and 16 in the backward
+    # pass - not one per BatchNorm layer and direction (64 + 4 + 64)
+    ncoll = net._train_engine._last["ops"].collectives
+    if ncoll != 33:
+        ok, detail = False, f"{ncoll} statistics collectives, expected 33"
+    if rank == 0 and ok:
         # ONE step of the oracle on the whole batch of 2*world clips
         msd = O.clone_state(sd, requires_grad=True)
         O.generator_loss(O.twostream_forward(msd, rgb_x, op_x, 2, training=True), rgb_t, op_t).backward()
