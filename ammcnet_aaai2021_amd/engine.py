@@ -389,16 +389,22 @@ class StreamGraph:
     """buffers + plan fragments of one U-Net stream at one input shape"""
 
     def __init__(self, bld: _Builder, sp: _StreamPack, B: int, H: int, W: int):
-        if H % 8 or W % 8:
-            raise ValueError(f"frame size {H}x{W} must be divisible by 8 (three 2x2 poolings)")
+        if H < 8 or W < 8:
+            raise ValueError(f"frame size {H}x{W}: three 2x2 poolings need at least 8x8")
         self.sp, self.B, self.H, self.W = sp, B, H, W
         self.bld = bld
         chans = (64, 128, 256, 512)
+        # level sizes as nn.MaxPool2d(2) leaves them (floor); where a level is odd, the transposed conv of the decoder
+        # gives 2 * floor(h / 2) = h - 1 rows and `up.forward` pads one zero row / column at the END
+        # (reference unet.py:53-56: F.pad(x1, (dX // 2, dX - dX // 2, dY // 2, dY - dY // 2)) with dX, dY in {0, 1}):
+        # the transposed conv writes at offset 0 of a zero-initialised slice that nothing else writes
+        self.hs = [H, H // 2, H // 2 // 2, H // 2 // 2 // 2]
+        self.ws = [W, W // 2, W // 2 // 2, W // 2 // 2 // 2]
         self.x_in = bld.act(B, H, W, sp.inc.cin_p)
         # concat buffers of the three decoder levels; first half = the encoder's skip tensor
-        self.cat = [bld.act(B, H >> i, W >> i, 2 * chans[i]) for i in range(3)]
+        self.cat = [bld.act(B, self.hs[i], self.ws[i], 2 * chans[i]) for i in range(3)]
         self.skip = [self.cat[i].slice(0, chans[i]) for i in range(3)]
-        self.x4 = bld.act(B, H >> 3, W >> 3, 512)
+        self.x4 = bld.act(B, self.hs[3], self.ws[3], 512)
         self.bottom = self.x4          # what the decoder consumes (replaced by vq / bridge outputs)
 
     def encode(self):
@@ -408,22 +414,22 @@ class StreamGraph:
         # every encoder level stores its skip tensor and, for the `down` block that follows (unet.py:36), the 2x2
         # max-pool of it: from the conv's own epilogue where the halo-patch kernel runs the layer, else by a pool launch
         mid = bld.act(B, H, W, 64)
-        pooled = bld.act(B, H >> 1, W >> 1, chans[0])
+        pooled = bld.act(B, self.hs[1], self.ws[1], chans[0])
         fused = bld.double_conv(self.x_in, sp.inc, mid, self.skip[0], name="inc", pool=pooled)
         for i in range(3):
-            h, w = H >> (i + 1), W >> (i + 1)
+            h, w = self.hs[i + 1], self.ws[i + 1]
             if not fused:
                 bld.maxpool(self.skip[i], pooled, name=f"down{i + 1}.pool")
             mid = bld.act(B, h, w, chans[i + 1])
             out = self.skip[i + 1] if i < 2 else self.x4
-            nxt = bld.act(B, h >> 1, w >> 1, chans[i + 1]) if i < 2 else None
+            nxt = bld.act(B, self.hs[i + 2], self.ws[i + 2], chans[i + 1]) if i < 2 else None
             fused = bld.double_conv(pooled, sp.down[i], mid, out, name=f"down{i + 1}", pool=nxt)
             pooled = nxt
 
     def memory(self):
         """enc 1x1 -> fused distance/top-k/gather -> dec 1x1 + residual  (unet.py:318-331, 379-387)"""
         bld, v = self.bld, self.sp.vq
-        B, h, w = self.B, self.H >> 3, self.W >> 3
+        B, h, w = self.B, self.hs[3], self.ws[3]
         n, d, m, k = B * h * w, v["d"], v["m"], v["k"]
         lib = bld.lib
         self.z = bld.act(B, h, w, d, halo=0)
@@ -461,10 +467,10 @@ class StreamGraph:
         for j, lvl in enumerate((2, 1, 0)):            # up1 -> level 2 (H/4), up2 -> level 1, up3 -> level 0
             wt, bias, dc = sp.up[j]
             c = chans[lvl]
-            h, w = H >> lvl, W >> lvl
+            h, w = self.hs[lvl], self.ws[lvl]
             mid = bld.act(B, h, w, c)
             out = bld.act(B, h, w, c)
-            if sp.up_fused[j] is not None and bld.up_conv_eligible(self.skip[lvl], c):
+            if sp.up_fused[j] is not None and bld.up_conv_eligible(self.skip[lvl], c) and (h, w) == (2 * y.H, 2 * y.W):
                 # transposed conv + concat + first conv as one launch; the up half of the concat buffer stays unused
                 bld.up_conv(y, self.skip[lvl], dc, sp.up_fused[j], mid, name=f"up{j + 1}.up+conv0")
                 bld.conv(mid, dc.w1, out, ntaps=9, cin=c, n=c, scale=dc.s1, shift=dc.b1, act=ACT_RELU, name=f"up{j + 1}.conv1")
@@ -536,7 +542,7 @@ class EvalEngine:
             r.memory()
             o.encode()
             o.memory()
-            h, w = H >> 3, W >> 3
+            h, w = r.hs[3], r.ws[3]
             # AMFT bridge: x = zx + O2F(zy); y = zy + F20(zx)   (unet.py:962-965)
             mid = bld.act(B, h, w, 512)
             xb = bld.act(B, h, w, 512)

@@ -65,9 +65,10 @@ def double_conv_eval(dc, x: torch.Tensor, pool_first: bool = False, residual: to
 def up_eval(upm, x1: torch.Tensor, x2: torch.Tensor):
     """`up.forward`: ConvTranspose into the second half of the concat buffer, skip into the first"""
     _need_cuda(x1)
-    if x1.shape[2] * 2 != x2.shape[2] or x1.shape[3] * 2 != x2.shape[3]:
-        raise ValueError("up: the skip tensor must be exactly twice the size of the upsampled one "
-                         "(frame sizes divisible by 8)")
+    dy, dx = x2.shape[2] - 2 * x1.shape[2], x2.shape[3] - 2 * x1.shape[3]
+    if dy not in (0, 1) or dx not in (0, 1):
+        raise ValueError("up: the skip tensor must be 2x the upsampled one, or one row / column more (what MaxPool2d(2) "
+                         "leaves of an odd level; `up.forward` pads that row / column with zeros, unet.py:53-56)")
     plan = Plan()
     bld = _Builder(plan, x1.device)
     pk = _Packer(x1.device)

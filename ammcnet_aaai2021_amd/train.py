@@ -436,7 +436,9 @@ class _Stream:
 
     def __init__(self, ops: _Ops, net, B, H, W, has_vq: bool):
         if H % 8 or W % 8:
-            raise ValueError(f"frame size {H}x{W} must be divisible by 8")
+            raise NotImplementedError(
+                f"training at frame size {H}x{W}: the training kernels need H and W divisible by 8 (every harness use of "
+                "the reference is 256x256); the evaluation engine takes any size >= 8 (odd levels padded as `up.forward` does)")
         ws, lib = ops.ws, ops.lib
         self.ops, self.net, self.B, self.H, self.W, self.has_vq = ops, net, B, H, W, has_vq
         self.cin = net.inc.conv.conv[0].weight.shape[1]
@@ -801,6 +803,182 @@ class TrainEngine:
         if reducer is not None:
             reducer.finish()
         return {k.data_ptr(): v for k, v in grads.items()}
+
+
+class BlockEngine:
+    """Training-mode forward / backward of ONE building block called on its own, as the reference's sub-modules can be
+    (`double_conv`, `inconv`, `down`, `up`, `bridge`: models/unet.py:8-59, 956-965) - the same units the whole-model
+    engine is made of, with the module-boundary layout changes around them and, unlike the whole-model engine, the
+    gradients of the block's INPUTS (a stand-alone block sits inside somebody else's autograd graph).  Input gradients
+    need >= 32 input channels (the input-gradient convolution's tiles); for thinner inputs - the 12 / 6-channel clips
+    of `inconv` - the input gets no gradient, as data does not need one."""
+
+    def __init__(self, module, kind: str, precision: Optional[str] = None):
+        precision = precision or TRAIN_PRECISION
+        if kind not in ("double_conv", "down", "up", "bridge"):
+            raise ValueError(kind)
+        self.module, self.kind, self.precision = module, kind, precision
+        self._ws: Dict = {}
+        self.generation = 0
+
+    def _get(self, shapes, device):
+        key = (shapes, device)
+        st = self._ws.get(key)
+        if st is not None:
+            return st
+        ws = _WS(device)
+        ops = _Ops(ws, self.precision)
+        m, kind = self.module, self.kind
+        B, C, H, W = shapes[0]
+        st = dict(ops=ops)
+        if kind in ("double_conv", "down"):
+            dc = m if kind == "double_conv" else m.mpconv[1]
+            cin = dc.conv[0].weight.shape[1]
+            if C != cin:
+                raise ValueError(f"{kind}: {C} input channels, the block has {cin}")
+            st["x"] = ws.act(B, H, W, _cin_pad(cin))
+            src = st["x"]
+            if kind == "down":
+                if H % 2 or W % 2:
+                    raise NotImplementedError("down in training mode: even frame sizes")
+                st["pooled"] = src = ws.act(B, H // 2, W // 2, _cin_pad(cin))
+                st["dpooled"] = ws.act(B, H // 2, W // 2, _cin_pad(cin))
+            cout = dc.conv[0].weight.shape[0]
+            st["y"] = ws.act(B, src.H, src.W, cout)
+            st["dy"] = ws.act(B, src.H, src.W, cout)
+            st["dc"] = _DoubleConv(ops, dc, src, st["y"], None, kind)
+            st["dx"] = ws.act(B, H, W, _cin_pad(cin)) if cin >= 32 else None
+        elif kind == "up":
+            (_, c2, h, w), (_, c, H2, W2) = shapes
+            if c2 != 2 * c or (H2, W2) != (2 * h, 2 * w):
+                raise NotImplementedError("up in training mode: x2 must have half the channels and exactly twice the size of x1")
+            st["x1"] = ws.act(B, h, w, c2)
+            st["cat"] = ws.act(B, H2, W2, c2)
+            st["y"], st["dy"] = ws.act(B, H2, W2, m.conv.conv[0].weight.shape[0]), ws.act(B, H2, W2, m.conv.conv[0].weight.shape[0])
+            st["dc"] = _DoubleConv(ops, m.conv, st["cat"], st["y"], None, "up")
+            st["dcat"], st["dx1"] = ws.act(B, H2, W2, c2), ws.act(B, h, w, c2)
+            st["wp"], st["b4"] = ws.buf(4 * c, c2), ws.buf(4 * c)
+            st["dwp"], st["wT"] = ws.zbuf(c2, 4 * c), ws.buf(c2, 4 * c)
+            st["scratch"] = ws.buf(ops.lib.ammc_chan_reduce_blocks(B * H2 * W2) * 512 + 1024)
+        else:                                   # bridge: x = zx + O2F(zy), y = zy + F20(zx)
+            st["zx"], st["zy"] = ws.act(B, H, W, C), ws.act(B, H, W, C)
+            st["xb"], st["yb"] = ws.act(B, H, W, C), ws.act(B, H, W, C)
+            st["dxb"], st["dyb"] = ws.act(B, H, W, C), ws.act(B, H, W, C)
+            st["dzx"], st["dzy"] = ws.act(B, H, W, C), ws.act(B, H, W, C)
+            st["o2f"] = _DoubleConv(ops, m.O2F, st["zy"], st["xb"], st["zx"], "bridge.O2F")
+            st["f2o"] = _DoubleConv(ops, m.F20, st["zx"], st["yb"], st["zy"], "bridge.F20")
+        self._ws[key] = st
+        return st
+
+    @staticmethod
+    def _load(ops, x: torch.Tensor, a: Act):
+        x = x.detach().float().contiguous()
+        _chk(ops.lib.ammc_nchw_to_nhwc_f32(_ptr(x), a.B, x.shape[1], a.H, a.W, a.pix0(), *a.strides, a.c, ops.s), "nchw_to_nhwc")
+
+    @staticmethod
+    def _store(ops, a: Act, c: Optional[int] = None) -> torch.Tensor:
+        c = c or a.c
+        y = torch.empty((a.B, c, a.H, a.W), device=a.buf.device, dtype=torch.float32)
+        _chk(ops.lib.ammc_nhwc_to_nchw_f32(a.pix0(), *a.strides, a.B, c, a.H, a.W, _ptr(y), ops.s), "nhwc_to_nchw")
+        return y
+
+    def forward(self, *inputs: torch.Tensor):
+        if not inputs[0].is_cuda:
+            raise _lib.AmmcHipError("the HIP path needs CUDA/HIP tensors; there is no CPU fallback")
+        st = self._get(tuple(tuple(x.shape) for x in inputs), inputs[0].device)
+        ops, lib = st["ops"], st["ops"].lib
+        ops.sync_group = False
+        self.generation += 1
+        st["generation"] = self.generation
+        self._last = st
+        if self.kind in ("double_conv", "down"):
+            self._load(ops, inputs[0], st["x"])
+            if self.kind == "down":
+                x, p = st["x"], st["pooled"]
+                _chk(lib.ammc_maxpool2x2_f32(x.pix0(), *x.strides, p.pix0(), *p.strides, p.B, p.H, p.W, p.c, ops.s), "pool")
+            _lockstep(ops, st["dc"].forward_gen())
+            return (self._store(ops, st["y"]),)
+        if self.kind == "up":
+            m, c = self.module, inputs[1].shape[1]
+            self._load(ops, inputs[0], st["x1"])
+            self._load(ops, inputs[1], st["cat"].slice(0, c))
+            _chk(lib.ammc_pack_convt_weight_f32(_ptr(m.up.weight.detach()), 2 * c, c, _ptr(st["wp"]), ops.s), "pack")
+            st["b4"].copy_(m.up.bias.detach().repeat(4))
+            ops.conv(st["x1"], st["wp"], st["cat"].slice(c, c), ntaps=1, cin=2 * c, n=4 * c, shift=st["b4"], up=2, cgroup=c,
+                     what="up.up")
+            _lockstep(ops, st["dc"].forward_gen())
+            return (self._store(ops, st["y"]),)
+        self._load(ops, inputs[0], st["zx"])
+        self._load(ops, inputs[1], st["zy"])
+        _lockstep(ops, st["o2f"].forward_gen(), st["f2o"].forward_gen())
+        return self._store(ops, st["xb"]), self._store(ops, st["yb"])
+
+    def backward(self, generation: int, gouts):
+        """-> ([gradient per input or None], {parameter data_ptr: gradient})"""
+        st = self._last
+        if st.get("generation") != generation:
+            raise RuntimeError("HIP training path: backward() called for a forward whose workspace has been reused")
+        ops, lib = st["ops"], st["ops"].lib
+        ops.ws.zero_step()
+        grads: Dict = {}
+        if self.kind in ("double_conv", "down"):
+            self._load(ops, gouts[0], st["dy"])
+            if self.kind == "double_conv":
+                _lockstep(ops, st["dc"].backward_gen(st["dy"], st["dx"], None, grads))
+                dx = self._store(ops, st["dx"], st["dc"].u0.cin) if st["dx"] is not None else None
+            else:
+                dpo = st["dpooled"] if st["dx"] is not None else None
+                _lockstep(ops, st["dc"].backward_gen(st["dy"], dpo, None, grads))
+                dx = None
+                if dpo is not None:
+                    x, out = st["x"], st["dx"]
+                    _chk(lib.ammc_maxpool2x2_bwd_f32(x.pix0(), *x.strides, dpo.pix0(), *dpo.strides, None, 0, 0, 0,
+                                                     out.pix0(), *out.strides, dpo.B, dpo.H, dpo.W, dpo.c, ops.s), "maxpool_bwd")
+                    dx = self._store(ops, out, st["dc"].u0.cin)
+            ins = [dx]
+        elif self.kind == "up":
+            m = self.module
+            c = m.up.weight.shape[1]
+            self._load(ops, gouts[0], st["dy"])
+            _lockstep(ops, st["dc"].backward_gen(st["dy"], st["dcat"], None, grads))
+            dx2 = self._store(ops, st["dcat"].slice(0, c), c)
+            dys = st["dcat"].slice(c, c)
+            grads[m.up.bias] = ops.chan_sum(dys, c, st["scratch"])
+            ops.wgrad(st["x1"], dys, st["dwp"], n=2 * c, cin=c, ntaps=4, a_step=2, what="up.up.wgrad")
+            dwt = torch.empty_like(m.up.weight)
+            _chk(lib.ammc_unpack_convt_wgrad_f32(_ptr(st["dwp"]), 2 * c, c, _ptr(dwt), ops.s), "unpack_convt")
+            grads[m.up.weight] = dwt
+            _chk(lib.ammc_transpose_pad_f32(_ptr(st["wp"]), 4 * c, 2 * c, 4 * c, _ptr(st["wT"]), ops.s), "transpose")
+            ops.conv(dys, st["wT"], st["dx1"], ntaps=4, cin=c, n=2 * c, x_step=2, what="up.up.dgrad")
+            ins = [self._store(ops, st["dx1"]), dx2]
+        else:
+            dxb = gouts[0] if gouts[0] is not None else torch.zeros_like(gouts[1])
+            dyb = gouts[1] if gouts[1] is not None else torch.zeros_like(gouts[0])
+            self._load(ops, dxb, st["dxb"])
+            self._load(ops, dyb, st["dyb"])
+            # x = zx + O2F(zy); y = zy + F20(zx): dzy = dyb + dgrad_O2F(dxb), dzx = dxb + dgrad_F20(dyb)
+            _lockstep(ops, st["o2f"].backward_gen(st["dxb"], st["dzy"], st["dyb"], grads),
+                      st["f2o"].backward_gen(st["dyb"], st["dzx"], st["dxb"], grads))
+            ins = [self._store(ops, st["dzx"]), self._store(ops, st["dzy"])]
+        return ins, {k.data_ptr(): v for k, v in grads.items()}
+
+
+class BlockFunction(torch.autograd.Function):
+    """(engine, n_inputs, *inputs, *params) -> the block's outputs, differentiable w.r.t. inputs and params"""
+
+    @staticmethod
+    def forward(ctx, engine: BlockEngine, n_inputs: int, *tensors):
+        outs = engine.forward(*tensors[:n_inputs])
+        ctx.engine, ctx.generation, ctx.params, ctx.n_inputs = engine, engine.generation, tensors[n_inputs:], n_inputs
+        return outs if len(outs) > 1 else outs[0]
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        ins, grads = ctx.engine.backward(ctx.generation, gouts)
+        out = [None, None] + [g if ctx.needs_input_grad[2 + i] else None for i, g in enumerate(ins)]
+        for p in ctx.params:
+            out.append(grads.get(p.data_ptr()))
+        return tuple(out)
 
 
 class HipPathFunction(torch.autograd.Function):

@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from . import ops
 from .engine import EvalEngine
-from .train import HipPathFunction, TrainEngine
+from .train import BlockEngine, BlockFunction, HipPathFunction, TrainEngine
 
 
 # Inference arithmetic: "s16" (default) = split-fp16 MFMA with fp32 accumulation: 22 significant bits per operand,
@@ -39,9 +39,20 @@ DEFAULT_PRECISION = os.environ.get("AMMC_PRECISION", "s16")
 def _no_training(mod):
     if mod.training:
         raise NotImplementedError(
-            f"{type(mod).__name__}: training mode is implemented at the model boundaries (UNet, UNetMem_v7, "
-            "twostream: one fused autograd.Function over the HIP kernels), not for a sub-module called on its "
-            "own; call .eval() for a stand-alone block - there is no ATen fallback")
+            f"{type(mod).__name__}: training mode exists for the models (UNet, UNetMem_v7, twostream) and for the conv "
+            "blocks (double_conv, inconv, down, up, bridge) called on their own, not for the memory block alone (its "
+            "only gradient is the commit term, which the models' engines produce); call .eval() - there is no ATen "
+            "fallback")
+
+
+def _run_block(mod, kind: str, owner, *inputs):
+    """training-mode forward of a stand-alone block: one autograd node over the HIP kernels (train.BlockEngine)"""
+    eng = owner.__dict__.get("_block_engine")
+    tprec = getattr(owner, "train_precision", None)
+    if eng is None or (tprec is not None and eng.precision != tprec):
+        eng = BlockEngine(mod, kind, tprec)
+        object.__setattr__(owner, "_block_engine", eng)
+    return BlockFunction.apply(eng, len(inputs), *inputs, *mod.parameters())
 
 
 def _fp32_engine(mod, kind: str) -> EvalEngine:
@@ -85,7 +96,8 @@ class double_conv(nn.Module):
                                   nn.ReLU(inplace=True))
 
     def forward(self, x):
-        _no_training(self)
+        if self.training:
+            return _run_block(self, "double_conv", self, x)
         return ops.double_conv_eval(self, x)
 
 
@@ -104,7 +116,8 @@ class down(nn.Module):
         self.mpconv = nn.Sequential(nn.MaxPool2d(2), double_conv(in_ch, out_ch))
 
     def forward(self, x):
-        _no_training(self)
+        if self.training:
+            return _run_block(self, "down", self, x)
         return ops.double_conv_eval(self.mpconv[1], x, pool_first=True)
 
 
@@ -115,7 +128,8 @@ class up(nn.Module):
         self.conv = double_conv(in_ch, out_ch)
 
     def forward(self, x1, x2):
-        _no_training(self)
+        if self.training:
+            return _run_block(self, "up", self, x1, x2)
         return ops.up_eval(self, x1, x2)
 
 
@@ -212,7 +226,8 @@ class bridge(nn.Module):
         self.F20 = double_conv(in_c, in_c)
 
     def forward(self, zx, zy):
-        _no_training(self)
+        if self.training:
+            return _run_block(self, "bridge", self, zx, zy)
         return (ops.double_conv_eval(self.O2F, zy, residual=zx),
                 ops.double_conv_eval(self.F20, zx, residual=zy))
 

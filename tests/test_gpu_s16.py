@@ -232,3 +232,21 @@ def test_benchmark_workload_b16_256_m2000_vs_reference_vectors(prec, mf):
         assert {f"conv_tap_s16<4, 1, 2, 4, 1, {mf}>", f"conv_tap_s16<4, 1, 2, 2, 1, {mf}>", f"conv_tap_s16<4, 2, 2, 2, 2, {mf}>",
                 f"conv_tap_s16<8, 1, 1, 1, 1, {mf}>", "conv_gemm_s16<128x128>", "conv_gemm_s16<128x64>"} <= kernels, kernels
         assert not eng.overflowed()
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 100, 100), (2, 36, 52), (1, 72, 96)])
+@pytest.mark.parametrize("prec", ["s16", "fp32"])
+def test_frame_sizes_not_divisible_by_8(B, H, W, prec):
+    """MaxPool2d(2) floors odd levels and `up.forward` pads the transposed conv's output by one zero row / column at the
+    end (reference unet.py:36, 53-56): 100 -> 50 -> 25 -> 12 -> (24 padded to 25) ...  Against the oracle, both
+    precisions; the quantised maps have the floored bottleneck size."""
+    net, sd = _net()
+    net.precision = prec
+    rgb_x, op_x, _, _ = S.make_clips(B, H, W, tag=f"odd-{B}-{H}-{W}")
+    with torch.no_grad():
+        rgb, op, (rd, od), (rq, oq) = net(rgb_x.to(DEV), op_x.to(DEV))
+        w = O.twostream_forward(O.clone_state(sd), rgb_x, op_x, 2)
+    assert rgb.shape == (B, 3, H, W) and rq.shape == (B, H // 2 // 2 // 2, W // 2 // 2 // 2, 64)
+    errs = dict(rgb=rel_err(rgb.cpu(), w[0]), op=rel_err(op.cpu(), w[1]), rd=rel_err(rd.cpu(), w[2][0]),
+                od=rel_err(od.cpu(), w[2][1]), rq=rel_err(rq.cpu(), w[3][0]), oq=rel_err(oq.cpu(), w[3][1]))
+    assert max(errs.values()) <= TOL, errs

@@ -370,3 +370,79 @@ def test_scale_shift_act_with_s16_output():
     _lib.check(lib.ammc_s16_to_nchw_f32(y16b.pix0(), *y16b.strides, B, C, H, W, _ptr(back), s), "decode")
     want = (x.interior() * scale + shift).permute(0, 3, 1, 2)
     assert float((back - want).abs().max()) <= 1e-6 * float(want.abs().max())
+
+
+def _block_state(mod, tag):
+    """deterministic parameters for a stand-alone block, BatchNorm affine as in `_mask_free_state` (no ReLU flips)"""
+    sd = {}
+    for k, v in mod.state_dict().items():
+        leaf = k.rsplit(".", 1)[-1]
+        if leaf == "num_batches_tracked":
+            sd[k] = torch.zeros_like(v)
+        elif v.dim() == 1 and (k[:-len(leaf)] + "running_mean") in mod.state_dict():
+            if leaf == "weight":
+                sd[k] = 0.2 * torch.sign(S.hashed_uniform(f"{tag}.{k}", tuple(v.shape)))
+            elif leaf == "bias":
+                sd[k] = torch.full_like(v, 2.0)
+            elif leaf == "running_var":
+                sd[k] = S.hashed_uniform(f"{tag}.{k}", tuple(v.shape), 0.5, 1.5)
+            else:
+                sd[k] = S.hashed_uniform(f"{tag}.{k}", tuple(v.shape)) * 0.1
+        else:
+            fan = v[0].numel() if v.dim() > 1 else 1
+            sd[k] = S.hashed_uniform(f"{tag}.{k}", tuple(v.shape)) * (1.5 / max(fan, 1)) ** 0.5
+    return sd
+
+
+@pytest.mark.parametrize("kind", ["double_conv", "inconv", "down", "up", "bridge"])
+def test_standalone_blocks_in_training_mode(kind):
+    """the reference's sub-modules are trainable on their own (models/unet.py:8-59, 956-965): outputs, parameter
+    gradients, INPUT gradients and the BatchNorm running statistics of one training-mode call of each block against
+    the oracle's autograd in float64 (mask-free BatchNorm affine: 1e-4 gates; `inconv`'s 12-channel input gets no
+    gradient - it is data)"""
+    torch.manual_seed(0)
+    mod = {"double_conv": lambda: A.double_conv(64, 128), "inconv": lambda: A.inconv(12, 64), "down": lambda: A.down(64, 128),
+           "up": lambda: A.up(128, 64), "bridge": lambda: A.bridge(64)}[kind]()
+    sd = _block_state(mod, kind)
+    mod.load_state_dict(sd)
+    mod = mod.to(DEV).train()
+    B, H, W = 2, 32, 32
+    if kind == "up":
+        ins = [S.hashed_uniform("blk-x1", (B, 128, H // 2, W // 2)), S.hashed_uniform("blk-x2", (B, 64, H, W))]
+    elif kind == "bridge":
+        ins = [S.hashed_uniform("blk-zx", (B, 64, H, W)), S.hashed_uniform("blk-zy", (B, 64, H, W))]
+    else:
+        ins = [S.hashed_uniform("blk-x", (B, 12 if kind == "inconv" else 64, H, W))]
+    want_dx = kind != "inconv"
+    xs = [t.to(DEV).requires_grad_(want_dx) for t in ins]
+    outs = mod(*xs)
+    outs = outs if isinstance(outs, tuple) else (outs,)
+    probes = [S.hashed_uniform(f"blk-r{i}", tuple(o.shape)).to(DEV) for i, o in enumerate(outs)]
+    sum((o * r).sum() for o, r in zip(outs, probes)).backward()
+    # oracle, float64
+    pref = "bridge." if kind == "bridge" else "p."
+    m = O.clone_state({pref + k: v.double() if v.is_floating_point() else v for k, v in sd.items()}, requires_grad=True)
+    xd = [t.double().requires_grad_(want_dx) for t in ins]
+    if kind == "double_conv":
+        w = (O.double_conv(m, "p.conv", xd[0], training=True),)
+    elif kind == "inconv":
+        w = (O.double_conv(m, "p.conv.conv", xd[0], training=True),)
+    elif kind == "down":
+        w = (O.down(m, "p", xd[0], training=True),)
+    elif kind == "up":
+        w = (O.up(m, "p", xd[0], xd[1], training=True),)
+    else:
+        w = O.bridge(m, xd[0], xd[1], training=True)
+    sum((o * r.double().cpu()).sum() for o, r in zip(w, probes)).backward()
+    for o, wo in zip(outs, w):
+        assert rel_err(o.detach().cpu(), wo.detach()) <= 1e-5
+    for name, p in mod.named_parameters():
+        assert _l2rel(p.grad.cpu(), m[pref + name].grad) <= 1e-4, name
+    if want_dx:
+        for x, xw in zip(xs, xd):
+            # (down: a max-pool near-tie can re-route single elements of the input gradient)
+            assert _l2rel(x.grad.cpu(), xw.grad) <= (2e-3 if kind == "down" else 1e-4)
+    nsd = mod.state_dict()
+    for k, v in m.items():
+        if not v.requires_grad and v.is_floating_point():
+            assert rel_err(nsd[k[len(pref):]].cpu().double(), v) <= 1e-5, k
