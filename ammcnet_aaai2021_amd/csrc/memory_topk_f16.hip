@@ -12,8 +12,10 @@
 //     (8 consecutive features of one slot) is ONE coalesced 16-B global load, 512 B per half
 //     wave; loads run a ring of PF steps ahead of the MFMAs - the codebook (8 MB at config 5)
 //     streams from L2 / Infinity Cache and never touches LDS;
-//   - wave w contracts slot tiles w, w+8, ...; each lane keeps the running top-K of its feature
-//     row in registers; the 16 partial lists per row are merged through LDS.
+//   - wave w contracts slot tiles in PAIRS (2 w, 2 w + 1), (2 w + 16, ...): a feature fragment read from LDS feeds
+//     two MFMAs.  With one tile per wave the kernel sat on the LDS ceiling - four 1-KB fragment reads per four MFMAs
+//     and wave, eight waves: 256 B/clk/CU, all the LDS has - at 0.17 of the fp16 MFMA peak; pairs halve that.  Each
+//     lane keeps the running top-K of its feature row in registers; the 16 partial lists per row are merged through LDS.
 // Roofline: MFMA fp16 (2*d*m flop per row against ~2*d + 4*k*d bytes): AI in the thousands.
 #include "ammc_common.h"
 #include <hip/hip_fp16.h>
@@ -27,7 +29,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int HBR = 128;          // feature rows per workgroup
 constexpr int HRT = HBR / 32;
 constexpr int HWAVES = 8;
-constexpr int PF = 8;             // A-fragment prefetch depth (k-steps of 16)
+constexpr int PF = 4;             // A-fragment prefetch depth (k-steps of 16; a step is 8 MFMAs = 256 cycles of the pipe)
+constexpr int TS = 2;             // slot tiles per wave iteration
 
 template <int K>
 __device__ __forceinline__ void topk_insert16(float (&v)[K], int (&ix)[K], float c, int s) {
@@ -108,44 +111,58 @@ __global__ __launch_bounds__(512, 1) void memory_topk_f16_kernel(
 
   const int ntile = mpad >> 5;
   const int nstep = d >> 4;                               // k-steps of 16 features
-  for (int tile = wave; tile < ntile; tile += HWAVES) {
-    const int s0 = tile << 5;
+  for (int tile = wave * TS; tile < ntile; tile += HWAVES * TS) {
     // lane (l31, h) at step t needs features [16t + 8h, +8) of slot s0 + l31: k-block 2t + h
-    const f16x8* ep = e_kblk + (int64_t)h * mpad + s0 + l31;
-    f32x16 acc[HRT];
+    const f16x8* ep[TS];
+    f32x16 acc[TS][HRT];
+    f16x8 ring[TS][PF];
 #pragma unroll
-    for (int t = 0; t < HRT; ++t)
+    for (int u = 0; u < TS; ++u) {
+      const int tl = tile + u < ntile ? tile + u : ntile - 1;           // (an odd tail tile is contracted twice, inserted once)
+      ep[u] = e_kblk + (int64_t)h * mpad + (tl << 5) + l31;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    f16x8 ring[PF];
+      for (int t = 0; t < HRT; ++t)
 #pragma unroll
-    for (int p = 0; p < PF; ++p)
-      if (p < nstep) ring[p] = ep[(int64_t)(2 * p) * mpad];
+        for (int r = 0; r < 16; ++r) acc[u][t][r] = 0.f;
+#pragma unroll
+      for (int p = 0; p < PF; ++p)
+        if (p < nstep) ring[u][p] = ep[u][(int64_t)(2 * p) * mpad];
+    }
     for (int t0 = 0; t0 < nstep; t0 += PF) {
 #pragma unroll
       for (int p = 0; p < PF; ++p) {
         const int t = t0 + p;
         if (t < nstep) {
-          const f16x8 af = ring[p];
-          if (t + PF < nstep) ring[p] = ep[(int64_t)(2 * (t + PF)) * mpad];
+          f16x8 af[TS];
+#pragma unroll
+          for (int u = 0; u < TS; ++u) {
+            af[u] = ring[u][p];
+            if (t + PF < nstep) ring[u][p] = ep[u][(int64_t)(2 * (t + PF)) * mpad];
+          }
           const int so = (((2 * t + h) ^ (l31 & 15)) << 3);
 #pragma unroll
           for (int rt = 0; rt < HRT; ++rt) {
             const f16x8 bf = *reinterpret_cast<const f16x8*>(xs + (size_t)(rt * 32 + l31) * d + so);
-            acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[rt], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < TS; ++u) acc[u][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u], bf, acc[u][rt], 0, 0, 0);
           }
         }
       }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int s = s0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (s < m) {
-        const float en = enorm16[s];
+    for (int u = 0; u < TS; ++u) {
+      if (tile + u >= ntile) break;
+      const int s0 = (tile + u) << 5;
 #pragma unroll
-        for (int rt = 0; rt < HRT; ++rt) {
-          const float dist = (xnorm[rt] - 2.f * acc[rt][r]) + en;
-          topk_insert16<K>(bv[rt], bi[rt], dist, s);
+      for (int r = 0; r < 16; ++r) {
+        const int s = s0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (s < m) {
+          const float en = enorm16[s];
+#pragma unroll
+          for (int rt = 0; rt < HRT; ++rt) {
+            const float dist = (xnorm[rt] - 2.f * acc[u][rt][r]) + en;
+            topk_insert16<K>(bv[rt], bi[rt], dist, s);
+          }
         }
       }
     }
