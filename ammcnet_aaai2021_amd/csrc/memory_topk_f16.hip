@@ -50,6 +50,25 @@ __device__ __forceinline__ void topk_insert16(float (&v)[K], int (&ix)[K], float
   }
 }
 
+// The same insertion when candidates arrive in increasing slot order (one lane's walk over its slot tiles: tiles ascend,
+// and so do the 16 slots of a tile's registers): a tie always loses to the entry already held, so strict comparisons
+// implement the (value, index) order - branch-free for the model's K = 2 (as in memory_topk.hip).
+template <int K>
+__device__ __forceinline__ void topk_insert16_ordered(float (&v)[K], int (&ix)[K], float c, int s) {
+  if (K == 2) {
+    // (after the first tiles almost no candidate beats the second best of its row: the whole wave skips the update)
+    if (c < v[1]) {
+      const bool lt0 = c < v[0];
+      v[1] = lt0 ? v[0] : c;
+      ix[1] = lt0 ? ix[0] : s;
+      v[0] = lt0 ? c : v[0];
+      ix[0] = lt0 ? s : ix[0];
+    }
+  } else {
+    topk_insert16<K>(v, ix, c, s);
+  }
+}
+
 template <int K>
 __global__ __launch_bounds__(512, 1) void memory_topk_f16_kernel(
     const float* __restrict__ x, const f16x8* __restrict__ e_kblk /* [d/8][mpad] */,
@@ -161,7 +180,7 @@ __global__ __launch_bounds__(512, 1) void memory_topk_f16_kernel(
 #pragma unroll
           for (int rt = 0; rt < HRT; ++rt) {
             const float dist = (xnorm[rt] - 2.f * acc[u][rt][r]) + en;
-            topk_insert16<K>(bv[rt], bi[rt], dist, s);
+            topk_insert16_ordered<K>(bv[rt], bi[rt], dist, s);
           }
         }
       }
