@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libammc_hip.so")
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU = 0, 1, 2, 3
 
@@ -69,6 +69,9 @@ SIGNATURES = {
     "ammc_conv_gemm_s16": (C.c_int, [C.POINTER(AmmcConvDesc), _p]),
     "ammc_pack_up_conv_f32": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _p, _p, _p]),
     "ammc_conv_up_s16": (C.c_int, [C.POINTER(AmmcConvDesc), _p, _i64, _i64, _i64, _i32, _p, _p, _p]),
+    "ammc_first_conv_image_floats": (C.c_int, []),
+    "ammc_pack_first_conv_f32": (C.c_int, [_p, _i32, _i32, _p, _p]),
+    "ammc_conv_first_s16": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _i64, _i64, _i64, _p, _p]),
     "ammc_conv_gemm_s16_variant": (C.c_int, [C.POINTER(AmmcConvDesc), C.c_char_p, _i32]),
     "ammc_split_rows_f32": (C.c_int, [_p, _i64, _p, _p]),
     "ammc_absmax_bits_f32": (C.c_int, [_p, _i64, _p, _p]),

@@ -159,6 +159,16 @@ class _Packer:
         _lib.check(self.lib.ammc_pack_convt_weight_f32(_ptr(w), cin, co, _ptr(out), self.stream()), "pack_convt")
         return self._split(out)
 
+    def first_conv(self, conv0: torch.nn.Conv2d) -> Optional[torch.Tensor]:
+        """filter image of `ammc_conv_first_s16` (csrc/conv_first_s16.hip), or None when the layer is not its case"""
+        cout, cin = conv0.weight.shape[0], conv0.weight.shape[1]
+        if cout != 64 or cin > 16:
+            return None
+        img = torch.empty(self.lib.ammc_first_conv_image_floats(), device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.ammc_pack_first_conv_f32(_ptr(conv0.weight.detach().contiguous()), cout, cin, _ptr(img),
+                                                     self.stream()), "pack_first_conv")
+        return img
+
     def up_conv(self, conv0: torch.nn.Conv2d, convt: torch.nn.ConvTranspose2d, scale: torch.Tensor,
                 shift: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """composed filters + border-class shifts of `ammc_conv_up_s16` (csrc/conv_up_s16.hip): the transposed conv of an
@@ -206,6 +216,7 @@ class _StreamPack:
 
     def __init__(self, pk: _Packer, net):
         self.inc = _DoubleConvPack(pk, net.inc.conv)
+        self.first = pk.first_conv(net.inc.conv.conv[0]) if pk.s16 else None      # S16 plans: the first layer from NCHW
         self.down = [_DoubleConvPack(pk, d.mpconv[1]) for d in (net.down1, net.down2, net.down3)]
         self.up = []
         self.up_fused = []        # S16 plans: (composed filters, border-class shifts) of ammc_conv_up_s16 per decoder level
@@ -329,10 +340,12 @@ class _Builder:
         return d
 
     def double_conv(self, x: Act, p: _DoubleConvPack, mid: Act, y: Act, res: Optional[Act] = None, name="dc",
-                    pool: Optional[Act] = None) -> bool:
-        """`pool`: where the 2x2 max-pool of the output goes; returns True when the second conv stored it itself"""
-        self.conv(x, p.w0, mid, ntaps=9, cin=p.cin_p, n=p.cout, scale=p.s0, shift=p.b0, act=ACT_RELU,
-                  name=f"{name}.conv0", cin_true=p.cin)
+                    pool: Optional[Act] = None, skip_first: bool = False) -> bool:
+        """`pool`: where the 2x2 max-pool of the output goes; returns True when the second conv stored it itself.
+        `skip_first`: the first conv is launched by the caller (`ammc_conv_first_s16`, straight from the NCHW input)"""
+        if not skip_first:
+            self.conv(x, p.w0, mid, ntaps=9, cin=p.cin_p, n=p.cout, scale=p.s0, shift=p.b0, act=ACT_RELU,
+                      name=f"{name}.conv0", cin_true=p.cin)
         fused = False
         if pool is not None and res is None and self.s16 and os.environ.get("AMMC_FUSE_POOL", "1") != "0":
             # the second output exists in the halo-patch kernel only: ask the library whether this layer gets it
@@ -415,7 +428,12 @@ class StreamGraph:
         # max-pool of it: from the conv's own epilogue where the halo-patch kernel runs the layer, else by a pool launch
         mid = bld.act(B, H, W, 64)
         pooled = bld.act(B, self.hs[1], self.ws[1], chans[0])
-        fused = bld.double_conv(self.x_in, sp.inc, mid, self.skip[0], name="inc", pool=pooled)
+        # the first layer reads the NCHW input itself where csrc/conv_first_s16.hip applies (launched per forward by
+        # EvalEngine._launch_all: the input pointer changes); else layout kernel + implicit GEMM
+        self.first_mid = mid if (bld.s16 and sp.first is not None and W % 32 == 0 and H % 8 == 0 and
+                                 os.environ.get("AMMC_FIRST_FUSED", "1") != "0") else None
+        fused = bld.double_conv(self.x_in, sp.inc, mid, self.skip[0], name="inc", pool=pooled,
+                                skip_first=self.first_mid is not None)
         for i in range(3):
             h, w = self.hs[i + 1], self.ws[i + 1]
             if not fused:
@@ -620,6 +638,14 @@ class EvalEngine:
         lib = self.lib
         streams: List[StreamGraph] = st["streams"]
         for s, x in zip(streams, xs):
+            if getattr(s, "first_mid", None) is not None:
+                m, p = s.first_mid, s.sp.inc
+                launch(lib.ammc_conv_first_s16,
+                       (_ptr(x), B, s.sp.cin, H, W, _ptr(s.sp.first), _ptr(p.s0), _ptr(p.b0), ACT_RELU, m.pix0(), *m.strides,
+                        st["overflow"].data_ptr()),
+                       dict(name="inc.conv0", kernel="conv_first_s16", flops=2.0 * B * H * W * 9 * s.sp.cin * 64,
+                            bytes=4.0 * B * H * W * (s.sp.cin + 64)))
+                continue
             launch(lib.ammc_nchw_to_s16_f32 if self.s16 else lib.ammc_nchw_to_nhwc_f32,
                    (_ptr(x), B, s.sp.cin, H, W, s.x_in.pix0(), *s.x_in.strides, s.sp.inc.cin_p),
                    dict(name="nchw_to_nhwc", kernel="nchw_to_nhwc", flops=0.0,

@@ -178,6 +178,16 @@ int ammc_pack_up_conv_f32(const float* w3_oihw, const float* wt_iohw, const floa
                           const float* shift, int32_t n, int32_t c, float* w2_out, float* shift9_out, void* stream);
 int ammc_conv_up_s16(const AmmcConvDesc* desc, const float* up_x, int64_t up_bs, int64_t up_rs, int64_t up_ps,
                      int32_t up_cin, const float* up_w, const float* shift9, void* stream);
+/* The first layer of a stream in inference (`inconv`'s first conv + BatchNorm(eval) + ReLU, models/unet.py:11-13, 23-30)
+ * straight from the module-boundary tensor: x is NCHW fp32 [batch][c <= 16][h][w] (zero padding applied by the kernel),
+ * y the S16 NHWC activation (64 channels, pixel (0,0), strides in elements).  Replaces ammc_nchw_to_s16_f32 +
+ * ammc_conv_gemm_s16 for that layer.  w_image = ammc_pack_first_conv_f32(OIHW [64][c][3][3]) (ammc_first_conv_image_floats()
+ * floats).  Needs w % 32 == 0, h % 8 == 0; AMMC_EUNSUP otherwise. */
+int ammc_first_conv_image_floats(void);
+int ammc_pack_first_conv_f32(const float* w_oihw, int32_t cout, int32_t cin, float* out, void* stream);
+int ammc_conv_first_s16(const float* x_nchw, int32_t batch, int32_t c, int32_t h, int32_t w, const float* w_image,
+                        const float* scale, const float* shift, int32_t act, float* y, int64_t y_bs, int64_t y_rs,
+                        int64_t y_ps, int32_t* overflow_flag, void* stream);
 /* Which kernel ammc_conv_gemm_s16 launches for this descriptor, as the NUL-terminated name rocprofv3 reports for it
  * (e.g. "conv_tap_s16<4, 1, 2, 4, 1>", "conv_gemm_s16<128x128>", "...+splitk4"), without launching anything: the same
  * argument checks and the same dispatch code run with the launch replaced by the label.  Tests pin kernel coverage on

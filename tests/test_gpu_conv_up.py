@@ -81,3 +81,38 @@ def test_conv_up_s16_rejects_what_it_does_not_take():
     d.y_ps, d.y_rs, d.y_bs = 64, 26 * 64, 10 * 26 * 64
     assert lib.ammc_conv_up_s16(C.byref(d), 0x400000, 8, 8, 8, 128, 0x500000, 0x600000, None) == -2
     assert lib.ammc_conv_up_s16(C.byref(d), None, 8, 8, 8, 128, 0x500000, 0x600000, None) == -1
+
+
+def _s16_round(t: torch.Tensor) -> torch.Tensor:
+    """the value an S16 pair (hi, lo) carries for an fp32 number (what the kernels' operands are), in float64"""
+    hi = t.half().float()
+    lo = ((t - hi) * 2048.0).half().float()
+    return hi.double() + lo.double() / 2048.0
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 12, 16, 32), (1, 6, 8, 64), (3, 12, 24, 96), (2, 3, 8, 32)])
+def test_conv_first_s16_vs_fp64(B, C, H, W):
+    """csrc/conv_first_s16.hip: `inconv`'s first conv + BN(eval) + ReLU straight from the NCHW fp32 clips (zero padding,
+    S16 split and im2col inside the kernel; reference unet.py:11-13, 23-30) against an fp64 convolution of the
+    S16-rounded operands; small images, so every patch touches the image border."""
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    tag = f"first-{B}-{C}-{H}-{W}"
+    x = (S.hashed_uniform(tag + "x", (B, C, H, W)) * 1.7).to(DEV)
+    w = (S.hashed_uniform(tag + "w", (64, C, 3, 3)) * (2.0 / (9 * C)) ** 0.5).to(DEV)
+    scale = S.hashed_uniform(tag + "s", (64,), 0.7, 1.3).to(DEV)
+    shift = S.hashed_uniform(tag + "b", (64,), -0.2, 0.2).to(DEV)
+    img = torch.empty(lib.ammc_first_conv_image_floats(), device=DEV)
+    _lib.check(lib.ammc_pack_first_conv_f32(_ptr(w), 64, C, _ptr(img), s), "pack_first")
+    ya = Act(torch.zeros(B, H + 2, W + 2, 64, device=DEV), B, H, W, 64, 0, 1)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _lib.check(lib.ammc_conv_first_s16(_ptr(x), B, C, H, W, _ptr(img), _ptr(scale), _ptr(shift), ACT_RELU, ya.pix0(),
+                                       *ya.strides, flag.data_ptr(), s), "conv_first_s16")
+    got = _s16_read(ya).double().cpu()
+    want = F.conv2d(_s16_round(x.cpu()), _s16_round(w.cpu()), padding=1)
+    want = (want * scale.double().cpu().view(1, -1, 1, 1) + shift.double().cpu().view(1, -1, 1, 1)).clamp_min(0)
+    err = float((got - want).abs().max() / want.abs().max())
+    assert err <= 3e-6, err
+    assert int(flag.item()) == 0
+    assert float(ya.buf[:, 0].abs().max()) == 0.0 and float(ya.buf[:, :, 0].abs().max()) == 0.0     # halo untouched
+    assert lib.ammc_conv_first_s16(_ptr(x), B, 17, H, W, _ptr(img), None, None, ACT_RELU, ya.pix0(), *ya.strides, None, s) == -2
