@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libammc_hip.so")
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU = 0, 1, 2, 3
 
@@ -65,6 +65,8 @@ SIGNATURES = {
     "ammc_pack_codebook_f32": (C.c_int, [_p, _i32, _i32, _p, _p, _p]),
     "ammc_memory_topk_blocks": (C.c_int, [_i32]),
     "ammc_memory_topk_fwd_f32": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
+    "ammc_pack_codebook_s16": (C.c_int, [_p, _i32, _i32, _p, _p]),
+    "ammc_memory_topk_fwd_s16": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
     "ammc_sum_partials_f32": (C.c_int, [_p, _i32, _f32, _p, _p]),
     "ammc_conv_gemm_s16": (C.c_int, [C.POINTER(AmmcConvDesc), _p]),
     "ammc_pack_up_conv_f32": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _p, _p, _p]),

@@ -1,0 +1,297 @@
+// Memory addressing (`Quantize_topk.forward`, reference Code/models/unet.py:282-297, 310-313) with the distance GEMM
+// on the fp16 MFMA pipe in fp32-EQUIVALENT arithmetic: features and slots are carried as (hi, lo) half pairs
+// (v = hi + lo 2^-11, 22 significant bits) and x . E is evaluated as hi hi + (hi lo + lo hi) 2^-11 with three
+// v_mfma_f32_32x32x16_f16 per 16 features and fp32 accumulation, exactly as in the S16 convolutions
+// (conv_gemm_s16.hip) - as accurate against fp64 as an fp32 dot product, at 16/3 of the fp32 MFMA rate.
+// Everything else is memory_topk.hip's: dist = (|x|^2 - 2 x.E) + |E|^2 with the fp32 norms, top-K with ties to the
+// lower slot, rows gathered from the fp32 codebook, commit distance and q_one from the fp32 features.
+//
+// (memory_topk.hip, the exact-fp32 form, spends its time on v_mfma_f32_32x32x2_f32 at 1/16 of this pipe's rate:
+// 85 us per stream at 2000 slots against a 27-us floor; config 5's fp16 kernel ranks with ROUNDED operands and is not
+// a parity path.  This one is the inference default for the model's 64-d embeddings.)
+//
+//   - a workgroup (4 waves) owns 32 feature rows: fp32 copy + S16 image in LDS (256 B per row = 16 slots of 16 B,
+//     XOR-swizzled by row: conflict-free ds_read_b128 of the B fragments);
+//   - wave w contracts slot tiles in pairs (2 w, 2 w + 1), (2 w + 8, ...); the codebook is pre-packed
+//     [D/8][Mpad][8 hi | 8 lo] (ammc_pack_codebook_s16), so a lane's A fragments are two coalesced 16-byte loads from
+//     L2; the NEXT pair's 16 loads are in flight during the current pair's 24 MFMAs (two register sets);
+//   - running top-K per lane in registers (ordered insertion), 8 partial lists per row merged through LDS.
+#include "ammc_common.h"
+#include <hip/hip_fp16.h>
+#include <math.h>
+
+namespace ammc_impl {
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int SBR = 32;          // feature rows per workgroup
+constexpr int SD = 64;           // embedding width this kernel is built for
+constexpr float S_LO_SCALE = 2048.f;
+constexpr float S_LO_INV = 1.f / 2048.f;
+
+template <int K>
+__device__ __forceinline__ void s_topk_insert(float (&v)[K], int (&ix)[K], float c, int s) {
+  if (c < v[K - 1] || (c == v[K - 1] && s < ix[K - 1])) {
+    v[K - 1] = c;
+    ix[K - 1] = s;
+#pragma unroll
+    for (int j = K - 1; j > 0; --j) {
+      const bool sw = v[j] < v[j - 1] || (v[j] == v[j - 1] && ix[j] < ix[j - 1]);
+      const float tv = sw ? v[j - 1] : v[j];
+      const int ti = sw ? ix[j - 1] : ix[j];
+      v[j - 1] = sw ? v[j] : v[j - 1];
+      ix[j - 1] = sw ? ix[j] : ix[j - 1];
+      v[j] = tv;
+      ix[j] = ti;
+    }
+  }
+}
+
+// candidates arrive in increasing slot order within a lane: strict comparisons implement the (value, index) order
+template <int K>
+__device__ __forceinline__ void s_topk_insert_ordered(float (&v)[K], int (&ix)[K], float c, int s) {
+  if (K == 2) {
+    const bool lt0 = c < v[0], lt1 = c < v[1];
+    v[1] = lt0 ? v[0] : (lt1 ? c : v[1]);
+    ix[1] = lt0 ? ix[0] : (lt1 ? s : ix[1]);
+    v[0] = lt0 ? c : v[0];
+    ix[0] = lt0 ? s : ix[0];
+  } else {
+    s_topk_insert<K>(v, ix, c, s);
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256, 2) void memory_topk_s16_kernel(
+    const float* __restrict__ x, const h16x8* __restrict__ e_s16 /* [8][mpad][2] */, const float* __restrict__ e_md,
+    const float* __restrict__ enorm, int n, int m, int mpad, int* __restrict__ idx_out, float* __restrict__ q_topk,
+    float* __restrict__ q_one, float* __restrict__ diff_partial) {
+  __shared__ __attribute__((aligned(16))) float xs[SBR * SD];            // fp32 features, swizzled 16-B slots
+  __shared__ __attribute__((aligned(16))) _Float16 xh[SBR * 2 * SD];     // S16 image: row = 8 hi slots | 8 lo slots
+  __shared__ float xx[SBR];
+  __shared__ float cand_v[SBR * 8 * K];
+  __shared__ int cand_i[SBR * 8 * K];
+  __shared__ int best[SBR * K];
+  __shared__ float red[256];
+  __shared__ float ens[4096];                                            // |E_s|^2 (memories of up to 4096 slots)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int r0 = blockIdx.x * SBR;
+  // the tile epilogues read 16 norms per lane and tile: from LDS (loaded once), not 16 exposed global loads
+  const float* en = enorm;
+  if (m <= 4096) {
+    for (int i = tid; i < m; i += 256) ens[i] = enorm[i];
+    en = ens;
+  }
+
+  // ---- stage the tile: thread = (row, group of 8 features) -------------------------------------------------------------
+  {
+    const int row = tid >> 3, kg = tid & 7;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    if (r0 + row < n) {
+      a = *reinterpret_cast<const f32x4*>(x + (int64_t)(r0 + row) * SD + kg * 8);
+      b = *reinterpret_cast<const f32x4*>(x + (int64_t)(r0 + row) * SD + kg * 8 + 4);
+    }
+    *reinterpret_cast<f32x4*>(xs + row * SD + (((2 * kg) ^ (row & 15)) << 2)) = a;
+    *reinterpret_cast<f32x4*>(xs + row * SD + (((2 * kg + 1) ^ (row & 15)) << 2)) = b;
+    h16x8 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float v = i < 4 ? a[i] : b[i - 4];
+      const _Float16 hv = (_Float16)v;
+      hi[i] = hv;
+      lo[i] = (_Float16)((v - (float)hv) * S_LO_SCALE);
+    }
+    *reinterpret_cast<h16x8*>(xh + row * 2 * SD + ((kg ^ (row & 15)) << 3)) = hi;
+    *reinterpret_cast<h16x8*>(xh + row * 2 * SD + (((8 + kg) ^ (row & 15)) << 3)) = lo;
+  }
+  __syncthreads();
+  if (tid < SBR) {
+    float s = 0.f;
+    for (int sl = 0; sl < SD / 4; ++sl) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xs + tid * SD + ((sl ^ (tid & 15)) << 2));
+      s += v[0] * v[0];
+      s += v[1] * v[1];
+      s += v[2] * v[2];
+      s += v[3] * v[3];
+    }
+    xx[tid] = s;
+  }
+  __syncthreads();
+
+  float bv[K];
+  int bi[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) { bv[j] = INFINITY; bi[j] = 0x7fffffff; }
+  const float xnorm = xx[l31];
+
+  // this lane's B fragments (its feature row, k-half h) for the four 16-feature steps: resident for the whole kernel
+  h16x8 bh[4], bx[4], bl2[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int kg = 2 * t + h;
+    bh[t] = *reinterpret_cast<const h16x8*>(xh + l31 * 2 * SD + ((kg ^ (l31 & 15)) << 3));
+    const h16x8 bl = *reinterpret_cast<const h16x8*>(xh + l31 * 2 * SD + (((8 + kg) ^ (l31 & 15)) << 3));
+    bx[t] = bh[t] * (_Float16)S_LO_INV;
+    bl2[t] = bl * (_Float16)S_LO_INV;
+  }
+
+  const int ntile = mpad >> 5;
+  // A fragments of one tile pair: [u][t] hi and lo of slot (tile + u) * 32 + l31, features 16 t + 8 h .. + 7
+#define S_LOAD(dst_h, dst_l, tile_)                                                                    \
+  _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                      \
+    const int tl_ = (tile_) + u < ntile ? (tile_) + u : ntile - 1;                                     \
+    const h16x8* ep_ = e_s16 + ((int64_t)h * mpad + (tl_ << 5) + l31) * 2;                             \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                    \
+      dst_h[u][t] = ep_[(int64_t)(2 * t) * mpad * 2];                                                  \
+      dst_l[u][t] = ep_[(int64_t)(2 * t) * mpad * 2 + 1];                                              \
+    }                                                                                                  \
+  }
+#define S_TILES(src_h, src_l, tile_)                                                                   \
+  {                                                                                                    \
+    f32x16 acc[2];                                                                                     \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                      \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;                                  \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                    \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src_h[u][t], bh[t], acc[u], 0, 0, 0);  \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src_l[u][t], bx[t], acc[u], 0, 0, 0);  \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src_h[u][t], bl2[t], acc[u], 0, 0, 0); \
+    }                                                                                                  \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                    \
+      if ((tile_) + u < ntile) {                                                                       \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                               \
+          const int s = (((tile_) + u) << 5) + (r & 3) + 8 * (r >> 2) + 4 * h;                         \
+          if (s < m) {                                                                                 \
+            const float dist = (xnorm - 2.f * acc[u][r]) + en[s];                                      \
+            s_topk_insert_ordered<K>(bv, bi, dist, s);                                                 \
+          }                                                                                            \
+        }                                                                                              \
+      }                                                                                                \
+    }                                                                                                  \
+  }
+  {
+    h16x8 ah0[2][4], al0[2][4], ah1[2][4], al1[2][4];
+    int tile = wave * 2;
+    if (tile < ntile) S_LOAD(ah0, al0, tile)
+    while (tile < ntile) {
+      if (tile + 8 < ntile) S_LOAD(ah1, al1, tile + 8)
+      S_TILES(ah0, al0, tile)
+      tile += 8;
+      if (tile >= ntile) break;
+      if (tile + 8 < ntile) S_LOAD(ah0, al0, tile + 8)
+      S_TILES(ah1, al1, tile)
+      tile += 8;
+    }
+  }
+#undef S_LOAD
+#undef S_TILES
+
+  // ---- merge the 8 partial lists of every row ---------------------------------------------------------------------------
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const int o = (l31 * 8 + wave * 2 + h) * K + j;
+    cand_v[o] = bv[j];
+    cand_i[o] = bi[j];
+  }
+  __syncthreads();
+  if (tid < SBR) {
+    float v[K];
+    int ix[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { v[j] = INFINITY; ix[j] = 0x7fffffff; }
+    for (int c = 0; c < 8 * K; ++c) s_topk_insert<K>(v, ix, cand_v[tid * 8 * K + c], cand_i[tid * 8 * K + c]);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      best[tid * K + j] = ix[j];
+      if (r0 + tid < n) idx_out[(int64_t)(r0 + tid) * K + j] = ix[j];
+    }
+  }
+  __syncthreads();
+
+  // ---- gather + commit distance (fp32 codebook, fp32 features) -------------------------------------------------------------
+  float part = 0.f;
+  constexpr int slots16 = SD / 4;
+  for (int p = tid; p < SBR * K * slots16; p += 256) {
+    const int sl = p % slots16;
+    const int rj = p / slots16;
+    const int j = rj % K, row = rj / K;
+    if (r0 + row >= n) continue;
+    const int s = best[row * K + j];
+    const f32x4 e = *reinterpret_cast<const f32x4*>(e_md + (int64_t)s * SD + sl * 4);
+    *reinterpret_cast<f32x4*>(q_topk + ((int64_t)(r0 + row) * K + j) * SD + sl * 4) = e;
+    if (j == 0) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + row * SD + ((sl ^ (row & 15)) << 2));
+      f32x4 q1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float df = e[i] - xv[i];
+        part += df * df;
+        q1[i] = xv[i] + df;
+      }
+      if (q_one) *reinterpret_cast<f32x4*>(q_one + (int64_t)(r0 + row) * SD + sl * 4) = q1;
+    }
+  }
+  red[tid] = part;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) diff_partial[blockIdx.x] = red[0];
+}
+
+// [d][m] fp32 -> [d/8][mpad][8 hi | 8 lo] halfs (slots >= m zero)
+__global__ __launch_bounds__(256) void pack_codebook_s16_kernel(const float* __restrict__ e_dm, int d, int m, int mpad,
+                                                                _Float16* __restrict__ out) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (int64_t)(d >> 3) * mpad) return;
+  const int s = (int)(gid % mpad), kb = (int)(gid / mpad);
+  h16x8 hi, lo;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float v = s < m ? e_dm[(int64_t)(kb * 8 + i) * m + s] : 0.f;
+    const _Float16 hv = (_Float16)v;
+    hi[i] = hv;
+    lo[i] = (_Float16)((v - (float)hv) * S_LO_SCALE);
+  }
+  *reinterpret_cast<h16x8*>(out + gid * 16) = hi;
+  *reinterpret_cast<h16x8*>(out + gid * 16 + 8) = lo;
+}
+
+template <int K>
+int launch_topk_s16(const float* x, const void* e_s16, const float* e_md, const float* enorm, int n, int m, int* idx,
+                    float* q_topk, float* q_one, float* diff_partial, hipStream_t stream) {
+  const int mpad = (m + 31) / 32 * 32;
+  hipLaunchKernelGGL(memory_topk_s16_kernel<K>, dim3((n + SBR - 1) / SBR), dim3(256), 0, stream, x,
+                     reinterpret_cast<const h16x8*>(e_s16), e_md, enorm, n, m, mpad, idx, q_topk, q_one, diff_partial);
+  return ammc_launch_status();
+}
+
+}  // namespace ammc_impl
+using namespace ammc_impl;
+
+extern "C" int ammc_pack_codebook_s16(const float* embed_dm, int32_t d, int32_t m, void* e_s16, void* stream) {
+  if (!embed_dm || !e_s16 || d <= 0 || (d % 8) || m <= 0) return AMMC_EINVAL;
+  const int mpad = (m + 31) / 32 * 32;
+  const int64_t total = (int64_t)(d >> 3) * mpad;
+  hipLaunchKernelGGL(pack_codebook_s16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     embed_dm, d, m, mpad, reinterpret_cast<_Float16*>(e_s16));
+  return ammc_launch_status();
+}
+
+// same workgroup geometry as ammc_memory_topk_fwd_f32: diff_partial has ammc_memory_topk_blocks(n) entries
+extern "C" int ammc_memory_topk_fwd_s16(const float* x, const void* e_s16, const float* embed_md, const float* enorm,
+                                        int32_t n, int32_t d, int32_t m, int32_t k, int32_t* idx_topk, float* q_topk,
+                                        float* q_one, float* diff_partial, void* stream) {
+  if (!x || !e_s16 || !embed_md || !enorm || !idx_topk || !q_topk || !diff_partial) return AMMC_EINVAL;
+  if (n <= 0 || m <= 0 || k <= 0 || k > m) return AMMC_EINVAL;
+  if (d != SD || k > 4) return AMMC_EUNSUP;                       // the model's embedding width; else the fp32 kernel
+  hipStream_t s = (hipStream_t)stream;
+  switch (k) {
+    case 1: return launch_topk_s16<1>(x, e_s16, embed_md, enorm, n, m, idx_topk, q_topk, q_one, diff_partial, s);
+    case 2: return launch_topk_s16<2>(x, e_s16, embed_md, enorm, n, m, idx_topk, q_topk, q_one, diff_partial, s);
+    case 3: return launch_topk_s16<3>(x, e_s16, embed_md, enorm, n, m, idx_topk, q_topk, q_one, diff_partial, s);
+    default: return launch_topk_s16<4>(x, e_s16, embed_md, enorm, n, m, idx_topk, q_topk, q_one, diff_partial, s);
+  }
+}

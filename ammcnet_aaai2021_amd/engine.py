@@ -199,6 +199,14 @@ class _Packer:
                    "pack_codebook")
         return e_md, enorm
 
+    def codebook_s16(self, embed: torch.Tensor) -> torch.Tensor:
+        """[d/8][mpad][8 hi | 8 lo] halfs: the slot operand of `ammc_memory_topk_fwd_s16`"""
+        d, m = embed.shape
+        mpad = (m + 31) // 32 * 32
+        out = torch.empty((d // 8, mpad, 16), device=self.device, dtype=torch.float16)
+        _lib.check(self.lib.ammc_pack_codebook_s16(_ptr(embed), d, m, out.data_ptr(), self.stream()), "pack_codebook_s16")
+        return out
+
 
 class _DoubleConvPack:
     def __init__(self, pk: _Packer, dc):
@@ -240,7 +248,8 @@ class _StreamPack:
             e_md, enorm = pk.codebook(q.quantize.embed)
             self.vq = dict(enc_w=enc_w, enc_b=q.enc.bias.detach(), dec_w=dec_w, dec_b=q.dec.bias.detach(),
                            embed=q.quantize.embed, e_md=e_md, enorm=enorm, d=q.quantize.dim,
-                           m=q.quantize.n_embed, k=q.quantize.k)
+                           m=q.quantize.n_embed, k=q.quantize.k,
+                           e_s16=pk.codebook_s16(q.quantize.embed) if (pk.s16 and q.quantize.dim == 64) else None)
 
 
 class _Builder:
@@ -459,10 +468,18 @@ class StreamGraph:
         self.diff_part = bld.buf(nblk)
         self.diff = bld.buf(1)
         bld.plan.keep.extend([self.idx, v["embed"], v["e_md"], v["enorm"]])
-        bld.plan.add(lib.ammc_memory_topk_fwd_f32, _ptr(self.z.buf), _ptr(v["embed"]), _ptr(v["e_md"]),
-                     _ptr(v["enorm"]), n, d, m, k, self.idx.data_ptr(), _ptr(self.qk.buf), _ptr(self.q_one),
-                     _ptr(self.diff_part), name="vq.memory_topk", flops=2.0 * n * d * m,
-                     nbytes=4.0 * (n * d + d * m + n * k * d + n * k + n * d), kernel="memory_topk")
+        if v.get("e_s16") is not None and os.environ.get("AMMC_MEMORY_S16", "1") != "0":
+            # S16 plans: the distance GEMM in fp32-equivalent split-fp16 arithmetic (csrc/memory_topk_s16.hip)
+            bld.plan.keep.append(v["e_s16"])
+            bld.plan.add(lib.ammc_memory_topk_fwd_s16, _ptr(self.z.buf), v["e_s16"].data_ptr(), _ptr(v["e_md"]),
+                         _ptr(v["enorm"]), n, d, m, k, self.idx.data_ptr(), _ptr(self.qk.buf), _ptr(self.q_one),
+                         _ptr(self.diff_part), name="vq.memory_topk", flops=2.0 * n * d * m,
+                         nbytes=4.0 * (n * d + d * m + n * k * d + n * k + n * d), kernel="memory_topk_s16")
+        else:
+            bld.plan.add(lib.ammc_memory_topk_fwd_f32, _ptr(self.z.buf), _ptr(v["embed"]), _ptr(v["e_md"]),
+                         _ptr(v["enorm"]), n, d, m, k, self.idx.data_ptr(), _ptr(self.qk.buf), _ptr(self.q_one),
+                         _ptr(self.diff_part), name="vq.memory_topk", flops=2.0 * n * d * m,
+                         nbytes=4.0 * (n * d + d * m + n * k * d + n * k + n * d), kernel="memory_topk")
         bld.plan.add(lib.ammc_sum_partials_f32, _ptr(self.diff_part), nblk, 1.0 / float(n * d), _ptr(self.diff),
                      name="vq.diff")
         self.x4q = bld.act(B, h, w, 512)

@@ -152,6 +152,16 @@ int ammc_memory_topk_fwd_f32(const float* x, const float* embed_dm, const float*
                              const float* enorm, int32_t n, int32_t d, int32_t m, int32_t k,
                              int32_t* idx_topk, float* q_topk, float* q_one,
                              float* diff_partial, void* stream);
+/* The same memory addressing with the distance GEMM on the fp16 MFMA pipe in fp32-EQUIVALENT arithmetic (features and
+ * slots as (hi, lo) half pairs, three MFMAs per product, fp32 accumulation; norms, gather, commit distance from the fp32
+ * data as in ammc_memory_topk_fwd_f32): the inference default for the model's embed_dim = 64 (d != 64: AMMC_EUNSUP, use
+ * the fp32 entry).  e_s16 = ammc_pack_codebook_s16(embed [d][m]): [d/8][mpad][8 hi | 8 lo] halfs, mpad = m rounded up
+ * to 32; enorm / embed_md from ammc_pack_codebook_f32; diff_partial has ammc_memory_topk_blocks(n) entries. */
+int ammc_pack_codebook_s16(const float* embed_dm, int32_t d, int32_t m, void* e_s16, void* stream);
+int ammc_memory_topk_fwd_s16(const float* x, const void* e_s16, const float* embed_md, const float* enorm, int32_t n,
+                             int32_t d, int32_t m, int32_t k, int32_t* idx_topk, float* q_topk, float* q_one,
+                             float* diff_partial, void* stream);
+
 /* diff = sum(partials) / count, fixed order (deterministic) */
 int ammc_sum_partials_f32(const float* partial, int32_t nparts, float inv_count, float* out, void* stream);
 

@@ -250,3 +250,58 @@ def test_frame_sizes_not_divisible_by_8(B, H, W, prec):
     errs = dict(rgb=rel_err(rgb.cpu(), w[0]), op=rel_err(op.cpu(), w[1]), rd=rel_err(rd.cpu(), w[2][0]),
                 od=rel_err(od.cpu(), w[2][1]), rq=rel_err(rq.cpu(), w[3][0]), oq=rel_err(oq.cpu(), w[3][1]))
     assert max(errs.values()) <= TOL, errs
+
+
+def _memory_s16(embed, x, k):
+    """`ammc_memory_topk_fwd_s16` on its own: embed [64, M] fp32, x [..., 64] -> (q_topk, diff, q_one, idx)"""
+    from ammcnet_aaai2021_amd.engine import _Packer
+    lib = _lib.load()
+    d, m = embed.shape
+    lead = x.shape[:-1]
+    x2 = x.to(DEV).float().contiguous().view(-1, d)
+    n = x2.shape[0]
+    pk = _Packer(torch.device(DEV))
+    e = embed.to(DEV).contiguous()
+    e_md, enorm = pk.codebook(e)
+    e16 = pk.codebook_s16(e)
+    idx = torch.empty((n, k), device=DEV, dtype=torch.int32)
+    qk = torch.empty((n, k * d), device=DEV)
+    q1 = torch.empty((n, d), device=DEV)
+    nblk = lib.ammc_memory_topk_blocks(n)
+    part = torch.empty(nblk, device=DEV)
+    diff = torch.empty(1, device=DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.ammc_memory_topk_fwd_s16(_ptr(x2), e16.data_ptr(), _ptr(e_md), _ptr(enorm), n, d, m, k, idx.data_ptr(),
+                                            _ptr(qk), _ptr(q1), _ptr(part), s), "memory_topk_s16")
+    _lib.check(lib.ammc_sum_partials_f32(_ptr(part), nblk, 1.0 / float(n * d), _ptr(diff), s), "sum")
+    return qk.view(*lead, k * d).cpu(), diff[0].cpu(), q1.view(*lead, d).cpu(), idx.view(*lead, k).cpu()
+
+
+@pytest.mark.parametrize("m,k,bhw", [(256, 2, (2, 8, 8)), (2000, 2, (3, 8, 8)), (256, 3, (1, 4, 8)), (256, 1, (1, 5, 7)),
+                                     (5000, 2, (1, 3, 11)), (33, 4, (2, 2, 2))])
+def test_memory_topk_s16(m, k, bhw):
+    """the S16 memory kernel (distance GEMM on the fp16 MFMA pipe, fp32-equivalent; the inference default at
+    embed_dim 64) against the oracle with the SAME gates as the exact-fp32 kernel (tests/test_gpu_parity.py): indices
+    equal wherever the margin exceeds fp32 noise, gathered rows bit exact, commit distance 1e-4; ragged n and m, more
+    slots than the norm cache holds"""
+    from test_gpu_parity import _check_quantize
+    embed = S.hashed_normal(f"gq:64:{m}", (64, m), 0.9)
+    x = S.hashed_normal(f"gqx:64:{m}", (*bhw, 64), 0.8)
+    qk, diff, q1, idx = _memory_s16(embed, x, k)
+    _check_quantize(x, embed, k, qk, diff, q1, idx)
+    assert _lib.load().ammc_memory_topk_fwd_s16(1, 1, 1, 1, 8, 128, m, k, 1, 1, 1, 1, None) == -2      # d != 64: the fp32 entry
+
+
+def test_memory_topk_s16_golden_and_tie():
+    g = np.load(os.path.join(GOLDEN, "quantize_cases.npz"))
+    for cname in ("m256", "m2000", "k3"):
+        c = json.loads(str(g[f"{cname}.cfg"]))
+        embed = S.hashed_normal(f"quantize_cases:{cname}:embed", (c["d"], c["m"]), 0.9)
+        x = S.hashed_normal(f"quantize_cases:{cname}:x", (*c["bhw"], c["d"]), 0.8)
+        qk, diff, _, _ = _memory_s16(embed, x, c["k"])
+        same = (qk.numpy() == g[f"{cname}.qk"]).all(axis=-1)
+        assert same.mean() > 0.98, cname
+        assert rel_err(diff, g[f"{cname}.diff"]) <= TOL
+    embed = S.hashed_normal("quantize_cases:tie:embed", (64, 256), 0.9)
+    qk, _, _, _ = _memory_s16(embed, torch.from_numpy(g["tie.x"]), 2)
+    assert np.array_equal(qk.numpy(), g["tie.qk"])                   # 1e-3 off the bisector: unambiguous
