@@ -19,6 +19,15 @@ except OSError:
 
 
 def label(name):
+    m0 = re.search(r"conv_up_s16_kernel<(\d+)>", name)
+    if m0:
+        return f"conv_up_s16<{m0.group(1)}>"
+    if "conv_first_s16_kernel" in name:
+        return "conv_first_s16"
+    if "memory_topk_s16_kernel" in name:                # (rocprofv3 leaves this one mangled)
+        return "memory_topk_s16"
+    if re.search(r"memory_topk_kernel", name):
+        return "memory_topk"
     m = re.search(r"(conv_gemm_s16|conv_gemm_f32|conv_tap_s16)_kernel<([^>]*)>", name)
     if not m:
         m2 = re.search(r"(memory_topk_f16|memory_topk|wgrad_tap3_s16|wgrad_tap_s16|wgrad_s16|wgrad_f32)\w*_kernel(<[^>]*>)?", name)
