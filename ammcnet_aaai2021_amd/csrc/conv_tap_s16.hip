@@ -55,7 +55,7 @@ constexpr int T_APIECES = T_HP * 8;                                             
 // the 32-byte S16 store of the MF = 0 epilogue, unchanged.
 template <int WGM, int WGN, int TM, int TN, int AS, int MF>
 // (hipcc: the second __launch_bounds__ argument is the minimum number of WAVES PER SIMD, i.e. 512 / it VGPRs)
-__global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)) void conv_tap_s16_kernel(TapArgs a) {
+__global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : (WGN * TN == 1 ? 3 : 2))) void conv_tap_s16_kernel(TapArgs a) {
   static_assert((WGM * WGN == 8 || WGM * WGN == 4) && WGM * TM == T_TH, "4 or 8 waves, 8 image rows");
   constexpr int NT = 64 * WGM * WGN;
   constexpr int T_AROUNDS = (T_APIECES + NT - 1) / NT;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : 2)
   constexpr int B_STAGE = BJ * (NT / 8) * 32;                    // a 32-filter slice is padded to 64 rows; floats)
   // filter-slice stages: 3 = slices t+1 and t+2 fly during step t; the 4-wave 128-filter variant keeps 2 (one slice
   // ahead) so that two workgroups fit a CU
-  constexpr int NB = (NT == 256 && BN == 128) ? 2 : 3;
+  constexpr int NB = (NT == 256 && (BN == 128 || BN == 32)) ? 2 : 3;     // (4-wave output layer: 52 KB, three workgroups per CU)
   constexpr int PD = NB - 1;
   constexpr int STAGES = AS * T_ASTAGE + NB * B_STAGE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -644,7 +644,7 @@ static int launch_tap(const TapArgs& a, hipStream_t stream, char* label, int lab
   constexpr int NT = 64 * WGM * WGN;
   constexpr int T_ASTAGE = (T_APIECES + NT - 1) / NT * NT * 4;
   constexpr int BJ = BN * 8 >= NT ? BN * 8 / NT : 1;
-  constexpr int NB = (NT == 256 && BN == 128) ? 2 : 3;
+  constexpr int NB = (NT == 256 && (BN == 128 || BN == 32)) ? 2 : 3;
   constexpr int STAGES = AS * T_ASTAGE + NB * BJ * (NT / 8) * 32;
   constexpr size_t lds = (size_t)STAGES * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS budget");
@@ -691,7 +691,9 @@ int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream, char* 
   const int64_t ntiles = (int64_t)d.batch * (d.height / T_TH) * (d.width / T_TW) * (d.n <= 64 ? 1 : d.n / 128);
   const bool wide4 = d.n > 64 && (mode == 4 || (mode == 1 && ntiles >= 512));          // the 4-wave 128-filter variant
   const int mf = mfo < 0 ? (wide4 ? 0 : 1) : mfo;
-  if (d.n == 32) return mf ? launch_tap<8, 1, 1, 1, 1, 1>(a, stream, label, label_len)     // the output layer: 2-3 filters, fp32 NCHW + tanh
+  // the output layer (2-3 filters, fp32 NCHW + tanh): 4 waves, 52 KB of LDS, THREE workgroups per CU (124 us against
+  // 128 for the 8-wave form at two per CU; the layer waits for its 45-KB patches, not for the matrix pipe)
+  if (d.n == 32) return mf ? launch_tap<4, 1, 2, 1, 1, 1>(a, stream, label, label_len)
                            : launch_tap<8, 1, 1, 1, 1, 0>(a, stream, label, label_len);
   if (d.n == 64) return mf ? launch_tap<4, 1, 2, 2, 1, 1>(a, stream, label, label_len)     // 4 waves of 64x64 (2 image rows x 64 filters), 2 workgroups per CU
                            : launch_tap<4, 1, 2, 2, 1, 0>(a, stream, label, label_len);

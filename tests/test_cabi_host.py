@@ -118,7 +118,7 @@ def test_s16_dispatch_of_the_benchmark_shapes():
     }
     for (hw, cin, n), label in want.items():
         assert s16_variant(_fake_desc(B, hw, hw, cin, n)) == label, (hw, cin, n)
-    assert s16_variant(_fake_desc(B, 256, 256, 64, 32, y_f32=1)) == "conv_tap_s16<8, 1, 1, 1, 1, 1>"      # outc
+    assert s16_variant(_fake_desc(B, 256, 256, 64, 32, y_f32=1)) == "conv_tap_s16<4, 1, 2, 1, 1, 1>"      # outc
     assert s16_variant(_fake_desc(B, 256, 256, 16, 64)).startswith("conv_gemm_s16<")                   # inc.0 (12 -> 16 channels)
     assert s16_variant(_fake_desc(B, 32, 32, 512, 1024, ntaps=1, up=2)).startswith("conv_gemm_s16<")   # ConvTranspose
     # small batches fall back to the implicit GEMM (split-K below 192 tiles)
