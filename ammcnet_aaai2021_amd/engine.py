@@ -97,8 +97,9 @@ class Plan:
         self.meta: List[dict] = []
         self.keep: List = []
 
-    def add(self, fn, *args, name: str = "", flops: float = 0.0, nbytes: float = 0.0, kernel: str = ""):
-        self.calls.append((fn, args, name))
+    def add(self, fn, *args, name: str = "", flops: float = 0.0, nbytes: float = 0.0, kernel: str = "", dyn=None):
+        """`dyn(ctx) -> args`: arguments resolved per forward (calls that read the caller's input tensors directly)"""
+        self.calls.append((fn, dyn if dyn is not None else args, name))
         self.meta.append(dict(name=name, flops=flops, bytes=nbytes, kernel=kernel))
 
     def run(self, stream: int):
@@ -410,7 +411,8 @@ class _Builder:
 class StreamGraph:
     """buffers + plan fragments of one U-Net stream at one input shape"""
 
-    def __init__(self, bld: _Builder, sp: _StreamPack, B: int, H: int, W: int):
+    def __init__(self, bld: _Builder, sp: _StreamPack, B: int, H: int, W: int, index: int = 0):
+        self.index = index                          # which input tensor of the forward this stream reads
         if H < 8 or W < 8:
             raise ValueError(f"frame size {H}x{W}: three 2x2 poolings need at least 8x8")
         self.sp, self.B, self.H, self.W = sp, B, H, W
@@ -441,8 +443,21 @@ class StreamGraph:
         # EvalEngine._launch_all: the input pointer changes); else layout kernel + implicit GEMM
         self.first_mid = mid if (bld.s16 and sp.first is not None and W % 32 == 0 and H % 8 == 0 and
                                  os.environ.get("AMMC_FIRST_FUSED", "1") != "0") else None
-        fused = bld.double_conv(self.x_in, sp.inc, mid, self.skip[0], name="inc", pool=pooled,
-                                skip_first=self.first_mid is not None)
+        if self.first_mid is not None:
+            p, si = sp.inc, self.index
+
+            def first_args(ctx, m=mid, p=p, si=si, B=B, H=H, W=W, cin=sp.cin, img=sp.first, flag=bld.overflow):
+                return (_ptr(ctx["x"][si]), B, cin, H, W, _ptr(img), _ptr(p.s0), _ptr(p.b0), ACT_RELU, m.pix0(), *m.strides,
+                        flag.data_ptr())
+            bld.plan.keep.extend([sp.first, p.s0, p.b0])
+            bld.plan.add(bld.lib.ammc_conv_first_s16, name="inc.conv0", kernel="conv_first_s16", dyn=first_args,
+                         flops=2.0 * B * H * W * 9 * sp.cin * 64, nbytes=4.0 * B * H * W * (sp.cin + 64))
+            # (Measured and dropped: running this layer and the next image chunk by image chunk, so that the 268-MB
+            # intermediate is read back from the Infinity Cache instead of HBM - 4 images per launch 6.73 -> 6.85 ms per step,
+            # 2 images 6.99: the smaller launches lose more than the cache gives; these layers are not HBM-bandwidth-bound.)
+            fused = bld.double_conv(self.x_in, sp.inc, mid, self.skip[0], name="inc", pool=pooled, skip_first=True)
+        else:
+            fused = bld.double_conv(self.x_in, sp.inc, mid, self.skip[0], name="inc", pool=pooled)
         for i in range(3):
             h, w = self.hs[i + 1], self.ws[i + 1]
             if not fused:
@@ -571,8 +586,8 @@ class EvalEngine:
         bld = _Builder(plan, device, self.s16, arena[1] if arena is not None and arena[0] >= B else None)
         st = {}
         if self.kind == "twostream":
-            r = StreamGraph(bld, self._packs["rgb"], B, H, W)
-            o = StreamGraph(bld, self._packs["op"], B, H, W)
+            r = StreamGraph(bld, self._packs["rgb"], B, H, W, index=0)
+            o = StreamGraph(bld, self._packs["op"], B, H, W, index=1)
             r.encode()
             r.memory()
             o.encode()
@@ -663,22 +678,17 @@ class EvalEngine:
         instead of leaving the device idle (reading the flag after the last launch cost 0.29 ms per forward, 4 %)."""
         lib = self.lib
         streams: List[StreamGraph] = st["streams"]
+        ctx = dict(x=xs)
         for s, x in zip(streams, xs):
             if getattr(s, "first_mid", None) is not None:
-                m, p = s.first_mid, s.sp.inc
-                launch(lib.ammc_conv_first_s16,
-                       (_ptr(x), B, s.sp.cin, H, W, _ptr(s.sp.first), _ptr(p.s0), _ptr(p.b0), ACT_RELU, m.pix0(), *m.strides,
-                        st["overflow"].data_ptr()),
-                       dict(name="inc.conv0", kernel="conv_first_s16", flops=2.0 * B * H * W * 9 * s.sp.cin * 64,
-                            bytes=4.0 * B * H * W * (s.sp.cin + 64)))
-                continue
+                continue                                    # the first layer reads the NCHW tensor itself (plan entries)
             launch(lib.ammc_nchw_to_s16_f32 if self.s16 else lib.ammc_nchw_to_nhwc_f32,
                    (_ptr(x), B, s.sp.cin, H, W, s.x_in.pix0(), *s.x_in.strides, s.sp.inc.cin_p),
                    dict(name="nchw_to_nhwc", kernel="nchw_to_nhwc", flops=0.0,
                         bytes=4.0 * B * H * W * (s.sp.cin + s.sp.inc.cin_p)))
         plan = st["plan"]
         for (fn, args, _), meta in zip(plan.calls, plan.meta):
-            launch(fn, args, meta)
+            launch(fn, args(ctx) if callable(args) else args, meta)
         st["flag_event"] = None
         if early_flag and st.get("overflow") is not None:
             if st.get("flag_host") is None:
