@@ -149,3 +149,87 @@ def test_conv_tap_fp32_output_with_fp32_residual(B, H, W, cin, n, variant, mf):
     err = float((got - want).abs().max() / want.abs().max())
     assert err <= 2e-6, err
     assert float(ya.buf[:, 0].abs().max()) == 0.0 and float(ya.buf[:, :, 0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,H,W,cout", [(8, 64, 96, 3), (3, 128, 128, 2)])
+def test_output_layer_vs_fp64(B, H, W, cout, mf):
+    """`outc` + tanh (reference unet.py:920, 998-1007) as the benchmark runs it: 32-filter tile with `n_store` real
+    filters, fp32 NCHW frames, bias, tanh, and the fused per-sample squared error of `psnr_error` (utils.py:141-148) -
+    both instances (MF 1: 4 waves, 16-filter MFMA tile, three workgroups per CU; MF 0: the 8-wave 32x32x16 form) against
+    fp64 on the S16-rounded operands"""
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    tag = f"outc-{B}-{H}-{W}-{cout}"
+    cin = 64
+    x = S.hashed_uniform(tag + "x", (B, cin, H, W)).to(DEV)
+    w = torch.zeros(32, cin, 3, 3)
+    w[:cout] = S.hashed_uniform(tag + "w", (cout, cin, 3, 3)) * (2.0 / (9 * cin)) ** 0.5
+    w = w.to(DEV)
+    bias = torch.zeros(32, device=DEV)
+    bias[:cout] = S.hashed_uniform(tag + "b", (cout,), -0.2, 0.2).to(DEV)
+    target = S.hashed_uniform(tag + "t", (B, cout, H, W)).to(DEV)
+    xa = _s16_act(x)
+    wp = torch.empty(32, 9 * cin, device=DEV)
+    _lib.check(lib.ammc_pack_conv_weight_f32(_ptr(w), 32, cin, 3, cin, _ptr(wp), s), "pack")
+    ws = torch.empty_like(wp)
+    _lib.check(lib.ammc_split_rows_f32(_ptr(wp), wp.numel(), _ptr(ws), s), "split")
+    y = torch.empty(B, cout, H, W, device=DEV)
+    sq = torch.zeros(B, device=DEV)
+    d = AmmcConvDesc()
+    d.x, d.w, d.y, d.shift = xa.tap0(), _ptr(ws), _ptr(y), _ptr(bias)
+    d.batch, d.height, d.width, d.cin, d.ntaps, d.n, d.up, d.cgroup, d.act, d.n_store, d.y_f32 = B, H, W, cin, 9, 32, 1, 32, 2, cout, 1
+    d.x_bs, d.x_rs, d.x_ps = xa.strides
+    d.y_bs, d.y_rs, d.y_ps, d.y_cs = cout * H * W, W, 1, H * W
+    d.sq_target, d.sq_acc = _ptr(target), _ptr(sq)
+    assert s16_variant(d) == ("conv_tap_s16<4, 1, 2, 1, 1, 1>" if mf else "conv_tap_s16<8, 1, 1, 1, 1, 0>")
+    _lib.check(lib.ammc_conv_gemm_s16(C.byref(d), s), "outc")
+    wsa = Act(ws.view(1, 1, 32, 9 * cin), 1, 1, 32, 9 * cin, 0, 0)
+    wr = _s16_read(wsa).view(9 * cin, 32).t().reshape(32, 9, cin).permute(0, 2, 1).reshape(32, cin, 3, 3).double().cpu()
+    want = torch.tanh(F.conv2d(_s16_read(xa).double().cpu(), wr[:cout], padding=1) + bias[:cout].double().cpu().view(1, -1, 1, 1))
+    assert float((y.double().cpu() - want).abs().max()) <= 2e-6
+    want_sq = ((target.double().cpu() - want) * 0.5).pow(2).sum(dim=(1, 2, 3))
+    assert float(((sq.double().cpu() - want_sq).abs() / want_sq).max()) <= 2e-5
+
+
+@pytest.mark.parametrize("case", ["enc", "dec"])
+def test_conv1x1_s16_vs_fp64(case):
+    """the memory block's 1x1 convs on `ammc_conv_gemm_s16` (unet.py:321-330, 386): `enc` 512 -> 64 with bias and an fp32
+    output (what the memory kernel reads), `dec` 128 -> 512 with bias and the S16 residual (`out += x`)"""
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    B, H, W = 16, 32, 32
+    cin, n = (512, 64) if case == "enc" else (128, 512)
+    x = S.hashed_uniform(case + "x", (B, cin, H, W)).to(DEV)
+    w = (S.hashed_uniform(case + "w", (n, cin, 1, 1)) * (1.0 / cin) ** 0.5).to(DEV)
+    bias = S.hashed_uniform(case + "b", (n,), -0.2, 0.2).to(DEV)
+    xa = _s16_act(x)
+    wp = torch.empty(n, cin, device=DEV)
+    _lib.check(lib.ammc_pack_conv_weight_f32(_ptr(w), n, cin, 1, cin, _ptr(wp), s), "pack")
+    ws = torch.empty_like(wp)
+    _lib.check(lib.ammc_split_rows_f32(_ptr(wp), wp.numel(), _ptr(ws), s), "split")
+    d = AmmcConvDesc()
+    d.x, d.w, d.shift = xa.pix0(), _ptr(ws), _ptr(bias)
+    d.batch, d.height, d.width, d.cin, d.ntaps, d.n, d.up, d.cgroup, d.act = B, H, W, cin, 1, n, 1, n, ACT_NONE
+    d.x_bs, d.x_rs, d.x_ps = xa.strides
+    wsa = Act(ws.view(1, 1, n, cin), 1, 1, n, cin, 0, 0)
+    wr = _s16_read(wsa).view(cin, n).t().reshape(n, cin, 1, 1).double().cpu()
+    want = F.conv2d(_s16_read(xa).double().cpu(), wr) + bias.double().cpu().view(1, -1, 1, 1)
+    if case == "enc":
+        ya = Act(torch.zeros(B, H, W, n, device=DEV), B, H, W, n, 0, 0)
+        d.y, d.y_f32 = ya.pix0(), 1
+        d.y_bs, d.y_rs, d.y_ps = ya.strides
+        assert s16_variant(d) == "conv_gemm_s16<128x64>"
+        _lib.check(lib.ammc_conv_gemm_s16(C.byref(d), s), "enc")
+        got = ya.interior().permute(0, 3, 1, 2).double().cpu()
+    else:
+        res = S.hashed_uniform(case + "r", (B, n, H, W)).to(DEV)
+        ra = _s16_act(res)
+        ya = Act(torch.zeros(B, H + 2, W + 2, n, device=DEV), B, H, W, n, 0, 1)
+        d.y, d.res = ya.pix0(), ra.pix0()
+        d.y_bs, d.y_rs, d.y_ps = ya.strides
+        d.r_bs, d.r_rs, d.r_ps = ra.strides
+        assert s16_variant(d) == "conv_gemm_s16<128x128>"
+        _lib.check(lib.ammc_conv_gemm_s16(C.byref(d), s), "dec")
+        got = _s16_read(ya).double().cpu()
+        want = want + _s16_read(ra).double().cpu()
+    assert float((got - want).abs().max() / want.abs().max()) <= 2e-6
