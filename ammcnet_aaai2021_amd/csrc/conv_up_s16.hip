@@ -337,37 +337,47 @@ __global__ __launch_bounds__(U_NT, 2) void conv_up_s16_kernel(UpArgs a) {
   if (d.overflow_flag && !(vmax <= 65504.f)) atomicOr(d.overflow_flag, 1);
 }
 
-// composed filters: out[co][(tap2 * 4 + cls) * cin2 + ci], fp32 (the caller splits them into S16)
+// composed filters: out[co][(tap2 * 4 + cls) * cin2 + ci], fp32 (the caller splits them into S16).
+// One workgroup per output filter co: its 9 x c filter values of the up half sit in LDS; thread ci streams its own
+// contiguous Wt[ci][:][2][2] (16 bytes per cu) once and accumulates all 16 (tap2, class) sums in double - every 3x3 tap
+// (r, s) lands in exactly one tap2 per class, so a cu costs 36 multiply-adds.  (The first form, one thread per output
+// element with strided reads of both operands, took 2.4 ms per decoder level.)
 __global__ __launch_bounds__(256) void up_compose_kernel(const float* __restrict__ w3, const float* __restrict__ wt,
                                                          int n, int c, float* __restrict__ out) {
+  extern __shared__ float a_s[];                       // [9][c]: W3[co][c + cu][r][s]
   const int cin2 = 2 * c;
-  const int64_t total = (int64_t)n * 16 * cin2;
-  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= total) return;
-  const int ci = (int)(gid % cin2);
-  const int q = (int)((gid / cin2) % 16);
-  const int co = (int)(gid / ((int64_t)16 * cin2));
-  const int tap2 = q >> 2, cls = q & 3;
-  const int sy = tap2 >> 1, sx = tap2 & 1, py = cls >> 1, px = cls & 1;
-  // taps r of the 3x3 window whose up-row 2 y + py + r - 1 lies in source row y + sy + py - 1, with its dy:
-  // py 0: sy 0 <- r 0 (dy 1); sy 1 <- r 1 (dy 0), r 2 (dy 1).  py 1: sy 0 <- r 0 (dy 0), r 1 (dy 1); sy 1 <- r 2 (dy 0)
-  double sum = 0.0;
-  for (int r = 0; r < 3; ++r) {
-    const int ur = py + r - 1;                              // up-row relative to 2 y
-    const int srow = ur < 0 ? -1 : (ur >> 1);               // source row relative to y
-    if (srow != sy + py - 1) continue;
-    const int dy = ur & 1;
-    for (int s = 0; s < 3; ++s) {
-      const int uc = px + s - 1;
-      const int scol = uc < 0 ? -1 : (uc >> 1);
-      if (scol != sx + px - 1) continue;
-      const int dx = uc & 1;
-      const float* w3p = w3 + (((int64_t)co * cin2 + c) * 3 + r) * 3 + s;       // + cu * 9
-      const float* wtp = wt + ((int64_t)ci * c * 2 + dy) * 2 + dx;              // + cu * 4
-      for (int cu = 0; cu < c; ++cu) sum += (double)w3p[(int64_t)cu * 9] * (double)wtp[(int64_t)cu * 4];
-    }
+  const int co = blockIdx.x;
+  for (int i = threadIdx.x; i < 9 * c; i += 256) {
+    const int rs = i / c, cu = i - rs * c;
+    a_s[i] = w3[((int64_t)co * cin2 + c + cu) * 9 + rs];
   }
-  out[gid] = (float)sum;
+  __syncthreads();
+  for (int ci = threadIdx.x; ci < cin2; ci += 256) {
+    double acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.0;
+    const f32x4* wp = reinterpret_cast<const f32x4*>(wt + (int64_t)ci * c * 4);
+    for (int cu = 0; cu < c; ++cu) {
+      const f32x4 w4 = wp[cu];                          // [dy][dx]
+#pragma unroll
+      for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int px = 0; px < 2; ++px)
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+              // up-row 2 y + py + r - 1: source row y + floor((py + r - 1) / 2) = y + sy + py - 1, dy = (py + r - 1) & 1
+              const int ur = py + r - 1, uc = px + s - 1;
+              const int sy = (ur < 0 ? -1 : (ur >> 1)) - (py - 1), sx = (uc < 0 ? -1 : (uc >> 1)) - (px - 1);
+              const int dy = ur & 1, dx = uc & 1;
+              const int q = (sy * 2 + sx) * 4 + py * 2 + px;
+              acc[q] += (double)a_s[(r * 3 + s) * c + cu] * (double)w4[dy * 2 + dx];
+            }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) out[((int64_t)co * 16 + q) * cin2 + ci] = (float)acc[q];
+  }
 }
 
 // shift9[ry][rx][co] = shift[co] + scale[co] * sum over the taps inside the image of W3[co][c + cu][r][s] * bt[cu]
@@ -412,8 +422,8 @@ extern "C" int ammc_pack_up_conv_f32(const float* w3_oihw, const float* wt_iohw,
                                      const float* shift, int32_t n, int32_t c, float* w2_out, float* shift9_out,
                                      void* stream) {
   if (!w3_oihw || !wt_iohw || !bt || !w2_out || !shift9_out || n <= 0 || c <= 0) return AMMC_EINVAL;
-  const int64_t total = (int64_t)n * 16 * 2 * c;
-  hipLaunchKernelGGL(up_compose_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w3_oihw,
+  if (((uintptr_t)wt_iohw & 15) || (size_t)9 * c * sizeof(float) > 48 * 1024) return AMMC_EINVAL;
+  hipLaunchKernelGGL(up_compose_kernel, dim3(n), dim3(256), (size_t)9 * c * sizeof(float), (hipStream_t)stream, w3_oihw,
                      wt_iohw, n, c, w2_out);
   hipLaunchKernelGGL(up_shift9_kernel, dim3((9 * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w3_oihw, bt, scale,
                      shift, n, c, shift9_out);
