@@ -44,45 +44,59 @@ struct FirstArgs {
   int batch, c, h, w_, act, tiles_x, tiles_y;
 };
 
-__global__ __launch_bounds__(256, 2) void conv_first_s16_kernel(FirstArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ws = smem;
-  float* Ps = smem + F_WFLOATS;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l15 = lane & 15, g4 = lane >> 4;
-  const int logical = ammc_xcd_remap(blockIdx.x, gridDim.x);
-  int sp = logical;
+// the halo pixels P = tid and 256 + tid of tile t: 16 channels each from the NCHW planes (zero outside the image / beyond
+// c).  Branch free - every load goes to a clamped, valid address and is zeroed afterwards - so that the loop body stays
+// one scheduling region and the compiler counts its vmcnt waits exactly (with a branch per load it fell back to
+// vmcnt(0) at the loop head, i.e. waited for the previous tile's stores).  CT = the channel count when known (12, 6).
+template <int CT>
+__device__ __forceinline__ int first_load_patch(const FirstArgs& a, int t, int tid, float (&v)[2][16]) {
+  int sp = t;
   const int tx = sp % a.tiles_x;
   sp /= a.tiles_x;
   const int ty = sp % a.tiles_y;
   const int b = sp / a.tiles_y;
-  const int y0 = ty * F_TH, x0 = tx * F_TW;
-
-  // ---- filters: one linear DMA of the pre-arranged image (10 rounds of 256 x 16 B) ------------------------------------
+  const int plane = a.h * a.w_;
+  const int nc = CT ? CT : a.c;
+  const float* xb = a.x + (int64_t)b * nc * plane;
+  int inb = 0;                                     // bit rnd: that halo pixel lies inside the image
 #pragma unroll
-  for (int j = 0; j < F_WFLOATS / 4 / 256; ++j)
-    __builtin_amdgcn_global_load_lds(a.w + (j * 256 + tid) * 4, Ws + (j * 256 + wave * 64) * 4, 16, 0, 0);
+  for (int rnd = 0; rnd < 2; ++rnd) {
+    const int P = rnd * 256 + tid;
+    const int hy = P / F_HW, hx = P - hy * F_HW;
+    const int yy = ty * F_TH - 1 + hy, xx = tx * F_TW - 1 + hx;
+    const bool in = P < F_HP && yy >= 0 && yy < a.h && xx >= 0 && xx < a.w_;
+    const int pix = in ? yy * a.w_ + xx : 0;
+    inb |= in ? (1 << rnd) : 0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      if (CT && c >= CT) {
+        v[rnd][c] = 0.f;
+      } else {
+        const int cc = CT ? c : (c < nc ? c : nc - 1);
+        v[rnd][c] = xb[cc * plane + pix];           // zeroed (outside the image, c >= nc) in first_store_patch: the
+      }                                             // values must not be touched before they are needed
+    }
+  }
+  return inb;
+}
 
-  // ---- patch: thread = halo pixel; its channels from the NCHW planes, split into (hi, lo), four 16-byte slots -----------
-  const int64_t plane = (int64_t)a.h * a.w_;
-  const float* xb = a.x + (int64_t)b * a.c * plane;
+// split into (hi, lo) and park in the patch image: four 16-byte slots per pixel
+__device__ __forceinline__ void first_store_patch(float* Ps, int tid, const float (&v)[2][16], int inb, int nc) {
 #pragma unroll
   for (int rnd = 0; rnd < 2; ++rnd) {
     const int P = rnd * 256 + tid;
     if (P < F_HP) {
-      const int hy = P / F_HW, hx = P - hy * F_HW;
-      const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
-      const bool in = yy >= 0 && yy < a.h && xx >= 0 && xx < a.w_;
-      float v[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) v[c] = (in && c < a.c) ? xb[(int64_t)c * plane + (int64_t)yy * a.w_ + xx] : 0.f;
       f16x8v hi[2], lo[2];
+      const bool in = (inb >> rnd) & 1;
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const _Float16 hv = (_Float16)v[c];
-        hi[c >> 3][c & 7] = hv;
-        lo[c >> 3][c & 7] = (_Float16)((v[c] - (float)hv) * F_LO_SCALE);
+      for (int g = 0; g < 2; ++g) {
+        float val[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) val[c] = (in && 8 * g + c < nc) ? v[rnd][8 * g + c] : 0.f;
+        ammc_u4 h, l;
+        ammc_s16_split8(val, h, l);
+        hi[g] = __builtin_bit_cast(f16x8v, h);
+        lo[g] = __builtin_bit_cast(f16x8v, l);
       }
       const int sw = (P >> 2) & 1;
       float* pp = Ps + P * 16;
@@ -92,8 +106,57 @@ __global__ __launch_bounds__(256, 2) void conv_first_s16_kernel(FirstArgs a) {
       *reinterpret_cast<f16x8v*>(pp + ((3 ^ sw) << 2)) = lo[1];
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+}
+
+// Persistent over tiles (two workgroups per CU, tile t = blockIdx.x + k gridDim.x): the 40-KB filter image is loaded once
+// per workgroup, the NEXT tile's patch is fetched into registers while the current one is contracted and stored, and
+// the barriers are raw s_barriers (a __syncthreads would wait for the epilogue's stores).  One tile per workgroup, as
+// first built: 107 us per stream at batch 16; this form 88 us.  Ablations (same box, per launch): without the stores
+// 71 us, without the MFMAs 74, without both 40, and with every patch load a cache hit on top 38 - the three parts
+// (VALU + LDS + barriers, 26 us of matrix pipe, 40 us of HBM stores) add up instead of overlapping at two 4-wave
+// workgroups per CU, and more workgroups do not fit beside the 40-KB filter image.
+template <int CT>
+__global__ __launch_bounds__(256, CT ? 2 : 1) void conv_first_s16_kernel(FirstArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ws = smem;
+  float* Ps = smem + F_WFLOATS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g4 = lane >> 4;
+  const int total = a.batch * a.tiles_y * a.tiles_x;
+
+  // ---- filters: one linear DMA of the pre-arranged image (10 rounds of 256 x 16 B) ------------------------------------
+#pragma unroll
+  for (int j = 0; j < F_WFLOATS / 4 / 256; ++j)
+    __builtin_amdgcn_global_load_lds(a.w + (j * 256 + tid) * 4, Ws + (j * 256 + wave * 64) * 4, 16, 0, 0);
+
+  // BatchNorm scale / shift: 2 x 64 floats in LDS (as registers they were 32 VGPRs too many for two waves per SIMD; as
+  // global loads inside the loop they would tie the epilogue to the vmcnt of the patch prefetch)
+  float* Ss = Ps + F_PFLOATS;
+  if (tid < 128) {
+    const int c = tid & 63;
+    Ss[tid] = tid < 64 ? (a.scale ? a.scale[c] : 1.f) : (a.shift ? a.shift[c] : 0.f);
+  }
+
+  float v[2][16];
+  int t = blockIdx.x;
+  const int nc = CT ? CT : a.c;
+  int inb = first_load_patch<CT>(a, t, tid, v);
+  first_store_patch(Ps, tid, v, inb, nc);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  float vmax = 0.f;
+  for (; t < total; t += gridDim.x) {
+  const int tn = t + gridDim.x;
+  if (tn < total) inb = first_load_patch<CT>(a, tn, tid, v);
+  int sp = t;
+  const int tx = sp % a.tiles_x;
+  sp /= a.tiles_x;
+  const int ty = sp % a.tiles_y;
+  const int b = sp / a.tiles_y;
+  const int y0 = ty * F_TH, x0 = tx * F_TW;
 
   // ---- contraction: wave w owns image rows 2 w, 2 w + 1 of the patch; pixel tile pt = (row pt >> 1, 16-pixel half pt & 1)
   f32x4 acc[4][4];
@@ -144,41 +207,48 @@ __global__ __launch_bounds__(256, 2) void conv_first_s16_kernel(FirstArgs a) {
     }
   }
 
+  // the next tile's patch replaces this one BEFORE the epilogue: the wait for its loads is a vmcnt(0) (the compiler
+  // counts conservatively around the inline asm of the S16 split), which here only covers the previous tile's stores,
+  // a whole contraction old - placed after the epilogue it would wait for the stores just issued
+  if (tn < total) {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // every wave is done with this tile's patch
+    asm volatile("" ::: "memory");
+    first_store_patch(Ps, tid, v, inb, nc);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+
   // ---- epilogue: lane = pixel l15 of tile pt; tiles 2 u, 2 u + 1 give it channels 32 u + 8 g4 .. + 7 -------------------
-  float vmax = 0.f;
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int c0 = 32 * u + 8 * g4;
     float sc[8], sh[8];
+    {
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(Ss + c0), s1 = *reinterpret_cast<const f32x4*>(Ss + c0 + 4);
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(Ss + 64 + c0), h1 = *reinterpret_cast<const f32x4*>(Ss + 64 + c0 + 4);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) sc[k] = 1.f, sh[k] = 0.f;
-    if (a.scale) {
-      const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.scale + c0), s1 = *reinterpret_cast<const f32x4*>(a.scale + c0 + 4);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) sc[k] = s0[k], sc[4 + k] = s1[k];
-    }
-    if (a.shift) {
-      const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.shift + c0), s1 = *reinterpret_cast<const f32x4*>(a.shift + c0 + 4);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) sh[k] = s0[k], sh[4 + k] = s1[k];
+      for (int k = 0; k < 4; ++k) sc[k] = s0[k], sc[4 + k] = s1[k], sh[k] = h0[k], sh[4 + k] = h1[k];
     }
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) {
       const int y = y0 + 2 * wave + (pt >> 1), x = x0 + 16 * (pt & 1) + l15;
-      f16x8v hi, lo;
+      float tv[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        float t = acc[pt][2 * u + (k >> 2)][k & 3] * sc[k] + sh[k];
-        if (a.act == AMMC_ACT_RELU) t = t > 0.f ? t : 0.f;
-        const _Float16 hv = (_Float16)t;
-        hi[k] = hv;
-        lo[k] = (_Float16)((t - (float)hv) * F_LO_SCALE);
-        vmax = fmaxf(vmax, fabsf(t));
+        tv[k] = acc[pt][2 * u + (k >> 2)][k & 3] * sc[k] + sh[k];
+        if (a.act == AMMC_ACT_RELU) tv[k] = fmaxf(tv[k], 0.f);
       }
-      f16x8v* yp = reinterpret_cast<f16x8v*>(a.y + ((int64_t)b * a.y_bs + (int64_t)y * a.y_rs + (int64_t)x * a.y_ps) + c0);
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) vmax = fmaxf(vmax, fmaxf(fabsf(tv[k]), fabsf(tv[k + 1])));
+      ammc_u4 hi, lo;
+      ammc_s16_split8(tv, hi, lo);
+      ammc_u4* yp = reinterpret_cast<ammc_u4*>(a.y + ((int64_t)b * a.y_bs + (int64_t)y * a.y_rs + (int64_t)x * a.y_ps) + c0);
       yp[0] = hi;
       yp[1] = lo;
     }
+  }
   }
   if (a.overflow_flag && !(vmax <= 65504.f)) atomicOr(a.overflow_flag, 1);
 }
@@ -224,16 +294,24 @@ extern "C" int ammc_conv_first_s16(const float* x_nchw, int32_t batch, int32_t c
   if (act != AMMC_ACT_NONE && act != AMMC_ACT_RELU) return AMMC_EUNSUP;
   if (((uintptr_t)w_image & 15) || ((uintptr_t)y & 31) || ((y_bs | y_rs | y_ps) & 7)) return AMMC_EINVAL;
   if ((int64_t)batch * y_bs >= (1LL << 31)) return AMMC_EUNSUP;
-  constexpr size_t lds = (size_t)(F_WFLOATS + F_PFLOATS) * sizeof(float);
+  constexpr size_t lds = (size_t)(F_WFLOATS + F_PFLOATS + 128) * sizeof(float);
   static_assert(lds <= 80 * 1024, "two workgroups per CU");
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_s16_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
   FirstArgs a;
   a.x = x_nchw, a.w = w_image, a.scale = scale, a.shift = shift, a.y = y, a.overflow_flag = overflow_flag;
   a.y_bs = y_bs, a.y_rs = y_rs, a.y_ps = y_ps;
   a.batch = batch, a.c = c, a.h = h, a.w_ = w, a.act = act;
   a.tiles_x = w / F_TW, a.tiles_y = h / F_TH;
-  hipLaunchKernelGGL(conv_first_s16_kernel, dim3(batch * a.tiles_y * a.tiles_x), dim3(256), lds, (hipStream_t)stream, a);
+  if ((int64_t)batch * c * h * w >= (1LL << 31)) return AMMC_EUNSUP;
+  const int total = batch * a.tiles_y * a.tiles_x;
+  const dim3 grid(total < 512 ? total : 512);
+#define FIRST_LAUNCH(CT)                                                                                              \
+  {                                                                                                                   \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_s16_kernel<CT>),                     \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+    if (e != hipSuccess) return (int)e;                                                                               \
+    hipLaunchKernelGGL(conv_first_s16_kernel<CT>, grid, dim3(256), lds, (hipStream_t)stream, a);                     \
+  }
+  if (c == 12) FIRST_LAUNCH(12) else if (c == 6) FIRST_LAUNCH(6) else FIRST_LAUNCH(0)
+#undef FIRST_LAUNCH
   return ammc_launch_status();
 }

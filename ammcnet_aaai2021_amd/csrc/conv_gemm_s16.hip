@@ -41,12 +41,10 @@ constexpr float LO_SCALE = 2048.f;
 constexpr float LO_INV = 1.f / 2048.f;
 
 __device__ __forceinline__ void split8(const float (&v)[8], f16x8& hi, f16x8& lo) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const _Float16 hv = (_Float16)v[i];
-    hi[i] = hv;
-    lo[i] = (_Float16)((v[i] - (float)hv) * LO_SCALE);
-  }
+  ammc_u4 h, l;
+  ammc_s16_split8(v, h, l);
+  hi = __builtin_bit_cast(f16x8, h);
+  lo = __builtin_bit_cast(f16x8, l);
 }
 
 __device__ __forceinline__ void join8(const f16x8& hi, const f16x8& lo, float (&v)[8]) {

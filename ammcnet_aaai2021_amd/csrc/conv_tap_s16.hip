@@ -32,7 +32,6 @@ struct TapArgs {
   int tiles_x, tiles_y, n_tiles, ncc, kpad, dbg;
 };
 
-constexpr float T_LO_SCALE = 2048.f;
 constexpr float T_LO_INV = 1.f / 2048.f;
 constexpr int T_TH = 8, T_TW = 32, T_HW = T_TW + 2, T_HP = (T_TH + 2) * T_HW;     // 340 halo pixels
 constexpr int T_APIECES = T_HP * 8;                                              // 2720 16-byte pieces
@@ -464,16 +463,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : (W
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] += (float)rh[k] + (float)rl[k] * T_LO_INV;
           }
-          f16x8t hi, lo;
+          ammc_u4 hi, lo;
+          ammc_s16_split8(v, hi, lo);
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
-            const _Float16 hv = (_Float16)v[k];
-            hi[k] = hv;
-            lo[k] = (_Float16)((v[k] - (float)hv) * T_LO_SCALE);
             vmax = fmaxf(vmax, fabsf(v[k]));
             if (TM == 2) pooled[k] = i == 0 ? v[k] : fmaxf(pooled[k], v[k]);
           }
-          f16x8t* yp = reinterpret_cast<f16x8t*>(d.y + ((int64_t)b * d.y_bs + (int64_t)y * d.y_rs + (int64_t)x * d.y_ps) + c0);
+          ammc_u4* yp = reinterpret_cast<ammc_u4*>(d.y + ((int64_t)b * d.y_bs + (int64_t)y * d.y_rs + (int64_t)x * d.y_ps) + c0);
           yp[0] = hi;
           yp[1] = lo;
         }
@@ -481,14 +478,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : (W
 #pragma unroll
           for (int k = 0; k < 8; ++k) pooled[k] = fmaxf(pooled[k], __shfl_xor(pooled[k], 1));
           if ((l15 & 1) == 0) {
-            f16x8t hi, lo;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              const _Float16 hv = (_Float16)pooled[k];
-              hi[k] = hv;
-              lo[k] = (_Float16)((pooled[k] - (float)hv) * T_LO_SCALE);
-            }
-            f16x8t* pp = reinterpret_cast<f16x8t*>(d.pool_y + ((int64_t)b * d.pool_bs + (int64_t)((y0 >> 1) + wm) * d.pool_rs +
+            ammc_u4 hi, lo;
+            ammc_s16_split8(pooled, hi, lo);
+            ammc_u4* pp = reinterpret_cast<ammc_u4*>(d.pool_y + ((int64_t)b * d.pool_bs + (int64_t)((y0 >> 1) + wm) * d.pool_rs +
                                                               (int64_t)((x0 >> 1) + 8 * c + (l15 >> 1)) * d.pool_ps) + c0);
             pp[0] = hi;
             pp[1] = lo;
@@ -599,16 +591,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : (W
 #pragma unroll
           for (int k = 0; k < 8; ++k) v[k] += (float)rh[k] + (float)rl[k] * T_LO_INV;
         }
-        f16x8t hi, lo;
+        ammc_u4 hi, lo;
+        ammc_s16_split8(v, hi, lo);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          const _Float16 hv = (_Float16)v[k];
-          hi[k] = hv;
-          lo[k] = (_Float16)((v[k] - (float)hv) * T_LO_SCALE);
           vmax = fmaxf(vmax, fabsf(v[k]));
           if (TM == 2) pooled[k] = i == 0 ? v[k] : fmaxf(pooled[k], v[k]);
         }
-        f16x8t* yp = reinterpret_cast<f16x8t*>(d.y + o_pix[i] + c0);
+        ammc_u4* yp = reinterpret_cast<ammc_u4*>(d.y + o_pix[i] + c0);
         yp[0] = hi;
         yp[1] = lo;
       }
@@ -616,15 +606,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : (W
 #pragma unroll
         for (int k = 0; k < 8; ++k) pooled[k] = fmaxf(pooled[k], __shfl_xor(pooled[k], 1));
         if ((l31 & 1) == 0) {
-          f16x8t hi, lo;
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const _Float16 hv = (_Float16)pooled[k];
-            hi[k] = hv;
-            lo[k] = (_Float16)((pooled[k] - (float)hv) * T_LO_SCALE);
-          }
-          f16x8t* pp = reinterpret_cast<f16x8t*>(d.pool_y + ((int64_t)b * d.pool_bs + (int64_t)((y0 >> 1) + wm) * d.pool_rs +
-                                                            (int64_t)((x0 >> 1) + (l31 >> 1)) * d.pool_ps) + c0);
+          ammc_u4 hi, lo;
+          ammc_s16_split8(pooled, hi, lo);
+          ammc_u4* pp = reinterpret_cast<ammc_u4*>(d.pool_y + ((int64_t)b * d.pool_bs + (int64_t)((y0 >> 1) + wm) * d.pool_rs +
+                                                          (int64_t)((x0 >> 1) + (l31 >> 1)) * d.pool_ps) + c0);
           pp[0] = hi;
           pp[1] = lo;
         }

@@ -321,15 +321,11 @@ __global__ __launch_bounds__(U_NT, 2) void conv_up_s16_kernel(UpArgs a) {
         if (d.act == AMMC_ACT_RELU) t = t > 0.f ? t : 0.f;
         v[k] = t;
       }
-      f16x8u hi, lo;
+      ammc_u4 hi, lo;
+      ammc_s16_split8(v, hi, lo);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const _Float16 hv = (_Float16)v[k];
-        hi[k] = hv;
-        lo[k] = (_Float16)((v[k] - (float)hv) * U_LO_SCALE);
-        vmax = fmaxf(vmax, fabsf(v[k]));
-      }
-      f16x8u* yp = reinterpret_cast<f16x8u*>(d.y + ((int64_t)b * d.y_bs + (int64_t)yg * d.y_rs + (int64_t)xg * d.y_ps) + c0);
+      for (int k = 0; k < 8; ++k) vmax = fmaxf(vmax, fabsf(v[k]));
+      ammc_u4* yp = reinterpret_cast<ammc_u4*>(d.y + ((int64_t)b * d.y_bs + (int64_t)yg * d.y_rs + (int64_t)xg * d.y_ps) + c0);
       yp[0] = hi;
       yp[1] = lo;
     }

@@ -44,6 +44,34 @@ def test_split_roundtrip_is_fp32_accurate():
     assert float(y[:, 0].abs().max()) == 0.0 and float(y[:, :, 0].abs().max()) == 0.0      # halo untouched
 
 
+def test_split_encoding_bits():
+    """the S16 encoder of the kernels (packed convert + mixed-precision fma, ammc_common.h) produces exactly
+    hi = fp16(t), lo = fp16((t - hi) * 2048), both round-to-nearest-even: normal range, fp16 subnormals, exact halves
+    (ties), the largest encodable values, zeros and negatives"""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    vals = torch.cat([
+        torch.randn(4096, generator=g) * torch.logspace(-9, 4, 4096),
+        torch.tensor([0.0, -0.0, 1.0, -1.0, 65504.0, -65504.0, 65503.99, 6.1e-5, 5.96e-8, 3e-8, 1.00048828125,
+                      1.000732421875, 0.333251953125 + 2.0 ** -13, 2049.0, 2050.0, -2051.0, 1e-30]),
+        (torch.arange(2048, dtype=torch.float32) + 0.5) * 2.0 ** -11 + 1.0,          # ties of the hi rounding
+    ]).float()
+    n = (vals.numel() // 8) * 8
+    vals = vals[:n].contiguous()
+    x = vals.view(1, 8, 1, n // 8).to(DEV)                       # 8 channels, W = n / 8 pixels of one row
+    W = n // 8
+    y = torch.zeros((1, 3, W + 2, 8), device=DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    ps, rs = 8, (W + 2) * 8
+    assert lib.ammc_nchw_to_s16_f32(_ptr(x), 1, 8, 1, W, _ptr(y, rs + ps), 3 * rs, rs, ps, 8, s) == 0
+    got = y[0, 1, 1:W + 1].cpu().contiguous().view(torch.float16).view(W, 2, 8)      # [pixel][hi | lo][channel]
+    t = vals.view(8, W).t().contiguous().numpy()                 # [pixel][channel]
+    hi = t.astype(np.float16)
+    lo = ((t - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+    assert np.array_equal(got[:, 0].numpy().view(np.uint16), hi.view(np.uint16))
+    assert np.array_equal(got[:, 1].numpy().view(np.uint16), lo.view(np.uint16))
+
+
 @pytest.mark.parametrize("name", ["twostream_64_b2_eval", "twostream_64_b2_m2000_eval", "twostream_256_b2_eval"])
 def test_twostream_s16_vs_oracle_and_golden(name):
     d = np.load(os.path.join(GOLDEN, f"{name}.npz"))
