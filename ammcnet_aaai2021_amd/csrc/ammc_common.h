@@ -54,6 +54,9 @@ __device__ __forceinline__ void ammc_s16_split8(const float (&v)[8], ammc_u4& hi
 // dispatch option "s16_mf" (capi_misc.hip): MFMA shape of the halo-patch kernel, -1 = per variant (the measured
 // faster one, default), 1 = v_mfma_f32_16x16x32_f16, 0 = v_mfma_f32_32x32x16_f16; AMMC_S16_MF / ammc_set_option
 int ammc_opt_s16_mf();
+// dispatch option "outc_stream": 1 = the output layer on conv_outc_s16.hip (default), 0 = on the halo-patch kernel;
+// AMMC_OUTC_STREAM / ammc_set_option
+int ammc_opt_outc_stream();
 
 static inline int ammc_ilog2(int v) {
   int l = 0;

@@ -9,6 +9,16 @@ extern "C" int ammc_abi_version(void) { return 26; }
 // dispatch options (ammc_common.h): initialised from the environment once, changed by ammc_set_option
 int g_ammc_s16_mf = -2;              // -2 = not read yet; -1 = auto (per variant); 0 / 1 = forced
 
+int g_ammc_outc_stream = -2;        // -2 = not read yet; 1 = the streaming output-layer kernel (default), 0 = halo-patch kernel
+
+int ammc_opt_outc_stream() {
+  if (g_ammc_outc_stream == -2) {
+    const char* e = getenv("AMMC_OUTC_STREAM");
+    g_ammc_outc_stream = e ? atoi(e) != 0 : 1;
+  }
+  return g_ammc_outc_stream;
+}
+
 int ammc_opt_s16_mf() {
   if (g_ammc_s16_mf == -2) {
     const char* e = getenv("AMMC_S16_MF");
@@ -22,6 +32,11 @@ extern "C" int ammc_set_option(const char* key, int32_t value) {
   if (!strcmp(key, "s16_mf")) {
     if (value < -1 || value > 1) return AMMC_EINVAL;
     g_ammc_s16_mf = value;
+    return AMMC_OK;
+  }
+  if (!strcmp(key, "outc_stream")) {
+    if (value < 0 || value > 1) return AMMC_EINVAL;
+    g_ammc_outc_stream = value;
     return AMMC_OK;
   }
   return AMMC_EUNSUP;

@@ -644,6 +644,8 @@ static int launch_tap(const TapArgs& a, hipStream_t stream, char* label, int lab
   return ammc_launch_status();
 }
 
+int conv_outc_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream, char* label, int label_len);
+
 // Called by ammc_conv_gemm_s16 (conv_gemm_s16.hip) after its argument checks.  Returns TAP_SKIP when the descriptor is
 // not this kernel's case (the caller then runs the implicit-GEMM kernel), else the launch status.
 int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream, char* label, int label_len) {
@@ -678,6 +680,10 @@ int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream, char* 
   const int mf = mfo < 0 ? (wide4 ? 0 : 1) : mfo;
   // the output layer (2-3 filters, fp32 NCHW + tanh): 4 waves, 52 KB of LDS, THREE workgroups per CU (124 us against
   // 128 for the 8-wave form at two per CU; the layer waits for its 45-KB patches, not for the matrix pipe)
+  if (d.n == 32) {
+    const int rc = conv_outc_s16_try(d, kpad, stream, label, label_len);      // the streaming form (conv_outc_s16.hip)
+    if (rc != TAP_SKIP) return rc;
+  }
   if (d.n == 32) return mf ? launch_tap<4, 1, 2, 1, 1, 1>(a, stream, label, label_len)
                            : launch_tap<8, 1, 1, 1, 1, 0>(a, stream, label, label_len);
   if (d.n == 64) return mf ? launch_tap<4, 1, 2, 2, 1, 1>(a, stream, label, label_len)     // 4 waves of 64x64 (2 image rows x 64 filters), 2 workgroups per CU

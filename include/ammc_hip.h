@@ -44,6 +44,8 @@ const char* ammc_error_string(int code);
 /* Dispatch options, for A/B measurements and for tests that must reach every kernel instance:
  *   "s16_mf"  MFMA shape of the halo-patch kernel (conv_tap_s16<..., MF>): -1 = the measured faster one per
  *             variant (default), 1 = v_mfma_f32_16x16x32_f16, 0 = v_mfma_f32_32x32x16_f16.  Initial value: AMMC_S16_MF.
+ *   "outc_stream"  1 = the output layer (32-filter tile, fp32 NCHW output) on the streaming kernel conv_outc_s16
+ *             (default), 0 = on the halo-patch kernel.  Initial value: AMMC_OUTC_STREAM.
  * Returns AMMC_EUNSUP for an unknown key, AMMC_EINVAL for a value out of range.  Not thread safe against
  * concurrent launches. */
 int ammc_set_option(const char* key, int32_t value);

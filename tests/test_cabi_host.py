@@ -118,7 +118,9 @@ def test_s16_dispatch_of_the_benchmark_shapes():
     }
     for (hw, cin, n), label in want.items():
         assert s16_variant(_fake_desc(B, hw, hw, cin, n)) == label, (hw, cin, n)
-    assert s16_variant(_fake_desc(B, 256, 256, 64, 32, y_f32=1)) == "conv_tap_s16<4, 1, 2, 1, 1, 1>"      # outc
+    outc = _fake_desc(B, 256, 256, 64, 32, y_f32=1)                                                    # outc: 3 real filters
+    outc.n_store, outc.act, outc.y_ps, outc.y_rs, outc.y_cs, outc.y_bs = 3, 2, 1, 256, 256 * 256, 3 * 256 * 256
+    assert s16_variant(outc) == "conv_outc_s16"
     assert s16_variant(_fake_desc(B, 256, 256, 16, 64)).startswith("conv_gemm_s16<")                   # inc.0 (12 -> 16 channels)
     assert s16_variant(_fake_desc(B, 32, 32, 512, 1024, ntaps=1, up=2)).startswith("conv_gemm_s16<")   # ConvTranspose
     # small batches fall back to the implicit GEMM (split-K below 192 tiles)
@@ -132,6 +134,9 @@ def test_s16_dispatch_of_the_benchmark_shapes():
     assert lib.ammc_set_option(b"s16_mf", 0) == 0
     assert s16_variant(_fake_desc(B, 256, 256, 64, 64)) == "conv_tap_s16<4, 1, 2, 2, 1, 0>"
     assert lib.ammc_set_option(b"s16_mf", -1) == 0 and lib.ammc_set_option(b"s16_mf", 2) == -1
+    assert lib.ammc_set_option(b"outc_stream", 0) == 0 and lib.ammc_set_option(b"outc_stream", 2) == -1
+    assert s16_variant(outc) == "conv_tap_s16<4, 1, 2, 1, 1, 1>"             # the halo-patch kernel's output-layer instance
+    assert lib.ammc_set_option(b"outc_stream", 1) == 0
     assert lib.ammc_set_option(b"no_such_option", 1) == -2
     bad = _fake_desc(1, 32, 32, 24, 64)                                      # cin not a power of two
     with pytest.raises(_lib.AmmcHipError):

@@ -151,13 +151,16 @@ def test_conv_tap_fp32_output_with_fp32_residual(B, H, W, cin, n, variant, mf):
     assert float(ya.buf[:, 0].abs().max()) == 0.0 and float(ya.buf[:, :, 0].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("B,H,W,cout", [(8, 64, 96, 3), (3, 128, 128, 2)])
-def test_output_layer_vs_fp64(B, H, W, cout, mf):
-    """`outc` + tanh (reference unet.py:920, 998-1007) as the benchmark runs it: 32-filter tile with `n_store` real
-    filters, fp32 NCHW frames, bias, tanh, and the fused per-sample squared error of `psnr_error` (utils.py:141-148) -
-    both instances (MF 1: 4 waves, 16-filter MFMA tile, three workgroups per CU; MF 0: the 8-wave 32x32x16 form) against
-    fp64 on the S16-rounded operands"""
+@pytest.fixture(params=[1, 0], ids=["stream", "tap"])
+def outc_stream(request):
+    """the output layer on its streaming kernel (default) and on the halo-patch kernel"""
     lib = _lib.load()
+    _lib.check(lib.ammc_set_option(b"outc_stream", request.param), "set_option")
+    yield request.param
+    _lib.check(lib.ammc_set_option(b"outc_stream", 1), "set_option")
+
+
+def _outc_case(lib, B, H, W, cout, score=True):
     s = torch.cuda.current_stream().cuda_stream
     tag = f"outc-{B}-{H}-{W}-{cout}"
     cin = 64
@@ -180,8 +183,52 @@ def test_output_layer_vs_fp64(B, H, W, cout, mf):
     d.batch, d.height, d.width, d.cin, d.ntaps, d.n, d.up, d.cgroup, d.act, d.n_store, d.y_f32 = B, H, W, cin, 9, 32, 1, 32, 2, cout, 1
     d.x_bs, d.x_rs, d.x_ps = xa.strides
     d.y_bs, d.y_rs, d.y_ps, d.y_cs = cout * H * W, W, 1, H * W
-    d.sq_target, d.sq_acc = _ptr(target), _ptr(sq)
-    assert s16_variant(d) == ("conv_tap_s16<4, 1, 2, 1, 1, 1>" if mf else "conv_tap_s16<8, 1, 1, 1, 1, 0>")
+    if score:
+        d.sq_target, d.sq_acc = _ptr(target), _ptr(sq)
+    keep = (x, w, bias, target, xa, wp, ws)
+    return d, y, sq, keep
+
+
+@pytest.mark.parametrize("B,H,W,cout", [(8, 64, 96, 3), (16, 256, 256, 3), (7, 80, 96, 2), (5, 128, 160, 3)])
+def test_output_layer_streaming_kernel_vs_halo_patch_kernel(B, H, W, cout):
+    """conv_outc_s16 (persistent, three patch stages, two accumulator sets) against conv_tap_s16<.., MF = 1> (one
+    accumulator set) on the same operands: frames equal to fp32 rounding of the sums (the benchmark's size; 210 tiles =
+    fewer than the grid; 400 tiles = workgroups with one and with two tiles), squared errors to the order of their
+    fp32 sums; without a target the frames are the same bits and nothing is written to sq_acc"""
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    out = {}
+    try:
+        for stream in (1, 0):
+            _lib.check(lib.ammc_set_option(b"outc_stream", stream), "set_option")
+            _lib.check(lib.ammc_set_option(b"s16_mf", 1), "set_option")
+            d, y, sq, keep = _outc_case(lib, B, H, W, cout)
+            assert s16_variant(d) == ("conv_outc_s16" if stream else "conv_tap_s16<4, 1, 2, 1, 1, 1>")
+            _lib.check(lib.ammc_conv_gemm_s16(C.byref(d), s), "outc")
+            out[stream] = (y.clone(), sq.clone())
+        d, y, sq, keep = _outc_case(lib, B, H, W, cout, score=False)
+        _lib.check(lib.ammc_set_option(b"outc_stream", 1), "set_option")
+        _lib.check(lib.ammc_conv_gemm_s16(C.byref(d), s), "outc")
+        assert torch.equal(y, out[1][0]) and float(sq.abs().max()) == 0.0
+    finally:
+        _lib.check(lib.ammc_set_option(b"outc_stream", 1), "set_option")
+        _lib.check(lib.ammc_set_option(b"s16_mf", -1), "set_option")
+    assert float((out[1][0] - out[0][0]).abs().max()) <= 1e-6
+    assert float(((out[1][1] - out[0][1]).abs() / out[0][1]).max()) <= 1e-5
+
+
+@pytest.mark.parametrize("B,H,W,cout", [(8, 64, 96, 3), (3, 128, 128, 2)])
+def test_output_layer_vs_fp64(B, H, W, cout, mf, outc_stream):
+    """`outc` + tanh (reference unet.py:920, 998-1007) as the benchmark runs it: 32-filter tile with `n_store` real
+    filters, fp32 NCHW frames, bias, tanh, and the fused per-sample squared error of `psnr_error` (utils.py:141-148) -
+    the streaming kernel (conv_outc_s16.hip) and both instances of the halo-patch kernel (MF 1: 4 waves, 16-filter MFMA
+    tile, three workgroups per CU; MF 0: the 8-wave 32x32x16 form) against fp64 on the S16-rounded operands"""
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    cin = 64
+    d, y, sq, (x, w, bias, target, xa, wp, ws) = _outc_case(lib, B, H, W, cout)
+    assert s16_variant(d) == ("conv_outc_s16" if outc_stream else
+                              ("conv_tap_s16<4, 1, 2, 1, 1, 1>" if mf else "conv_tap_s16<8, 1, 1, 1, 1, 0>"))
     _lib.check(lib.ammc_conv_gemm_s16(C.byref(d), s), "outc")
     wsa = Act(ws.view(1, 1, 32, 9 * cin), 1, 1, 32, 9 * cin, 0, 0)
     wr = _s16_read(wsa).view(9 * cin, 32).t().reshape(32, 9, cin).permute(0, 2, 1).reshape(32, cin, 3, 3).double().cpu()

@@ -258,7 +258,7 @@ def test_benchmark_workload_b16_256_m2000_vs_reference_vectors(prec, mf):
     if prec == "s16":
         kernels = {m["kernel"] for m in st["plan"].meta} | {s.outc_kernel for s in st["streams"]}
         assert {f"conv_tap_s16<4, 1, 2, 4, 1, {mf}>", f"conv_tap_s16<4, 1, 2, 2, 1, {mf}>", f"conv_tap_s16<4, 2, 2, 2, 2, {mf}>",
-                "conv_tap_s16<4, 1, 2, 1, 1, 1>" if mf else "conv_tap_s16<8, 1, 1, 1, 1, 0>", "conv_up_s16<2>", "conv_up_s16<4>",
+                "conv_outc_s16", "conv_first_s16", "conv_up_s16<2>", "conv_up_s16<4>",
                 "memory_topk_s16", "conv_gemm_s16<128x128>", "conv_gemm_s16<128x64>"} <= kernels, kernels
         assert all(s.first_mid is not None for s in st["streams"])                  # conv_first_s16 took the first layers
         assert not eng.overflowed()

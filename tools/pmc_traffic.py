@@ -24,6 +24,8 @@ def label(name):
         return f"conv_up_s16<{m0.group(1)}>"
     if "conv_first_s16_kernel" in name:
         return "conv_first_s16"
+    if "conv_outc_s16_kernel" in name:
+        return "conv_outc_s16"
     if "memory_topk_s16_kernel" in name:                # (rocprofv3 leaves this one mangled)
         return "memory_topk_s16"
     if re.search(r"memory_topk_kernel", name):
