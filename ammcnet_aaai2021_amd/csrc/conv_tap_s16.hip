@@ -631,8 +631,9 @@ static int launch_tap(const TapArgs& a, hipStream_t stream, char* label, int lab
   constexpr int BJ = BN * 8 >= NT ? BN * 8 / NT : 1;
   constexpr int NB = (NT == 256 && (BN == 128 || BN == 32)) ? 2 : 3;
   constexpr int STAGES = AS * T_ASTAGE + NB * BJ * (NT / 8) * 32;
-  constexpr size_t lds = (size_t)STAGES * sizeof(float);
-  static_assert(lds <= 160 * 1024, "LDS budget");
+  static const size_t pad = getenv("AMMC_TAP_LDSPAD") ? (size_t)atoi(getenv("AMMC_TAP_LDSPAD")) : 0;   // occupancy experiments
+  const size_t lds = (size_t)STAGES * sizeof(float) + pad;
+  static_assert((size_t)STAGES * sizeof(float) <= 160 * 1024, "LDS budget");
   auto kern = conv_tap_s16_kernel<WGM, WGN, TM, TN, AS, MF>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
