@@ -90,11 +90,12 @@ def _s16_round(t: torch.Tensor) -> torch.Tensor:
     return hi.double() + lo.double() / 2048.0
 
 
-@pytest.mark.parametrize("B,C,H,W", [(2, 12, 16, 32), (1, 6, 8, 64), (3, 12, 24, 96), (2, 3, 8, 32)])
+@pytest.mark.parametrize("B,C,H,W", [(2, 12, 16, 32), (1, 6, 8, 64), (3, 12, 24, 96), (2, 3, 8, 32), (5, 12, 256, 256), (9, 6, 136, 256)])
 def test_conv_first_s16_vs_fp64(B, C, H, W):
     """csrc/conv_first_s16.hip: `inconv`'s first conv + BN(eval) + ReLU straight from the NCHW fp32 clips (zero padding,
     S16 split and im2col inside the kernel; reference unet.py:11-13, 23-30) against an fp64 convolution of the
-    S16-rounded operands; small images, so every patch touches the image border."""
+    S16-rounded operands; small images, so every patch touches the image border, and two sizes with more tiles than
+    the persistent grid of 512 workgroups (1280 and 1224: workgroups with two and with three tiles)."""
     lib = _lib.load()
     s = torch.cuda.current_stream().cuda_stream
     tag = f"first-{B}-{C}-{H}-{W}"
