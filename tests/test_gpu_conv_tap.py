@@ -160,10 +160,9 @@ def outc_stream(request):
     _lib.check(lib.ammc_set_option(b"outc_stream", 1), "set_option")
 
 
-def _outc_case(lib, B, H, W, cout, score=True):
+def _outc_case(lib, B, H, W, cout, score=True, cin=64):
     s = torch.cuda.current_stream().cuda_stream
     tag = f"outc-{B}-{H}-{W}-{cout}"
-    cin = 64
     x = S.hashed_uniform(tag + "x", (B, cin, H, W)).to(DEV)
     w = torch.zeros(32, cin, 3, 3)
     w[:cout] = S.hashed_uniform(tag + "w", (cout, cin, 3, 3)) * (2.0 / (9 * cin)) ** 0.5
@@ -189,12 +188,13 @@ def _outc_case(lib, B, H, W, cout, score=True):
     return d, y, sq, keep
 
 
-@pytest.mark.parametrize("B,H,W,cout", [(8, 64, 96, 3), (16, 256, 256, 3), (7, 80, 96, 2), (5, 128, 160, 3)])
-def test_output_layer_streaming_kernel_vs_halo_patch_kernel(B, H, W, cout):
+@pytest.mark.parametrize("B,H,W,cout,cin", [(8, 64, 96, 3, 64), (16, 256, 256, 3, 64), (7, 80, 96, 2, 64), (5, 128, 160, 3, 64),
+                                             (5, 128, 160, 3, 32), (8, 64, 96, 1, 32)])
+def test_output_layer_streaming_kernel_vs_halo_patch_kernel(B, H, W, cout, cin):
     """conv_outc_s16 (persistent, three patch stages, two accumulator sets) against conv_tap_s16<.., MF = 1> (one
     accumulator set) on the same operands: frames equal to fp32 rounding of the sums (the benchmark's size; 210 tiles =
-    fewer than the grid; 400 tiles = workgroups with one and with two tiles), squared errors to the order of their
-    fp32 sums; without a target the frames are the same bits and nothing is written to sq_acc"""
+    fewer than the grid; 400 tiles = workgroups with one and with two tiles; 32 input channels = one unit per tile),
+    squared errors to the order of their fp32 sums; without a target the frames are the same bits and nothing is written to sq_acc"""
     lib = _lib.load()
     s = torch.cuda.current_stream().cuda_stream
     out = {}
@@ -202,11 +202,11 @@ def test_output_layer_streaming_kernel_vs_halo_patch_kernel(B, H, W, cout):
         for stream in (1, 0):
             _lib.check(lib.ammc_set_option(b"outc_stream", stream), "set_option")
             _lib.check(lib.ammc_set_option(b"s16_mf", 1), "set_option")
-            d, y, sq, keep = _outc_case(lib, B, H, W, cout)
+            d, y, sq, keep = _outc_case(lib, B, H, W, cout, cin=cin)
             assert s16_variant(d) == ("conv_outc_s16" if stream else "conv_tap_s16<4, 1, 2, 1, 1, 1>")
             _lib.check(lib.ammc_conv_gemm_s16(C.byref(d), s), "outc")
             out[stream] = (y.clone(), sq.clone())
-        d, y, sq, keep = _outc_case(lib, B, H, W, cout, score=False)
+        d, y, sq, keep = _outc_case(lib, B, H, W, cout, score=False, cin=cin)
         _lib.check(lib.ammc_set_option(b"outc_stream", 1), "set_option")
         _lib.check(lib.ammc_conv_gemm_s16(C.byref(d), s), "outc")
         assert torch.equal(y, out[1][0]) and float(sq.abs().max()) == 0.0
