@@ -203,6 +203,25 @@ def test_fused_maxpool_matches_pool_kernel(monkeypatch):
     assert abs(float(a[2][0]) - float(b[2][0])) <= 1e-6 * abs(float(b[2][0]))
 
 
+def test_forward_is_bitwise_repeatable_at_the_benchmark_size():
+    """race detector for the DMA-pipelined kernels (counted vmcnt waits, raw barriers, persistent workgroups): the
+    inference forward has no atomics on its frame path, so twelve forwards of the same batch (16 clips, 256x256: every
+    kernel instance of the benchmark, eight tiles per persistent workgroup) must give the same bits"""
+    net, _ = _net(2000, 2)
+    rgb_x, op_x, _, _ = (t.to(DEV) for t in S.make_clips(16, 256, 256, tag="repeat"))
+    ref = None
+    with torch.no_grad():
+        for i in range(12):
+            out = net(rgb_x, op_x)
+            got = (out[0].clone(), out[1].clone(), out[3][0].clone(), out[3][1].clone())
+            if ref is None:
+                ref = got
+            else:
+                for a, b in zip(got, ref):
+                    assert torch.equal(a, b), i
+    assert getattr(net, "s16_fallbacks", 0) == 0
+
+
 @pytest.mark.parametrize("B,H,W", [(1, 256, 256), (3, 64, 96), (5, 32, 64), (24, 64, 64), (7, 128, 32), (2, 8, 8), (9, 96, 160)])
 def test_s16_dispatch_is_consistent_across_shapes(B, H, W):
     """which kernel a layer gets (halo-patch variants, implicit GEMM, split-K, fused pooling) depends on batch and frame
