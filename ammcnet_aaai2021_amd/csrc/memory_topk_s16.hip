@@ -61,7 +61,10 @@ __device__ __forceinline__ void s_topk_insert_ordered(float (&v)[K], int (&ix)[K
   }
 }
 
-template <int K>
+// NL: the slot norms are read from LDS (memories of up to 4096 slots).  A template argument, not a pointer chosen at run
+// time: a pointer that may be LDS or global is a FLAT pointer, and every flat load makes the compiler wait
+// vmcnt(0) - i.e. for the codebook fragments just requested for the next tile pair.
+template <int K, bool NL>
 __global__ __launch_bounds__(256, 2) void memory_topk_s16_kernel(
     const float* __restrict__ x, const h16x8* __restrict__ e_s16 /* [8][mpad][2] */, const float* __restrict__ e_md,
     const float* __restrict__ enorm, int n, int m, int mpad, int* __restrict__ idx_out, float* __restrict__ q_topk,
@@ -79,10 +82,8 @@ __global__ __launch_bounds__(256, 2) void memory_topk_s16_kernel(
   const int h = lane >> 5, l31 = lane & 31;
   const int r0 = blockIdx.x * SBR;
   // the tile epilogues read 16 norms per lane and tile: from LDS (loaded once), not 16 exposed global loads
-  const float* en = enorm;
-  if (m <= 4096) {
+  if (NL) {
     for (int i = tid; i < m; i += 256) ens[i] = enorm[i];
-    en = ens;
   }
 
   // ---- stage the tile: thread = (row, group of 8 features) -------------------------------------------------------------
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void memory_topk_s16_kernel(
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                               \
           const int s = (((tile_) + u) << 5) + (r & 3) + 8 * (r >> 2) + 4 * h;                         \
           if (s < m) {                                                                                 \
-            const float dist = (xnorm - 2.f * acc[u][r]) + en[s];                                      \
+            const float dist = (xnorm - 2.f * acc[u][r]) + (NL ? ens[s] : enorm[s]);                   \
             s_topk_insert_ordered<K>(bv, bi, dist, s);                                                 \
           }                                                                                            \
         }                                                                                              \
@@ -172,14 +173,19 @@ __global__ __launch_bounds__(256, 2) void memory_topk_s16_kernel(
   }
   {
     h16x8 ah0[2][4], al0[2][4], ah1[2][4], al1[2][4];
+    // (the prefetch loads are UNCONDITIONAL - S_LOAD clamps the tile index - because a load the compiler cannot be
+    // sure was issued makes it count its vmcnt waits as if it was not: the waits of the current pair then also cover
+    // the pair just requested and the prefetch is gone; seen in the ISA as vmcnt(15) .. vmcnt(0) inside the MFMAs)
     int tile = wave * 2;
-    if (tile < ntile) S_LOAD(ah0, al0, tile)
+    S_LOAD(ah0, al0, tile)
     while (tile < ntile) {
-      if (tile + 8 < ntile) S_LOAD(ah1, al1, tile + 8)
+      S_LOAD(ah1, al1, tile + 8)
+      __builtin_amdgcn_sched_barrier(0);         // (else the scheduler sinks these loads behind the MFMAs to save registers)
       S_TILES(ah0, al0, tile)
       tile += 8;
       if (tile >= ntile) break;
-      if (tile + 8 < ntile) S_LOAD(ah0, al0, tile + 8)
+      S_LOAD(ah0, al0, tile + 8)
+      __builtin_amdgcn_sched_barrier(0);
       S_TILES(ah1, al1, tile)
       tile += 8;
     }
@@ -263,8 +269,12 @@ template <int K>
 int launch_topk_s16(const float* x, const void* e_s16, const float* e_md, const float* enorm, int n, int m, int* idx,
                     float* q_topk, float* q_one, float* diff_partial, hipStream_t stream) {
   const int mpad = (m + 31) / 32 * 32;
-  hipLaunchKernelGGL(memory_topk_s16_kernel<K>, dim3((n + SBR - 1) / SBR), dim3(256), 0, stream, x,
-                     reinterpret_cast<const h16x8*>(e_s16), e_md, enorm, n, m, mpad, idx, q_topk, q_one, diff_partial);
+  if (m <= 4096)
+    hipLaunchKernelGGL((memory_topk_s16_kernel<K, true>), dim3((n + SBR - 1) / SBR), dim3(256), 0, stream, x,
+                       reinterpret_cast<const h16x8*>(e_s16), e_md, enorm, n, m, mpad, idx, q_topk, q_one, diff_partial);
+  else
+    hipLaunchKernelGGL((memory_topk_s16_kernel<K, false>), dim3((n + SBR - 1) / SBR), dim3(256), 0, stream, x,
+                       reinterpret_cast<const h16x8*>(e_s16), e_md, enorm, n, m, mpad, idx, q_topk, q_one, diff_partial);
   return ammc_launch_status();
 }
 
