@@ -69,7 +69,9 @@ __device__ __forceinline__ void topk_insert16_ordered(float (&v)[K], int (&ix)[K
   }
 }
 
-template <int K>
+// NSTEP = d / 16, a template argument: the k-loop is fully unrolled (across the back edge of a run-time loop the
+// compiler drains the register ring with vmcnt(0) every PF steps)
+template <int K, int NSTEP>
 __global__ __launch_bounds__(512, 1) void memory_topk_f16_kernel(
     const float* __restrict__ x, const f16x8* __restrict__ e_kblk /* [d/8][mpad] */,
     const float* __restrict__ e_md, const float* __restrict__ enorm16, int n, int d, int m, int mpad,
@@ -85,6 +87,7 @@ __global__ __launch_bounds__(512, 1) void memory_topk_f16_kernel(
   float* xx = reinterpret_cast<float*>(smem_raw + region0);             // [HBR]
   int* best = reinterpret_cast<int*>(xx + HBR);                         // [HBR][K]
   float* red = reinterpret_cast<float*>(best + HBR * K);                // [512]
+  float* enl = red + 512;                                               // [HWAVES][TS * 32]: slot norms of a wave's tile pair
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
@@ -129,12 +132,28 @@ __global__ __launch_bounds__(512, 1) void memory_topk_f16_kernel(
   for (int t = 0; t < HRT; ++t) xnorm[t] = xx[t * 32 + l31];
 
   const int ntile = mpad >> 5;
-  const int nstep = d >> 4;                               // k-steps of 16 features
+  constexpr int nstep = NSTEP;                            // k-steps of 16 features (d == 16 NSTEP: the launcher checks)
   for (int tile = wave * TS; tile < ntile; tile += HWAVES * TS) {
     // lane (l31, h) at step t needs features [16t + 8h, +8) of slot s0 + l31: k-block 2t + h
     const f16x8* ep[TS];
     f32x16 acc[TS][HRT];
     f16x8 ring[TS][PF];
+    // The codebook fragments run PF k-steps ahead in a register ring.  Every load of this loop is UNCONDITIONAL (the
+    // steps past the end re-load the last one) and the k-loop is fully unrolled: a prefetch behind a condition is counted
+    // by the compiler's waitcnt pass as not issued, and the back edge of a run-time k-loop drains the ring, so the first
+    // form of this loop waited vmcnt(0) at EVERY step - a prefetch depth of one step instead of PF.  The request of step
+    // t + PF is pinned before the MFMAs of step t (sched_barrier); the source offset advances incrementally behind an
+    // opaque asm, like the swizzle of the LDS fragment addresses (hoisted out of the tile loop, the 32 x 4 addresses of
+    // the unrolled steps spill).
+    {
+      // |E_s|^2 of the 64 slots of this tile pair: one 4-byte LDS-DMA per lane into the wave's own row of `enl`,
+      // requested first, read in the epilogue (no registers; older than every ring load)
+      const int s_ = ((tile + (lane >> 5) < ntile ? tile + (lane >> 5) : ntile - 1) << 5) + l31;
+      __builtin_amdgcn_global_load_lds(enorm16 + (s_ < m ? s_ : m - 1), enl + wave * (TS * 32), 4, 0, 0);
+    }
+    const int64_t kstride = (int64_t)2 * mpad;                           // f16x8 elements between k-steps
+    const int swz = l31 & 15;
+    const _Float16* xrow = xs + (size_t)l31 * d;
 #pragma unroll
     for (int u = 0; u < TS; ++u) {
       const int tl = tile + u < ntile ? tile + u : ntile - 1;           // (an odd tail tile is contracted twice, inserted once)
@@ -143,29 +162,36 @@ __global__ __launch_bounds__(512, 1) void memory_topk_f16_kernel(
       for (int t = 0; t < HRT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[u][t][r] = 0.f;
-#pragma unroll
-      for (int p = 0; p < PF; ++p)
-        if (p < nstep) ring[u][p] = ep[u][(int64_t)(2 * p) * mpad];
     }
-    for (int t0 = 0; t0 < nstep; t0 += PF) {
 #pragma unroll
-      for (int p = 0; p < PF; ++p) {
-        const int t = t0 + p;
-        if (t < nstep) {
-          f16x8 af[TS];
+    for (int p = 0; p < PF; ++p)                                         // nstep >= 8 > PF (d % 128 == 0)
 #pragma unroll
-          for (int u = 0; u < TS; ++u) {
-            af[u] = ring[u][p];
-            if (t + PF < nstep) ring[u][p] = ep[u][(int64_t)(2 * (t + PF)) * mpad];
-          }
-          const int so = (((2 * t + h) ^ (l31 & 15)) << 3);
+      for (int u = 0; u < TS; ++u) ring[u][p] = ep[u][(int64_t)p * kstride];
+    int64_t eoff = (int64_t)PF * kstride;        // wave uniform; opaque so that the 32 offsets are not pre-computed
+    asm volatile("" : "+s"(eoff));               // (on the pointer itself the asm would turn it into a FLAT pointer)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int rt = 0; rt < HRT; ++rt) {
-            const f16x8 bf = *reinterpret_cast<const f16x8*>(xs + (size_t)(rt * 32 + l31) * d + so);
+    for (int t = 0; t < nstep; ++t) {
+      const int p = t % PF;
+      f16x8 af[TS];
 #pragma unroll
-            for (int u = 0; u < TS; ++u) acc[u][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u], bf, acc[u][rt], 0, 0, 0);
-          }
-        }
+      for (int u = 0; u < TS; ++u) {
+        af[u] = ring[u][p];
+        ring[u][p] = ep[u][eoff];                                        // step t + PF (past the end: the last step again)
+      }
+      if (t + PF + 1 < nstep) {
+        eoff += kstride;
+        asm volatile("" : "+s"(eoff));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      int sw = swz;                                                      // (opaque: the 32 x 4 fragment addresses of the
+      asm volatile("" : "+v"(sw));                                       //  unrolled steps must not be hoisted into registers)
+      const int so = (((2 * t + h) ^ sw) << 3);
+#pragma unroll
+      for (int rt = 0; rt < HRT; ++rt) {
+        const f16x8 bf = *reinterpret_cast<const f16x8*>(xrow + (size_t)(rt * 32) * d + so);
+#pragma unroll
+        for (int u = 0; u < TS; ++u) acc[u][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u], bf, acc[u][rt], 0, 0, 0);
       }
     }
 #pragma unroll
@@ -176,7 +202,7 @@ __global__ __launch_bounds__(512, 1) void memory_topk_f16_kernel(
       for (int r = 0; r < 16; ++r) {
         const int s = s0 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (s < m) {
-          const float en = enorm16[s];
+          const float en = enl[wave * (TS * 32) + u * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
 #pragma unroll
           for (int rt = 0; rt < HRT; ++rt) {
             const float dist = (xnorm[rt] - 2.f * acc[u][rt][r]) + en;
@@ -263,12 +289,12 @@ __global__ __launch_bounds__(256) void pack_codebook_f16_kernel(const float* __r
   if (s < m) enorm16[s] = nrm;
 }
 
-template <int K>
-int launch_topk16(const float* x, const void* e_kblk, const float* e_md, const float* enorm16, int n, int d, int m,
-                  int* idx, float* q_topk, float* q_one, float* diff_partial, hipStream_t stream) {
+template <int K, int NSTEP>
+int launch_topk16n(const float* x, const void* e_kblk, const float* e_md, const float* enorm16, int n, int d, int m,
+                   int* idx, float* q_topk, float* q_one, float* diff_partial, hipStream_t stream) {
   const size_t region0 = std::max((size_t)HBR * d * 2, (size_t)HBR * 16 * K * 8);
-  const size_t lds = region0 + sizeof(float) * (HBR + HBR * K + 512);
-  auto kern = memory_topk_f16_kernel<K>;
+  const size_t lds = region0 + sizeof(float) * (HBR + HBR * K + 512 + HWAVES * TS * 32);
+  auto kern = memory_topk_f16_kernel<K, NSTEP>;
   if (lds > 160 * 1024) return AMMC_EUNSUP;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -280,6 +306,18 @@ int launch_topk16(const float* x, const void* e_kblk, const float* e_md, const f
                      reinterpret_cast<const f16x8*>(e_kblk), e_md, enorm16, n, d, m, mpad, idx, q_topk, q_one,
                      diff_partial);
   return ammc_launch_status();
+}
+
+template <int K>
+int launch_topk16(const float* x, const void* e_kblk, const float* e_md, const float* enorm16, int n, int d, int m,
+                  int* idx, float* q_topk, float* q_one, float* diff_partial, hipStream_t stream) {
+  switch (d) {                                  // d % 128 == 0, d <= 512 (checked by the caller)
+    case 128: return launch_topk16n<K, 8>(x, e_kblk, e_md, enorm16, n, d, m, idx, q_topk, q_one, diff_partial, stream);
+    case 256: return launch_topk16n<K, 16>(x, e_kblk, e_md, enorm16, n, d, m, idx, q_topk, q_one, diff_partial, stream);
+    case 384: return launch_topk16n<K, 24>(x, e_kblk, e_md, enorm16, n, d, m, idx, q_topk, q_one, diff_partial, stream);
+    case 512: return launch_topk16n<K, 32>(x, e_kblk, e_md, enorm16, n, d, m, idx, q_topk, q_one, diff_partial, stream);
+  }
+  return AMMC_EUNSUP;
 }
 
 }  // namespace ammc_impl
