@@ -137,13 +137,16 @@ __global__ __launch_bounds__(256, 2) void memory_topk_kernel(
     float e0[32], e1[32], n0[16], n1[16];            // ... and its 16 |E_s|^2 (they were 16 exposed loads per tile)
 #define TOPK_LOAD_E(dst, ndst, tile_)                                                     \
     {                                                                                 \
-      const int slot_ = ((tile_) << 5) + l31;                                         \
-      const bool sv_ = slot_ < m;                                                     \
-      const float* ep_ = e_dm + (sv_ ? slot_ : 0) + (int64_t)(4 * h) * m;             \
+      /* unconditional, clamped (a slot >= m contracts a copy of slot m - 1 and is never inserted; a tile past  \
+         the end reloads the last one): a load behind a condition makes the compiler count its vmcnt waits as   \
+         if it was not issued, and the waits for the current tile then cover the tile just requested */        \
+      const int tc_ = (tile_) < ntile ? (tile_) : ntile - 1;                          \
+      const int slot_ = (tc_ << 5) + l31;                                             \
+      const float* ep_ = e_dm + (slot_ < m ? slot_ : m - 1) + (int64_t)(4 * h) * m;   \
       _Pragma("unroll") for (int i = 0; i < 32; ++i)                                  \
-        dst[i] = sv_ ? ep_[(int64_t)(8 * (i >> 2) + (i & 3)) * m] : 0.f;              \
+        dst[i] = ep_[(int64_t)(8 * (i >> 2) + (i & 3)) * m];                          \
       _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                \
-        const int s_ = ((tile_) << 5) + (r & 3) + 8 * (r >> 2) + 4 * h;               \
+        const int s_ = (tc_ << 5) + (r & 3) + 8 * (r >> 2) + 4 * h;                   \
         ndst[r] = enorm[s_ < m ? s_ : m - 1];                                         \
       }                                                                               \
     }
@@ -164,13 +167,15 @@ __global__ __launch_bounds__(256, 2) void memory_topk_kernel(
       TOPK_TILE_EPILOGUE((tile_) << 5, nsrc[r])                                       \
     }
     int tile = wave;
-    if (tile < ntile) TOPK_LOAD_E(e0, n0, tile)
+    TOPK_LOAD_E(e0, n0, tile)
     while (tile < ntile) {
-      if (tile + 4 < ntile) TOPK_LOAD_E(e1, n1, tile + 4)
+      TOPK_LOAD_E(e1, n1, tile + 4)
+      __builtin_amdgcn_sched_barrier(0);
       TOPK_TILE64(e0, n0, tile)
       tile += 4;
       if (tile >= ntile) break;
-      if (tile + 4 < ntile) TOPK_LOAD_E(e0, n0, tile + 4)
+      TOPK_LOAD_E(e0, n0, tile + 4)
+      __builtin_amdgcn_sched_barrier(0);
       TOPK_TILE64(e1, n1, tile)
       tile += 4;
     }
