@@ -372,8 +372,16 @@ class _Builder:
 
     def up_conv_eligible(self, skip: Act, n: int) -> bool:
         """does csrc/conv_up_s16.hip take this decoder level?  (mirrors the checks of `ammc_conv_up_s16`)"""
-        return (self.s16 and os.environ.get("AMMC_UP_FUSED", "1") != "0" and skip.W % 32 == 0 and skip.H % 8 == 0
-                and skip.c % 32 == 0 and (n == 64 or n % 128 == 0))
+        mode = os.environ.get("AMMC_UP_FUSED", "1")
+        if not (self.s16 and mode != "0" and skip.W % 32 == 0 and skip.H % 8 == 0 and skip.c % 32 == 0
+                and (n == 64 or n % 128 == 0)):
+            return False
+        # one workgroup per 8 x 32 output tile and 128 filters: below ~128 of them the chip is empty and the two
+        # launches it replaces (implicit GEMMs with split-K) win - measured at 256x256: batch 1, up1 (32 tiles) 203 us
+        # against 74, up2 (64) 105 against 69; batch 2, up2 (128) 110 against 114; up3 (256 per clip) always ahead
+        # (AMMC_UP_FUSED=2 forces the fused kernel)
+        tiles = skip.B * (skip.H // 8) * (skip.W // 32) * max(1, n // 128)
+        return tiles >= 128 or mode == "2"
 
     def up_conv(self, x2: Act, skip: Act, p: _DoubleConvPack, fused, y: Act, name="up"):
         """ConvTranspose2d(x2) + cat([skip, .]) + conv3x3 + BN + ReLU as ONE launch (reference unet.py:50-59, first conv
