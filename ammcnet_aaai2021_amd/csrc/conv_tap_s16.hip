@@ -363,6 +363,23 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : (W
 #undef TAP_ISSUE_A
 #undef TAP_ISSUE_B
 
+  // BatchNorm scale / shift of eight consecutive channels.  In the S16 epilogues the NEXT group's constants are requested
+  // before the current group is stored: d.y may alias d.scale for all the compiler knows, so it keeps every load behind
+  // the stores that precede it in program order - and VMEM operations retire in order, so the wait for a group's
+  // constants was also a wait for the previous group's stores to be acknowledged: up to eight exposed store round trips
+  // per tile (a large part of the per-tile "intercept" of DESIGN.md section 8).
+#define TAP_LOAD_SCSH(c0_, sc_, sh_)                                                                       \
+  {                                                                                                        \
+    _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) sc_[k_] = 1.f, sh_[k_] = 0.f;                         \
+    if (d.scale) {                                                                                         \
+      const f32x4 s0_ = *reinterpret_cast<const f32x4*>(d.scale + (c0_)), s1_ = *reinterpret_cast<const f32x4*>(d.scale + (c0_) + 4); \
+      _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) sc_[k_] = s0_[k_], sc_[4 + k_] = s1_[k_];           \
+    }                                                                                                      \
+    if (d.shift) {                                                                                         \
+      const f32x4 s0_ = *reinterpret_cast<const f32x4*>(d.shift + (c0_)), s1_ = *reinterpret_cast<const f32x4*>(d.shift + (c0_) + 4); \
+      _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) sh_[k_] = s0_[k_], sh_[4 + k_] = s1_[k_];           \
+    }                                                                                                      \
+  }
   // ---- epilogue, straight from the accumulators ---------------------------------------------------------------
   // The MFMAs take the filter fragment as the row operand, so an accumulator tile has PIXELS on lanes (lane l31 =
   // pixel x0 + l31 of image row wm*TM + i) and CHANNELS on registers: register r of lane half h is MFMA row
@@ -427,22 +444,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : (W
       return;
     }
     float vmax = 0.f;
+    float scb[2][8], shb[2][8];
+    TAP_LOAD_SCSH(cbase, scb[0], shb[0])
 #pragma unroll
     for (int u = 0; u < FT / 2; ++u) {
       const int c0 = cbase + 32 * u;                            // this lane's S16 group
-      float sc[8], sh[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) sc[k] = 1.f, sh[k] = 0.f;
-      if (d.scale) {
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.scale + c0), s1 = *reinterpret_cast<const f32x4*>(d.scale + c0 + 4);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) sc[k] = s0[k], sc[4 + k] = s1[k];
-      }
-      if (d.shift) {
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.shift + c0), s1 = *reinterpret_cast<const f32x4*>(d.shift + c0 + 4);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) sh[k] = s0[k], sh[4 + k] = s1[k];
-      }
+      if (u + 1 < FT / 2) TAP_LOAD_SCSH(cbase + 32 * (u + 1), scb[(u + 1) & 1], shb[(u + 1) & 1])
+      const float (&sc)[8] = scb[u & 1];
+      const float (&sh)[8] = shb[u & 1];
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         float pooled[8];
@@ -557,24 +566,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : (W
   // S16 output [+ S16 residual] [+ the 2x2 max-pool of it as a second output: rows 2 wm, 2 wm + 1 are this wave's two
   // row tiles and the horizontal neighbour is the next lane, so the window never leaves the wave]
   float vmax = 0.f;
+  float scb[2][8], shb[2][8];
+  TAP_LOAD_SCSH(n0 + wn * TN * 32 + 8 * h, scb[0], shb[0])
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
       const int c0 = n0 + (wn * TN + j) * 32 + 8 * (2 * o + h);  // this lane's S16 group
-      float sc[8], sh[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) sc[k] = 1.f, sh[k] = 0.f;
-      if (d.scale) {
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.scale + c0), s1 = *reinterpret_cast<const f32x4*>(d.scale + c0 + 4);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) sc[k] = s0[k], sc[4 + k] = s1[k];
-      }
-      if (d.shift) {
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(d.shift + c0), s1 = *reinterpret_cast<const f32x4*>(d.shift + c0 + 4);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) sh[k] = s0[k], sh[4 + k] = s1[k];
-      }
+      const int g = 2 * j + o;                                   // group index; the next one is (j, 1) or (j + 1, 0)
+      if (g + 1 < 2 * TN)
+        TAP_LOAD_SCSH(n0 + (wn * TN + (g + 1) / 2) * 32 + 8 * (2 * ((g + 1) & 1) + h), scb[(g + 1) & 1], shb[(g + 1) & 1])
+      const float (&sc)[8] = scb[g & 1];
+      const float (&sh)[8] = shb[g & 1];
       float pooled[8];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
