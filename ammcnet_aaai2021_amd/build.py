@@ -43,14 +43,18 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, variant: str = "") -> str:
+    """variant: an A/B build next to the shipped one (`libammc_hip_<variant>.so`, flags from AMMC_HIPCC_FLAGS; tools
+    select it with AMMC_LIB=<path>).  The shipped library and its stamp are not touched."""
     dig = _digest()
+    LIB = globals()["LIB"] if not variant else os.path.join(HERE, f"libammc_hip_{variant}.so")
+    STAMP = globals()["STAMP"] if not variant else os.path.join(HERE, f".libammc_hip_{variant}.stamp")
     if not force and os.path.exists(LIB) and os.path.exists(STAMP):
         with open(STAMP) as fp:
             if fp.read().strip() == dig:
                 return LIB
     objs = []
-    obj_dir = os.path.join(HERE, "build")
+    obj_dir = os.path.join(HERE, "build" + ("_" + variant if variant else ""))
     os.makedirs(obj_dir, exist_ok=True)
     procs = []
     for src in sources():
@@ -75,4 +79,5 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    var = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else ""
+    print(build(force="--force" in sys.argv, verbose=True, variant=var))

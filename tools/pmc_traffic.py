@@ -1,7 +1,7 @@
 """HBM-side bytes per launch of every conv kernel from the FETCH_SIZE / WRITE_SIZE passes of tools/profile_bench.sh
 (separate rocprofv3 --pmc runs), keyed by the labels bench.py uses:
 
-    python tools/pmc_traffic.py gpurun_out/prof_<tag> <precision> [batch size n_embed commit] > profiles/rNN_<precision>_pmc_traffic.json
+    python tools/pmc_traffic.py gpurun_out/prof_<tag> <precision> [--mode infer|train|stress] [--commit sha] [batch size n_embed] > profiles/rNN_<precision>_pmc_traffic.json
 
 FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B: MI355X_MICROARCH.md, HBM section); rocprofv3 reports KB."""
 import csv, glob, json, re, sys
@@ -9,9 +9,24 @@ from collections import defaultdict
 
 root, prec = sys.argv[1], sys.argv[2]
 extra = sys.argv[3:]
-workload = {"batch": int(extra[0]) if len(extra) > 0 else 16, "size": int(extra[1]) if len(extra) > 1 else 256,
-            "n_embed": int(extra[2]) if len(extra) > 2 else 2000}
-commit = extra[3] if len(extra) > 3 else None
+mode, commit = "infer", None
+if "--mode" in extra:
+    i = extra.index("--mode")
+    mode = extra[i + 1]
+    del extra[i:i + 2]
+if "--commit" in extra:
+    i = extra.index("--commit")
+    commit = extra[i + 1]
+    del extra[i:i + 2]
+if mode == "stress":          # bench.py --mode stress: BASELINE.json configs[4] (its --batch counts frames of 1024 rows)
+    workload = {"mode": "stress", "rows": 1024 * (int(extra[0]) if extra else 256), "slots": 8192, "dim": 512, "k": 2}
+elif mode == "train":         # bench.py --mode train: configs[2]
+    workload = {"mode": "train", "batch": int(extra[0]) if extra else 32, "size": int(extra[1]) if len(extra) > 1 else 256,
+                "n_embed": 256}
+else:
+    workload = {"batch": int(extra[0]) if len(extra) > 0 else 16, "size": int(extra[1]) if len(extra) > 1 else 256,
+                "n_embed": int(extra[2]) if len(extra) > 2 else 2000}
+    commit = commit or (extra[3] if len(extra) > 3 else None)
 try:
     command = open(f"{root}/command.txt").read().strip()
 except OSError:
