@@ -27,12 +27,37 @@ namespace ammc_s16 {
 
 typedef _Float16 f16x8t __attribute__((ext_vector_type(8)));
 
+// -DAMMC_TAP_STAMP (diagnostic builds only; tools/micro/tap_stamps.py): wave 0 of every tile records s_memrealtime
+// (100 MHz) at the phase boundaries of its tile into a buffer that nothing else reads
+#ifdef AMMC_TAP_STAMP
+static unsigned long long* g_tap_stamps = nullptr;
+extern "C" void ammc_debug_set_tap_stamps(void* p) { g_tap_stamps = (unsigned long long*)p; }
+#define TAP_STAMP(slot) { if (a.stamps && threadIdx.x == 0 && (slot) < 16) a.stamps[(int64_t)vb * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define TAP_STAMP(slot)
+#endif
+
 struct TapArgs {
   AmmcConvDesc d;
   int tiles_x, tiles_y, n_tiles, ncc, kpad, dbg;
+  int total, delay;                 // persistent form: number of tiles; start delay of class B in 10-ns ticks
+  unsigned long long* stamps;       // diagnostic builds (AMMC_TAP_STAMP)
 };
 
 constexpr float T_LO_INV = 1.f / 2048.f;
+
+// LDS-DMA of 16 bytes per lane, hidden from the compiler (KH loop): `lds_byte` = the wave-uniform LDS byte address the
+// wave's 1 KB goes to, `off` = this lane's byte offset from the wave-uniform `base`.  Why not the builtin: hipcc books
+// __builtin_amdgcn_global_load_lds as a FLAT access to both memories ("pending flat"), after which every wait it inserts
+// for an LDS fragment read is lgkmcnt(0) until both counters have been drained - the reads of the NEXT chunk issued ahead
+// of the MFMAs of this one would be waited for at once.  In asm the compiler sees neither the memory operation (so the
+// vmcnt waits are written by hand, as asm as well: a builtin wait it believes redundant is dropped) nor M0, which is
+// saved and restored in the statement (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void tap_dma16(const float* base, unsigned off, unsigned lds_byte) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(off), "s"(base), "s"(lds_byte) : "memory");
+}
 constexpr int T_TH = 8, T_TW = 32, T_HW = T_TW + 2, T_HP = (T_TH + 2) * T_HW;     // 340 halo pixels
 constexpr int T_APIECES = T_HP * 8;                                              // 2720 16-byte pieces
 // the patch stage is padded to whole rounds of the workgroup's threads so that EVERY wave issues every round (the
@@ -52,10 +77,15 @@ constexpr int T_APIECES = T_HP * 8;                                             
 // filter rows of a stage are stored tile by tile, tile t row r = filter 32 (t >> 1) + 8 (r >> 2) + 4 (t & 1) + (r & 3),
 // so that the four registers of filter tiles 2 u and 2 u + 1 of a lane are EIGHT CONSECUTIVE channels of one pixel:
 // the 32-byte S16 store of the MF = 0 epilogue, unchanged.
-template <int WGM, int WGN, int TM, int TN, int AS, int MF>
-// (hipcc: the second __launch_bounds__ argument is the minimum number of WAVES PER SIMD, i.e. 512 / it VGPRs)
-__global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : (WGN * TN == 1 ? 3 : 2))) void conv_tap_s16_kernel(TapArgs a) {
+// One output tile (8 x 32 pixels x BN filters) of one workgroup.  `vb` / `nvb` = the tile's block id and the number of
+// tiles (what blockIdx.x / gridDim.x are when every tile is its own workgroup); `hiprio` = this workgroup belongs to the
+// class that runs at the higher wave priority (see below).
+//
+// KH = 1 (4-wave, one patch stage, 32x32x16): the k-half-major software pipeline, see "KH" below.
+template <int WGM, int WGN, int TM, int TN, int AS, int MF, int KH = 0>
+__device__ __forceinline__ void conv_tap_s16_tile(const TapArgs& a, const int vb, const int nvb, const bool hiprio) {
   static_assert((WGM * WGN == 8 || WGM * WGN == 4) && WGM * TM == T_TH, "4 or 8 waves, 8 image rows");
+  static_assert(!KH || (AS == 1 && MF == 0 && WGM == 4 && WGN == 1 && TM == 2 && (TN == 2 || TN == 4)), "KH: 4 waves of 64 x (64 | 128)");
   constexpr int NT = 64 * WGM * WGN;
   constexpr int T_AROUNDS = (T_APIECES + NT - 1) / NT;
   constexpr int T_ASTAGE = T_AROUNDS * NT * 4;             // floats
@@ -66,12 +96,24 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : (W
   constexpr int B_STAGE = BJ * (NT / 8) * 32;                    // a 32-filter slice is padded to 64 rows; floats)
   // filter-slice stages: 3 = slices t+1 and t+2 fly during step t; the 4-wave 128-filter variant keeps 2 (one slice
   // ahead) so that two workgroups fit a CU
-  constexpr int NB = (NT == 256 && (BN == 128 || BN == 32)) ? 2 : 3;     // (4-wave output layer: 52 KB, three workgroups per CU)
+  constexpr int NB = KH ? 2 : (NT == 256 && (BN == 128 || BN == 32)) ? 2 : 3;     // (4-wave output layer: 52 KB, three workgroups per CU)
   constexpr int PD = NB - 1;
-  constexpr int STAGES = AS * T_ASTAGE + NB * B_STAGE;
+  // KH: the patch is two half-patches (channels 0-15 | 16-31 of the block), each 340 pixels x 64 B + 768 B that the last
+  // DMA round of wave 1 spills into, and a 1-KB dump that the (all out of range) last round of waves 2, 3 is pointed at
+  constexpr int K_HPIECES = T_HP * 4, K_HROUNDS = 6, K_HSTRIDE = (T_HP * 64 + 768) / 4, K_ADUMP = 2 * K_HSTRIDE;
+  static_assert(K_HROUNDS * 256 >= K_HPIECES && (K_HROUNDS - 1) * 256 + 128 <= K_HPIECES + 48 && 5 * 256 + 64 <= K_HPIECES, "half-patch rounds");
+  constexpr int A_FLOATS = KH ? K_ADUMP + 256 : AS * T_ASTAGE;
+  constexpr int STAGES = A_FLOATS + NB * B_STAGE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
-  float* Bs = smem + AS * T_ASTAGE;
+  float* Bs = smem + A_FLOATS;
+  // BatchNorm scale / shift of this tile's BN filters: [BN scale | BN shift] behind the stages (1 KB reserved), fetched
+  // by one LDS-DMA per wave at the start of the tile (every wave writes the same bytes).  The epilogue reads them with
+  // ds_read: its only vector-memory operations are then its stores.  Read with global loads they tied the epilogue to
+  // its own stores - vector-memory operations retire in order, so the wait for the constants of channel group g + 1 was
+  // a wait for the acknowledgement of the stores of group g - 1: eight store round trips per tile, 9.4 of the 92 us a
+  // 128 -> 128 tile at 128 x 128 lasts (tools/micro/tap_stamps.py).
+  float* SCs = smem + STAGES;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -84,7 +126,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : (W
   const int g4 = lane >> 4;            //         S16 group of the 32-channel block (MFMA k = 8 g4 .. 8 g4 + 7)
   const AmmcConvDesc& d = a.d;
 
-  const int logical = ammc_xcd_remap(blockIdx.x, gridDim.x);
+  const int logical = ammc_xcd_remap(vb, nvb);
   // Two workgroups share a CU (AS == 1).  Started together they stay in phase: both stream their patch, both run
   // their MFMAs and both store their tile at the same moments, so the chip alternates between an idle matrix pipe and
   // an idle memory system (the stores of one round of 512 tiles alone are 5-9 us at the full HBM rate).  Every other
@@ -93,7 +135,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : (W
   // the other's MFMAs.  Measured with the layer launched back to back (same box): 128x128 128->128 169 -> 155 us,
   // 256x256 64->64 224 -> 212 us; inside the model, where kernels of different shapes follow each other, the dispatch
   // order is less regular and the step time moves within its noise (AMMC_S16_DBG=-1 turns it off for A/Bs).
-  if (AS == 1 && a.dbg != -1 && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_setprio(1);
+  if (AS == 1 && a.dbg != -1 && hiprio) __builtin_amdgcn_s_setprio(1);
   const int n0 = (logical % a.n_tiles) * BN;
   int sp = logical / a.n_tiles;
   const int tx = sp % a.tiles_x;
@@ -339,12 +381,205 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : (W
     bs = bs + 1 == NB ? 0 : bs + 1;                                                                        \
   }
 
+  // ---- KH: k-half-major software pipeline ---------------------------------------------------------------------------
+  // What the tap-by-tap loop above leaves on the table (tools/micro/tap_stamps.py, 128 -> 128 at 128 x 128): a workgroup
+  // ALONE on its CU reaches 46 % of the matrix pipe - every k-step begins with twelve fragment reads whose latency nothing
+  // covers, every tap ends in a DMA wait and a barrier, every block in a patch reload (1.7 us) - and two workgroups
+  // interleave to 66-71 %.  Here a block of 32 channels is swept as 18 STEPS of 16 channels, half-major: steps 0-8 =
+  // the nine taps over channels 0-15, steps 9-17 = the taps over channels 16-31, so that
+  //  * half 0 of the patch is dead after step 8 and is refilled with the NEXT block's channels while half 1 is swept
+  //    (and half 1 after step 17): no exposed patch reload, no second stage (the two half-patches are separate LDS
+  //    images of 64-byte rows: slot q of pixel p holds logical slot q ^ ((p >> 2) & 3), conflict free for ds_read_b128
+  //    from any start pixel since 16 lanes of a group cover 16 distinct pixels mod 16);
+  //  * a filter stage holds a PAIR of steps (same 128-byte rows and fragment addresses as a tap's two k-steps before;
+  //    only the DMA source differs), two stages, one barrier per pair, placed before the pair's LAST chunk: behind it
+  //    the next pair's slice has landed for everybody and this pair's stage is free, so the slice after next is
+  //    requested there and has a whole pair to arrive;
+  //  * fragments are read one CHUNK (12 MFMAs: two image rows x two filter tiles x three products) ahead into a second
+  //    register set, pinned by sched_barrier (left alone hipcc sinks the reads to their use and waits lgkmcnt(0)).
+  if constexpr (KH != 0) {
+    constexpr int JC = TN == 4 ? 1 : 2;              // filter tiles per chunk: 6 or 12 MFMAs
+    constexpr int CS = TN / JC;                      // chunks per step
+    constexpr int LB = CS == 1 ? 2 : 1;              // buffers of the lo pixel fragments (only read by the scaling at a step's first chunk)
+    // byte offsets of this lane's DMA pieces from wave-uniform bases (the patch of the tile; the filter matrix)
+    unsigned ka_off[K_HROUNDS];
+#pragma unroll
+    for (int j = 0; j < K_HROUNDS; ++j) {
+      int p = j * NT + tid;
+      p = p < K_HPIECES ? p : K_HPIECES - 1;
+      const int hp = p >> 2;
+      const int ls = (p & 3) ^ ((hp >> 2) & 3);
+      const int hy = hp / T_HW;
+      const int hx = hp - hy * T_HW;
+      ka_off[j] = 4u * (unsigned)((int)((int64_t)hy * d.x_rs + (int64_t)hx * d.x_ps) + 4 * ls);
+    }
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+    const int ksl = (tid & 7) ^ ((tid >> 4) & 7);    // logical slot of this thread's filter piece: (step of the pair, group of the half, hi / lo)
+    const bool ku1 = (ksl >> 2) != 0;
+    unsigned kb_off[BJ];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      int row = j * (NT / 8) + (tid >> 3) + n0;
+      row = row < d.n ? row : d.n - 1;
+      kb_off[j] = 4u * (unsigned)(row * a.kpad + 4 * (ksl & 3));
+    }
+#define K_ISSUE_A(j, ccx, hf)                                                                              \
+  {                                                                                                        \
+    const unsigned dst_ = lds0 + 4u * (unsigned)(((j) == K_HROUNDS - 1 && uwave >= 2) ? K_ADUMP : (hf) * K_HSTRIDE + ((j) * NT + uwave * 64) * 4); \
+    tap_dma16(xpatch + (ccx) * 32 + (hf) * 16, ka_off[j], dst_);                                           \
+  }
+#define K_OFFB(sg, ccx) (((((sg) % 9) * a.ncc) + (ccx)) * 32 + ((sg) / 9) * 16)
+#define K_ISSUE_B(k, ccx, stage)                                                                           \
+  {                                                                                                        \
+    const int o0_ = K_OFFB(2 * (k), ccx), o1_ = K_OFFB(2 * (k) + 1, ccx);                                  \
+    const unsigned off_ = 4u * (unsigned)(ku1 ? o1_ : o0_);                                                \
+    _Pragma("unroll") for (int j_ = 0; j_ < BJ; ++j_) {                                                    \
+      const unsigned dst_ = lds0 + 4u * (unsigned)(A_FLOATS + (stage) * B_STAGE + (j_ * NT + uwave * 64) * 4); \
+      tap_dma16(d.w, kb_off[j_] + off_, dst_);                                                             \
+    }                                                                                                      \
+  }
+    f16x8t ra_h[2][TM], ra_l[LB][TM], sa_h[TM], sa_l[TM], rb_h[2][JC], rb_l[2][JC];
+#define K_LOAD_A(sg, buf)                                                                                  \
+  _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) {                                                      \
+    int hp_ = hpb[i_] + (((sg) % 9) / 3) * T_HW + (((sg) % 9) % 3);                                        \
+    asm volatile("" : "+v"(hp_));                                                                          \
+    const float* ap_ = As + ((sg) / 9) * K_HSTRIDE + hp_ * 16;                                             \
+    const int q_ = (2 * h) ^ ((hp_ >> 2) & 3);                                                             \
+    ra_h[buf][i_] = *reinterpret_cast<const f16x8t*>(ap_ + (q_ << 2));                                     \
+    ra_l[LB == 2 ? (buf) : 0][i_] = *reinterpret_cast<const f16x8t*>(ap_ + ((q_ ^ 1) << 2));               \
+  }
+#define K_LOAD_B(sg, c, buf)                                                                               \
+  {                                                                                                        \
+    const float* Bc_ = Bs + ((((sg) >> 1) & 1) ^ bs0) * B_STAGE + b_row;                                   \
+    const int ls_ = (((sg) & 1) << 2) | (h << 1);                                                          \
+    _Pragma("unroll") for (int jj_ = 0; jj_ < JC; ++jj_) {                                                 \
+      rb_h[buf][jj_] = *reinterpret_cast<const f16x8t*>(Bc_ + (JC * (c) + jj_) * 1024 + ((ls_ ^ swzb) << 2));       \
+      rb_l[buf][jj_] = *reinterpret_cast<const f16x8t*>(Bc_ + (JC * (c) + jj_) * 1024 + (((ls_ | 1) ^ swzb) << 2)); \
+    }                                                                                                      \
+  }
+    // chunk (sg, c): [reads of the next chunk's fragments] | 6 JC MFMAs.  qn = the chunk's index inside the block.
+#define K_CHUNK(sg, c)                                                                                     \
+  {                                                                                                        \
+    constexpr int qn_ = (sg) * CS + (c);                                                                   \
+    constexpr int nsg_ = ((c) + 1 < CS) ? (sg) : ((sg) + 1) % 18;                                          \
+    constexpr int nc_ = ((c) + 1 < CS) ? (c) + 1 : 0;                                                      \
+    if ((sg) == 17 && (c) == CS - 1) {          /* the next chunk belongs to the next block: other stage parity */ \
+      const int keep_ = bs0;                                                                               \
+      bs0 ^= 1;                                                                                            \
+      K_LOAD_B(nsg_, nc_, (qn_ + 1) & 1)                                                                   \
+      bs0 = keep_;                                                                                         \
+    } else {                                                                                               \
+      K_LOAD_B(nsg_, nc_, (qn_ + 1) & 1)                                                                   \
+    }                                                                                                      \
+    if ((c) == CS - 1) { K_LOAD_A(((sg) + 1) % 18, ((sg) + 1) & 1) }                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    /* everything but the reads just issued (LDS reads return in order): left to itself hipcc waits lgkmcnt(0) here */ \
+    __builtin_amdgcn_s_waitcnt(0xC07F | ((2 * JC + ((c) == CS - 1 ? 2 * TM : 0)) << 8));                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    if ((c) == 0) {                                                                                        \
+      _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) {                                                  \
+        sa_h[i_] = ra_h[(sg) & 1][i_] * (_Float16)T_LO_INV;                                                \
+        sa_l[i_] = ra_l[LB == 2 ? ((sg) & 1) : 0][i_] * (_Float16)T_LO_INV;                                \
+      }                                                                                                    \
+    }                                                                                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) _Pragma("unroll") for (int jj_ = 0; jj_ < JC; ++jj_) \
+      hh[i_][JC * (c) + jj_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rb_h[qn_ & 1][jj_], ra_h[(sg) & 1][i_], hh[i_][JC * (c) + jj_], 0, 0, 0); \
+    _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) _Pragma("unroll") for (int jj_ = 0; jj_ < JC; ++jj_) \
+      hh[i_][JC * (c) + jj_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rb_l[qn_ & 1][jj_], sa_h[i_], hh[i_][JC * (c) + jj_], 0, 0, 0); \
+    _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) _Pragma("unroll") for (int jj_ = 0; jj_ < JC; ++jj_) \
+      hh[i_][JC * (c) + jj_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rb_h[qn_ & 1][jj_], sa_l[i_], hh[i_][JC * (c) + jj_], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+  }
+    // s_waitcnt through the builtin (gfx9 encoding: vmcnt[3:0] | expcnt << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14), so that
+    // the compiler's own wait insertion KNOWS the fragment reads are complete: behind an inline-asm wait it still
+    // counts them as pending and puts lgkmcnt(0) - instead of lgkmcnt(reads of the next chunk) - in front of the MFMAs
+#define K_WAIT(n)                                                                                          \
+  {                                                                                                        \
+    if ((n) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                  \
+    __builtin_amdgcn_s_waitcnt(0xC07F);          /* lgkmcnt(0) */                                          \
+  }
+    // the point P(k) between the last two chunks of pair k: every fragment of this pair's stage has been read, the
+    // slice of pair k + 1 (requested behind P(k - 1)) has landed; half-patch refills requested behind P(4) / P(8) may
+    // still be in flight at P(5) / P(0) (six rounds, issued after that slice: counted)
+#define K_POINT(k)                                                                                         \
+  {                                                                                                        \
+    if (((k) == 5 && !lastcc) || ((k) == 0 && cc > 0)) K_WAIT(6) else K_WAIT(0)                            \
+    __builtin_amdgcn_s_barrier();                                                                          \
+    if ((k) + 2 < 9) {                                                                                     \
+      K_ISSUE_B((k) + 2, cc, ((k) & 1) ^ bs0)                                                              \
+    } else if (!lastcc) {                                                                                  \
+      K_ISSUE_B((k) + 2 - 9, cc + 1, ((k) & 1) ^ bs0)                                                      \
+    }                                                                                                      \
+    if ((k) == 4 && !lastcc) { _Pragma("unroll") for (int j_ = 0; j_ < K_HROUNDS; ++j_) K_ISSUE_A(j_, cc + 1, 0) } \
+    if ((k) == 8 && !lastcc) { _Pragma("unroll") for (int j_ = 0; j_ < K_HROUNDS; ++j_) K_ISSUE_A(j_, cc + 1, 1) } \
+  }
+#define K_STEP_HEAD(sg) K_CHUNK(sg, 0) if (CS > 2) { K_CHUNK(sg, 1) K_CHUNK(sg, CS - 2) }
+#define K_PAIR(k)                                                                                          \
+  {                                                                                                        \
+    if (CS == 1) {                                                                                         \
+      K_CHUNK(2 * (k), 0) K_POINT(k) K_CHUNK(2 * (k) + 1, 0)                                               \
+    } else if (CS == 2) {                                                                                  \
+      K_CHUNK(2 * (k), 0) K_CHUNK(2 * (k), 1) K_CHUNK(2 * (k) + 1, 0) K_POINT(k) K_CHUNK(2 * (k) + 1, 1)   \
+    } else {                                                                                               \
+      K_CHUNK(2 * (k), 0) K_CHUNK(2 * (k), 1) K_CHUNK(2 * (k), 2) K_CHUNK(2 * (k), 3)                      \
+      K_CHUNK(2 * (k) + 1, 0) K_CHUNK(2 * (k) + 1, 1) K_CHUNK(2 * (k) + 1, 2) K_POINT(k) K_CHUNK(2 * (k) + 1, 3) \
+    }                                                                                                      \
+  }
+    TAP_STAMP(0)
+    if (d.scale || d.shift) {
+      const int pc = lane < BN / 4 ? lane : (lane < BN / 2 ? lane - BN / 4 : 0);
+      const float* sbase = d.scale ? d.scale : d.shift;
+      const float* mine = (lane < BN / 4 || lane >= BN / 2) ? sbase : (d.shift ? d.shift : d.scale);
+      tap_dma16(sbase, (unsigned)((const char*)(mine + n0 + 4 * pc) - (const char*)sbase), lds0 + 4u * (unsigned)STAGES);
+    }
+#pragma unroll
+    for (int j = 0; j < K_HROUNDS; ++j) { K_ISSUE_A(j, 0, 0) }
+#pragma unroll
+    for (int j = 0; j < K_HROUNDS; ++j) { K_ISSUE_A(j, 0, 1) }
+    {
+      const int cc = 0;
+      K_ISSUE_B(0, cc, 0)
+      K_ISSUE_B(1, cc, 1)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    TAP_STAMP(1)
+    int bs0 = 0;
+    K_LOAD_A(0, 0)
+    K_LOAD_B(0, 0, 0)
+    for (int cc = 0; cc < a.ncc; ++cc) {
+      const bool lastcc = cc + 1 == a.ncc;
+      K_PAIR(0) K_PAIR(1) K_PAIR(2) K_PAIR(3) K_PAIR(4) K_PAIR(5) K_PAIR(6) K_PAIR(7) K_PAIR(8)
+      bs0 ^= 1;
+      TAP_STAMP(2 + 2 * cc)
+    }
+#undef K_ISSUE_A
+#undef K_ISSUE_B
+#undef K_OFFB
+#undef K_LOAD_A
+#undef K_LOAD_B
+#undef K_CHUNK
+#undef K_WAIT
+#undef K_POINT
+#undef K_STEP_HEAD
+#undef K_PAIR
+  } else {
+  TAP_STAMP(0)
+  if (d.scale || d.shift) {
+    const int pc = lane < BN / 4 ? lane : (lane < BN / 2 ? lane - BN / 4 : 0);
+    const float* base = (lane < BN / 4 || lane >= BN / 2) ? (d.scale ? d.scale : d.shift) : (d.shift ? d.shift : d.scale);
+    __builtin_amdgcn_global_load_lds(base + n0 + 4 * pc, SCs, 16, 0, 0);
+  }
 #pragma unroll
   for (int j = 0; j < T_AROUNDS; ++j) { TAP_ISSUE_A(j, 0, 0); }
   TAP_ISSUE_B(0, 0);
   if (PD == 2) { TAP_ISSUE_B(a.ncc, 1); }
   TAP_WAIT((PD - 1) * BJ);
   __syncthreads();
+  TAP_STAMP(1)
   int bs = 0;
   for (int cc = 0; cc < a.ncc; ++cc) {
     const bool lastcc = cc + 1 == a.ncc;
@@ -353,9 +588,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : (W
       TAP_WAIT(0);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      TAP_STAMP(2 + 2 * cc - 1)
     }
     TAP_STEP(0) TAP_STEP(1) TAP_STEP(2) TAP_STEP(3) TAP_STEP(4) TAP_STEP(5) TAP_STEP(6) TAP_STEP(7) TAP_STEP(8)
+    TAP_STAMP(2 + 2 * cc)
   }
+  }                                              // (the tap-by-tap loop: !KH)
 #undef TAP_WAIT
 #undef TAP_STEP
 #undef TAP_COMPUTE
@@ -363,20 +601,17 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : (W
 #undef TAP_ISSUE_A
 #undef TAP_ISSUE_B
 
-  // BatchNorm scale / shift of eight consecutive channels.  In the S16 epilogues the NEXT group's constants are requested
-  // before the current group is stored: d.y may alias d.scale for all the compiler knows, so it keeps every load behind
-  // the stores that precede it in program order - and VMEM operations retire in order, so the wait for a group's
-  // constants was also a wait for the previous group's stores to be acknowledged: up to eight exposed store round trips
-  // per tile (a large part of the per-tile "intercept" of DESIGN.md section 8).
+  // BatchNorm scale / shift of eight consecutive channels, from the tile's LDS copy (see SCs above); the NEXT group's
+  // constants are read before the current group is stored.
 #define TAP_LOAD_SCSH(c0_, sc_, sh_)                                                                       \
   {                                                                                                        \
     _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) sc_[k_] = 1.f, sh_[k_] = 0.f;                         \
     if (d.scale) {                                                                                         \
-      const f32x4 s0_ = *reinterpret_cast<const f32x4*>(d.scale + (c0_)), s1_ = *reinterpret_cast<const f32x4*>(d.scale + (c0_) + 4); \
+      const f32x4 s0_ = *reinterpret_cast<const f32x4*>(SCs + (c0_) - n0), s1_ = *reinterpret_cast<const f32x4*>(SCs + (c0_) - n0 + 4); \
       _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) sc_[k_] = s0_[k_], sc_[4 + k_] = s1_[k_];           \
     }                                                                                                      \
     if (d.shift) {                                                                                         \
-      const f32x4 s0_ = *reinterpret_cast<const f32x4*>(d.shift + (c0_)), s1_ = *reinterpret_cast<const f32x4*>(d.shift + (c0_) + 4); \
+      const f32x4 s0_ = *reinterpret_cast<const f32x4*>(SCs + BN + (c0_) - n0), s1_ = *reinterpret_cast<const f32x4*>(SCs + BN + (c0_) - n0 + 4); \
       _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) sh_[k_] = s0_[k_], sh_[4 + k_] = s1_[k_];           \
     }                                                                                                      \
   }
@@ -400,8 +635,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : (W
       for (int j = 0; j < FT; ++j) {
         const int c0 = cbase + 32 * (j >> 1) + 4 * (j & 1);
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if (d.scale) sc = *reinterpret_cast<const f32x4*>(d.scale + c0);
-        if (d.shift) sh = *reinterpret_cast<const f32x4*>(d.shift + c0);
+        if (d.scale) sc = *reinterpret_cast<const f32x4*>(SCs + c0 - n0);
+        if (d.shift) sh = *reinterpret_cast<const f32x4*>(SCs + BN + c0 - n0);
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
           const int y = y0 + wm * TM + (pt >> 1), x = x0 + 16 * (pt & 1) + l15;
@@ -498,6 +733,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : (W
       }
     }
     if (d.overflow_flag && !(vmax <= 65504.f)) atomicOr(d.overflow_flag, 1);   // |v| beyond the half range (or NaN)
+    TAP_STAMP(14)
+#ifdef AMMC_TAP_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TAP_STAMP(15)
+#endif
     return;
   }
   int o_pix[TM], r_pix[TM];
@@ -520,8 +760,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : (W
       for (int q = 0; q < 4; ++q) {                             // register quad q: channels c0 .. c0 + 3
         const int c0 = n0 + (wn * TN + j) * 32 + 8 * (2 * (q >> 1) + h) + 4 * (q & 1);
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if (d.scale) sc = *reinterpret_cast<const f32x4*>(d.scale + c0);
-        if (d.shift) sh = *reinterpret_cast<const f32x4*>(d.shift + c0);
+        if (d.scale) sc = *reinterpret_cast<const f32x4*>(SCs + c0 - n0);
+        if (d.shift) sh = *reinterpret_cast<const f32x4*>(SCs + BN + c0 - n0);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           f32x4 v;
@@ -570,6 +810,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : (W
   TAP_LOAD_SCSH(n0 + wn * TN * 32 + 8 * h, scb[0], shb[0])
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
+    TAP_STAMP(10 + j)
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
       const int c0 = n0 + (wn * TN + j) * 32 + 8 * (2 * o + h);  // this lane's S16 group
@@ -595,6 +836,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : (W
           for (int k = 0; k < 8; ++k) v[k] += (float)rh[k] + (float)rl[k] * T_LO_INV;
         }
         ammc_u4 hi, lo;
+#ifdef AMMC_TAP_STAMP
+        if (a.dbg == 12) {          // ablation: no conversion (raw accumulator bits stored)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) hi[k] = __float_as_uint(v[k]), lo[k] = __float_as_uint(v[4 + k]);
+        } else
+#endif
         ammc_s16_split8(v, hi, lo);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -602,8 +849,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : (W
           if (TM == 2) pooled[k] = i == 0 ? v[k] : fmaxf(pooled[k], v[k]);
         }
         ammc_u4* yp = reinterpret_cast<ammc_u4*>(d.y + o_pix[i] + c0);
+#ifdef AMMC_TAP_STAMP
+        if (a.dbg == 11) {          // ablation: no stores (values kept alive)
+          asm volatile("" :: "v"(hi), "v"(lo));
+        } else
+#endif
+        {
         yp[0] = hi;
         yp[1] = lo;
+        }
       }
       if (TM == 2 && d.pool_y) {
 #pragma unroll
@@ -620,30 +874,78 @@ __global__ __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : (W
     }
   }
   if (d.overflow_flag && !(vmax <= 65504.f)) atomicOr(d.overflow_flag, 1);   // |v| beyond the half range (or NaN)
+  TAP_STAMP(14)
+#ifdef AMMC_TAP_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TAP_STAMP(15)
+#endif
 }
 
-template <int WGM, int WGN, int TM, int TN, int AS = 2, int MF = 0>
+// (hipcc: the second __launch_bounds__ argument is the minimum number of WAVES PER SIMD, i.e. 512 / it VGPRs)
+#define TAP_BOUNDS __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : (WGN * TN == 1 ? 3 : 2)))
+template <int WGM, int WGN, int TM, int TN, int AS, int MF, int KH>
+__global__ TAP_BOUNDS void conv_tap_s16_kernel(TapArgs a) {
+  conv_tap_s16_tile<WGM, WGN, TM, TN, AS, MF, KH>(a, blockIdx.x, gridDim.x, (blockIdx.x >> 8) & 1);
+}
+
+// Persistent form: the grid is what the chip holds at once (two 4-wave workgroups per CU: 512; one 8-wave: 256) and a
+// workgroup walks the tiles vb = blockIdx.x, blockIdx.x + gridDim.x, ...  Why: workgroups that are dispatched as slots
+// free up start their tiles TOGETHER with their CU-mate (tools/micro/census.hip: the two workgroups of a CU start within
+// 0.08 us of each other in every round, and only in the FIRST round is the pair (b, b + 256)), so both stream their patch,
+// both contract and both store at the same moments, on every CU of the chip at once: the matrix pipe idles through
+// every memory phase and HBM idles through every contraction.  Here the pairing is fixed for the whole launch -
+// blockIdx.x and blockIdx.x + 256 share a CU - and class B (blockIdx.x >= gridDim.x / 2) starts `a.delay` ticks of the
+// 100-MHz clock late, i.e. about half a tile behind its CU-mate, and stays there: one workgroup's memory phases run
+// behind the other's MFMAs.
+template <int WGM, int WGN, int TM, int TN, int AS, int MF, int KH>
+__global__ TAP_BOUNDS void conv_tap_s16_pers_kernel(TapArgs a) {
+  const bool class_b = blockIdx.x >= (gridDim.x >> 1);
+  if (class_b && a.delay > 0) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < a.delay) __builtin_amdgcn_s_sleep(8);
+  }
+  for (int vb = blockIdx.x; vb < a.total; vb += gridDim.x)
+    conv_tap_s16_tile<WGM, WGN, TM, TN, AS, MF, KH>(a, vb, a.total, false);
+}
+
+template <int WGM, int WGN, int TM, int TN, int AS = 2, int MF = 0, int KH = 0>
 static int launch_tap(const TapArgs& a, hipStream_t stream, char* label, int label_len) {
   if (label) {                                     // the name rocprofv3 prints for this instance
-    snprintf(label, label_len, "conv_tap_s16<%d, %d, %d, %d, %d, %d>", WGM, WGN, TM, TN, AS, MF);
+    if (KH) snprintf(label, label_len, "conv_tap_s16<%d, %d, %d, %d, %d, %d, %d>", WGM, WGN, TM, TN, AS, MF, KH);
+    else snprintf(label, label_len, "conv_tap_s16<%d, %d, %d, %d, %d, %d>", WGM, WGN, TM, TN, AS, MF);
     return AMMC_OK;
   }
   constexpr int BN = WGN * TN * 32;
   constexpr int NT = 64 * WGM * WGN;
   constexpr int T_ASTAGE = (T_APIECES + NT - 1) / NT * NT * 4;
   constexpr int BJ = BN * 8 >= NT ? BN * 8 / NT : 1;
-  constexpr int NB = (NT == 256 && (BN == 128 || BN == 32)) ? 2 : 3;
-  constexpr int STAGES = AS * T_ASTAGE + NB * BJ * (NT / 8) * 32;
+  constexpr int NB = KH ? 2 : (NT == 256 && (BN == 128 || BN == 32)) ? 2 : 3;
+  constexpr int A_FLOATS = KH ? 2 * ((T_HP * 64 + 768) / 4) + 256 : AS * T_ASTAGE;       // as in conv_tap_s16_tile
+  constexpr int STAGES = A_FLOATS + NB * BJ * (NT / 8) * 32 + 256;      // + 1 KB: scale / shift of the tile's filters
   static const size_t pad = getenv("AMMC_TAP_LDSPAD") ? (size_t)atoi(getenv("AMMC_TAP_LDSPAD")) : 0;   // occupancy experiments
   const size_t lds = (size_t)STAGES * sizeof(float) + pad;
   static_assert((size_t)STAGES * sizeof(float) <= 160 * 1024, "LDS budget");
-  auto kern = conv_tap_s16_kernel<WGM, WGN, TM, TN, AS, MF>;
+  auto kern = conv_tap_s16_kernel<WGM, WGN, TM, TN, AS, MF, KH>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) return (int)e;
   TapArgs b = a;
   b.n_tiles = a.d.n / BN;
   const int grid = a.d.batch * a.tiles_y * a.tiles_x * b.n_tiles;
+  // persistent form (AMMC_TAP_PERS: 0 = off, 1 = when a workgroup gets at least two tiles); class B's delay in units of
+  // AMMC_TAP_DELAY x 0.01 us per 32-channel block of a tile
+  static const int pers = getenv("AMMC_TAP_PERS") ? atoi(getenv("AMMC_TAP_PERS")) : 0;
+  static const int delay_unit = getenv("AMMC_TAP_DELAY") ? atoi(getenv("AMMC_TAP_DELAY")) : 0;
+  const int resident = NT == 256 && lds <= 80 * 1024 ? 512 : 256;
+  if (pers && AS == 1 && NT == 256 && grid >= 2 * resident) {
+    auto pk = conv_tap_s16_pers_kernel<WGM, WGN, TM, TN, AS, MF, KH>;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    b.total = grid;
+    b.delay = delay_unit * a.ncc;
+    hipLaunchKernelGGL(pk, dim3(resident), dim3(NT), lds, stream, b);
+    return ammc_launch_status();
+  }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, stream, b);
   return ammc_launch_status();
 }
@@ -674,6 +976,12 @@ int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream, char* 
   a.kpad = kpad;
   a.dbg = dbg;
   a.n_tiles = 0;
+  a.total = a.delay = 0;
+#ifdef AMMC_TAP_STAMP
+  a.stamps = g_tap_stamps;
+#else
+  a.stamps = nullptr;
+#endif
   // the MFMA shape per variant (option "s16_mf": -1 = the measured faster one, 0 / 1 = forced for A/Bs).  Measured at
   // batch 16, 256x256 on one MI355X: output layer 147 -> 123 us and 64-filter layers 306 -> 293 us
   // with 16x16x32, 128-filter layers 213 -> 220 us (twice the MFMA instructions leave the fragment reads and the
@@ -690,11 +998,14 @@ int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream, char* 
   }
   if (d.n == 32) return mf ? launch_tap<4, 1, 2, 1, 1, 1>(a, stream, label, label_len)
                            : launch_tap<8, 1, 1, 1, 1, 0>(a, stream, label, label_len);
+  static const int kh = getenv("AMMC_TAP_KH") ? atoi(getenv("AMMC_TAP_KH")) : 0;
+  if (d.n == 64 && kh) return launch_tap<4, 1, 2, 2, 1, 0, 1>(a, stream, label, label_len);
   if (d.n == 64) return mf ? launch_tap<4, 1, 2, 2, 1, 1>(a, stream, label, label_len)     // 4 waves of 64x64 (2 image rows x 64 filters), 2 workgroups per CU
                            : launch_tap<4, 1, 2, 2, 1, 0>(a, stream, label, label_len);
   // 4 waves of 64x128 (one accumulator set), two workgroups per CU: fewer LDS reads per MFMA and the neighbour's
   // MFMAs behind every prologue / epilogue - once there are two workgroups for every CU (measured: 128x128 layers
   // +10 %, 64x64 +6 %, but 32x32 at batch 16 = one workgroup per CU -19 %)
+  if (kh && (mode == 4 || (mode == 1 && tiles >= 512))) return launch_tap<4, 1, 2, 4, 1, 0, 1>(a, stream, label, label_len);
   if (mode == 4 || (mode == 1 && tiles >= 512))
     return mf ? launch_tap<4, 1, 2, 4, 1, 1>(a, stream, label, label_len) : launch_tap<4, 1, 2, 4, 1, 0>(a, stream, label, label_len);
   return mf ? launch_tap<4, 2, 2, 2, 2, 1>(a, stream, label, label_len) : launch_tap<4, 2, 2, 2, 2, 0>(a, stream, label, label_len);

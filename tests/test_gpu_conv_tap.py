@@ -2,6 +2,7 @@
 the same S16-rounded operands: shapes that the dispatcher sends to it (>= 192 tiles, Cin % 32 == 0, W % 32 == 0,
 H % 8 == 0, N = 64 | 128k) with folded-BN scale/shift, ReLU, an S16 residual, and a channel-sliced input (the
 concat buffers of the decoder).  Tolerance 2e-6 of max|ref| (fp32-equivalent arithmetic, fp32 accumulation)."""
+import os
 import ctypes as C
 
 import pytest
@@ -91,7 +92,8 @@ def test_conv_tap_s16_vs_fp64(B, H, W, cin, n, relu, res, sliced, variant, mf):
         pa = Act(torch.zeros(B, H // 2 + 2, W // 2 + 2, n, device=DEV), B, H // 2, W // 2, n, 0, 1)
         d.pool_y = pa.pix0()
         d.pool_bs, d.pool_rs, d.pool_ps = pa.strides
-    assert s16_variant(d) == (variant % mf if "%d" in variant else variant)                   # the library's own dispatch: this case reaches that kernel
+    if not os.environ.get("AMMC_TAP_KH"):          # (experiments force other instances through the environment)
+        assert s16_variant(d) == (variant % mf if "%d" in variant else variant)               # the library's own dispatch: this case reaches that kernel
     _lib.check(lib.ammc_conv_gemm_s16(C.byref(d), s), "conv_gemm_s16")
     got = _s16_read(ya).double().cpu()
     # reference on the operands as the kernel sees them (S16 round trip of x, w and the residual)
@@ -140,7 +142,8 @@ def test_conv_tap_fp32_output_with_fp32_residual(B, H, W, cin, n, variant, mf):
     d.x_bs, d.x_rs, d.x_ps = xa.strides
     d.y_bs, d.y_rs, d.y_ps = ya.strides
     d.r_bs, d.r_rs, d.r_ps = res.strides
-    assert s16_variant(d) == (variant % mf if "%d" in variant else variant)
+    if not os.environ.get("AMMC_TAP_KH"):
+        assert s16_variant(d) == (variant % mf if "%d" in variant else variant)
     _lib.check(lib.ammc_conv_gemm_s16(C.byref(d), s), "conv_gemm_s16")
     got = ya.interior().permute(0, 3, 1, 2).double().cpu()
     wsa = Act(ws.view(1, 1, n, 9 * cin), 1, 1, n, 9 * cin, 0, 0)

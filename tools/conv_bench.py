@@ -10,8 +10,6 @@ import sys
 sys.path.insert(0, '.')
 import torch
 from ammcnet_aaai2021_amd import _lib
-from ammcnet_aaai2021_amd._lib import ACT_RELU, AmmcConvDesc
-from ammcnet_aaai2021_amd.engine import Act, _ptr
 
 lib = _lib.load()
 dev = "cuda:0"
@@ -19,28 +17,11 @@ NET = [(256, 256, 64, 64), (128, 128, 64, 128), (128, 128, 128, 128), (64, 64, 1
        (32, 32, 256, 512), (32, 32, 512, 512), (64, 64, 512, 256), (128, 128, 256, 128), (256, 256, 128, 64)]
 
 
-def s16_of(t):
-    out = torch.empty_like(t)
-    _lib.check(lib.ammc_split_rows_f32(_ptr(t), t.numel(), _ptr(out), torch.cuda.current_stream().cuda_stream), "split")
-    return out
+from tools.conv_bench_lib import make_desc
 
 
 def bench(B, H, W, cin, n, reps):
-    g = torch.Generator(device=dev)
-    g.manual_seed(1)
-    x32 = torch.zeros(B, H + 2, W + 2, cin, device=dev)
-    x32[:, 1:-1, 1:-1].copy_(torch.randn(B, H, W, cin, device=dev, generator=g))
-    xa = Act(s16_of(x32), B, H, W, cin, 0, 1)
-    del x32
-    ya = Act(torch.zeros(B, H + 2, W + 2, n, device=dev), B, H, W, n, 0, 1)
-    ws = s16_of(torch.randn(n, 9 * cin, device=dev, generator=g) * (2.0 / (9 * cin)) ** 0.5)
-    scale = torch.ones(n, device=dev)
-    shift = torch.zeros(n, device=dev)
-    d = AmmcConvDesc()
-    d.x, d.w, d.y, d.scale, d.shift = xa.tap0(), _ptr(ws), ya.pix0(), _ptr(scale), _ptr(shift)
-    d.batch, d.height, d.width, d.cin, d.ntaps, d.n, d.up, d.cgroup, d.act = B, H, W, cin, 9, n, 1, n, ACT_RELU
-    d.x_bs, d.x_rs, d.x_ps = xa.strides
-    d.y_bs, d.y_rs, d.y_ps = ya.strides
+    d, keep = make_desc(B, H, W, cin, n)
     s = torch.cuda.current_stream().cuda_stream
     label = C.create_string_buffer(96)
     lib.ammc_conv_gemm_s16_variant(C.byref(d), label, 96)
