@@ -53,9 +53,18 @@ constexpr float T_LO_INV = 1.f / 2048.f;
 // of the MFMAs of this one would be waited for at once.  In asm the compiler sees neither the memory operation (so the
 // vmcnt waits are written by hand, as asm as well: a builtin wait it believes redundant is dropped) nor M0, which is
 // saved and restored in the statement (cdna_hip_programming.md section 5.7).
+// the same with a full 64-bit address per lane (lanes of one instruction reading from unrelated allocations)
+__device__ __forceinline__ void tap_dma16_ptr(const float* src, unsigned lds_byte) {
+  unsigned keep;
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(lds_byte) : "memory");
+}
 __device__ __forceinline__ void tap_dma16(const float* base, unsigned off, unsigned lds_byte) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+  // (s_nop 4: `base` / `lds_byte` may have been written by the SALU instruction just before the statement, and a
+  // vector-memory instruction must not read an SGPR sooner than five wait states after a scalar write - the compiler pads
+  // its own instructions, never the inside of an asm statement; without it a launch now and then read a stale base)
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(off), "s"(base), "s"(lds_byte) : "memory");
 }
 constexpr int T_TH = 8, T_TW = 32, T_HW = T_TW + 2, T_HP = (T_TH + 2) * T_HW;     // 340 halo pixels
@@ -398,36 +407,48 @@ __device__ __forceinline__ void conv_tap_s16_tile(const TapArgs& a, const int vb
   //  * fragments are read one CHUNK (12 MFMAs: two image rows x two filter tiles x three products) ahead into a second
   //    register set, pinned by sched_barrier (left alone hipcc sinks the reads to their use and waits lgkmcnt(0)).
   if constexpr (KH != 0) {
-    constexpr int JC = TN == 4 ? 1 : 2;              // filter tiles per chunk: 6 or 12 MFMAs
+#ifndef AMMC_KH_JC4
+#define AMMC_KH_JC4 1
+#define AMMC_KH_JC2 1
+#define AMMC_KH_PF4 1
+#define AMMC_KH_PF2 2
+#endif
+    constexpr int JC = TN == 4 ? AMMC_KH_JC4 : AMMC_KH_JC2;   // filter tiles per chunk: 6 or 12 MFMAs
     constexpr int CS = TN / JC;                      // chunks per step
-    constexpr int LB = CS == 1 ? 2 : 1;              // buffers of the lo pixel fragments (only read by the scaling at a step's first chunk)
-    // byte offsets of this lane's DMA pieces from wave-uniform bases (the patch of the tile; the filter matrix)
-    unsigned ka_off[K_HROUNDS];
-#pragma unroll
-    for (int j = 0; j < K_HROUNDS; ++j) {
-      int p = j * NT + tid;
-      p = p < K_HPIECES ? p : K_HPIECES - 1;
-      const int hp = p >> 2;
-      const int ls = (p & 3) ^ ((hp >> 2) & 3);
-      const int hy = hp / T_HW;
-      const int hx = hp - hy * T_HW;
-      ka_off[j] = 4u * (unsigned)((int)((int64_t)hy * d.x_rs + (int64_t)hx * d.x_ps) + 4 * ls);
-    }
+    constexpr int PF = TN == 4 ? AMMC_KH_PF4 : AMMC_KH_PF2;   // fragments are read PF chunks ahead (PF + 1 register sets)
+    static_assert(PF == 1 || (PF == 2 && CS >= 2), "two chunks ahead needs a pair of at least four chunks");
+    constexpr int LB = CS <= PF ? 2 : 1;             // buffers of the lo pixel fragments (only read by the scaling at a step's first chunk)
+    // byte offsets of this lane's DMA pieces from wave-uniform bases (the patch of the tile; the filter matrix), kept
+    // in no register at all between refills: piece p + 256 of a half-patch is halo pixel hp + 64 = one row down and 30 to the right, or two
+    // rows down and 4 to the left (its slot swizzle, (hp >> 2) & 3, is the same), and the filter rows of a thread are
+    // 32 rows apart - the offsets of rounds 1 .. 5 are rebuilt from round 0 at each refill (a few VALU operations per
+    // round, twice per block) instead of living in registers through the contraction
+    const unsigned ka_step_a = 4u * (unsigned)(int)(d.x_rs + 30 * d.x_ps), ka_step_b = 4u * (unsigned)(int)(2 * d.x_rs - 4 * d.x_ps);
+    // the last piece of a half-patch (round 5 clamps to it): pixel 339 = (9, 33), its slot 3 ^ ((339 >> 2) & 3) = 3
+    const unsigned ka_last = 4u * (unsigned)((int)(9 * d.x_rs + 33 * d.x_ps) + 4 * (3 ^ ((339 >> 2) & 3)));
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
     const int ksl = (tid & 7) ^ ((tid >> 4) & 7);    // logical slot of this thread's filter piece: (step of the pair, group of the half, hi / lo)
     const bool ku1 = (ksl >> 2) != 0;
-    unsigned kb_off[BJ];
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) {
-      int row = j * (NT / 8) + (tid >> 3) + n0;
-      row = row < d.n ? row : d.n - 1;
-      kb_off[j] = 4u * (unsigned)(row * a.kpad + 4 * (ksl & 3));
-    }
-#define K_ISSUE_A(j, ccx, hf)                                                                              \
+    const unsigned kb_off0 = 4u * (unsigned)(((tid >> 3) + n0) * a.kpad + 4 * (ksl & 3));     // (KH serves n = 64 or n % 128 == 0: every row exists)
+    const unsigned kb_rstep = 4u * 32u * (unsigned)a.kpad;
+    // all six rounds of one half-patch
+#define K_ISSUE_HALF(ccx, hf)                                                                              \
   {                                                                                                        \
-    const unsigned dst_ = lds0 + 4u * (unsigned)(((j) == K_HROUNDS - 1 && uwave >= 2) ? K_ADUMP : (hf) * K_HSTRIDE + ((j) * NT + uwave * 64) * 4); \
-    tap_dma16(xpatch + (ccx) * 32 + (hf) * 16, ka_off[j], dst_);                                           \
+    int t_ = tid;                                                                                          \
+    asm volatile("" : "+v"(t_));     /* rebuilt here from the thread id: held in registers it was spilled */     \
+    const int hp0_ = t_ >> 2;                                                                              \
+    const int hy0_ = hp0_ / T_HW;                                                                          \
+    int hx_ = hp0_ - hy0_ * T_HW;                                                                          \
+    unsigned off_ = 4u * (unsigned)(hy0_ * (int)d.x_rs + hx_ * (int)d.x_ps + 4 * ((t_ & 3) ^ ((hp0_ >> 2) & 3))); \
+    _Pragma("unroll") for (int j_ = 0; j_ < K_HROUNDS; ++j_) {                                             \
+      const unsigned dst_ = lds0 + 4u * (unsigned)((j_ == K_HROUNDS - 1 && uwave >= 2) ? K_ADUMP : (hf) * K_HSTRIDE + (j_ * NT + uwave * 64) * 4); \
+      const unsigned src_ = (j_ == K_HROUNDS - 1 && j_ * NT + tid >= K_HPIECES) ? ka_last : off_;          \
+      tap_dma16(xpatch + (ccx) * 32 + (hf) * 16, src_, dst_);                                              \
+      const bool wrap_ = hx_ >= 4;                                                                         \
+      off_ += wrap_ ? ka_step_b : ka_step_a;                                                               \
+      hx_ += wrap_ ? -4 : 30;                                                                              \
+    }                                                                                                      \
   }
 #define K_OFFB(sg, ccx) (((((sg) % 9) * a.ncc) + (ccx)) * 32 + ((sg) / 9) * 16)
 #define K_ISSUE_B(k, ccx, stage)                                                                           \
@@ -436,13 +457,13 @@ __device__ __forceinline__ void conv_tap_s16_tile(const TapArgs& a, const int vb
     const unsigned off_ = 4u * (unsigned)(ku1 ? o1_ : o0_);                                                \
     _Pragma("unroll") for (int j_ = 0; j_ < BJ; ++j_) {                                                    \
       const unsigned dst_ = lds0 + 4u * (unsigned)(A_FLOATS + (stage) * B_STAGE + (j_ * NT + uwave * 64) * 4); \
-      tap_dma16(d.w, kb_off[j_] + off_, dst_);                                                             \
+      tap_dma16(d.w, kb_off0 + j_ * kb_rstep + off_, dst_);                                                \
     }                                                                                                      \
   }
-    f16x8t ra_h[2][TM], ra_l[LB][TM], sa_h[TM], sa_l[TM], rb_h[2][JC], rb_l[2][JC];
+    f16x8t ra_h[2][TM], ra_l[LB][TM], sa_h[TM], sa_l[TM], rb_h[PF + 1][JC], rb_l[PF + 1][JC];
 #define K_LOAD_A(sg, buf)                                                                                  \
   _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) {                                                      \
-    int hp_ = hpb[i_] + (((sg) % 9) / 3) * T_HW + (((sg) % 9) % 3);                                        \
+    int hp_ = hpb[0] + (i_ + ((sg) % 9) / 3) * T_HW + (((sg) % 9) % 3);                                    \
     asm volatile("" : "+v"(hp_));                                                                          \
     const float* ap_ = As + ((sg) / 9) * K_HSTRIDE + hp_ * 16;                                             \
     const int q_ = (2 * h) ^ ((hp_ >> 2) & 3);                                                             \
@@ -458,24 +479,27 @@ __device__ __forceinline__ void conv_tap_s16_tile(const TapArgs& a, const int vb
       rb_l[buf][jj_] = *reinterpret_cast<const f16x8t*>(Bc_ + (JC * (c) + jj_) * 1024 + (((ls_ | 1) ^ swzb) << 2)); \
     }                                                                                                      \
   }
-    // chunk (sg, c): [reads of the next chunk's fragments] | 6 JC MFMAs.  qn = the chunk's index inside the block.
+    // chunk (sg, c): [reads of the fragments of the chunk PF ahead] | 6 JC MFMAs.  qn = the chunk's index inside the
+    // block.  The pixel fragments of step sg + 1 are read in chunk (sg, CS - PF).  LDS reads return in order, so before
+    // the MFMAs it is enough that nothing but the reads issued in this chunk and (PF = 2) in the previous one is
+    // outstanding; written as a builtin wait, or hipcc inserts lgkmcnt(0).
 #define K_CHUNK(sg, c)                                                                                     \
   {                                                                                                        \
     constexpr int qn_ = (sg) * CS + (c);                                                                   \
-    constexpr int nsg_ = ((c) + 1 < CS) ? (sg) : ((sg) + 1) % 18;                                          \
-    constexpr int nc_ = ((c) + 1 < CS) ? (c) + 1 : 0;                                                      \
-    if ((sg) == 17 && (c) == CS - 1) {          /* the next chunk belongs to the next block: other stage parity */ \
+    constexpr int tq_ = qn_ + PF;                                                                          \
+    constexpr int nsg_ = (tq_ / CS) % 18, nc_ = tq_ % CS;                                                  \
+    if (tq_ / CS >= 18) {                       /* that chunk belongs to the next block: other stage parity */ \
       const int keep_ = bs0;                                                                               \
       bs0 ^= 1;                                                                                            \
-      K_LOAD_B(nsg_, nc_, (qn_ + 1) & 1)                                                                   \
+      K_LOAD_B(nsg_, nc_, tq_ % (PF + 1))                                                                  \
       bs0 = keep_;                                                                                         \
     } else {                                                                                               \
-      K_LOAD_B(nsg_, nc_, (qn_ + 1) & 1)                                                                   \
+      K_LOAD_B(nsg_, nc_, tq_ % (PF + 1))                                                                  \
     }                                                                                                      \
-    if ((c) == CS - 1) { K_LOAD_A(((sg) + 1) % 18, ((sg) + 1) & 1) }                                       \
+    if ((c) == CS - PF) { K_LOAD_A(((sg) + 1) % 18, ((sg) + 1) & 1) }                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
-    /* everything but the reads just issued (LDS reads return in order): left to itself hipcc waits lgkmcnt(0) here */ \
-    __builtin_amdgcn_s_waitcnt(0xC07F | ((2 * JC + ((c) == CS - 1 ? 2 * TM : 0)) << 8));                   \
+    __builtin_amdgcn_s_waitcnt(0xC07F | ((2 * JC + ((c) == CS - PF ? 2 * TM : 0) +                         \
+                                          (PF == 2 ? 2 * JC + ((c) == CS - PF + 1 ? 2 * TM : 0) : 0)) << 8)); \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
     if ((c) == 0) {                                                                                        \
       _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) {                                                  \
@@ -484,11 +508,11 @@ __device__ __forceinline__ void conv_tap_s16_tile(const TapArgs& a, const int vb
       }                                                                                                    \
     }                                                                                                      \
     _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) _Pragma("unroll") for (int jj_ = 0; jj_ < JC; ++jj_) \
-      hh[i_][JC * (c) + jj_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rb_h[qn_ & 1][jj_], ra_h[(sg) & 1][i_], hh[i_][JC * (c) + jj_], 0, 0, 0); \
+      hh[i_][JC * (c) + jj_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rb_h[qn_ % (PF + 1)][jj_], ra_h[(sg) & 1][i_], hh[i_][JC * (c) + jj_], 0, 0, 0); \
     _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) _Pragma("unroll") for (int jj_ = 0; jj_ < JC; ++jj_) \
-      hh[i_][JC * (c) + jj_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rb_l[qn_ & 1][jj_], sa_h[i_], hh[i_][JC * (c) + jj_], 0, 0, 0); \
+      hh[i_][JC * (c) + jj_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rb_l[qn_ % (PF + 1)][jj_], sa_h[i_], hh[i_][JC * (c) + jj_], 0, 0, 0); \
     _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) _Pragma("unroll") for (int jj_ = 0; jj_ < JC; ++jj_) \
-      hh[i_][JC * (c) + jj_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rb_h[qn_ & 1][jj_], sa_l[i_], hh[i_][JC * (c) + jj_], 0, 0, 0); \
+      hh[i_][JC * (c) + jj_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rb_h[qn_ % (PF + 1)][jj_], sa_l[i_], hh[i_][JC * (c) + jj_], 0, 0, 0); \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
   }
     // s_waitcnt through the builtin (gfx9 encoding: vmcnt[3:0] | expcnt << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14), so that
@@ -512,32 +536,26 @@ __device__ __forceinline__ void conv_tap_s16_tile(const TapArgs& a, const int vb
     } else if (!lastcc) {                                                                                  \
       K_ISSUE_B((k) + 2 - 9, cc + 1, ((k) & 1) ^ bs0)                                                      \
     }                                                                                                      \
-    if ((k) == 4 && !lastcc) { _Pragma("unroll") for (int j_ = 0; j_ < K_HROUNDS; ++j_) K_ISSUE_A(j_, cc + 1, 0) } \
-    if ((k) == 8 && !lastcc) { _Pragma("unroll") for (int j_ = 0; j_ < K_HROUNDS; ++j_) K_ISSUE_A(j_, cc + 1, 1) } \
+    if ((k) == 4 && !lastcc) K_ISSUE_HALF(cc + 1, 0)                                                       \
+    if ((k) == 8 && !lastcc) K_ISSUE_HALF(cc + 1, 1)                                                       \
   }
-#define K_STEP_HEAD(sg) K_CHUNK(sg, 0) if (CS > 2) { K_CHUNK(sg, 1) K_CHUNK(sg, CS - 2) }
-#define K_PAIR(k)                                                                                          \
-  {                                                                                                        \
-    if (CS == 1) {                                                                                         \
-      K_CHUNK(2 * (k), 0) K_POINT(k) K_CHUNK(2 * (k) + 1, 0)                                               \
-    } else if (CS == 2) {                                                                                  \
-      K_CHUNK(2 * (k), 0) K_CHUNK(2 * (k), 1) K_CHUNK(2 * (k) + 1, 0) K_POINT(k) K_CHUNK(2 * (k) + 1, 1)   \
-    } else {                                                                                               \
-      K_CHUNK(2 * (k), 0) K_CHUNK(2 * (k), 1) K_CHUNK(2 * (k), 2) K_CHUNK(2 * (k), 3)                      \
-      K_CHUNK(2 * (k) + 1, 0) K_CHUNK(2 * (k) + 1, 1) K_CHUNK(2 * (k) + 1, 2) K_POINT(k) K_CHUNK(2 * (k) + 1, 3) \
-    }                                                                                                      \
+    // chunk x (0 .. 2 CS - 1) of pair k; P(k) sits in front of the pair's chunk 2 CS - PF: the chunks behind it read
+    // the first fragments of the next pair
+#define K_PCHUNK(k, x)                                                                                     \
+  if ((x) < 2 * CS) {                                                                                      \
+    if ((x) == 2 * CS - PF) K_POINT(k)                                                                     \
+    K_CHUNK(2 * (k) + ((x) >= CS ? 1 : 0), ((x) >= CS ? (x) - CS : (x)))                                   \
   }
+#define K_PAIR(k) { K_PCHUNK(k, 0) K_PCHUNK(k, 1) K_PCHUNK(k, 2) K_PCHUNK(k, 3) K_PCHUNK(k, 4) K_PCHUNK(k, 5) K_PCHUNK(k, 6) K_PCHUNK(k, 7) }
     TAP_STAMP(0)
     if (d.scale || d.shift) {
       const int pc = lane < BN / 4 ? lane : (lane < BN / 2 ? lane - BN / 4 : 0);
       const float* sbase = d.scale ? d.scale : d.shift;
       const float* mine = (lane < BN / 4 || lane >= BN / 2) ? sbase : (d.shift ? d.shift : d.scale);
-      tap_dma16(sbase, (unsigned)((const char*)(mine + n0 + 4 * pc) - (const char*)sbase), lds0 + 4u * (unsigned)STAGES);
+      tap_dma16_ptr(mine + n0 + 4 * pc, lds0 + 4u * (unsigned)STAGES);      // (scale and shift are separate allocations)
     }
-#pragma unroll
-    for (int j = 0; j < K_HROUNDS; ++j) { K_ISSUE_A(j, 0, 0) }
-#pragma unroll
-    for (int j = 0; j < K_HROUNDS; ++j) { K_ISSUE_A(j, 0, 1) }
+    K_ISSUE_HALF(0, 0)
+    K_ISSUE_HALF(0, 1)
     {
       const int cc = 0;
       K_ISSUE_B(0, cc, 0)
@@ -550,13 +568,14 @@ __device__ __forceinline__ void conv_tap_s16_tile(const TapArgs& a, const int vb
     int bs0 = 0;
     K_LOAD_A(0, 0)
     K_LOAD_B(0, 0, 0)
+    if (PF == 2) { K_LOAD_B(1 / CS, 1 % CS, 1) }
     for (int cc = 0; cc < a.ncc; ++cc) {
       const bool lastcc = cc + 1 == a.ncc;
       K_PAIR(0) K_PAIR(1) K_PAIR(2) K_PAIR(3) K_PAIR(4) K_PAIR(5) K_PAIR(6) K_PAIR(7) K_PAIR(8)
       bs0 ^= 1;
       TAP_STAMP(2 + 2 * cc)
     }
-#undef K_ISSUE_A
+#undef K_ISSUE_HALF
 #undef K_ISSUE_B
 #undef K_OFFB
 #undef K_LOAD_A
@@ -564,7 +583,7 @@ __device__ __forceinline__ void conv_tap_s16_tile(const TapArgs& a, const int vb
 #undef K_CHUNK
 #undef K_WAIT
 #undef K_POINT
-#undef K_STEP_HEAD
+#undef K_PCHUNK
 #undef K_PAIR
   } else {
   TAP_STAMP(0)
@@ -689,7 +708,7 @@ __device__ __forceinline__ void conv_tap_s16_tile(const TapArgs& a, const int vb
       const float (&sh)[8] = shb[u & 1];
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        float pooled[8];
+        float pooled[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const int pt = 2 * i + c;
@@ -709,10 +728,12 @@ __device__ __forceinline__ void conv_tap_s16_tile(const TapArgs& a, const int vb
           }
           ammc_u4 hi, lo;
           ammc_s16_split8(v, hi, lo);
+          // range check: two values per v_max3_f32 (|.| is an operand modifier); the pooling maximum only when asked for
 #pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            vmax = fmaxf(vmax, fabsf(v[k]));
-            if (TM == 2) pooled[k] = i == 0 ? v[k] : fmaxf(pooled[k], v[k]);
+          for (int k = 0; k < 8; k += 2) vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(v[k])), __builtin_fabsf(v[k + 1]));
+          if (TM == 2 && d.pool_y) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pooled[k] = i == 0 ? v[k] : fmaxf(pooled[k], v[k]);
           }
           ammc_u4* yp = reinterpret_cast<ammc_u4*>(d.y + ((int64_t)b * d.y_bs + (int64_t)y * d.y_rs + (int64_t)x * d.y_ps) + c0);
           yp[0] = hi;
@@ -819,7 +840,7 @@ __device__ __forceinline__ void conv_tap_s16_tile(const TapArgs& a, const int vb
         TAP_LOAD_SCSH(n0 + (wn * TN + (g + 1) / 2) * 32 + 8 * (2 * ((g + 1) & 1) + h), scb[(g + 1) & 1], shb[(g + 1) & 1])
       const float (&sc)[8] = scb[g & 1];
       const float (&sh)[8] = shb[g & 1];
-      float pooled[8];
+      float pooled[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         float v[8];
@@ -843,10 +864,12 @@ __device__ __forceinline__ void conv_tap_s16_tile(const TapArgs& a, const int vb
         } else
 #endif
         ammc_s16_split8(v, hi, lo);
+        // range check: two values per v_max3_f32 (|.| is an operand modifier); the pooling maximum only when asked for
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          vmax = fmaxf(vmax, fabsf(v[k]));
-          if (TM == 2) pooled[k] = i == 0 ? v[k] : fmaxf(pooled[k], v[k]);
+        for (int k = 0; k < 8; k += 2) vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(v[k])), __builtin_fabsf(v[k + 1]));
+        if (TM == 2 && d.pool_y) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) pooled[k] = i == 0 ? v[k] : fmaxf(pooled[k], v[k]);
         }
         ammc_u4* yp = reinterpret_cast<ammc_u4*>(d.y + o_pix[i] + c0);
 #ifdef AMMC_TAP_STAMP
@@ -998,16 +1021,23 @@ int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream, char* 
   }
   if (d.n == 32) return mf ? launch_tap<4, 1, 2, 1, 1, 1>(a, stream, label, label_len)
                            : launch_tap<8, 1, 1, 1, 1, 0>(a, stream, label, label_len);
-  static const int kh = getenv("AMMC_TAP_KH") ? atoi(getenv("AMMC_TAP_KH")) : 0;
-  if (d.n == 64 && kh) return launch_tap<4, 1, 2, 2, 1, 0, 1>(a, stream, label, label_len);
+  // The 4-wave forms (two workgroups per CU) run the k-half-major software pipeline (KH, 32x32x16) by default
+  // (AMMC_TAP_KH: 0 = the tap-by-tap loop everywhere, 1 = default, 2 = KH wherever it exists).  Measured per layer on
+  // random operands at batch 16 (tools/conv_bench.py --net, one box, us; tap-by-tap 4-wave / KH / 8-wave 16x16x32):
+  // 128x128 64->128 113 / 109 / 125, 128->128 202 / 192 / 203, 256->128 366 / 354 / 354; 64x64 (512 tiles = ONE round
+  // of two workgroups per CU, nothing for a second workgroup to hide behind) 128->256 100 / 98 / 97.5, 256->256
+  // 185 / 181 / 170, 512->256 351 / 340 / 314: from two rounds up the 4-wave KH form, below that the 8-wave form.
+  static const int kh = getenv("AMMC_TAP_KH") ? atoi(getenv("AMMC_TAP_KH")) : 1;
+  if (d.n == 64 && kh && mfo < 0) return launch_tap<4, 1, 2, 2, 1, 0, 1>(a, stream, label, label_len);
   if (d.n == 64) return mf ? launch_tap<4, 1, 2, 2, 1, 1>(a, stream, label, label_len)     // 4 waves of 64x64 (2 image rows x 64 filters), 2 workgroups per CU
                            : launch_tap<4, 1, 2, 2, 1, 0>(a, stream, label, label_len);
   // 4 waves of 64x128 (one accumulator set), two workgroups per CU: fewer LDS reads per MFMA and the neighbour's
-  // MFMAs behind every prologue / epilogue - once there are two workgroups for every CU (measured: 128x128 layers
-  // +10 %, 64x64 +6 %, but 32x32 at batch 16 = one workgroup per CU -19 %)
-  if (kh && (mode == 4 || (mode == 1 && tiles >= 512))) return launch_tap<4, 1, 2, 4, 1, 0, 1>(a, stream, label, label_len);
-  if (mode == 4 || (mode == 1 && tiles >= 512))
+  // MFMAs behind every prologue / epilogue - once there are two workgroups for every CU
+  if (mfo < 0 && ((kh == 1 && mode == 1 && tiles >= 1024) || (kh == 2 && tiles >= 512) || (kh && mode == 4)))
+    return launch_tap<4, 1, 2, 4, 1, 0, 1>(a, stream, label, label_len);
+  if (mode == 4 || (mode == 1 && tiles >= 512 && (!kh || mfo >= 0)))
     return mf ? launch_tap<4, 1, 2, 4, 1, 1>(a, stream, label, label_len) : launch_tap<4, 1, 2, 4, 1, 0>(a, stream, label, label_len);
+  if (mfo < 0) return launch_tap<4, 2, 2, 2, 2, 1>(a, stream, label, label_len);
   return mf ? launch_tap<4, 2, 2, 2, 2, 1>(a, stream, label, label_len) : launch_tap<4, 2, 2, 2, 2, 0>(a, stream, label, label_len);
 }
 

@@ -115,7 +115,7 @@ def twostream_eval(ref, hw, batch, n_embed, name, full, rows=None, q_step=1, gri
     print(name, {k: getattr(v, "shape", None) for k, v in list(out.items())[:8]})
 
 
-def twostream_train(ref, hw, batch, name):
+def twostream_train(ref, hw, batch, name, out_step=1):
     cfg = dict(in_channel=(12, 6), out_channel=(3, 2), embed_dim=64, n_embed=256, k=2)
     sd = S.make_twostream_state(**cfg)
     net = ref.get_twostream(cfg["in_channel"], cfg["out_channel"], 64, 256, 2)
@@ -127,8 +127,8 @@ def twostream_train(ref, hw, batch, name):
     # streams + the two commit terms; all lambdas 1.
     loss = torch.norm(rgb - rgb_t, p=2, dim=1).mean() + torch.norm(op - op_t, p=2, dim=1).mean() + (rd + od).sum()
     loss.backward()
-    out = {"loss": loss.detach().numpy(), "rgb": rgb.detach().numpy(), "op": op.detach().numpy(),
-           "rgb_diff": rd.detach().numpy(), "op_diff": od.detach().numpy()}
+    out = {"loss": loss.detach().numpy(), "rgb": sub(rgb, out_step), "op": sub(op, out_step),
+           "rgb_diff": rd.detach().numpy(), "op_diff": od.detach().numpy(), "out_step": np.int64(out_step)}
     for k, p in net.named_parameters():
         g = p.grad.detach()
         out[f"gn.{k}"] = np.float64(g.double().norm().item())
@@ -358,6 +358,9 @@ def main():
     # the benchmark's own workload (BASELINE.json configs[1]): batch 16, 256x256, 2000 slots
     twostream_eval(ref, 256, 16, 2000, "twostream_256_b16_m2000_eval", full=False, rows=(0, 7, 15), q_step=4, grid=8)
     twostream_train(ref, 64, 2, "twostream_64_b2_train")
+    # the training benchmark's frame size (BASELINE.json configs[2] shape at batch 2): loss, strided outputs, every
+    # gradient's norm + 64 samples, post-step buffers
+    twostream_train(ref, 256, 2, "twostream_256_b2_train", out_step=4)
     score_fusion_golden()
     discriminator_and_losses()
     flownet2sd_golden()

@@ -105,14 +105,14 @@ def test_s16_dispatch_of_the_benchmark_shapes():
     from ammcnet_aaai2021_amd.engine import s16_variant
     B = 16
     want = {
-        (256, 64, 64): "conv_tap_s16<4, 1, 2, 2, 1, 1>",          # inc.1, up3.1
-        (256, 128, 64): "conv_tap_s16<4, 1, 2, 2, 1, 1>",         # up3.0
-        (128, 64, 128): "conv_tap_s16<4, 1, 2, 4, 1, 0>",         # down1.0 ... the dominant variant (>= 512 tiles)
-        (128, 128, 128): "conv_tap_s16<4, 1, 2, 4, 1, 0>",
-        (128, 256, 128): "conv_tap_s16<4, 1, 2, 4, 1, 0>",
-        (64, 128, 256): "conv_tap_s16<4, 1, 2, 4, 1, 0>",
-        (64, 256, 256): "conv_tap_s16<4, 1, 2, 4, 1, 0>",
-        (64, 512, 256): "conv_tap_s16<4, 1, 2, 4, 1, 0>",
+        (256, 64, 64): "conv_tap_s16<4, 1, 2, 2, 1, 0, 1>",       # inc.1, up3.1: the k-half-major pipeline (KH), 64 filters
+        (256, 128, 64): "conv_tap_s16<4, 1, 2, 2, 1, 0, 1>",      # up3.0
+        (128, 64, 128): "conv_tap_s16<4, 1, 2, 4, 1, 0, 1>",      # down1.0 ... KH, 128 filters (two rounds of 512 workgroups and up)
+        (128, 128, 128): "conv_tap_s16<4, 1, 2, 4, 1, 0, 1>",
+        (128, 256, 128): "conv_tap_s16<4, 1, 2, 4, 1, 0, 1>",
+        (64, 128, 256): "conv_tap_s16<4, 2, 2, 2, 2, 1>",         # 512 tiles = one round of two workgroups per CU: the 8-wave variant
+        (64, 256, 256): "conv_tap_s16<4, 2, 2, 2, 2, 1>",
+        (64, 512, 256): "conv_tap_s16<4, 2, 2, 2, 2, 1>",
         (32, 256, 512): "conv_tap_s16<4, 2, 2, 2, 2, 1>",         # 256 tiles: the 8-wave variant
         (32, 512, 512): "conv_tap_s16<4, 2, 2, 2, 2, 1>",
     }

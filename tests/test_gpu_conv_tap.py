@@ -40,7 +40,24 @@ def _s16_read(a: Act) -> torch.Tensor:
 V64, V128, V8W = "conv_tap_s16<4, 1, 2, 2, 1, %d>", "conv_tap_s16<4, 1, 2, 4, 1, %d>", "conv_tap_s16<4, 2, 2, 2, 2, %d>"
 
 
-@pytest.fixture(params=[1, 0], ids=["mfma16x16x32", "mfma32x32x16"])
+# what the DEFAULT dispatch (s16_mf = -1) makes of a forced-shape label: the k-half-major pipelines (KH, a seventh template
+# argument) for 64 filters and for 128-filter layers of at least 1024 tiles, the 8-wave 16x16x32 form for the rest
+def default_label(variant, tiles):
+    if variant == V64:
+        return "conv_tap_s16<4, 1, 2, 2, 1, 0, 1>"
+    if variant == V128:
+        return "conv_tap_s16<4, 1, 2, 4, 1, 0, 1>" if tiles >= 1024 else V8W % 1
+    return variant % 1 if "%d" in variant else variant
+
+
+def expected_label(variant, mf, d):
+    if mf >= 0:
+        return variant % mf if "%d" in variant else variant
+    tiles = d.batch * (d.height // 8) * (d.width // 32) * (1 if d.n <= 64 else d.n // 128)
+    return default_label(variant, tiles)
+
+
+@pytest.fixture(params=[-1, 1, 0], ids=["default", "mfma16x16x32", "mfma32x32x16"])
 def mf(request):
     lib = _lib.load()
     _lib.check(lib.ammc_set_option(b"s16_mf", request.param), "set_option")
@@ -58,7 +75,9 @@ def mf(request):
     (16, 64, 64, 32, 256, False, False, False, V128),     # 512 tiles, two N tiles
     (8, 128, 128, 128, 128, True, True, False, V128),     # 512 tiles, residual
     (32, 64, 64, 128, 128, True, False, True, V128),      # sliced input (the decoder's concat buffer)
-    (16, 128, 128, 64, 128, True, False, False, V128),    # down1.0 of the benchmark
+    (16, 128, 128, 64, 128, True, False, False, V128),    # down1.0 of the benchmark (1024 tiles: the KH instance by default)
+    (16, 128, 128, 128, 128, True, True, False, V128),    # 1024 tiles, four channel blocks, residual
+    (64, 64, 64, 128, 128, True, False, True, V128),      # 1024 tiles, sliced input
 ])
 def test_conv_tap_s16_vs_fp64(B, H, W, cin, n, relu, res, sliced, variant, mf):
     lib = _lib.load()
@@ -93,7 +112,7 @@ def test_conv_tap_s16_vs_fp64(B, H, W, cin, n, relu, res, sliced, variant, mf):
         d.pool_y = pa.pix0()
         d.pool_bs, d.pool_rs, d.pool_ps = pa.strides
     if not os.environ.get("AMMC_TAP_KH"):          # (experiments force other instances through the environment)
-        assert s16_variant(d) == (variant % mf if "%d" in variant else variant)               # the library's own dispatch: this case reaches that kernel
+        assert s16_variant(d) == expected_label(variant, mf, d)                               # the library's own dispatch: this case reaches that kernel
     _lib.check(lib.ammc_conv_gemm_s16(C.byref(d), s), "conv_gemm_s16")
     got = _s16_read(ya).double().cpu()
     # reference on the operands as the kernel sees them (S16 round trip of x, w and the residual)
@@ -143,7 +162,7 @@ def test_conv_tap_fp32_output_with_fp32_residual(B, H, W, cin, n, variant, mf):
     d.y_bs, d.y_rs, d.y_ps = ya.strides
     d.r_bs, d.r_rs, d.r_ps = res.strides
     if not os.environ.get("AMMC_TAP_KH"):
-        assert s16_variant(d) == (variant % mf if "%d" in variant else variant)
+        assert s16_variant(d) == expected_label(variant, mf, d)
     _lib.check(lib.ammc_conv_gemm_s16(C.byref(d), s), "conv_gemm_s16")
     got = ya.interior().permute(0, 3, 1, 2).double().cpu()
     wsa = Act(ws.view(1, 1, n, 9 * cin), 1, 1, n, 9 * cin, 0, 0)

@@ -239,7 +239,7 @@ def test_s16_dispatch_is_consistent_across_shapes(B, H, W):
         assert abs(float(x) - float(y)) <= 1e-5 * abs(float(y))
 
 
-@pytest.mark.parametrize("prec,mf", [("s16", 1), ("s16", 0), ("fp32", 1)])
+@pytest.mark.parametrize("prec,mf", [("s16", -1), ("s16", 1), ("s16", 0), ("fp32", 1)])
 def test_benchmark_workload_b16_256_m2000_vs_reference_vectors(prec, mf):
     """BASELINE.json configs[1] exactly as bench.py runs it (batch 16, 256x256, 2000 slots) against vectors recorded
     from the reference (`twostream.forward`, unet.py:981-1007): frames, commit scalars, quantised maps, per-sample
@@ -276,8 +276,11 @@ def test_benchmark_workload_b16_256_m2000_vs_reference_vectors(prec, mf):
     assert max(errs.values()) <= TOL, errs
     if prec == "s16":
         kernels = {m["kernel"] for m in st["plan"].meta} | {s.outc_kernel for s in st["streams"]}
-        assert {f"conv_tap_s16<4, 1, 2, 4, 1, {mf}>", f"conv_tap_s16<4, 1, 2, 2, 1, {mf}>", f"conv_tap_s16<4, 2, 2, 2, 2, {mf}>",
-                "conv_outc_s16", "conv_first_s16", "conv_up_s16<2>", "conv_up_s16<4>",
+        # mf = -1: the default dispatch, i.e. what bench.py runs and reports (the k-half-major pipelines for the 4-wave
+        # layers of two rounds and more, the 8-wave 16x16x32 form below); 0 / 1: one MFMA shape forced, tap-by-tap loops
+        taps = ({"conv_tap_s16<4, 1, 2, 4, 1, 0, 1>", "conv_tap_s16<4, 1, 2, 2, 1, 0, 1>", "conv_tap_s16<4, 2, 2, 2, 2, 1>"} if mf < 0 else
+                {f"conv_tap_s16<4, 1, 2, 4, 1, {mf}>", f"conv_tap_s16<4, 1, 2, 2, 1, {mf}>", f"conv_tap_s16<4, 2, 2, 2, 2, {mf}>"})
+        assert taps | {"conv_outc_s16", "conv_first_s16", "conv_up_s16<2>", "conv_up_s16<4>",
                 "memory_topk_s16", "conv_gemm_s16<128x128>", "conv_gemm_s16<128x64>"} <= kernels, kernels
         assert all(s.first_mid is not None for s in st["streams"])                  # conv_first_s16 took the first layers
         assert not eng.overflowed()
