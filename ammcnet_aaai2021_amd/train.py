@@ -963,6 +963,149 @@ class BlockEngine:
         return ins, {k.data_ptr(): v for k, v in grads.items()}
 
 
+class MemoryBlockEngine:
+    """Training-mode forward / backward of the memory block called on its own, as the reference's modules can be:
+    `Quantize_topk` (models/unet.py:282-316: the lookups, the commit term, the EMA update of the codebook buffers
+    whenever `self.training`), `enc_quan_dec_topk` (:318-331) and `enc_quan_dec_res_topk` (:379-387).  One autograd node:
+    forward = [1x1 enc] -> fused distance / top-k / gather kernel -> EMA update AFTER the lookups -> [1x1 dec (+ x)];
+    backward = the gradient of the commit term 2 (z - e_idx) / (n d) plus the straight-through gradient of `quantize`
+    (`ammc_commit_bwd_f32`), the weight / bias / input gradients of the two 1x1 convolutions.  The gathered rows
+    (`quantize_topk`) come out of a buffer: no gradient reaches anything through them, exactly as in the reference."""
+
+    def __init__(self, module, kind: str, precision: Optional[str] = None):
+        if kind not in ("quantize", "vq", "vq_res"):
+            raise ValueError(kind)
+        self.module, self.kind = module, kind
+        self.precision = "fp32"                     # 1x1 convolutions and the lookups run on the exact-fp32 kernels
+        self._ws: Dict = {}
+        self.generation = 0
+
+    def _get(self, shape, device):
+        key = (shape, device)
+        st = self._ws.get(key)
+        if st is not None:
+            return st
+        ws = _WS(device)
+        ops = _Ops(ws, "fp32")
+        lib = ops.lib
+        qz = self.module if self.kind == "quantize" else self.module.quantize
+        d, m, k = qz.dim, qz.n_embed, qz.k
+        st = dict(ops=ops, d=d, m=m, k=k)
+        if self.kind == "quantize":
+            B, h, w, dd = shape
+            if dd != d:
+                raise ValueError(f"Quantize_topk: last dimension {dd}, the codebook has {d}")
+        else:
+            B, C, h, w = shape
+            cin = self.module.enc.weight.shape[1]
+            if C != cin or C % 32:
+                raise NotImplementedError(f"memory block in training mode: {C} input channels (the block has {cin}; multiples of 32)")
+            st["x"], st["y"], st["dy"], st["dx"] = ws.act(B, h, w, C), ws.act(B, h, w, C), ws.act(B, h, w, C), ws.act(B, h, w, C)
+            st["enc_wp"], st["dec_wp"] = ws.buf(d, C), ws.buf(C, _kpad(k * d))
+            st["enc_dwp"], st["dec_dwp"] = ws.zbuf(max(d, 32), C), ws.zbuf(C, _kpad(k * d))
+            st["enc_wT"] = ws.buf(C, _kpad(d))
+            st["scratch"] = ws.buf(lib.ammc_chan_reduce_blocks(B * h * w) * 512 + 1024)
+        n = B * h * w
+        st.update(B=B, h=h, w=w, n=n, z=ws.act(B, h, w, d, halo=0), qk=ws.act(B, h, w, k * d, halo=0), dz=ws.act(B, h, w, d, halo=0),
+                  q_one=ws.buf(B, h, w, d), idx=ws.buf(n, k, dtype=torch.int32), nblk=lib.ammc_memory_topk_blocks(n),
+                  e_md=ws.buf(m, d), enorm=ws.buf(m))
+        st["part"] = ws.buf(st["nblk"])
+        self._ws[key] = st
+        return st
+
+    def forward(self, x: torch.Tensor):
+        if not x.is_cuda:
+            raise _lib.AmmcHipError("the HIP path needs CUDA/HIP tensors; there is no CPU fallback")
+        st = self._get(tuple(x.shape), x.device)
+        o, lib = st["ops"], st["ops"].lib
+        o.sync_group = False
+        s = o.s
+        self.generation += 1
+        st["generation"] = self.generation
+        self._last = st
+        d, m, k, n = st["d"], st["m"], st["k"], st["n"]
+        if self.kind == "quantize":
+            qz = self.module
+            st["z"].buf.view(-1).copy_(x.detach().float().reshape(-1))
+        else:
+            q, qz = self.module, self.module.quantize
+            C = st["x"].c
+            BlockEngine._load(o, x, st["x"])
+            _chk(lib.ammc_pack_conv_weight_f32(_ptr(q.enc.weight.detach()), d, C, 1, C, _ptr(st["enc_wp"]), s), "pack")
+            _chk(lib.ammc_pack_conv_weight_f32(_ptr(q.dec.weight.detach()), C, k * d, 1, _kpad(k * d), _ptr(st["dec_wp"]), s), "pack")
+            o.conv(st["x"], st["enc_wp"], st["z"], ntaps=1, cin=C, n=d, shift=q.enc.bias.detach(), what="vq.enc")
+        _chk(lib.ammc_pack_codebook_f32(_ptr(qz.embed), d, m, _ptr(st["e_md"]), _ptr(st["enorm"]), s), "codebook")
+        _chk(lib.ammc_memory_topk_fwd_f32(_ptr(st["z"].buf), _ptr(qz.embed), _ptr(st["e_md"]), _ptr(st["enorm"]), n, d, m, k,
+                                          st["idx"].data_ptr(), _ptr(st["qk"].buf), _ptr(st["q_one"]), _ptr(st["part"]), s), "memory_topk")
+        diff = torch.empty(1, device=o.dev, dtype=torch.float32)
+        _chk(lib.ammc_sum_partials_f32(_ptr(st["part"]), st["nblk"], 1.0 / float(n * d), _ptr(diff), s), "diff")
+        # the EMA update AFTER the lookups (unet.py:291-309); e_md keeps the pre-update rows for the backward
+        _chk(lib.ammc_codebook_ema_f32(_ptr(st["z"].buf), st["idx"].data_ptr(), k, n, d, m, float(qz.decay), float(1 - qz.decay),
+                                       float(qz.eps), _ptr(qz.cluster_size), _ptr(qz.embed_avg), _ptr(qz.embed), s), "codebook_ema")
+        if self.kind == "quantize":
+            return st["qk"].buf.view(st["B"], st["h"], st["w"], k * d).clone(), diff[0], st["q_one"].clone()
+        o.conv(st["qk"], st["dec_wp"], st["y"], ntaps=1, cin=k * d, n=st["x"].c, shift=q.dec.bias.detach(),
+               res=st["x"] if self.kind == "vq_res" else None, what="vq.dec")
+        return BlockEngine._store(o, st["y"]), diff, st["q_one"].clone()
+
+    def backward(self, generation: int, gouts):
+        st = self._last
+        if st.get("generation") != generation:
+            raise RuntimeError("HIP training path: backward() called for a forward whose workspace has been reused")
+        o, lib = st["ops"], st["ops"].lib
+        s = o.s
+        o.ws.zero_step()
+        d, m, k, n = st["d"], st["m"], st["k"], st["n"]
+        g_out, g_diff, g_q1 = gouts
+        grads: Dict = {}
+        ddiff = g_diff.detach().float().reshape(1).contiguous() if g_diff is not None else None
+        dq = g_q1.detach().float().contiguous() if g_q1 is not None else None
+        _chk(lib.ammc_commit_bwd_f32(_ptr(st["z"].buf), _ptr(st["e_md"]), st["idx"].data_ptr(), k,
+                                     _ptr(ddiff) if ddiff is not None else None, _ptr(dq) if dq is not None else None,
+                                     _ptr(st["dz"].buf), n, d, s), "commit_bwd")
+        if self.kind == "quantize":
+            return [st["dz"].buf.view(st["B"], st["h"], st["w"], d).clone()], {}
+        q = self.module
+        C, kd = st["x"].c, k * d
+        if g_out is not None:
+            BlockEngine._load(o, g_out, st["dy"])
+            grads[q.dec.bias] = o.chan_sum(st["dy"], C, st["scratch"])
+            o.wgrad(st["dy"], st["qk"], st["dec_dwp"], n=C, cin=kd, ntaps=1, what="vq.dec.wgrad")
+            dw = torch.empty_like(q.dec.weight)
+            _chk(lib.ammc_unpack_conv_wgrad_f32(_ptr(st["dec_dwp"]), C, kd, 1, _kpad(kd), _ptr(dw), s), "unpack")
+            grads[q.dec.weight] = dw
+        grads[q.enc.bias] = o.chan_sum(st["dz"], d, st["scratch"])
+        o.wgrad(st["dz"], st["x"], st["enc_dwp"], n=max(d, 32), cin=C, ntaps=1, what="vq.enc.wgrad")
+        dwe = torch.empty_like(q.enc.weight)
+        _chk(lib.ammc_unpack_conv_wgrad_f32(_ptr(st["enc_dwp"]), d, C, 1, C, _ptr(dwe), s), "unpack")
+        grads[q.enc.weight] = dwe
+        _chk(lib.ammc_transpose_pad_f32(_ptr(st["enc_wp"]), d, C, _kpad(d), _ptr(st["enc_wT"]), s), "transpose")
+        o.conv(st["dz"], st["enc_wT"], st["dx"], ntaps=1, cin=_kpad(d), n=C,
+               res=st["dy"] if (self.kind == "vq_res" and g_out is not None) else None, what="vq.enc.dgrad")
+        return [BlockEngine._store(o, st["dx"])], {k_.data_ptr(): v for k_, v in grads.items()}
+
+
+class MemoryBlockFunction(torch.autograd.Function):
+    """(engine, input, *params) -> (out | quantize_topk, diff, quantize_one), differentiable w.r.t. input and params"""
+
+    @staticmethod
+    def forward(ctx, engine: MemoryBlockEngine, x, *params):
+        outs = engine.forward(x)
+        ctx.engine, ctx.generation, ctx.params = engine, engine.generation, params
+        ctx.set_materialize_grads(False)
+        if engine.kind == "quantize":
+            ctx.mark_non_differentiable(outs[0])
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        ins, grads = ctx.engine.backward(ctx.generation, gouts)
+        out = [None, ins[0] if ctx.needs_input_grad[1] else None]
+        for p in ctx.params:
+            out.append(grads.get(p.data_ptr()))
+        return tuple(out)
+
+
 class BlockFunction(torch.autograd.Function):
     """(engine, n_inputs, *inputs, *params) -> the block's outputs, differentiable w.r.t. inputs and params"""
 

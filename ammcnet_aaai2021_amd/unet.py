@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from . import ops
 from .engine import EvalEngine
-from .train import BlockEngine, BlockFunction, HipPathFunction, TrainEngine
+from .train import BlockEngine, BlockFunction, HipPathFunction, MemoryBlockEngine, MemoryBlockFunction, TrainEngine
 
 
 # Inference arithmetic: "s16" (default) = split-fp16 MFMA with fp32 accumulation: 22 significant bits per operand,
@@ -37,13 +37,15 @@ DEFAULT_PRECISION = os.environ.get("AMMC_PRECISION", "s16")
 DEFAULT_S16_GUARD = os.environ.get("AMMC_S16_GUARD", "1") != "0"      # (A/B measurements of the guard's cost only)
 
 
-def _no_training(mod):
-    if mod.training:
-        raise NotImplementedError(
-            f"{type(mod).__name__}: training mode exists for the models (UNet, UNetMem_v7, twostream) and for the conv "
-            "blocks (double_conv, inconv, down, up, bridge) called on their own, not for the memory block alone (its "
-            "only gradient is the commit term, which the models' engines produce); call .eval() - there is no ATen "
-            "fallback")
+def _run_memory(mod, kind: str, x):
+    """training-mode forward of the memory block on its own (`Quantize_topk`, `enc_quan_dec_topk`,
+    `enc_quan_dec_res_topk`): one autograd node over the HIP kernels; the EMA buffers are updated in place as the
+    reference does whenever `self.training` (models/unet.py:298-309)"""
+    eng = mod.__dict__.get("_block_engine")
+    if eng is None or eng.kind != kind:
+        eng = MemoryBlockEngine(mod, kind)
+        object.__setattr__(mod, "_block_engine", eng)
+    return MemoryBlockFunction.apply(eng, x, *mod.parameters())
 
 
 def _run_block(mod, kind: str, owner, *inputs):
@@ -169,7 +171,8 @@ class Quantize_topk(nn.Module):
         self.register_buffer("embed_avg", embed.clone())
 
     def forward(self, input):
-        _no_training(self)
+        if self.training:
+            return _run_memory(self, "quantize", input)
         return ops.quantize_topk_eval(self, input)
 
     def embed_code(self, embed_id):
@@ -184,7 +187,8 @@ class enc_quan_dec_topk(nn.Module):
         self.dec = nn.Conv2d(embed_dim * k, in_c, 1)
 
     def forward(self, x):
-        _no_training(self)
+        if self.training:
+            return _run_memory(self, "vq", x)
         return ops.vq_block_eval(self, x, residual=False)
 
 
@@ -194,7 +198,8 @@ class enc_quan_dec_res_topk(nn.Module):
         self.quan = enc_quan_dec_topk(in_c, embed_dim, n_embed, k=k)
 
     def forward(self, x):
-        _no_training(self)
+        if self.training:
+            return _run_memory(self.quan, "vq_res", x)
         return ops.vq_block_eval(self.quan, x, residual=True)
 
 

@@ -69,7 +69,7 @@ def test_no_silent_fallback():
         net(torch.zeros(1, 12, 64, 64), torch.zeros(1, 6, 64, 64))
     with pytest.raises(_lib.AmmcHipError):                                   # stand-alone conv block in .train(): HIP only too
         net.rgb.inc(torch.zeros(1, 12, 16, 16))
-    with pytest.raises(NotImplementedError):                                 # the memory block alone has no training form
+    with pytest.raises(_lib.AmmcHipError):                                   # the memory block alone in .train(): HIP only too
         net.rgb.vq_down3(torch.zeros(1, 512, 4, 4))
 
 

@@ -34,3 +34,37 @@ def test_memory_topk_f16(d, m, k, n):
     chosen = dist.gather(1, idx)
     assert bool(((chosen - srt[:, :k]).abs() <= 4e-3 * scale[:, None]).all())
     assert rel_err(diff.cpu(), wdiff) <= 5e-3
+
+
+def test_memory_topk_f16_65536_rows_chunked_oracle():
+    """config 5 at 65,536 rows (512 workgroups of 128 rows; the bench runs 262,144): ONE launch, checked against the
+    oracle chunk by chunk (4,096 rows each) with the gates above"""
+    d, m, k, n, chunk = 512, 8192, 2, 65536, 4096
+    embed = S.hashed_normal("s16:big:e", (d, m), 0.9)
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(n, d, generator=g) * 0.8
+    qk, diff, q1, idx = ops.quantize_topk_f16(embed.to(DEV), x.view(1, 1, n, d).to(DEV), k)
+    idx = idx.cpu().reshape(n, k).long()
+    qk = qk.cpu().reshape(n, k * d)
+    e64 = embed.double()
+    en = e64.pow(2).sum(0, keepdim=True)
+    agree_all, sq = 0, 0.0
+    for c0 in range(0, n, chunk):
+        xs = x[c0:c0 + chunk]
+        wqk, _, widx, _, flat, wq1 = O.quantize_topk(xs.view(1, 1, chunk, d), embed, k)
+        widx = widx.reshape(chunk, k)
+        dist = flat.double().pow(2).sum(1, keepdim=True) - 2 * flat.double() @ e64 + en
+        srt = dist.sort(dim=1).values
+        margin = (srt[:, 1:k + 1] - srt[:, :k]).min(dim=1).values
+        scale = flat.double().pow(2).sum(1) + en.mean()
+        safe = margin > 4e-3 * scale
+        got = idx[c0:c0 + chunk]
+        assert torch.equal(got[safe], widx[safe]), c0
+        same = (got == widx).all(dim=1)
+        agree_all += int(same.sum())
+        assert torch.equal(qk[c0:c0 + chunk][same], wqk.reshape(chunk, k * d)[same]), c0
+        chosen = dist.gather(1, got)
+        assert bool(((chosen - srt[:, :k]).abs() <= 4e-3 * scale[:, None]).all()), c0
+        sq += float((wq1.reshape(chunk, d).double() - flat.double()).pow(2).sum())
+    assert agree_all / n > 0.9, agree_all / n
+    assert abs(float(diff) - sq / (n * d)) <= 5e-3 * sq / (n * d)
