@@ -784,6 +784,7 @@ class EvalEngine:
                 if t is not None:
                     dst.copy_(t.detach())
             g["graph"].replay()
+            st["flag_event"] = None              # replays copy nothing to the host: `overflowed` reads the device flag itself
             outs = [y.clone() for y in g["y"]]
             sq = [a.clone() if a is not None else None for a in g["acc"]]
         else:
@@ -807,7 +808,9 @@ class EvalEngine:
             outs = [torch.empty((B, s.sp.cout, H, W), device=x0.device, dtype=torch.float32) for s in streams]
             tt = [t.detach().float().contiguous() if t is not None else None for t in tg]
             sq = [torch.zeros(B, device=x0.device, dtype=torch.float32) if t is not None else None for t in tg]
-            self._launch_all(st, B, H, W, xs, outs, tt, sq, stream, launch, early_flag=self.s16)
+            # (no pinned-memory copy / event while the caller captures this forward into its own graph)
+            self._launch_all(st, B, H, W, xs, outs, tt, sq, stream, launch,
+                             early_flag=self.s16 and not torch.cuda.is_current_stream_capturing())
             if timed:
                 torch.cuda.synchronize()
                 self.timings = [(m, e0.elapsed_time(e1)) for m, e0, e1 in recs]

@@ -176,9 +176,39 @@ def train_step(model: torch.nn.Module, optimizer: torch.optim.Optimizer, rgb: to
     op_in = op[:, :-1].reshape(b, -1, *op.shape[-2:])
     optimizer.zero_grad(set_to_none=True)
     loss = generator_loss(model(rgb_in, op_in), rgb[:, -1], op[:, -1], **lams)
+    watch = _FiniteWatch(loss)
     loss.backward()
-    optimizer.step()
+    watch.step(optimizer)
     return loss.detach()
+
+
+class _FiniteWatch:
+    """`optimizer.step()` unless the loss is non-finite, without stalling the device.  The split-fp16 training kernels
+    (`train_precision = "s16"`, the default) encode their operands in half range: an activation beyond 65504 becomes inf
+    in the re-encoding and reaches the loss as inf / NaN; stepping would write that into the Adam moments and the
+    weights for good.  The verdict on the loss is copied to pinned host memory right after the FORWARD (one 1-byte copy
+    + an event, queued before the backward's kernels); `step` waits for that event only - by then the host has enqueued
+    the whole backward, so the device keeps working while the host waits - and refuses the step loudly.  (The
+    BatchNorm / EMA buffers of the refused step were updated in place by its forward, as the reference's would be.)"""
+
+    def __init__(self, *losses):
+        self.flag = torch.empty(len(losses), dtype=torch.bool).pin_memory() if losses[0].is_cuda else None
+        fin = torch.stack([torch.isfinite(v.detach()).all() for v in losses])
+        if self.flag is not None:
+            self.flag.copy_(fin, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
+        else:
+            self.flag, self.event = fin, None
+
+    def step(self, optimizer) -> None:
+        if self.event is not None:
+            self.event.synchronize()
+        if not bool(self.flag.all()):
+            raise FloatingPointError(
+                "non-finite training loss: an operand left the fp16 range of the split-fp16 kernels (or the run diverged); "
+                "optimizer.step() was NOT taken - set model.train_precision = 'fp32' to train this step on the exact kernels")
+        optimizer.step()
 
 
 # ---- the remaining loss terms and the alternating G / D step (SURVEY.md 8(f)2) -----------------------------------
@@ -257,9 +287,10 @@ def train_step_gan(generator: torch.nn.Module, discriminator: torch.nn.Module, o
             p.requires_grad_(True)
     g_loss = generator_loss_full(out, rgb_t, op_t, d_gen, flow_pred, flow_gt, **lams)
     d_loss = discriminate_loss(discriminator(rgb_t), discriminator(out[0].detach()))
+    watch = _FiniteWatch(d_loss, g_loss)
     optimizer_D.zero_grad(set_to_none=True)
     d_loss.backward()
-    optimizer_D.step()
+    watch.step(optimizer_D)
     optimizer_G.zero_grad(set_to_none=True)
     g_loss.backward()
     optimizer_G.step()

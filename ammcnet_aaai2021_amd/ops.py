@@ -5,7 +5,7 @@ functions run ONE block on freshly allocated buffers through the same C-ABI
 kernels, so that `double_conv(...)`, `down(...)`, `up(...)`, `bridge(...)`,
 `Quantize_topk(...)` and the vq block work when called on their own, exactly
 as the reference's sub-modules do, and so that every kernel has a per-op
-parity test (tests/test_gpu_ops.py).  No ATen compute here either.
+parity test (tests/test_gpu_parity.py, tests/test_gpu_s16.py).  No ATen compute here either.
 """
 from __future__ import annotations
 

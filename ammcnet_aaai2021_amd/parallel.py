@@ -104,13 +104,32 @@ class BucketedGradReducer:
             if self._pending_bytes >= self.bucket_bytes:
                 self._launch()
 
+    def _flat_for(self, slot: int, members: List[torch.Tensor]) -> torch.Tensor:
+        """the persistent flat buffer of the `slot`-th bucket of a step: the bucket composition is the same every step
+        (the backward pushes the same tensors in the same order), so the buffer is allocated once and only re-made
+        when the total size or dtype / device changes - no `torch.cat` allocation per bucket per step"""
+        n = sum(t.numel() for t in members)
+        flat = self._flats.get(slot) if hasattr(self, "_flats") else None
+        if not hasattr(self, "_flats"):
+            self._flats = {}
+        if flat is None or flat.numel() != n or flat.dtype != members[0].dtype or flat.device != members[0].device:
+            flat = torch.empty(n, dtype=members[0].dtype, device=members[0].device)
+            self._flats[slot] = flat
+        return flat
+
     def _launch(self) -> None:
         if not self._pending:
             return
         members = self._pending
-        flat = torch.cat([t.reshape(-1) for t in members])
+        flat = self._flat_for(len(self._inflight), members)
+        views, off = [], 0
+        for t in members:
+            n = t.numel()
+            views.append(flat[off:off + n].view_as(t))
+            off += n
+        torch._foreach_copy_(views, [t.detach() for t in members])          # one fused gather into the bucket
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._inflight.append((flat, members, work))
+        self._inflight.append((views, members, work))
         self._pending, self._pending_bytes = [], 0
         self.buckets_launched += 1
 
@@ -119,13 +138,10 @@ class BucketedGradReducer:
             return
         self._launch()
         inv = 1.0 / self.world
-        for flat, members, work in self._inflight:
+        for views, members, work in self._inflight:
             work.wait()
-            off = 0
-            for t in members:
-                n = t.numel()
-                t.copy_(flat[off:off + n].view_as(t)).mul_(inv)
-                off += n
+            torch._foreach_mul_(views, inv)                                  # average in the bucket ...
+            torch._foreach_copy_([t.detach() for t in members], views)       # ... and scatter back in place
         self._inflight = []
 
 

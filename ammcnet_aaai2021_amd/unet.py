@@ -72,12 +72,16 @@ def _run(mod, kind: str, n_inputs: int, *inputs):
         if mod._engine is None or mod._engine.precision != prec:
             object.__setattr__(mod, "_engine", EvalEngine(mod, kind, prec))
         out = mod._engine.forward(*inputs)
-        if prec == "s16" and getattr(mod, "s16_guard", DEFAULT_S16_GUARD):
+        object.__setattr__(mod, "_last_engine", mod._engine)          # the engine that produced `out` (quant_befor / quant_after)
+        if prec == "s16" and getattr(mod, "s16_guard", DEFAULT_S16_GUARD) and not torch.cuda.is_current_stream_capturing():
             # Reading the flag is one 4-byte copy to pinned memory queued ahead of the two output layers
             # (EvalEngine._launch_all): the wait ends while the device still has work queued, < 1 % at batch 16
             # (DESIGN.md section 3); the harness loop avoids even that, see `forward_scored(defer_guard=True)`.
+            # Under a caller's stream capture nothing may be read back or waited for: the flag stays sticky on the
+            # device and the caller checks it after the replay (`model._engine.take_overflow()` / `.overflowed()`).
             if mod._engine.overflowed():
                 out = _fp32_engine(mod, kind).forward(*inputs)
+                object.__setattr__(mod, "_last_engine", mod._engine_fp32)
                 object.__setattr__(mod, "s16_fallbacks", getattr(mod, "s16_fallbacks", 0) + 1)
         return out
     tprec = getattr(mod, "train_precision", None)            # None: train.TRAIN_PRECISION (AMMC_TRAIN_PRECISION, "s16")
@@ -257,8 +261,9 @@ class twostream(nn.Module):
             out = (rgb, op, (rd, od), (rq, oq))
             self._quant_src = (None, befor, after)
         else:
-            st = self._engine._last["streams"][0]
-            self._quant_src = (self._engine, st.x4, st.x4q)
+            eng = getattr(self, "_last_engine", None) or self._engine      # the fp32 engine after an S16 range fallback
+            st = eng._last["streams"][0]
+            self._quant_src = (eng, st.x4, st.x4q)
         return out
 
     def forward_scored(self, rgb_x, op_x, rgb_target, op_target=None, defer_guard: bool = False, exact: bool = False):

@@ -87,16 +87,72 @@ def spawn_ranks(args) -> int:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
+    # poll: when one rank fails (out of memory, parity exit code 3, an exception before the process group exists) the
+    # others would sit in a barrier until the RCCL timeout - stop them and return the code of the rank that failed first
+    rc, live = 0, list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = abs(code)
+                for q in live:
+                    q.terminate()
     for p in procs:
-        rc = max(rc, abs(p.wait()))
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
     return rc
+
+
+def pin_to_gpu_numa_node(local_rank: int):
+    """Best effort, before anything touches the GPU: restrict this rank to the CPUs of the NUMA node its GPU hangs off
+    (sysfs only: the KFD topology lists the GPUs in enumeration order with their PCI location, the PCI device names its
+    NUMA node).  Host-side launch latency and the pinned-memory copies of a rank then stay on one socket instead of
+    wandering over both.  Returns a description for the JSON line, or None when the topology cannot be read."""
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        gpus = []
+        for node in sorted(os.listdir(base), key=int):
+            props = dict(ln.split() for ln in open(f"{base}/{node}/properties") if len(ln.split()) == 2)
+            if int(props.get("simd_count", "0")) > 0:
+                gpus.append(props)
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+        idx = local_rank
+        if vis:
+            ids = [int(v) for v in vis.split(",") if v.strip().isdigit()]
+            if local_rank < len(ids):
+                idx = ids[local_rank]
+        p = gpus[idx]
+        loc, dom = int(p["location_id"]), int(p.get("domain", "0"))
+        bdf = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7:x}"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return {"gpu": idx, "pci": bdf, "numa_node": node, "cpus": len(cpus)}
+    except Exception:
+        return None
 
 
 def init_ranks(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and os.environ.get("AMMC_BENCH_SHARE_GPU", "0") == "0" and os.environ.get("AMMC_BENCH_NUMA", "1") != "0":
+        global NUMA_PIN
+        NUMA_PIN = pin_to_gpu_numa_node(local_rank)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -145,10 +201,13 @@ class Clock:
         return elapsed
 
 
+NUMA_PIN = None
+
+
 def backend_info(dist, world):
     if dist is None:
         return {"rccl_ranks": 1}
-    return {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend()}
+    return {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "rank0_cpu_affinity": NUMA_PIN}
 
 
 # ---- CPU baselines ("port": the oracle restatement, on this host) ---------------------------------------------------------

@@ -53,6 +53,26 @@ def test_bench_two_ranks(mode, extra, launcher):
         assert rec["roofline"]["bound"] == "mfma" and rec["roofline"]["frac"] > 0
 
 
+@pytest.mark.parametrize("mode,extra,units", [("infer", ["--batch", "1", "--size", "64", "--no-cpu-baseline"], 1),
+                                               ("train", ["--batch", "1", "--size", "64"], 1),
+                                               ("stress", ["--batch", "1"], 1024)])
+def test_bench_eight_ranks_self_spawned(mode, extra, units):
+    """the shape of the driver's 8-GPU run on the one test GPU: `python bench.py --gpus 8` starts eight ranks itself
+    (port handling, RANK / LOCAL_RANK / WORLD_SIZE, teardown), every rank runs its share, rank 0 prints ONE line whose
+    value is the sum over the eight ranks and whose `rccl_ranks` is read back from the process group"""
+    env = dict(os.environ, AMMC_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--mode", mode] + extra
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["rccl_ranks"] == 8 and rec["scaling"] == "weak"
+    assert abs(rec["value"] - 8 * units / (rec["ms_per_step"] * 1e-3)) <= 0.02 * rec["value"]
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "AMMC_BENCH_SHARE_GPU")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], env=env, cwd=ROOT,
