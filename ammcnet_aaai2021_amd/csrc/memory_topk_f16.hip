@@ -80,10 +80,14 @@ __global__ __launch_bounds__(512, 1) void memory_topk_f16_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // region 0: the x tile [HBR][d] halfs (swizzled 16-B slots) during the contraction, then re-used for
   // the candidate lists [HBR][16][K] (value, index); region 1: |x|^2, final indices, reduction scratch
-  const size_t region0 = max((size_t)HBR * d * 2, (size_t)HBR * 16 * K * 8);
+  // (candidate rows are 16 K + 1 words long: with 16 K the 32 lanes of a half wave - consecutive feature rows - wrote
+  // and read words 128 B apart, i.e. two banks: 32-way conflicts, the 15 % of this kernel's LDS cycles that the round-2
+  // counters showed as SQ_LDS_BANK_CONFLICT)
+  constexpr int CROW = 16 * K + 1;
+  const size_t region0 = max((size_t)HBR * d * 2, (size_t)HBR * CROW * 8);
   _Float16* xs = reinterpret_cast<_Float16*>(smem_raw);
   float* cand_v = reinterpret_cast<float*>(smem_raw);
-  int* cand_i = reinterpret_cast<int*>(cand_v + HBR * 16 * K);
+  int* cand_i = reinterpret_cast<int*>(cand_v + HBR * CROW);
   float* xx = reinterpret_cast<float*>(smem_raw + region0);             // [HBR]
   int* best = reinterpret_cast<int*>(xx + HBR);                         // [HBR][K]
   float* red = reinterpret_cast<float*>(best + HBR * K);                // [512]
@@ -110,14 +114,17 @@ __global__ __launch_bounds__(512, 1) void memory_topk_f16_kernel(
     *reinterpret_cast<f16x8*>(xs + (size_t)row * d + ((sl ^ (row & 15)) << 3)) = hv;
   }
   __syncthreads();
-  if (tid < HBR) {
+  {                                    // |x|^2 of the fp16 rows: four lanes per row, a quarter of the slots each
+    const int row = tid >> 2, q = tid & 3;
     float s = 0.f;
-    for (int sl = 0; sl < slots; ++sl) {
-      const f16x8 v = *reinterpret_cast<const f16x8*>(xs + (size_t)tid * d + ((sl ^ (tid & 15)) << 3));
+    for (int sl = q; sl < slots; sl += 4) {
+      const f16x8 v = *reinterpret_cast<const f16x8*>(xs + (size_t)row * d + ((sl ^ (row & 15)) << 3));
 #pragma unroll
       for (int i = 0; i < 8; ++i) s += (float)v[i] * (float)v[i];
     }
-    xx[tid] = s;
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    if (q == 0) xx[row] = s;
   }
   __syncthreads();
 
@@ -219,7 +226,7 @@ __global__ __launch_bounds__(512, 1) void memory_topk_f16_kernel(
   for (int t = 0; t < HRT; ++t)
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      const int o = ((t * 32 + l31) * 16 + wave * 2 + h) * K + j;
+      const int o = (t * 32 + l31) * CROW + (wave * 2 + h) * K + j;
       cand_v[o] = bv[t][j];
       cand_i[o] = bi[t][j];
     }
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(512, 1) void memory_topk_f16_kernel(
     int ix[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) { v[j] = INFINITY; ix[j] = 0x7fffffff; }
-    for (int c = 0; c < 16 * K; ++c) topk_insert16<K>(v, ix, cand_v[tid * 16 * K + c], cand_i[tid * 16 * K + c]);
+    for (int c = 0; c < 16 * K; ++c) topk_insert16<K>(v, ix, cand_v[tid * CROW + c], cand_i[tid * CROW + c]);
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       best[tid * K + j] = ix[j];
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(256) void pack_codebook_f16_kernel(const float* __r
 template <int K, int NSTEP>
 int launch_topk16n(const float* x, const void* e_kblk, const float* e_md, const float* enorm16, int n, int d, int m,
                    int* idx, float* q_topk, float* q_one, float* diff_partial, hipStream_t stream) {
-  const size_t region0 = std::max((size_t)HBR * d * 2, (size_t)HBR * 16 * K * 8);
+  const size_t region0 = std::max((size_t)HBR * d * 2, (size_t)HBR * (16 * K + 1) * 8);
   const size_t lds = region0 + sizeof(float) * (HBR + HBR * K + 512 + HWAVES * TS * 32);
   auto kern = memory_topk_f16_kernel<K, NSTEP>;
   if (lds > 160 * 1024) return AMMC_EUNSUP;
