@@ -418,6 +418,18 @@ def run_train(args, rank, world, dev, dist, steps, warmup, with_cpu):
 
 # ---- configs[4]: the memory-addressing kernel alone ------------------------------------------------------------------------
 
+def stress_traffic(n_rows):
+    """HBM-side bytes per launch of the stress kernel from the committed PMC passes (null when the profile was taken at
+    another row count)"""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_stress_pmc_traffic.json")))[::-1]:
+        with open(path) as fp:
+            prof = json.load(fp)
+        if prof.get("workload", {}).get("rows") == n_rows and "memory_topk_f16" in prof.get("kernels", {}):
+            return prof["kernels"]["memory_topk_f16"]["traffic_bytes_per_launch"]
+    return None
+
+
 def stress_parity(ms, x, qk, idx, d, m, k, rows=4096):
     """the bench's OWN launch against the CPU oracle (`Quantize_topk.forward`, fp32) on a slice of its rows: indices
     must agree wherever the distance margin exceeds what fp16 operands can resolve (4e-3 of the distance scale, the
@@ -500,7 +512,9 @@ def run_stress(args, rank, world, dev, dist, steps, warmup, with_cpu):
         "whole_path_tflops": round(rows * steps / elapsed * 2.0 * d * m / 1e12 / world, 2),
         "parity": parity,
         "roofline": {"kernel": "memory_topk_f16", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": None,
+                     "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": stress_traffic(n),
+                     "mfma_busy_frac": pmc_busy("memory_topk_f16", "stress")[0] if frames_per_gpu == 256 else None,
+                     "mfma_busy_source": pmc_busy("memory_topk_f16", "stress")[1] if frames_per_gpu == 256 else None,
                      "flops_per_launch": ms.flops(n), "avg_launch_us": round(us, 2), "launches_per_step": 1,
                      "algorithmic_bytes_per_launch": ms.algorithmic_bytes(n)},
         "cpu_baseline": cpu_baseline_stress(d, m, k) if with_cpu else None,
@@ -582,6 +596,33 @@ def pmc_traffic(kernel: str, precision: str, args):
     return None, None
 
 
+def pmc_busy(kernel: str, mode: str):
+    """share of the launch's shader cycles (at the clock the chip held) in which a SIMD's matrix pipe was busy:
+    (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs), from the committed PMC passes of this very
+    command (tools/profile_round.sh -> profiles/rNN_<mode>_pmc_busy.json; counters cannot be read live)."""
+    import glob
+    import re
+
+    def norm(name):
+        name = re.sub(r"^ammc\w*::", "", name).replace("_kernel", "")
+        m = re.match(r"(conv_tap_s16)<(.*)>$", name)
+        if m:                                         # the template's seventh argument (KH) is 0 for the tap-by-tap forms
+            a = [v.strip() for v in m.group(2).split(",")]
+            if len(a) == 7 and a[6] == "0":
+                a = a[:6]
+            name = f"{m.group(1)}<{', '.join(a)}>"
+        return re.sub(r"<[^>]*>$", "", name) if name.startswith("memory_topk") else name
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{mode}_pmc_busy.json")))[::-1]:
+        with open(path) as fp:
+            prof = json.load(fp)
+        for k, v in prof.get("kernels", {}).items():
+            if norm(k) == norm(kernel) and "mfma_busy_frac" in v:
+                return v["mfma_busy_frac"], {"file": os.path.relpath(path, ROOT), "command": prof.get("workload"),
+                                             "commit": prof.get("commit")}
+    return None, None
+
+
 def roofline_of(dom, reps, precision, args):
     name, a = dom
     s16 = precision == "s16"
@@ -590,9 +631,11 @@ def roofline_of(dom, reps, precision, args):
     # per algorithmic product, so frac <= 1/3 by construction against the dense fp16 peak
     peak = PEAK_F16_MFMA_TFLOPS if s16 else PEAK_F32_MFMA_TFLOPS
     traffic, source = pmc_traffic(name, precision, args)
+    busy, busy_src = pmc_busy(name, "infer") if (args.batch, args.size, args.n_embed, precision) == (16, 256, 2000, "s16") else (None, None)
     return {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
             "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": source,
             "mfma_issue_frac": round((3.0 if s16 else 1.0) * achieved / peak, 4),
+            "mfma_busy_frac": busy, "mfma_busy_source": busy_src,
             "flops_per_launch": a["flops"] / a["launches"], "avg_launch_us": round(1e3 * a["ms"] / a["launches"], 2),
             "launches_per_step": a["launches"] // reps,
             "algorithmic_bytes_per_launch": a["bytes"] / a["launches"]}
