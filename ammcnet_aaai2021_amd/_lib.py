@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # AMMC_LIB: another build of the SAME library (A/B measurements: `python -m ammcnet_aaai2021_amd.build --variant x`)
 LIB_PATH = os.environ.get("AMMC_LIB") or os.path.join(HERE, "libammc_hip.so")
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU = 0, 1, 2, 3
 
@@ -31,7 +31,7 @@ class AmmcConvDesc(C.Structure):
         ("x_bs", _i64), ("x_rs", _i64), ("x_ps", _i64),
         ("y_bs", _i64), ("y_rs", _i64), ("y_ps", _i64),
         ("r_bs", _i64), ("r_rs", _i64), ("r_ps", _i64),
-        ("y_cs", _i64), ("x_step", _i32), ("y_f32", _i32), ("reserved2", _i32), ("reserved3", _i32), ("overflow_flag", _p),
+        ("y_cs", _i64), ("x_step", _i32), ("y_f32", _i32), ("s16_mf", _i32), ("outc_stream", _i32), ("overflow_flag", _p),
         ("splitk_ws", _p), ("splitk_ws_floats", _i64), ("sq_target", _p), ("sq_acc", _p),
         ("pool_y", _p), ("pool_bs", _i64), ("pool_rs", _i64), ("pool_ps", _i64),
     ]

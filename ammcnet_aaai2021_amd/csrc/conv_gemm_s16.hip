@@ -637,7 +637,7 @@ static int conv_gemm_s16_dispatch(const AmmcConvDesc* desc, void* stream, char* 
   const AmmcConvDesc& d = *desc;
   if (d.batch <= 0 || d.height <= 0 || d.width <= 0) return AMMC_EINVAL;
   if (d.ntaps != 9 && d.ntaps != 1 && d.ntaps != 4) return AMMC_EINVAL;
-  if (d.reserved2) return AMMC_EUNSUP;
+  if (d.s16_mf < 0 || d.s16_mf > 2 || d.outc_stream < 0 || d.outc_stream > 2) return AMMC_EINVAL;
   if (d.ntaps != 1 && (d.cin < 8 || (d.cin & (d.cin - 1)))) return AMMC_EUNSUP;    // whole groups of 8
   if (d.x_step < 0 || d.x_step > 2) return AMMC_EINVAL;
   if (d.ntaps == 1 && (d.cin <= 0 || d.cin % 32)) return AMMC_EUNSUP;

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(O_NT, 1) void conv_outc_s16_kernel(OutcArgs a) {
 // kernel's (the halo-patch kernel then takes it), else the launch status.
 int conv_outc_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream, char* label, int label_len) {
   constexpr int OUTC_SKIP = -12345;
-  if (!ammc_opt_outc_stream()) return OUTC_SKIP;
+  if (!(d.outc_stream ? d.outc_stream - 1 : ammc_opt_outc_stream())) return OUTC_SKIP;   // per call, else the process default
   const int ns = d.n_store > 0 ? d.n_store : d.n;
   if (d.ntaps != 9 || d.up != 1 || d.x_step > 1 || !d.y_f32 || d.n != 32 || ns > 4 || d.res || d.pool_y) return OUTC_SKIP;
   if (d.cin % 32 || d.cin / 32 > O_MAXCC || d.width % O_TW || d.height % O_TH) return OUTC_SKIP;

@@ -1009,7 +1009,7 @@ int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream, char* 
   // batch 16, 256x256 on one MI355X: output layer 147 -> 123 us and 64-filter layers 306 -> 293 us
   // with 16x16x32, 128-filter layers 213 -> 220 us (twice the MFMA instructions leave the fragment reads and the
   // 2^-11 scaling half the issue slots), the 8-wave two-accumulator variant 165 -> 158 us
-  const int mfo = ammc_opt_s16_mf();
+  const int mfo = d.s16_mf ? d.s16_mf - 1 : ammc_opt_s16_mf();      // the call's own choice, else the process default
   const int64_t ntiles = (int64_t)d.batch * (d.height / T_TH) * (d.width / T_TW) * (d.n <= 64 ? 1 : d.n / 128);
   const bool wide4 = d.n > 64 && (mode == 4 || (mode == 1 && ntiles >= 512));          // the 4-wave 128-filter variant
   const int mf = mfo < 0 ? (wide4 ? 0 : 1) : mfo;

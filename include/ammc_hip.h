@@ -46,8 +46,9 @@ const char* ammc_error_string(int code);
  *             variant (default), 1 = v_mfma_f32_16x16x32_f16, 0 = v_mfma_f32_32x32x16_f16.  Initial value: AMMC_S16_MF.
  *   "outc_stream"  1 = the output layer (32-filter tile, fp32 NCHW output) on the streaming kernel conv_outc_s16
  *             (default), 0 = on the halo-patch kernel.  Initial value: AMMC_OUTC_STREAM.
- * Returns AMMC_EUNSUP for an unknown key, AMMC_EINVAL for a value out of range.  Not thread safe against
- * concurrent launches. */
+ * Returns AMMC_EUNSUP for an unknown key, AMMC_EINVAL for a value out of range.  These are PROCESS defaults
+ * (not thread safe against concurrent launches); a caller that needs a per-call choice sets the descriptor fields
+ * `s16_mf` / `outc_stream` instead, which take precedence and touch no global state. */
 int ammc_set_option(const char* key, int32_t value);
 
 /*
@@ -93,8 +94,8 @@ typedef struct AmmcConvDesc {
   int64_t y_cs;          /* output channel stride: 0/1 = NHWC; H*W (with y_ps=1, y_rs=W) = NCHW    */
   int32_t x_step;        /* 0/1; 2 = the input is at twice the resolution of m (with ntaps=4: the  */
   int32_t y_f32;         /* (2x2 stride-2 gather of the ConvTranspose dgrad).  y_f32: ammc_conv_gemm_s16 only, 1 = fp32 output */
-  int32_t reserved2;     /* 0 */
-  int32_t reserved3;
+  int32_t s16_mf;        /* ammc_conv_gemm_s16 only, per CALL (re-entrant): 0 = the process default (ammc_set_option "s16_mf"), 1 = v_mfma_f32_32x32x16_f16, */
+  int32_t outc_stream;   /* 2 = v_mfma_f32_16x16x32_f16 forced.  outc_stream: 0 = process default, 1 = halo-patch kernel, 2 = streaming kernel */
   int32_t* overflow_flag; /* ammc_conv_gemm_s16 only, may be NULL: set to 1 when an S16 output exceeds the half range */
   float* splitk_ws;      /* ammc_conv_gemm_s16 only, may be NULL: fp32 workspace that lets small-M layers split K    */
   int64_t splitk_ws_floats; /* over workgroups ([ksplit][M][N] partial tiles + a finishing kernel)                   */

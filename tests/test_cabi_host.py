@@ -5,6 +5,8 @@ import json
 import os
 import re
 
+import ctypes as C
+
 import pytest
 import torch
 
@@ -128,7 +130,20 @@ def test_s16_dispatch_of_the_benchmark_shapes():
     assert s16_variant(d) == "conv_gemm_s16<128x128>"
     d.splitk_ws, d.splitk_ws_floats = 0x400000, 8 << 20
     assert s16_variant(d).startswith("conv_gemm_s16<128x128>+splitk")
-    lib = _lib.load()                                                        # the A/B switch of the MFMA shape
+    # per-CALL choices through the descriptor (re-entrant: no process state is touched)
+    dd = _fake_desc(B, 128, 128, 128, 128)
+    dd.s16_mf = 2
+    assert s16_variant(dd) == "conv_tap_s16<4, 1, 2, 4, 1, 1>"
+    dd.s16_mf = 1
+    assert s16_variant(dd) == "conv_tap_s16<4, 1, 2, 4, 1, 0>"
+    assert s16_variant(_fake_desc(B, 128, 128, 128, 128)) == "conv_tap_s16<4, 1, 2, 4, 1, 0, 1>"      # the default is untouched
+    outc.outc_stream = 1
+    assert s16_variant(outc) == "conv_tap_s16<4, 1, 2, 1, 1, 1>"
+    outc.outc_stream = 0
+    assert s16_variant(outc) == "conv_outc_s16"
+    dd.s16_mf = 3
+    assert _lib.load().ammc_conv_gemm_s16_variant(C.byref(dd), C.create_string_buffer(64), 64) == -1     # AMMC_EINVAL
+    lib = _lib.load()                                                        # the process-wide A/B switch of the MFMA shape
     assert lib.ammc_set_option(b"s16_mf", 1) == 0
     assert s16_variant(_fake_desc(B, 128, 128, 128, 128)) == "conv_tap_s16<4, 1, 2, 4, 1, 1>"
     assert lib.ammc_set_option(b"s16_mf", 0) == 0
