@@ -40,7 +40,6 @@ extern "C" void ammc_debug_set_tap_stamps(void* p) { g_tap_stamps = (unsigned lo
 struct TapArgs {
   AmmcConvDesc d;
   int tiles_x, tiles_y, n_tiles, ncc, kpad, dbg;
-  int total, delay;                 // persistent form: number of tiles; start delay of class B in 10-ns ticks
   unsigned long long* stamps;       // diagnostic builds (AMMC_TAP_STAMP)
 };
 
@@ -911,25 +910,10 @@ __global__ TAP_BOUNDS void conv_tap_s16_kernel(TapArgs a) {
   conv_tap_s16_tile<WGM, WGN, TM, TN, AS, MF, KH>(a, blockIdx.x, gridDim.x, (blockIdx.x >> 8) & 1);
 }
 
-// Persistent form: the grid is what the chip holds at once (two 4-wave workgroups per CU: 512; one 8-wave: 256) and a
-// workgroup walks the tiles vb = blockIdx.x, blockIdx.x + gridDim.x, ...  Why: workgroups that are dispatched as slots
-// free up start their tiles TOGETHER with their CU-mate (tools/micro/census.hip: the two workgroups of a CU start within
-// 0.08 us of each other in every round, and only in the FIRST round is the pair (b, b + 256)), so both stream their patch,
-// both contract and both store at the same moments, on every CU of the chip at once: the matrix pipe idles through
-// every memory phase and HBM idles through every contraction.  Here the pairing is fixed for the whole launch -
-// blockIdx.x and blockIdx.x + 256 share a CU - and class B (blockIdx.x >= gridDim.x / 2) starts `a.delay` ticks of the
-// 100-MHz clock late, i.e. about half a tile behind its CU-mate, and stays there: one workgroup's memory phases run
-// behind the other's MFMAs.
-template <int WGM, int WGN, int TM, int TN, int AS, int MF, int KH>
-__global__ TAP_BOUNDS void conv_tap_s16_pers_kernel(TapArgs a) {
-  const bool class_b = blockIdx.x >= (gridDim.x >> 1);
-  if (class_b && a.delay > 0) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < a.delay) __builtin_amdgcn_s_sleep(8);
-  }
-  for (int vb = blockIdx.x; vb < a.total; vb += gridDim.x)
-    conv_tap_s16_tile<WGM, WGN, TM, TN, AS, MF, KH>(a, vb, a.total, false);
-}
+// (A persistent form of this kernel - 512 workgroups walking the tiles, blockIdx.x and blockIdx.x + 256 sharing a CU for
+// the whole launch, class B started half a tile late so that one workgroup's memory phases run behind the other's MFMAs -
+// was built and measured in round 3: 1-4 % SLOWER at every delay.  Removed; DESIGN.md section 5, round 3, has the numbers
+// and tools/micro/census.hip the placement measurement.)
 
 template <int WGM, int WGN, int TM, int TN, int AS = 2, int MF = 0, int KH = 0>
 static int launch_tap(const TapArgs& a, hipStream_t stream, char* label, int label_len) {
@@ -955,20 +939,6 @@ static int launch_tap(const TapArgs& a, hipStream_t stream, char* label, int lab
   TapArgs b = a;
   b.n_tiles = a.d.n / BN;
   const int grid = a.d.batch * a.tiles_y * a.tiles_x * b.n_tiles;
-  // persistent form (AMMC_TAP_PERS: 0 = off, 1 = when a workgroup gets at least two tiles); class B's delay in units of
-  // AMMC_TAP_DELAY x 0.01 us per 32-channel block of a tile
-  static const int pers = getenv("AMMC_TAP_PERS") ? atoi(getenv("AMMC_TAP_PERS")) : 0;
-  static const int delay_unit = getenv("AMMC_TAP_DELAY") ? atoi(getenv("AMMC_TAP_DELAY")) : 0;
-  const int resident = NT == 256 && lds <= 80 * 1024 ? 512 : 256;
-  if (pers && AS == 1 && NT == 256 && grid >= 2 * resident) {
-    auto pk = conv_tap_s16_pers_kernel<WGM, WGN, TM, TN, AS, MF, KH>;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    b.total = grid;
-    b.delay = delay_unit * a.ncc;
-    hipLaunchKernelGGL(pk, dim3(resident), dim3(NT), lds, stream, b);
-    return ammc_launch_status();
-  }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, stream, b);
   return ammc_launch_status();
 }
@@ -999,7 +969,6 @@ int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream, char* 
   a.kpad = kpad;
   a.dbg = dbg;
   a.n_tiles = 0;
-  a.total = a.delay = 0;
 #ifdef AMMC_TAP_STAMP
   a.stamps = g_tap_stamps;
 #else
