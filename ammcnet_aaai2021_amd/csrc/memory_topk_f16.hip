@@ -88,7 +88,7 @@ __global__ __launch_bounds__(512, 1) void memory_topk_f16_kernel(
   _Float16* xs = reinterpret_cast<_Float16*>(smem_raw);
   float* cand_v = reinterpret_cast<float*>(smem_raw);
   int* cand_i = reinterpret_cast<int*>(cand_v + HBR * CROW);
-  float* xx = reinterpret_cast<float*>(smem_raw + region0);             // [HBR]
+  float* xx = reinterpret_cast<float*>(smem_raw + region0);             // [HBR] (unused since the ranking dropped |x|^2)
   int* best = reinterpret_cast<int*>(xx + HBR);                         // [HBR][K]
   float* red = reinterpret_cast<float*>(best + HBR * K);                // [512]
   float* enl = red + 512;                                               // [HWAVES][TS * 32]: slot norms of a wave's tile pair
@@ -114,29 +114,12 @@ __global__ __launch_bounds__(512, 1) void memory_topk_f16_kernel(
     *reinterpret_cast<f16x8*>(xs + (size_t)row * d + ((sl ^ (row & 15)) << 3)) = hv;
   }
   __syncthreads();
-  {                                    // |x|^2 of the fp16 rows: four lanes per row, a quarter of the slots each
-    const int row = tid >> 2, q = tid & 3;
-    float s = 0.f;
-    for (int sl = q; sl < slots; sl += 4) {
-      const f16x8 v = *reinterpret_cast<const f16x8*>(xs + (size_t)row * d + ((sl ^ (row & 15)) << 3));
-#pragma unroll
-      for (int i = 0; i < 8; ++i) s += (float)v[i] * (float)v[i];
-    }
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    if (q == 0) xx[row] = s;
-  }
-  __syncthreads();
-
   float bv[HRT][K];
   int bi[HRT][K];
 #pragma unroll
   for (int t = 0; t < HRT; ++t)
 #pragma unroll
     for (int j = 0; j < K; ++j) { bv[t][j] = INFINITY; bi[t][j] = 0x7fffffff; }
-  float xnorm[HRT];
-#pragma unroll
-  for (int t = 0; t < HRT; ++t) xnorm[t] = xx[t * 32 + l31];
 
   const int ntile = mpad >> 5;
   constexpr int nstep = NSTEP;                            // k-steps of 16 features (d == 16 NSTEP: the launcher checks)
@@ -201,20 +184,33 @@ __global__ __launch_bounds__(512, 1) void memory_topk_f16_kernel(
         for (int u = 0; u < TS; ++u) acc[u][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u], bf, acc[u][rt], 0, 0, 0);
       }
     }
+    // The ranking needs |E_s|^2 - 2 x.E_s only (|x|^2 is the same for every slot of a row; the commit distance is
+    // recomputed in fp32 by the gather phase): one FMA per candidate.  A tile's 16 candidates of a row are first reduced
+    // to their minimum (v_min3: 8 operations); only a tile whose minimum beats the row's K-th best - after the first few
+    // tiles almost none - runs the ordered insertion.  (The first form spent ~770 VALU operations per tile pair and wave
+    // on this epilogue, a third of the pair's MFMA time; now ~200.)
 #pragma unroll
     for (int u = 0; u < TS; ++u) {
       if (tile + u >= ntile) break;
       const int s0 = (tile + u) << 5;
+      float en[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int s = s0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (s < m) {
-          const float en = enl[wave * (TS * 32) + u * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+        const int o = (r & 3) + 8 * (r >> 2) + 4 * h;
+        en[r] = s0 + o < m ? enl[wave * (TS * 32) + u * 32 + o] : INFINITY;       // slots beyond m never win
+      }
 #pragma unroll
-          for (int rt = 0; rt < HRT; ++rt) {
-            const float dist = (xnorm[rt] - 2.f * acc[u][rt][r]) + en;
-            topk_insert16_ordered<K>(bv[rt], bi[rt], dist, s);
-          }
+      for (int rt = 0; rt < HRT; ++rt) {
+        float dist[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dist[r] = __builtin_fmaf(acc[u][rt][r], -2.f, en[r]);
+        float mn = __builtin_fminf(__builtin_fminf(dist[0], dist[1]), dist[2]);
+#pragma unroll
+        for (int r = 3; r + 1 < 16; r += 2) mn = __builtin_fminf(__builtin_fminf(mn, dist[r]), dist[r + 1]);
+        mn = __builtin_fminf(mn, dist[15]);
+        if (mn < bv[rt][K - 1]) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) topk_insert16_ordered<K>(bv[rt], bi[rt], dist[r], s0 + (r & 3) + 8 * (r >> 2) + 4 * h);
         }
       }
     }
