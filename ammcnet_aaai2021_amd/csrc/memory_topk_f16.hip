@@ -29,7 +29,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int HBR = 128;          // feature rows per workgroup
 constexpr int HRT = HBR / 32;
 constexpr int HWAVES = 8;
-constexpr int PF = 4;             // A-fragment prefetch depth (k-steps of 16; a step is 8 MFMAs = 256 cycles of the pipe)
+constexpr int PF = 4;             // A-fragment prefetch depth (6: the same; 8: spills) (k-steps of 16; a step is 8 MFMAs = 256 cycles of the pipe)
 constexpr int TS = 2;             // slot tiles per wave iteration
 
 template <int K>
@@ -135,11 +135,14 @@ __global__ __launch_bounds__(512, 1) void memory_topk_f16_kernel(
     // t + PF is pinned before the MFMAs of step t (sched_barrier); the source offset advances incrementally behind an
     // opaque asm, like the swizzle of the LDS fragment addresses (hoisted out of the tile loop, the 32 x 4 addresses of
     // the unrolled steps spill).
+    // |E_s|^2 of the 64 slots of this tile pair: one 4-byte load per lane, requested first (older than every ring load),
+    // parked in a register and handed to the wave's row of `enl` right before the epilogue.  (It was an LDS-DMA: hipcc
+    // books __builtin_amdgcn_global_load_lds as a FLAT access, after which every wait it inserts for an LDS read is
+    // lgkmcnt(0) - the fragment reads of the k-loop could not be issued ahead of the MFMAs that do not need them.)
+    float en_reg;
     {
-      // |E_s|^2 of the 64 slots of this tile pair: one 4-byte LDS-DMA per lane into the wave's own row of `enl`,
-      // requested first, read in the epilogue (no registers; older than every ring load)
       const int s_ = ((tile + (lane >> 5) < ntile ? tile + (lane >> 5) : ntile - 1) << 5) + l31;
-      __builtin_amdgcn_global_load_lds(enorm16 + (s_ < m ? s_ : m - 1), enl + wave * (TS * 32), 4, 0, 0);
+      en_reg = enorm16[s_ < m ? s_ : m - 1];
     }
     const int64_t kstride = (int64_t)2 * mpad;                           // f16x8 elements between k-steps
     const int swz = l31 & 15;
@@ -160,6 +163,18 @@ __global__ __launch_bounds__(512, 1) void memory_topk_f16_kernel(
     int64_t eoff = (int64_t)PF * kstride;        // wave uniform; opaque so that the 32 offsets are not pre-computed
     asm volatile("" : "+s"(eoff));               // (on the pointer itself the asm would turn it into a FLAT pointer)
     __builtin_amdgcn_sched_barrier(0);
+    // feature fragments one k-step ahead in a second register set (left to itself hipcc reads each fragment right in
+    // front of its two MFMAs and waits lgkmcnt(0): four exposed LDS latencies per k-step, 48 % of the matrix pipe)
+    f16x8 bf[2][HRT];
+#define MT_LOAD_B(t_, buf_)                                                                                \
+  {                                                                                                        \
+    int sw_ = swz;                                                       /* (opaque: the 32 x 4 fragment addresses of the */ \
+    asm volatile("" : "+v"(sw_));                                        /*  unrolled steps must not be hoisted into registers) */ \
+    const int so_ = (((2 * (t_) + h) ^ sw_) << 3);                                                         \
+    _Pragma("unroll") for (int rt = 0; rt < HRT; ++rt)                                                     \
+      bf[buf_][rt] = *reinterpret_cast<const f16x8*>(xrow + (size_t)(rt * 32) * d + so_);                  \
+  }
+    MT_LOAD_B(0, 0)
 #pragma unroll
     for (int t = 0; t < nstep; ++t) {
       const int p = t % PF;
@@ -173,17 +188,17 @@ __global__ __launch_bounds__(512, 1) void memory_topk_f16_kernel(
         eoff += kstride;
         asm volatile("" : "+s"(eoff));
       }
+      MT_LOAD_B((t + 1 < nstep ? t + 1 : t), (t + 1) & 1)
       __builtin_amdgcn_sched_barrier(0);
-      int sw = swz;                                                      // (opaque: the 32 x 4 fragment addresses of the
-      asm volatile("" : "+v"(sw));                                       //  unrolled steps must not be hoisted into registers)
-      const int so = (((2 * t + h) ^ sw) << 3);
+      __builtin_amdgcn_s_waitcnt(0xC07F | (HRT << 8));                   // lgkmcnt(HRT): everything but the reads just issued
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int rt = 0; rt < HRT; ++rt) {
-        const f16x8 bf = *reinterpret_cast<const f16x8*>(xrow + (size_t)(rt * 32) * d + so);
+      for (int rt = 0; rt < HRT; ++rt)
 #pragma unroll
-        for (int u = 0; u < TS; ++u) acc[u][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u], bf, acc[u][rt], 0, 0, 0);
-      }
+        for (int u = 0; u < TS; ++u) acc[u][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u], bf[t & 1][rt], acc[u][rt], 0, 0, 0);
     }
+#undef MT_LOAD_B
+    enl[wave * (TS * 32) + lane] = en_reg;                               // (same wave writes and reads: no barrier)
     // The ranking needs |E_s|^2 - 2 x.E_s only (|x|^2 is the same for every slot of a row; the commit distance is
     // recomputed in fp32 by the gather phase): one FMA per candidate.  A tile's 16 candidates of a row are first reduced
     // to their minimum (v_min3: 8 operations); only a tile whose minimum beats the row's K-th best - after the first few
