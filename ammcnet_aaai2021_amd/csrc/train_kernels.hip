@@ -452,36 +452,46 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_s16_kernel(
 
 // MaxPool2d(2) backward (+ the gradient that reaches the same tensor through the skip path):
 // dx[2y+i][2x+j] = add[2y+i][2x+j] + (first max position in row-major window order ? dp[y][x] : 0)
+// x / add / dx are fh x fw (fh = 2h or 2h+1): the last row / column of an odd size belongs to no window (MaxPool2d floors)
+// and receives only `add` (or zero); the grid covers ceil(fh/2) x ceil(fw/2) window positions.
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(
     const float* __restrict__ x, Tensor3 xt, const float* __restrict__ dp, Tensor3 pt,
-    const float* __restrict__ add, Tensor3 at, float* __restrict__ dx, Tensor3 ot, int M, int h, int w, int C4) {
+    const float* __restrict__ add, Tensor3 at, float* __restrict__ dx, Tensor3 ot, int M, int h, int w, int fh, int fw,
+    int C4) {
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (gid >= (int64_t)M * C4) return;
+  const int hh = (fh + 1) >> 1, ww = (fw + 1) >> 1;
   const int c4 = (int)(gid % C4);
   const int m = (int)(gid / C4);
-  const int xx = m % w, q = m / w, yy = q % h, b = q / h;
-  const float* s = x + (int64_t)b * xt.bs + (int64_t)(2 * yy) * xt.rs + (int64_t)(2 * xx) * xt.ps + c4 * 4;
-  const f32x4 g = *reinterpret_cast<const f32x4*>(dp + (int64_t)b * pt.bs + (int64_t)yy * pt.rs + (int64_t)xx * pt.ps + c4 * 4);
-  f32x4 v[4];
-  v[0] = *reinterpret_cast<const f32x4*>(s);
-  v[1] = *reinterpret_cast<const f32x4*>(s + xt.ps);
-  v[2] = *reinterpret_cast<const f32x4*>(s + xt.rs);
-  v[3] = *reinterpret_cast<const f32x4*>(s + xt.rs + xt.ps);
+  const int xx = m % ww, q = m / ww, yy = q % hh, b = q / hh;
   f32x4 o[4];
+  if (yy < h && xx < w) {
+    const float* s = x + (int64_t)b * xt.bs + (int64_t)(2 * yy) * xt.rs + (int64_t)(2 * xx) * xt.ps + c4 * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dp + (int64_t)b * pt.bs + (int64_t)yy * pt.rs + (int64_t)xx * pt.ps + c4 * 4);
+    f32x4 v[4];
+    v[0] = *reinterpret_cast<const f32x4*>(s);
+    v[1] = *reinterpret_cast<const f32x4*>(s + xt.ps);
+    v[2] = *reinterpret_cast<const f32x4*>(s + xt.rs);
+    v[3] = *reinterpret_cast<const f32x4*>(s + xt.rs + xt.ps);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int arg = 0;
-    float best = v[0][i];
+    for (int i = 0; i < 4; ++i) {
+      int arg = 0;
+      float best = v[0][i];
 #pragma unroll
-    for (int j = 1; j < 4; ++j)
-      if (v[j][i] > best) { best = v[j][i]; arg = j; }
+      for (int j = 1; j < 4; ++j)
+        if (v[j][i] > best) { best = v[j][i]; arg = j; }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j][i] = (j == arg) ? g[i] : 0.f;
+      for (int j = 0; j < 4; ++j) o[j][i] = (j == arg) ? g[i] : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int64_t po = (int64_t)(j >> 1);
     const int64_t qo = (int64_t)(j & 1);
+    if (2 * yy + po >= fh || 2 * xx + qo >= fw) continue;
     if (add) {
       const f32x4 a = *reinterpret_cast<const f32x4*>(add + (int64_t)b * at.bs + (2 * yy + po) * at.rs + (2 * xx + qo) * at.ps + c4 * 4);
 #pragma unroll
@@ -868,12 +878,13 @@ int ammc_reduce_partials_f32(const float* partial, int32_t nblocks, int32_t qc, 
 int ammc_maxpool2x2_bwd_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, const float* dp, int64_t p_bs,
                             int64_t p_rs, int64_t p_ps, const float* add, int64_t a_bs, int64_t a_rs, int64_t a_ps,
                             float* dx, int64_t o_bs, int64_t o_rs, int64_t o_ps, int32_t batch, int32_t h, int32_t w,
-                            int32_t c, void* stream) {
+                            int32_t in_h, int32_t in_w, int32_t c, void* stream) {
   if (!x || !dp || !dx || batch <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3)) return AMMC_EINVAL;
-  const int M = batch * h * w;
+  if ((in_h >> 1) != h || (in_w >> 1) != w) return AMMC_EINVAL;
+  const int M = batch * ((in_h + 1) >> 1) * ((in_w + 1) >> 1);
   Tensor3 xt{x_bs, x_rs, x_ps}, pt{p_bs, p_rs, p_ps}, at{a_bs, a_rs, a_ps}, ot{o_bs, o_rs, o_ps};
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblk((int64_t)M * (c >> 2))), dim3(256), 0, (hipStream_t)stream, x, xt,
-                     dp, pt, add, at, dx, ot, M, h, w, c >> 2);
+                     dp, pt, add, at, dx, ot, M, h, w, in_h, in_w, c >> 2);
   return ammc_launch_status();
 }
 

@@ -61,7 +61,15 @@ class Act:
         return _ptr(self.buf, self.halo * (self.rs + self.ps) + self.c_off)
 
     def slice(self, c_off: int, c: int) -> "Act":
-        return Act(self.buf, self.B, self.H, self.W, c, self.c_off + c_off, self.halo)
+        a = Act(self.buf, self.B, self.H, self.W, c, self.c_off + c_off, self.halo)
+        a.rs, a.bs = self.rs, self.bs
+        return a
+
+    def crop(self, H: int, W: int) -> "Act":
+        """the top-left H x W pixels of the same buffer (strides unchanged)"""
+        a = Act(self.buf, self.B, self.H, self.W, self.c, self.c_off, self.halo)
+        a.H, a.W = H, W
+        return a
 
     def interior(self) -> torch.Tensor:
         """NHWC view [B,H,W,c] (for tests / debugging)"""

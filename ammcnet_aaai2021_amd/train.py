@@ -122,7 +122,9 @@ class _Ops:
         buf = self._shadows.get(key)
         if buf is None:
             buf = self._shadows[key] = self.ws.buf(*a.buf.shape)
-        return Act(buf, a.B, a.H, a.W, a.c, a.c_off, a.halo)
+        t = Act(buf, a.B, a.H, a.W, a.c, a.c_off, a.halo)
+        t.rs, t.bs = a.rs, a.bs                       # (a cropped view keeps its buffer's strides)
+        return t
 
     def to_s16(self, x: Act, rescale: bool = False, have_amax: bool = False, amax: Optional[torch.Tensor] = None):
         """re-encode the fp32 buffer behind `x` into its S16 twin; `rescale` (gradients): first bring it into the half
@@ -435,10 +437,8 @@ class _Stream:
     """one U-Net stream (`UNet` / `UNetMem_v7`) in training mode"""
 
     def __init__(self, ops: _Ops, net, B, H, W, has_vq: bool):
-        if H % 8 or W % 8:
-            raise NotImplementedError(
-                f"training at frame size {H}x{W}: the training kernels need H and W divisible by 8 (every harness use of "
-                "the reference is 256x256); the evaluation engine takes any size >= 8 (odd levels padded as `up.forward` does)")
+        if H < 8 or W < 8:
+            raise ValueError(f"frame size {H}x{W}: three 2x2 poolings need at least 8x8")
         ws, lib = ops.ws, ops.lib
         self.ops, self.net, self.B, self.H, self.W, self.has_vq = ops, net, B, H, W, has_vq
         self.cin = net.inc.conv.conv[0].weight.shape[1]
@@ -623,9 +623,11 @@ class _Stream:
             c = CHANS[lvl]
             m = self.up_mods[j]
             yield from self.up_dc[j].backward_gen(self.du[j], self.dcat[lvl], None, grads)
-            dys = self.dcat[lvl].slice(c, c)                         # gradient of the ConvTranspose output
-            grads[m.up.bias] = o.chan_sum(dys, c, self.scratch)
             x_in = self.dec_in if j == 0 else self.up_out[j - 1]
+            # gradient of the ConvTranspose output: the top-left 2h x 2w of the skip-sized tensor (`up.forward` pads an
+            # odd level on the right / bottom, models/unet_parts.py; the pad's gradient is dropped)
+            dys = self.dcat[lvl].slice(c, c).crop(2 * x_in.H, 2 * x_in.W)
+            grads[m.up.bias] = o.chan_sum(dys, c, self.scratch)
             o.wgrad(x_in, dys, self.up_dwp[j], n=2 * c, cin=c, ntaps=4, a_step=2, what=f"up{j + 1}.up.wgrad")
             dwt = torch.empty_like(m.up.weight)
             _chk(lib.ammc_unpack_convt_wgrad_f32(_ptr(self.up_dwp[j]), 2 * c, c, _ptr(dwt), s), "unpack_convt")
@@ -667,7 +669,7 @@ class _Stream:
             yield from self.down[i].backward_gen(dy, self.dpooled[i], None, grads)
             sk, dpo, add, out = self.skip[i], self.dpooled[i], self.dcat[i].slice(0, CHANS[i]), self.dskip_tot[i]
             _chk(lib.ammc_maxpool2x2_bwd_f32(sk.pix0(), *sk.strides, dpo.pix0(), *dpo.strides, add.pix0(), *add.strides,
-                                             out.pix0(), *out.strides, dpo.B, dpo.H, dpo.W, dpo.c, s), "maxpool_bwd")
+                                             out.pix0(), *out.strides, dpo.B, dpo.H, dpo.W, sk.H, sk.W, dpo.c, s), "maxpool_bwd")
             dy = out
         yield from self.inc.backward_gen(dy, None, None, grads)
 
@@ -839,8 +841,6 @@ class BlockEngine:
             st["x"] = ws.act(B, H, W, _cin_pad(cin))
             src = st["x"]
             if kind == "down":
-                if H % 2 or W % 2:
-                    raise NotImplementedError("down in training mode: even frame sizes")
                 st["pooled"] = src = ws.act(B, H // 2, W // 2, _cin_pad(cin))
                 st["dpooled"] = ws.act(B, H // 2, W // 2, _cin_pad(cin))
             cout = dc.conv[0].weight.shape[0]
@@ -850,8 +850,9 @@ class BlockEngine:
             st["dx"] = ws.act(B, H, W, _cin_pad(cin)) if cin >= 32 else None
         elif kind == "up":
             (_, c2, h, w), (_, c, H2, W2) = shapes
-            if c2 != 2 * c or (H2, W2) != (2 * h, 2 * w):
-                raise NotImplementedError("up in training mode: x2 must have half the channels and exactly twice the size of x1")
+            if c2 != 2 * c or (H2 // 2, W2 // 2) != (h, w):
+                raise NotImplementedError("up in training mode: x2 must have half the channels and twice the size of x1 "
+                                          "(+1 for an odd level, padded on the right / bottom as `up.forward` does)")
             st["x1"] = ws.act(B, h, w, c2)
             st["cat"] = ws.act(B, H2, W2, c2)
             st["y"], st["dy"] = ws.act(B, H2, W2, m.conv.conv[0].weight.shape[0]), ws.act(B, H2, W2, m.conv.conv[0].weight.shape[0])
@@ -933,7 +934,7 @@ class BlockEngine:
                 if dpo is not None:
                     x, out = st["x"], st["dx"]
                     _chk(lib.ammc_maxpool2x2_bwd_f32(x.pix0(), *x.strides, dpo.pix0(), *dpo.strides, None, 0, 0, 0,
-                                                     out.pix0(), *out.strides, dpo.B, dpo.H, dpo.W, dpo.c, ops.s), "maxpool_bwd")
+                                                     out.pix0(), *out.strides, dpo.B, dpo.H, dpo.W, x.H, x.W, dpo.c, ops.s), "maxpool_bwd")
                     dx = self._store(ops, out, st["dc"].u0.cin)
             ins = [dx]
         elif self.kind == "up":
@@ -942,7 +943,7 @@ class BlockEngine:
             self._load(ops, gouts[0], st["dy"])
             _lockstep(ops, st["dc"].backward_gen(st["dy"], st["dcat"], None, grads))
             dx2 = self._store(ops, st["dcat"].slice(0, c), c)
-            dys = st["dcat"].slice(c, c)
+            dys = st["dcat"].slice(c, c).crop(2 * st["x1"].H, 2 * st["x1"].W)
             grads[m.up.bias] = ops.chan_sum(dys, c, st["scratch"])
             ops.wgrad(st["x1"], dys, st["dwp"], n=2 * c, cin=c, ntaps=4, a_step=2, what="up.up.wgrad")
             dwt = torch.empty_like(m.up.weight)

@@ -367,11 +367,13 @@ int ammc_bn_bwd_apply_s16_f32(const float* c_raw, int64_t c_bs, int64_t c_rs, in
 int ammc_chan_sum_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, int32_t batch, int32_t h, int32_t w,
                       int32_t c, float* partial, void* stream);
 int ammc_reduce_partials_f32(const float* partial, int32_t nblocks, int32_t qc, float scale, float* out, void* stream);
-/* nn.MaxPool2d(2) backward (+ `add`, the gradient reaching the same tensor through the skip) */
+/* nn.MaxPool2d(2) backward (+ `add`, the gradient reaching the same tensor through the skip).  h, w: the pooled size;
+ * in_h, in_w: the size of x / add / dx (2h or 2h+1: the last row / column of an odd size is in no window and gets `add`
+ * alone, as MaxPool2d's floor does) */
 int ammc_maxpool2x2_bwd_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, const float* dp, int64_t p_bs,
                             int64_t p_rs, int64_t p_ps, const float* add, int64_t a_bs, int64_t a_rs, int64_t a_ps,
                             float* dx, int64_t o_bs, int64_t o_rs, int64_t o_ps, int32_t batch, int32_t h, int32_t w,
-                            int32_t c, void* stream);
+                            int32_t in_h, int32_t in_w, int32_t c, void* stream);
 /* torch.tanh backward at the module boundary: NCHW (dout, out) -> NHWC d(pre-tanh), cp channels */
 int ammc_tanh_bwd_nhwc_f32(const float* dout_nchw, const float* out_nchw, int32_t batch, int32_t c, int32_t h,
                            int32_t w, float* y, int64_t y_bs, int64_t y_rs, int64_t y_ps, int32_t cp, void* stream);

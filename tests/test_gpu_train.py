@@ -38,7 +38,8 @@ def _l2rel(a, b):
 
 
 def _train_step(net, sd, batch, hw, tag, k=2, train_precision="s16"):
-    rgb_x, op_x, rgb_t, op_t = S.make_clips(batch, hw, hw, tag=tag)
+    h, w = hw if isinstance(hw, tuple) else (hw, hw)
+    rgb_x, op_x, rgb_t, op_t = S.make_clips(batch, h, w, tag=tag)
     net.train()
     net.train_precision = train_precision
     out = net(rgb_x.to(DEV), op_x.to(DEV))
@@ -114,8 +115,9 @@ def _oracle_grads(sd, clips, dtype):
     return float(loss.detach()), {k: v.grad.double() for k, v in m.items() if v.requires_grad}, [o.detach() for o in out[:2]]
 
 
+@pytest.mark.parametrize("hw", [(64, 64), (50, 36), (27, 21)])
 @pytest.mark.parametrize("train_precision", ["s16", "fp32"])
-def test_gradients_without_relu_flips_match_the_fp64_oracle(train_precision):
+def test_gradients_without_relu_flips_match_the_fp64_oracle(train_precision, hw):
     """The tight gradient gate.  On the ordinary fixtures a pre-activation within rounding noise of 0 flips its ReLU
     mask and moves whole gradient entries (the reference's own fp32 and fp64 gradients differ by 2e-3 there), so those
     gates cannot be tight.  Here no mask can flip (`_mask_free_state`), the truth is the oracle in FLOAT64, and every
@@ -125,9 +127,11 @@ def test_gradients_without_relu_flips_match_the_fp64_oracle(train_precision):
     move forward values in the 6th digit, which re-routes ~0.01 % of the pooling windows (tools/train_fp32_debug.py:
     the inputs of `maxpool2x2_bwd` agree to 6e-6, its outputs to 1.7e-2); the S16 kernels' tree sums stay below the
     tie gaps of this fixture.  For `train_precision = "fp32"` the tensors upstream of a max-pool are therefore held
-    to 8e-3 only; everything else, and every tensor of the default S16 path, to the tight gate."""
+    to 8e-3 only; everything else, and every tensor of the default S16 path, to the tight gate.
+    50x36 (-> 25x18 -> 12x9 -> 6x4) and 27x21 (-> 13x10 -> 6x5 -> 3x2): levels of odd size, which MaxPool2d floors and
+    `up.forward` pads on the right / bottom (models/unet_parts.py)."""
     sd = _mask_free_state()
-    clips = S.make_clips(2, 64, 64, tag="maskfree")
+    clips = S.make_clips(2, hw[0], hw[1], tag="maskfree")
     loss64, g64, out64 = _oracle_grads(sd, clips, torch.float64)
     _, g32, _ = _oracle_grads(sd, clips, torch.float32)
     net = A.get_twostream((12, 6), (3, 2), 64, 256, 2)
@@ -254,6 +258,36 @@ def test_train_step_at_sizes_the_halo_patch_kernels_take():
     errs = np.array(errs)
     # (ReLU-kink noise as above; on this fixture the exact-fp32 kernels land at 7e-3 / 2.7e-3, the S16 ones at 5e-3 / 1.5e-3)
     assert errs.max() <= GTOL and np.median(errs) <= 4e-3 and errs.min() <= 1e-5, (errs.max(), np.median(errs), errs.min())
+    nsd = net.state_dict()
+    for key, v in msd.items():
+        if key not in dict(net.named_parameters()):
+            assert rel_err(nsd[key].cpu().double(), v.double()) <= 1e-4, key
+
+
+@pytest.mark.parametrize("train_precision", ["s16", "fp32"])
+@pytest.mark.parametrize("B,H,W", [(2, 100, 100)])
+def test_train_step_at_sizes_not_divisible_by_8(B, H, W, train_precision):
+    """100 -> 50 -> 25 -> 12: MaxPool2d floors, the 12 -> 24 ConvTranspose output is padded to 25 on the right / bottom
+    (`up.forward`, models/unet_parts.py) and the pad's gradient dropped; the un-pooled last row / column of an odd level
+    gets the skip gradient alone.  Same gates as the 128x128 test."""
+    sd = S.make_twostream_state()
+    net = A.get_twostream((12, 6), (3, 2), 64, 256, 2)
+    net.load_state_dict(sd)
+    net = net.to(DEV)
+    out, loss, want, wloss, msd = _train_step(net, sd, B, (H, W), f"train-{H}x{W}", train_precision=train_precision)
+    assert rel_err(out[0].detach().cpu(), want[0]) <= 1e-4 and rel_err(out[1].detach().cpu(), want[1]) <= 1e-4
+    assert abs(float(loss) - float(wloss)) <= 1e-4 * abs(float(wloss))
+    errs, names = [], []
+    for name, p in net.named_parameters():
+        ref = msd[name].grad
+        if ref is None or float(ref.abs().max()) == 0.0:
+            continue
+        assert p.grad is not None, name
+        errs.append(_l2rel(p.grad.cpu(), ref))
+        names.append(name)
+    errs = np.array(errs)
+    worst = names[int(errs.argmax())]
+    assert errs.max() <= GTOL and np.median(errs) <= 4e-3, (worst, errs.max(), np.median(errs), errs.min())
     nsd = net.state_dict()
     for key, v in msd.items():
         if key not in dict(net.named_parameters()):
@@ -394,19 +428,20 @@ def _block_state(mod, tag):
     return sd
 
 
+@pytest.mark.parametrize("hw", [(32, 32), (27, 21)])
 @pytest.mark.parametrize("kind", ["double_conv", "inconv", "down", "up", "bridge"])
-def test_standalone_blocks_in_training_mode(kind):
+def test_standalone_blocks_in_training_mode(kind, hw):
     """the reference's sub-modules are trainable on their own (models/unet.py:8-59, 956-965): outputs, parameter
     gradients, INPUT gradients and the BatchNorm running statistics of one training-mode call of each block against
     the oracle's autograd in float64 (mask-free BatchNorm affine: 1e-4 gates; `inconv`'s 12-channel input gets no
-    gradient - it is data)"""
+    gradient - it is data).  27x21: `down` floors, `up` pads the 26x20 ConvTranspose output on the right / bottom."""
     torch.manual_seed(0)
     mod = {"double_conv": lambda: A.double_conv(64, 128), "inconv": lambda: A.inconv(12, 64), "down": lambda: A.down(64, 128),
            "up": lambda: A.up(128, 64), "bridge": lambda: A.bridge(64)}[kind]()
     sd = _block_state(mod, kind)
     mod.load_state_dict(sd)
     mod = mod.to(DEV).train()
-    B, H, W = 2, 32, 32
+    B, (H, W) = 2, hw
     if kind == "up":
         ins = [S.hashed_uniform("blk-x1", (B, 128, H // 2, W // 2)), S.hashed_uniform("blk-x2", (B, 64, H, W))]
     elif kind == "bridge":
