@@ -578,21 +578,45 @@ def kernel_table(net, rgb_x, op_x, reps=3):
     return per_kernel, dom, reps
 
 
+def _norm_kernel(name: str) -> str:
+    """one spelling for a kernel across bench labels and rocprofv3's demangled names"""
+    import re
+    name = re.sub(r"^ammc\w*::", "", name).replace("_kernel", "")
+    m = re.match(r"(conv_tap_s16)<(.*)>$", name)
+    if m:                                         # the template's seventh argument (KH) is 0 for the tap-by-tap forms
+        a = [v.strip() for v in m.group(2).split(",")]
+        if len(a) == 7 and a[6] == "0":
+            a = a[:6]
+        name = f"{m.group(1)}<{', '.join(a)}>"
+    return re.sub(r"<[^>]*>$", "", name) if name.startswith("memory_topk") else name
+
+
+def _profiles(suffixes):
+    """committed profile files, newest round tag first (r03c > r03b > r02)"""
+    import glob
+    paths = []
+    for sfx in suffixes:
+        paths += glob.glob(os.path.join(ROOT, "profiles", f"r*_{sfx}"))
+    return sorted(set(paths), key=lambda q: os.path.basename(q).split("_")[0], reverse=True)
+
+
 def pmc_traffic(kernel: str, precision: str, args):
     """HBM-side bytes per launch cannot be read live: they come from the committed PMC passes of THIS command
-    (tools/profile_bench.sh -> profiles/rNN_<precision>_pmc_traffic.json).  Null unless that profile was taken with
-    this run's batch / frame size / slots; the provenance travels with the number."""
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{precision}_pmc_traffic.json")))[::-1]:
+    (tools/profile_round.sh -> profiles/rNN_infer_pmc_traffic.json; rounds 1-2: rNN_<precision>_pmc_traffic.json).  Null
+    unless that profile was taken with this run's precision / batch / frame size / slots; the provenance travels with
+    the number."""
+    names = [f"{precision}_pmc_traffic.json"] + (["infer_pmc_traffic.json"] if precision == "s16" else [])
+    for path in _profiles(names):
         with open(path) as fp:
             prof = json.load(fp)
         wl = prof.get("workload", {"batch": 16, "size": 256, "n_embed": 2000})       # round-1 files: the default command
         if (wl.get("batch"), wl.get("size"), wl.get("n_embed")) != (args.batch, args.size, args.n_embed):
             continue
-        v = prof["kernels"].get(kernel, {}).get("traffic_bytes_per_launch")
-        if v is not None:
-            return v, {"file": os.path.relpath(path, ROOT), "command": prof.get("source"), "workload": wl,
-                       "commit": prof.get("commit")}
+        for k, row in prof["kernels"].items():
+            v = row.get("traffic_bytes_per_launch")
+            if v is not None and _norm_kernel(k) == _norm_kernel(kernel):
+                return v, {"file": os.path.relpath(path, ROOT), "command": prof.get("source"), "workload": wl,
+                           "commit": prof.get("commit")}
     return None, None
 
 
@@ -600,24 +624,11 @@ def pmc_busy(kernel: str, mode: str):
     """share of the launch's shader cycles (at the clock the chip held) in which a SIMD's matrix pipe was busy:
     (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs), from the committed PMC passes of this very
     command (tools/profile_round.sh -> profiles/rNN_<mode>_pmc_busy.json; counters cannot be read live)."""
-    import glob
-    import re
-
-    def norm(name):
-        name = re.sub(r"^ammc\w*::", "", name).replace("_kernel", "")
-        m = re.match(r"(conv_tap_s16)<(.*)>$", name)
-        if m:                                         # the template's seventh argument (KH) is 0 for the tap-by-tap forms
-            a = [v.strip() for v in m.group(2).split(",")]
-            if len(a) == 7 and a[6] == "0":
-                a = a[:6]
-            name = f"{m.group(1)}<{', '.join(a)}>"
-        return re.sub(r"<[^>]*>$", "", name) if name.startswith("memory_topk") else name
-
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{mode}_pmc_busy.json")))[::-1]:
+    for path in _profiles([f"{mode}_pmc_busy.json"]):
         with open(path) as fp:
             prof = json.load(fp)
         for k, v in prof.get("kernels", {}).items():
-            if norm(k) == norm(kernel) and "mfma_busy_frac" in v:
+            if _norm_kernel(k) == _norm_kernel(kernel) and "mfma_busy_frac" in v:
                 return v["mfma_busy_frac"], {"file": os.path.relpath(path, ROOT), "command": prof.get("workload"),
                                              "commit": prof.get("commit")}
     return None, None
