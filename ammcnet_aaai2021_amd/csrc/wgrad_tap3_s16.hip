@@ -175,52 +175,71 @@ __global__ __launch_bounds__(W3_NT, 2) void wgrad_tap3_s16_kernel(WgradTap3Args 
   const uint32_t g_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)Gs;
   const uint32_t a_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)As;
 
-  // one tap of one k-step: 4 transposed reads, 3 MFMAs; the reads of taps T + 1 and T + 2 are in flight during the
-  // MFMAs of tap T (three register sets, counted lgkmcnt).  Y (image row of the patch), T and S are literals.
-  u32x2u ar[3][4];
-#define W3_AREAD(Y, T, S)                                                                                     \
+  // A wave's RPW image rows of a patch are ONE flat sequence of NU = 18 RPW steps (step U: row Y0 + U / 18, x half
+  // (U / 9) & 1, tap U % 9; all literals): 4 transposed reads + 3 MFMAs per step, the A reads of steps U + 1 and U + 2 in
+  // flight during the MFMAs of step U (three register sets) ACROSS half-row boundaries, and the six G reads of the next
+  // half-row issued at tap 5 of the current one into a second raw set - a half-row no longer starts cold (14 reads, then
+  // a full LDS round trip, four times per patch).  Waits are counted: LDS reads return in order, so step U needs
+  // everything issued up to A(U) and tolerates what was issued after it.  Issue order around a boundary:
+  //   ... A(t7) [step t5, before its wait], G(next) [step t5, after it], A(t8) [t6], A(next t0) [t7], A(next t1) [t8] ...
+  u32x2u ar[3][4], graw[2][6];
+  f16x8u gf_hi, gf_x1, gf_x2;
+#define W3_AREAD(Y0, U, S)                                                                                    \
   {                                                                                                           \
-    constexpr int off_ = (((Y) + (T) / 3) * W3_HW + (T) % 3) * W3_ARB;                                        \
-    constexpr int k_ = (2 * ((Y) + (T) / 3) + (T) % 3) & 3;                                                   \
+    constexpr int y_ = (Y0) + (U) / 18, xh_ = ((U) / 9) & 1, t_ = (U) % 9;                                    \
+    constexpr int off_ = ((y_ + t_ / 3) * W3_HW + t_ % 3 + 16 * xh_) * W3_ARB;                                \
+    constexpr int k_ = (2 * (y_ + t_ / 3) + t_ % 3) & 3;                                                      \
+    static_assert(off_ + 12 * W3_ARB < 65536, "ds offset");                                                   \
     const uint32_t a1_ = abase + a_sw_x1[k_], a2_ = abase + a_sw_x2[k_];                                      \
     ar[S][0] = w3_read_tr16<off_>(a1_);                                                                       \
     ar[S][1] = w3_read_tr16<off_ + 4 * W3_ARB>(a1_);                                                          \
     ar[S][2] = w3_read_tr16<off_ + 8 * W3_ARB>(a2_);                                                          \
     ar[S][3] = w3_read_tr16<off_ + 12 * W3_ARB>(a2_);                                                         \
   }
-#define W3_TAP(Y, T)                                                                                          \
+#define W3_GREAD(Y0, HH, S)                                                                                   \
   {                                                                                                           \
-    if ((T) + 2 <= 8) {                                                                                       \
-      W3_AREAD(Y, ((T) + 2 <= 8 ? (T) + 2 : 0), (((T) + 2) % 3));                                             \
-      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                                      \
-    } else if ((T) == 7) {                                                                                    \
-      asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                                      \
-    } else {                                                                                                  \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+    constexpr int gp_ = (((Y0) + (HH) / 2) * 32 + 16 * ((HH) & 1)) * W3_GRB;                                  \
+    static_assert(gp_ + 12 * W3_GRB < 65536, "ds offset");                                                    \
+    graw[S][0] = w3_read_tr16<gp_>(ghi);                                                                      \
+    graw[S][1] = w3_read_tr16<gp_ + 4 * W3_GRB>(ghi);                                                         \
+    graw[S][2] = w3_read_tr16<gp_>(g1);                                                                       \
+    graw[S][3] = w3_read_tr16<gp_ + 4 * W3_GRB>(g1);                                                          \
+    graw[S][4] = w3_read_tr16<gp_ + 8 * W3_GRB>(g2);                                                          \
+    graw[S][5] = w3_read_tr16<gp_ + 12 * W3_GRB>(g2);                                                         \
+  }
+#define W3_STEP(Y0, U)                                                                                        \
+  {                                                                                                           \
+    constexpr int t_ = (U) % 9, hh_ = (U) / 9;                                                                \
+    constexpr bool nxt_ = hh_ + 1 < NH;                                                                       \
+    if ((U) + 2 < NU) W3_AREAD(Y0, ((U) + 2 < NU ? (U) + 2 : 0), (((U) + 2) % 3))                             \
+    constexpr int cnt_ = ((U) + 1 < NU ? 4 : 0) + ((U) + 2 < NU ? 4 : 0) + (((t_ == 6 || t_ == 7) && nxt_) ? 6 : 0); \
+    __builtin_amdgcn_s_waitcnt(0xC07F | (cnt_ << 8));                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    if (t_ == 0) {                                                                                            \
+      gf_hi = w3_frag(graw[hh_ & 1][0], graw[hh_ & 1][1]);                                                    \
+      gf_x1 = w3_frag(graw[hh_ & 1][2], graw[hh_ & 1][3]) * cg;                                               \
+      gf_x2 = w3_frag(graw[hh_ & 1][4], graw[hh_ & 1][5]) * cg;                                               \
     }                                                                                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                                        \
-    const f16x8u ax1_ = w3_frag(ar[(T) % 3][0], ar[(T) % 3][1]), ax2_ = w3_frag(ar[(T) % 3][2], ar[(T) % 3][3]); \
+    if (t_ == 5 && nxt_) W3_GREAD(Y0, (nxt_ ? hh_ + 1 : 0), ((hh_ + 1) & 1))                                  \
+    const f16x8u ax1_ = w3_frag(ar[(U) % 3][0], ar[(U) % 3][1]), ax2_ = w3_frag(ar[(U) % 3][2], ar[(U) % 3][3]); \
     const f16x8u ahi_ = upper ? ax2_ : ax1_;                                                                  \
-    acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf_hi, ahi_, acc[T], 0, 0, 0);                            \
-    acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf_x1, ax1_, acc[T], 0, 0, 0);                            \
-    acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf_x2, ax2_, acc[T], 0, 0, 0);                            \
-  }
-#define W3_ROW(Y)                                                                                             \
-  _Pragma("unroll 1") for (int xh = 0; xh < 2; ++xh) {                                                        \
-    const uint32_t gpix_ = (uint32_t)(((Y) * 32 + 16 * xh) * W3_GRB);                                         \
-    const uint32_t ghi_ = gst + g_lane_hi + gpix_, g1_ = gst + g_lane_x1 + gpix_, g2_ = gst + g_lane_x2 + gpix_; \
-    const u32x2u gh0 = w3_read_tr16<0>(ghi_), gh1 = w3_read_tr16<4 * W3_GRB>(ghi_);                           \
-    const u32x2u gx0 = w3_read_tr16<0>(g1_), gx1 = w3_read_tr16<4 * W3_GRB>(g1_);                             \
-    const u32x2u gx2 = w3_read_tr16<8 * W3_GRB>(g2_), gx3 = w3_read_tr16<12 * W3_GRB>(g2_);                   \
-    const uint32_t abase = ast + a_lane + (uint32_t)(16 * xh * W3_ARB);                                       \
-    W3_AREAD(Y, 0, 0)                                                                                         \
-    W3_AREAD(Y, 1, 1)                                                                                         \
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                                        \
+    acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf_hi, ahi_, acc[t_], 0, 0, 0);                          \
+    acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf_x1, ax1_, acc[t_], 0, 0, 0);                          \
+    acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf_x2, ax2_, acc[t_], 0, 0, 0);                          \
     __builtin_amdgcn_sched_barrier(0);                                                                        \
-    const f16x8u gf_hi = w3_frag(gh0, gh1), gf_x1 = w3_frag(gx0, gx1) * cg, gf_x2 = w3_frag(gx2, gx3) * cg;   \
-    W3_TAP(Y, 0) W3_TAP(Y, 1) W3_TAP(Y, 2) W3_TAP(Y, 3) W3_TAP(Y, 4) W3_TAP(Y, 5) W3_TAP(Y, 6) W3_TAP(Y, 7)   \
-    W3_TAP(Y, 8)                                                                                              \
   }
+#define W3_STEP9(Y0, U) W3_STEP(Y0, U) W3_STEP(Y0, (U) + 1) W3_STEP(Y0, (U) + 2) W3_STEP(Y0, (U) + 3) W3_STEP(Y0, (U) + 4) \
+  W3_STEP(Y0, (U) + 5) W3_STEP(Y0, (U) + 6) W3_STEP(Y0, (U) + 7) W3_STEP(Y0, (U) + 8)
+#define W3_SEQ(Y0)                                                                                            \
+  {                                                                                                           \
+    W3_GREAD(Y0, 0, 0)                                                                                        \
+    W3_AREAD(Y0, 0, 0)                                                                                        \
+    W3_AREAD(Y0, 1, 1)                                                                                        \
+    W3_STEP9(Y0, 0) W3_STEP9(Y0, 9)                                                                           \
+    if (RPW == 2) { W3_STEP9(Y0, (RPW == 2 ? 18 : 0)) W3_STEP9(Y0, (RPW == 2 ? 27 : 9)) }                     \
+  }
+  constexpr int NH = 2 * RPW, NU = 18 * RPW;
+  static_assert(RPW == 1 || RPW == 2, "rows per wave");
 
   W3_ISSUE(p_begin, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -230,20 +249,23 @@ __global__ __launch_bounds__(W3_NT, 2) void wgrad_tap3_s16_kernel(WgradTap3Args 
     const int stage = (pt - p_begin) & 1;
     if (pt + 1 < p_end) W3_ISSUE(pt + 1, stage ^ 1);
     const uint32_t gst = g_base + (uint32_t)(stage * W3_GSTAGE * 4);
-    const uint32_t ast = a_base + (uint32_t)(stage * W3_ASTAGE * 4);
-    if (0 / RPW == wp) { W3_ROW(0) }                     // (uniform per wave; the row is a literal in the offsets)
-    if (1 / RPW == wp) { W3_ROW(1) }
-    if (PH == 4) {
-      if (2 / RPW == wp) { W3_ROW(2) }
-      if (3 / RPW == wp) { W3_ROW(3) }
+    const uint32_t abase = a_base + (uint32_t)(stage * W3_ASTAGE * 4) + a_lane;
+    const uint32_t ghi = gst + g_lane_hi, g1 = gst + g_lane_x1, g2 = gst + g_lane_x2;
+    if (0 == wp) { W3_SEQ(0) }                           // (uniform per wave; the rows are literals in the offsets)
+    if (NP >= 2 && 1 == wp) { W3_SEQ((NP >= 2 ? RPW : 0)) }
+    if (NP == 4) {
+      if (2 == wp) { W3_SEQ((NP == 4 ? 2 * RPW : 0)) }
+      if (3 == wp) { W3_SEQ((NP == 4 ? 3 * RPW : 0)) }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 #undef W3_ISSUE
-#undef W3_TAP
 #undef W3_AREAD
-#undef W3_ROW
+#undef W3_GREAD
+#undef W3_STEP
+#undef W3_STEP9
+#undef W3_SEQ
 
   // ---- add to the packed gradient: row = gradient channel (registers), column = tap * Cin + c (lanes) -------------
   const float inv = a.g_inv_scale ? a.g_inv_scale[0] : 1.f;
