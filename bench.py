@@ -38,6 +38,9 @@ import torch  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters
 PEAK_F16_MFMA_TFLOPS = 2500.0     # dense fp16/bf16 MFMA
 PEAK_HBM_GBS = 8000.0
+# What the board sustains at its 1400 W cap on fp16 MFMA with register-resident RANDOM operands and nothing else running
+# (tools/micro/mfma_power.hip, profiles/r03_mfma_power.txt; constant operands reach the 2.5 PFLOP/s issue peak at 2.39 GHz)
+POWER_CEILING_TFLOPS = {"32x32x16": 1675.0, "16x16x32": 1889.0}
 PARITY_TOL = 1e-4                 # BASELINE.json north_star: 1e-4 relative fp32
 PARITY_FIXTURE = os.path.join(ROOT, "tests", "golden", "twostream_256_b16_m2000_eval.npz")
 TRAIN_FIXTURE = os.path.join(ROOT, "tests", "golden", "twostream_256_b2_train.npz")
@@ -388,6 +391,7 @@ def run_train(args, rank, world, dev, dist, steps, warmup, with_cpu):
             ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
             roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": None, "mfma_issue_frac": round((3.0 if s16 else 1.0) * ach / peak, 4),
+                    "power_ceiling": power_ceiling("wgrad_tap3_s16", 3.0 * ach) if s16 else None,
                     "flops_per_launch": f["flops"] / f["launches"], "avg_launch_us": round(1e3 * f["ms"] / f["launches"], 2),
                     "launches_per_step": f["launches"], "share_of_step": round(f["ms"] / (1e3 * elapsed / steps), 4)}
     if rank != 0:
@@ -513,6 +517,7 @@ def run_stress(args, rank, world, dev, dist, steps, warmup, with_cpu):
         "parity": parity,
         "roofline": {"kernel": "memory_topk_f16", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": stress_traffic(n),
+                     "power_ceiling": power_ceiling("memory_topk_f16", ach),
                      "mfma_busy_frac": pmc_busy("memory_topk_f16", "stress")[0] if frames_per_gpu == 256 else None,
                      "mfma_busy_source": pmc_busy("memory_topk_f16", "stress")[1] if frames_per_gpu == 256 else None,
                      "flops_per_launch": ms.flops(n), "avg_launch_us": round(us, 2), "launches_per_step": 1,
@@ -576,6 +581,22 @@ def kernel_table(net, rgb_x, op_x, reps=3):
                                  gbs=round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1) if a["bytes"] else None)
     dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
     return per_kernel, dom, reps
+
+
+def power_ceiling(kernel: str, issued_tflops: float):
+    """the roofline's second denominator: issued fp16 MFMA rate against the power-limited rate of the kernel's MFMA shape"""
+    import re
+    shape = "32x32x16"
+    m = re.match(r"conv_tap_s16<(.*)>", kernel)
+    if m:
+        a = [v.strip() for v in m.group(1).split(",")]
+        shape = "16x16x32" if len(a) >= 6 and a[5] == "1" else "32x32x16"
+    elif kernel.startswith(("conv_up_s16", "conv_outc_s16", "conv_first_s16")):
+        shape = "16x16x32"
+    peak = POWER_CEILING_TFLOPS[shape]
+    return {"mfma_shape": shape, "power_limited_issue_peak": peak, "unit": "TFLOP/s of issued fp16 MFMA at the 1400 W cap, "
+            "register-resident random operands", "source": "profiles/r03_mfma_power.txt (tools/micro/mfma_power.hip)",
+            "issued": round(issued_tflops, 1), "frac": round(issued_tflops / peak, 4)}
 
 
 def _norm_kernel(name: str) -> str:
@@ -646,6 +667,7 @@ def roofline_of(dom, reps, precision, args):
     return {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
             "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": source,
             "mfma_issue_frac": round((3.0 if s16 else 1.0) * achieved / peak, 4),
+            "power_ceiling": power_ceiling(name, 3.0 * achieved) if s16 else None,
             "mfma_busy_frac": busy, "mfma_busy_source": busy_src,
             "flops_per_launch": a["flops"] / a["launches"], "avg_launch_us": round(1e3 * a["ms"] / a["launches"], 2),
             "launches_per_step": a["launches"] // reps,

@@ -14,15 +14,20 @@ def s16_of(t):
     return out
 
 
-def make_desc(B, H, W, cin, n):
+def make_desc(B, H, W, cin, n, const=False):
+    """const: every activation 0.5, every filter tap 0.01 (no operand toggling: the chip holds a higher clock)"""
     g = torch.Generator(device=dev)
     g.manual_seed(1)
     x32 = torch.zeros(B, H + 2, W + 2, cin, device=dev)
-    x32[:, 1:-1, 1:-1].copy_(torch.randn(B, H, W, cin, device=dev, generator=g))
+    if const:
+        x32[:, 1:-1, 1:-1] = 0.5
+    else:
+        x32[:, 1:-1, 1:-1].copy_(torch.randn(B, H, W, cin, device=dev, generator=g))
     xa = Act(s16_of(x32), B, H, W, cin, 0, 1)
     del x32
     ya = Act(torch.zeros(B, H + 2, W + 2, n, device=dev), B, H, W, n, 0, 1)
-    ws = s16_of(torch.randn(n, 9 * cin, device=dev, generator=g) * (2.0 / (9 * cin)) ** 0.5)
+    w32 = torch.full((n, 9 * cin), 0.01, device=dev) if const else torch.randn(n, 9 * cin, device=dev, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    ws = s16_of(w32)
     scale = torch.ones(n, device=dev)
     shift = torch.zeros(n, device=dev)
     d = AmmcConvDesc()
