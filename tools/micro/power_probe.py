@@ -115,6 +115,15 @@ def conv_case(B, Hh, W, cin, n, const=False, mf=0):
 
 print("idle:", (rd(H["power"]) or 0) / 1e6 if H else None, "W", flush=True)
 keep = []
+if "--stress" in sys.argv:                                 # config 5: the fp16 memory-addressing kernel at the bench's size
+    from ammcnet_aaai2021_amd import synthetic as S
+    from ammcnet_aaai2021_amd.workload import MemoryStress
+    ms = MemoryStress(S.hashed_normal("stress:e", (512, 8192), 0.9).to("cuda:0"), 2)
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(4321)
+    xs = torch.randn(256 * 1024, 512, device="cuda:0", generator=g) * 0.8
+    run_case("memory_topk_f16, 262144 rows x 8192 slots x 512", lambda s: ms.run(xs), ms.flops(xs.shape[0]))
+    sys.exit(0)
 if "--variants" in sys.argv:                               # forced MFMA shapes; AMMC_TAP_KH from the environment
     for shape in [(16, 128, 128, 128, 128), (16, 128, 128, 64, 128), (16, 256, 256, 64, 64), (16, 64, 64, 256, 256)]:
         for mf in (0, 1, 2):
