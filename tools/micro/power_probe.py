@@ -124,6 +124,32 @@ if "--stress" in sys.argv:                                 # config 5: the fp16 
     xs = torch.randn(256 * 1024, 512, device="cuda:0", generator=g) * 0.8
     run_case("memory_topk_f16, 262144 rows x 8192 slots x 512", lambda s: ms.run(xs), ms.flops(xs.shape[0]))
     sys.exit(0)
+if "--wgrad" in sys.argv:                                  # the 3x3 weight-gradient layers of the training step, batch 32
+    from ammcnet_aaai2021_amd._lib import AmmcWgradDesc
+    from ammcnet_aaai2021_amd.engine import Act, _ptr
+    dev = "cuda:0"
+    for (B, Hh, W, cin, n) in [(32, 128, 128, 128, 128), (32, 64, 64, 256, 256), (32, 256, 256, 64, 64), (32, 32, 32, 512, 512)]:
+        g = torch.Generator(device=dev).manual_seed(1)
+        s0 = torch.cuda.current_stream().cuda_stream
+        A32 = Act(torch.zeros(B, Hh + 2, W + 2, cin, device=dev), B, Hh, W, cin, 0, 1)
+        A32.interior().copy_(torch.rand(B, Hh, W, cin, device=dev, generator=g) * 2 - 1)
+        G32 = Act(torch.zeros(B, Hh + 2, W + 2, n, device=dev), B, Hh, W, n, 0, 1)
+        G32.interior().copy_(torch.rand(B, Hh, W, n, device=dev, generator=g) * 2 - 1)
+        A16 = Act(torch.empty_like(A32.buf), B, Hh, W, cin, 0, 1)
+        G16 = Act(torch.empty_like(G32.buf), B, Hh, W, n, 0, 1)
+        _lib.check(lib.ammc_split_rows_f32(_ptr(A32.buf), A32.buf.numel(), _ptr(A16.buf), s0), "split a")
+        _lib.check(lib.ammc_split_rows_f32(_ptr(G32.buf), G32.buf.numel(), _ptr(G16.buf), s0), "split g")
+        kpad = (9 * cin + 31) // 32 * 32
+        dwp = torch.zeros(max(n, 32), kpad, device=dev)
+        zeros = torch.zeros(1024, device=dev)
+        d = AmmcWgradDesc()
+        d.g, d.a, d.dw, d.zeros = G16.pix0(), A16.tap0(), _ptr(dwp), _ptr(zeros)
+        d.batch, d.height, d.width, d.n, d.cin, d.ntaps, d.a_step = B, Hh, W, n, cin, 9, 1
+        d.g_bs, d.g_rs, d.g_ps = G16.strides
+        d.a_bs, d.a_rs, d.a_ps = A16.strides
+        run_case(f"wgrad {cin}->{n} @{Hh} b{B}", lambda s: lib.ammc_conv_wgrad_s16(C.byref(d), None, s), 2.0 * B * Hh * W * n * cin * 9)
+        del A32, G32, A16, G16
+    sys.exit(0)
 if "--variants" in sys.argv:                               # forced MFMA shapes; AMMC_TAP_KH from the environment
     for shape in [(16, 128, 128, 128, 128), (16, 128, 128, 64, 128), (16, 256, 256, 64, 64), (16, 64, 64, 256, 256)]:
         for mf in (0, 1, 2):
