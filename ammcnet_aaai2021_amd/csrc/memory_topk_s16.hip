@@ -72,8 +72,11 @@ __global__ __launch_bounds__(256, 2) void memory_topk_s16_kernel(
   __shared__ __attribute__((aligned(16))) float xs[SBR * SD];            // fp32 features, swizzled 16-B slots
   __shared__ __attribute__((aligned(16))) _Float16 xh[SBR * 2 * SD];     // S16 image: row = 8 hi slots | 8 lo slots
   __shared__ float xx[SBR];
-  __shared__ float cand_v[SBR * 8 * K];
-  __shared__ int cand_i[SBR * 8 * K];
+  // (candidate rows are 8 K + 1 words long: with 8 K the 32 lanes of a half wave - consecutive feature rows - hit two
+  // banks, the LDS bank conflicts the round-3 counters showed for this kernel)
+  constexpr int CROW = 8 * K + 1;
+  __shared__ float cand_v[SBR * CROW];
+  __shared__ int cand_i[SBR * CROW];
   __shared__ int best[SBR * K];
   __shared__ float red[256];
   __shared__ float ens[4096];                                            // |E_s|^2 (memories of up to 4096 slots)
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void memory_topk_s16_kernel(
   // ---- merge the 8 partial lists of every row ---------------------------------------------------------------------------
 #pragma unroll
   for (int j = 0; j < K; ++j) {
-    const int o = (l31 * 8 + wave * 2 + h) * K + j;
+    const int o = l31 * CROW + (wave * 2 + h) * K + j;
     cand_v[o] = bv[j];
     cand_i[o] = bi[j];
   }
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void memory_topk_s16_kernel(
     int ix[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) { v[j] = INFINITY; ix[j] = 0x7fffffff; }
-    for (int c = 0; c < 8 * K; ++c) s_topk_insert<K>(v, ix, cand_v[tid * 8 * K + c], cand_i[tid * 8 * K + c]);
+    for (int c = 0; c < 8 * K; ++c) s_topk_insert<K>(v, ix, cand_v[tid * CROW + c], cand_i[tid * CROW + c]);
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       best[tid * K + j] = ix[j];
