@@ -57,6 +57,9 @@ int ammc_opt_s16_mf();
 // dispatch option "outc_stream": 1 = the output layer on conv_outc_s16.hip (default), 0 = on the halo-patch kernel;
 // AMMC_OUTC_STREAM / ammc_set_option
 int ammc_opt_outc_stream();
+// dispatch option "memory_rt": rows per workgroup of memory_topk_s16, 0 = by size (default), 1 = 32, 2 = 64;
+// AMMC_MEMORY_RT / ammc_set_option
+int ammc_opt_memory_rt();
 
 static inline int ammc_ilog2(int v) {
   int l = 0;

@@ -19,6 +19,17 @@ int ammc_opt_outc_stream() {
   return g_ammc_outc_stream;
 }
 
+int g_ammc_memory_rt = -2;          // -2 = not read yet; 0 = by size (default), 1 / 2 = 32- / 64-row workgroups of memory_topk_s16
+
+int ammc_opt_memory_rt() {
+  if (g_ammc_memory_rt == -2) {
+    const char* e = getenv("AMMC_MEMORY_RT");
+    const int v = e ? atoi(e) : 0;
+    g_ammc_memory_rt = v == 1 || v == 2 ? v : 0;
+  }
+  return g_ammc_memory_rt;
+}
+
 int ammc_opt_s16_mf() {
   if (g_ammc_s16_mf == -2) {
     const char* e = getenv("AMMC_S16_MF");
@@ -37,6 +48,11 @@ extern "C" int ammc_set_option(const char* key, int32_t value) {
   if (!strcmp(key, "outc_stream")) {
     if (value < 0 || value > 1) return AMMC_EINVAL;
     g_ammc_outc_stream = value;
+    return AMMC_OK;
+  }
+  if (!strcmp(key, "memory_rt")) {
+    if (value < 0 || value > 2) return AMMC_EINVAL;
+    g_ammc_memory_rt = value;
     return AMMC_OK;
   }
   return AMMC_EUNSUP;

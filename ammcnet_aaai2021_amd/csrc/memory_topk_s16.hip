@@ -13,18 +13,18 @@
 //   - a workgroup (4 waves) owns 32 feature rows: fp32 copy + S16 image in LDS (256 B per row = 16 slots of 16 B,
 //     XOR-swizzled by row: conflict-free ds_read_b128 of the B fragments);
 //   - wave w contracts slot tiles in pairs (2 w, 2 w + 1), (2 w + 8, ...); the codebook is pre-packed
-//     [D/8][Mpad][8 hi | 8 lo] (ammc_pack_codebook_s16), so a lane's A fragments are two coalesced 16-byte loads from
+//     [D/8][hi | lo][Mpad][8] (ammc_pack_codebook_s16), so a lane's A fragments are two coalesced 16-byte loads from
 //     L2; the NEXT pair's 16 loads are in flight during the current pair's 24 MFMAs (two register sets);
 //   - running top-K per lane in registers (ordered insertion), 8 partial lists per row merged through LDS.
 #include "ammc_common.h"
 #include <hip/hip_fp16.h>
 #include <math.h>
+#include <stdlib.h>
 
 namespace ammc_impl {
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int SBR = 32;          // feature rows per workgroup
 constexpr int SD = 64;           // embedding width this kernel is built for
 constexpr float S_LO_SCALE = 2048.f;
 constexpr float S_LO_INV = 1.f / 2048.f;
@@ -61,32 +61,39 @@ __device__ __forceinline__ void s_topk_insert_ordered(float (&v)[K], int (&ix)[K
   }
 }
 
-// NL: the slot norms are read from LDS (memories of up to 4096 slots).  A template argument, not a pointer chosen at run
-// time: a pointer that may be LDS or global is a FLAT pointer, and every flat load makes the compiler wait
-// vmcnt(0) - i.e. for the codebook fragments just requested for the next tile pair.
-template <int K, bool NL>
-__global__ __launch_bounds__(256, 2) void memory_topk_s16_kernel(
-    const float* __restrict__ x, const h16x8* __restrict__ e_s16 /* [8][mpad][2] */, const float* __restrict__ e_md,
-    const float* __restrict__ enorm, int n, int m, int mpad, int* __restrict__ idx_out, float* __restrict__ q_topk,
+// NL: the slot norms are read from LDS (memories of up to 4096 slots; 2048 for RT = 2).  A template argument, not a
+// pointer chosen at run time: a pointer that may be LDS or global is a FLAT pointer, and every flat load makes the
+// compiler wait vmcnt(0) - i.e. for the codebook fragments just requested for the next tile group.
+// RT: 32-row tiles per workgroup.  RT = 1: 4 waves x 32 rows, two workgroups per CU, a wave contracts slot tiles in
+// PAIRS.  RT = 2: 8 waves x 64 rows, one workgroup per CU, a wave contracts ONE slot tile against both row tiles - the
+// same 24 MFMAs per step from half the codebook bytes: every CU pulls the whole S16 codebook (516 KB at 2000 slots)
+// through its vector L1 once per workgroup, and with two 32-row workgroups per CU that fill path (64 B/clk) was the
+// bound - 264 MB per launch at 16384 rows, ~13 us of the kernel's 33 with neither MFMAs nor epilogue (ablations).
+// Results are bit-identical between the two (same accumulation order per output, same commit partial per 32 rows).
+template <int K, bool NL, int RT>
+__global__ __launch_bounds__(256 * RT, 2) void memory_topk_s16_kernel(
+    const float* __restrict__ x, const h16x8* __restrict__ e_s16 /* [8 k-blocks][hi | lo][mpad] */, const float* __restrict__ e_md,
+    const float* __restrict__ enorm, int n, int m, int mpad, int nparts, int* __restrict__ idx_out, float* __restrict__ q_topk,
     float* __restrict__ q_one, float* __restrict__ diff_partial) {
+  constexpr int SBR = 32 * RT, NT = 256 * RT, NW = 4 * RT, U = 2 / RT;   // rows, threads, waves, slot tiles per step
   __shared__ __attribute__((aligned(16))) float xs[SBR * SD];            // fp32 features, swizzled 16-B slots
   __shared__ __attribute__((aligned(16))) _Float16 xh[SBR * 2 * SD];     // S16 image: row = 8 hi slots | 8 lo slots
   __shared__ float xx[SBR];
-  // (candidate rows are 8 K + 1 words long: with 8 K the 32 lanes of a half wave - consecutive feature rows - hit two
-  // banks, the LDS bank conflicts the round-3 counters showed for this kernel)
-  constexpr int CROW = 8 * K + 1;
+  // (candidate rows are 2 NW K + 1 words long: with an even length the 32 lanes of a half wave - consecutive feature
+  // rows - hit two banks, the LDS bank conflicts the round-3 counters showed for this kernel)
+  constexpr int CROW = 2 * NW * K + 1;
   __shared__ float cand_v[SBR * CROW];
   __shared__ int cand_i[SBR * CROW];
   __shared__ int best[SBR * K];
-  __shared__ float red[256];
-  __shared__ float ens[4096];                                            // |E_s|^2 (memories of up to 4096 slots)
+  __shared__ float red[NT];
+  __shared__ float ens[RT == 2 ? 2048 : 4096];                           // |E_s|^2
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   const int r0 = blockIdx.x * SBR;
   // the tile epilogues read 16 norms per lane and tile: from LDS (loaded once), not 16 exposed global loads
   if (NL) {
-    for (int i = tid; i < m; i += 256) ens[i] = enorm[i];
+    for (int i = tid; i < m; i += NT) ens[i] = enorm[i];
   }
 
   // ---- stage the tile: thread = (row, group of 8 features) -------------------------------------------------------------
@@ -124,62 +131,82 @@ __global__ __launch_bounds__(256, 2) void memory_topk_s16_kernel(
   }
   __syncthreads();
 
-  float bv[K];
-  int bi[K];
+  float bv[RT][K];
+  int bi[RT][K];
+  float xnorm[RT];
 #pragma unroll
-  for (int j = 0; j < K; ++j) { bv[j] = INFINITY; bi[j] = 0x7fffffff; }
-  const float xnorm = xx[l31];
-
-  // this lane's B fragments (its feature row, k-half h) for the four 16-feature steps: resident for the whole kernel
-  h16x8 bh[4], bx[4], bl2[4];
+  for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int kg = 2 * t + h;
-    bh[t] = *reinterpret_cast<const h16x8*>(xh + l31 * 2 * SD + ((kg ^ (l31 & 15)) << 3));
-    const h16x8 bl = *reinterpret_cast<const h16x8*>(xh + l31 * 2 * SD + (((8 + kg) ^ (l31 & 15)) << 3));
-    bx[t] = bh[t] * (_Float16)S_LO_INV;
-    bl2[t] = bl * (_Float16)S_LO_INV;
+    for (int j = 0; j < K; ++j) { bv[rt][j] = INFINITY; bi[rt][j] = 0x7fffffff; }
+    xnorm[rt] = xx[l31 + 32 * rt];
   }
 
+  // this lane's B fragments (its feature rows, k-half h) for the four 16-feature steps: resident for the whole kernel
+  h16x8 bh[RT][4], bx[RT][4], bl2[RT][4];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int kg = 2 * t + h, row = l31 + 32 * rt;
+      bh[rt][t] = *reinterpret_cast<const h16x8*>(xh + row * 2 * SD + ((kg ^ (row & 15)) << 3));
+      const h16x8 bl = *reinterpret_cast<const h16x8*>(xh + row * 2 * SD + (((8 + kg) ^ (row & 15)) << 3));
+      bx[rt][t] = bh[rt][t] * (_Float16)S_LO_INV;
+      bl2[rt][t] = bl * (_Float16)S_LO_INV;
+    }
+
   const int ntile = mpad >> 5;
-  // A fragments of one tile pair: [u][t] hi and lo of slot (tile + u) * 32 + l31, features 16 t + 8 h .. + 7
+  // A fragments of one step: [u][t] hi and lo of slot (tile + u) * 32 + l31, features 16 t + 8 h .. + 7
 #define S_LOAD(dst_h, dst_l, tile_)                                                                    \
-  _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                      \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                      \
     const int tl_ = (tile_) + u < ntile ? (tile_) + u : ntile - 1;                                     \
-    const h16x8* ep_ = e_s16 + ((int64_t)h * mpad + (tl_ << 5) + l31) * 2;                             \
+    const h16x8* ep_ = e_s16 + ((int64_t)(2 * h) * mpad + (tl_ << 5) + l31);                           \
     _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                    \
-      dst_h[u][t] = ep_[(int64_t)(2 * t) * mpad * 2];                                                  \
-      dst_l[u][t] = ep_[(int64_t)(2 * t) * mpad * 2 + 1];                                              \
+      dst_h[u][t] = ep_[(int64_t)(4 * t) * mpad];                                                      \
+      dst_l[u][t] = ep_[(int64_t)(4 * t + 1) * mpad];                                                  \
     }                                                                                                  \
   }
 #define S_TILES(src_h, src_l, tile_)                                                                   \
   {                                                                                                    \
-    f32x16 acc[2];                                                                                     \
-    _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                      \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;                                  \
+    f32x16 acc[U][RT];                                                                                 \
+    _Pragma("unroll") for (int u = 0; u < U; ++u)                                                      \
+      _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[u][rt][r] = 0.f;                            \
     _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                    \
-      _Pragma("unroll") for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src_h[u][t], bh[t], acc[u], 0, 0, 0);  \
-      _Pragma("unroll") for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src_l[u][t], bx[t], acc[u], 0, 0, 0);  \
-      _Pragma("unroll") for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src_h[u][t], bl2[t], acc[u], 0, 0, 0); \
+      _Pragma("unroll") for (int u = 0; u < U; ++u) _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)  \
+        acc[u][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src_h[u][t], bh[rt][t], acc[u][rt], 0, 0, 0);  \
+      _Pragma("unroll") for (int u = 0; u < U; ++u) _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)  \
+        acc[u][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src_l[u][t], bx[rt][t], acc[u][rt], 0, 0, 0);  \
+      _Pragma("unroll") for (int u = 0; u < U; ++u) _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)  \
+        acc[u][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src_h[u][t], bl2[rt][t], acc[u][rt], 0, 0, 0); \
     }                                                                                                  \
-    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                    \
+    /* the 16 slot norms of a tile first (independent LDS reads, one wait), +inf for slots beyond m: such a candidate  \
+       never wins (strict comparisons against a list that starts at +inf), so the insertion needs no per-candidate      \
+       branch - the first form's `if (s < m)` around an LDS read cost an exposed LDS latency and an exec-mask branch   \
+       per candidate, a quarter of this kernel's time */                                               \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                    \
       if ((tile_) + u < ntile) {                                                                       \
+        const int s0_ = ((tile_) + u) << 5;                                                            \
+        float en_[16];                                                                                 \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                               \
-          const int s = (((tile_) + u) << 5) + (r & 3) + 8 * (r >> 2) + 4 * h;                         \
-          if (s < m) {                                                                                 \
-            const float dist = (xnorm - 2.f * acc[u][r]) + (NL ? ens[s] : enorm[s]);                   \
-            s_topk_insert_ordered<K>(bv, bi, dist, s);                                                 \
-          }                                                                                            \
+          const int s = s0_ + (r & 3) + 8 * (r >> 2) + 4 * h;                                          \
+          const int sc = s < m ? s : m - 1;                                                            \
+          const float e_ = NL ? ens[sc] : enorm[sc];                                                   \
+          en_[r] = s < m ? e_ : INFINITY;                                                              \
         }                                                                                              \
+        _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                              \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
+            const float dist = (xnorm[rt] - 2.f * acc[u][rt][r]) + en_[r];                             \
+            s_topk_insert_ordered<K>(bv[rt], bi[rt], dist, s0_ + (r & 3) + 8 * (r >> 2) + 4 * h);      \
+          }                                                                                            \
       }                                                                                                \
     }                                                                                                  \
   }
   {
-    h16x8 ah0[2][4], al0[2][4], ah1[2][4], al1[2][4];
+    h16x8 ah0[U][4], al0[U][4], ah1[U][4], al1[U][4];
     // (the prefetch loads are UNCONDITIONAL - S_LOAD clamps the tile index - because a load the compiler cannot be
-    // sure was issued makes it count its vmcnt waits as if it was not: the waits of the current pair then also cover
-    // the pair just requested and the prefetch is gone; seen in the ISA as vmcnt(15) .. vmcnt(0) inside the MFMAs)
-    int tile = wave * 2;
+    // sure was issued makes it count its vmcnt waits as if it was not: the waits of the current step then also cover
+    // the step just requested and the prefetch is gone; seen in the ISA as vmcnt(15) .. vmcnt(0) inside the MFMAs)
+    int tile = wave * U;                          // NW waves x U tiles = 8 tiles per round in both forms
     S_LOAD(ah0, al0, tile)
     while (tile < ntile) {
       S_LOAD(ah1, al1, tile + 8)
@@ -196,20 +223,22 @@ __global__ __launch_bounds__(256, 2) void memory_topk_s16_kernel(
 #undef S_LOAD
 #undef S_TILES
 
-  // ---- merge the 8 partial lists of every row ---------------------------------------------------------------------------
+  // ---- merge the 2 NW partial lists of every row ------------------------------------------------------------------------
 #pragma unroll
-  for (int j = 0; j < K; ++j) {
-    const int o = l31 * CROW + (wave * 2 + h) * K + j;
-    cand_v[o] = bv[j];
-    cand_i[o] = bi[j];
-  }
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const int o = (l31 + 32 * rt) * CROW + (wave * 2 + h) * K + j;
+      cand_v[o] = bv[rt][j];
+      cand_i[o] = bi[rt][j];
+    }
   __syncthreads();
   if (tid < SBR) {
     float v[K];
     int ix[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) { v[j] = INFINITY; ix[j] = 0x7fffffff; }
-    for (int c = 0; c < 8 * K; ++c) s_topk_insert<K>(v, ix, cand_v[tid * CROW + c], cand_i[tid * CROW + c]);
+    for (int c = 0; c < 2 * NW * K; ++c) s_topk_insert<K>(v, ix, cand_v[tid * CROW + c], cand_i[tid * CROW + c]);
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       best[tid * K + j] = ix[j];
@@ -218,13 +247,14 @@ __global__ __launch_bounds__(256, 2) void memory_topk_s16_kernel(
   }
   __syncthreads();
 
-  // ---- gather + commit distance (fp32 codebook, fp32 features) -------------------------------------------------------------
+  // ---- gather + commit distance (fp32 codebook, fp32 features): 256 threads per 32 rows, one partial per 32 rows ------------
   float part = 0.f;
   constexpr int slots16 = SD / 4;
-  for (int p = tid; p < SBR * K * slots16; p += 256) {
+  const int half = tid >> 8, t8 = tid & 255;                      // (RT = 1: half = 0)
+  for (int p = t8; p < 32 * K * slots16; p += 256) {
     const int sl = p % slots16;
     const int rj = p / slots16;
-    const int j = rj % K, row = rj / K;
+    const int j = rj % K, row = 32 * half + rj / K;
     if (r0 + row >= n) continue;
     const int s = best[row * K + j];
     const f32x4 e = *reinterpret_cast<const f32x4*>(e_md + (int64_t)s * SD + sl * 4);
@@ -244,13 +274,13 @@ __global__ __launch_bounds__(256, 2) void memory_topk_s16_kernel(
   red[tid] = part;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o) red[tid] += red[tid + o];
+    if (t8 < o) red[tid] += red[tid + o];
     __syncthreads();
   }
-  if (tid == 0) diff_partial[blockIdx.x] = red[0];
+  if (t8 == 0 && (int)blockIdx.x * RT + half < nparts) diff_partial[blockIdx.x * RT + half] = red[tid];
 }
 
-// [d][m] fp32 -> [d/8][mpad][8 hi | 8 lo] halfs (slots >= m zero)
+// [d][m] fp32 -> [d/8][hi | lo][mpad][8] halfs (slots >= m zero)
 __global__ __launch_bounds__(256) void pack_codebook_s16_kernel(const float* __restrict__ e_dm, int d, int m, int mpad,
                                                                 _Float16* __restrict__ out) {
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -264,20 +294,30 @@ __global__ __launch_bounds__(256) void pack_codebook_s16_kernel(const float* __r
     hi[i] = hv;
     lo[i] = (_Float16)((v - (float)hv) * S_LO_SCALE);
   }
-  *reinterpret_cast<h16x8*>(out + gid * 16) = hi;
-  *reinterpret_cast<h16x8*>(out + gid * 16 + 8) = lo;
+  // plane-major within a k-block: [kb][hi | lo][mpad][8] - the 32 lanes of a half wave read 512 contiguous bytes per
+  // load (interleaved [8 hi | 8 lo] rows made every load touch twice the cache lines it used)
+  *reinterpret_cast<h16x8*>(out + ((int64_t)(2 * kb) * mpad + s) * 8) = hi;
+  *reinterpret_cast<h16x8*>(out + ((int64_t)(2 * kb + 1) * mpad + s) * 8) = lo;
 }
 
 template <int K>
 int launch_topk_s16(const float* x, const void* e_s16, const float* e_md, const float* enorm, int n, int m, int* idx,
                     float* q_topk, float* q_one, float* diff_partial, hipStream_t stream) {
   const int mpad = (m + 31) / 32 * 32;
-  if (m <= 4096)
-    hipLaunchKernelGGL((memory_topk_s16_kernel<K, true>), dim3((n + SBR - 1) / SBR), dim3(256), 0, stream, x,
-                       reinterpret_cast<const h16x8*>(e_s16), e_md, enorm, n, m, mpad, idx, q_topk, q_one, diff_partial);
+  const int nparts = (n + 31) / 32;                                 // = ammc_memory_topk_blocks(n): one commit partial per 32 rows
+  const h16x8* e = reinterpret_cast<const h16x8*>(e_s16);
+  // 64-row workgroups (half the codebook traffic per CU) once they fill the chip; option "memory_rt" forces a form
+  const int force = ammc_opt_memory_rt();
+  const bool rt2 = K <= 2 && m <= 2048 && (force == 2 || (force != 1 && n >= 64 * 256));   // (K > 2: candidate lists outgrow the LDS)
+  if (rt2)
+    hipLaunchKernelGGL((memory_topk_s16_kernel<(K <= 2 ? K : 1), true, 2>), dim3((n + 63) / 64), dim3(512), 0, stream, x, e,
+                       e_md, enorm, n, m, mpad, nparts, idx, q_topk, q_one, diff_partial);
+  else if (m <= 4096)
+    hipLaunchKernelGGL((memory_topk_s16_kernel<K, true, 1>), dim3(nparts), dim3(256), 0, stream, x, e, e_md, enorm, n, m,
+                       mpad, nparts, idx, q_topk, q_one, diff_partial);
   else
-    hipLaunchKernelGGL((memory_topk_s16_kernel<K, false>), dim3((n + SBR - 1) / SBR), dim3(256), 0, stream, x,
-                       reinterpret_cast<const h16x8*>(e_s16), e_md, enorm, n, m, mpad, idx, q_topk, q_one, diff_partial);
+    hipLaunchKernelGGL((memory_topk_s16_kernel<K, false, 1>), dim3(nparts), dim3(256), 0, stream, x, e, e_md, enorm, n, m,
+                       mpad, nparts, idx, q_topk, q_one, diff_partial);
   return ammc_launch_status();
 }
 

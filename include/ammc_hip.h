@@ -46,6 +46,8 @@ const char* ammc_error_string(int code);
  *             variant (default), 1 = v_mfma_f32_16x16x32_f16, 0 = v_mfma_f32_32x32x16_f16.  Initial value: AMMC_S16_MF.
  *   "outc_stream"  1 = the output layer (32-filter tile, fp32 NCHW output) on the streaming kernel conv_outc_s16
  *             (default), 0 = on the halo-patch kernel.  Initial value: AMMC_OUTC_STREAM.
+ *   "memory_rt"  feature rows per workgroup of ammc_memory_topk_fwd_s16: 0 = by size (64 from 16384 rows up, k <= 2,
+ *             m <= 2048; default), 1 = 32, 2 = 64.  Results are bit-identical.  Initial value: AMMC_MEMORY_RT.
  * Returns AMMC_EUNSUP for an unknown key, AMMC_EINVAL for a value out of range.  These are PROCESS defaults
  * (not thread safe against concurrent launches); a caller that needs a per-call choice sets the descriptor fields
  * `s16_mf` / `outc_stream` instead, which take precedence and touch no global state. */
@@ -158,7 +160,7 @@ int ammc_memory_topk_fwd_f32(const float* x, const float* embed_dm, const float*
 /* The same memory addressing with the distance GEMM on the fp16 MFMA pipe in fp32-EQUIVALENT arithmetic (features and
  * slots as (hi, lo) half pairs, three MFMAs per product, fp32 accumulation; norms, gather, commit distance from the fp32
  * data as in ammc_memory_topk_fwd_f32): the inference default for the model's embed_dim = 64 (d != 64: AMMC_EUNSUP, use
- * the fp32 entry).  e_s16 = ammc_pack_codebook_s16(embed [d][m]): [d/8][mpad][8 hi | 8 lo] halfs, mpad = m rounded up
+ * the fp32 entry).  e_s16 = ammc_pack_codebook_s16(embed [d][m]): [d/8][hi | lo][mpad][8] halfs (opaque to callers), mpad = m rounded up
  * to 32; enorm / embed_md from ammc_pack_codebook_f32; diff_partial has ammc_memory_topk_blocks(n) entries. */
 int ammc_pack_codebook_s16(const float* embed_dm, int32_t d, int32_t m, void* e_s16, void* stream);
 int ammc_memory_topk_fwd_s16(const float* x, const void* e_s16, const float* embed_md, const float* enorm, int32_t n,

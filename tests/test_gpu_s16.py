@@ -329,6 +329,28 @@ def _memory_s16(embed, x, k):
     return qk.view(*lead, k * d).cpu(), diff[0].cpu(), q1.view(*lead, d).cpu(), idx.view(*lead, k).cpu()
 
 
+@pytest.mark.parametrize("m,k,bhw", [(2000, 2, (4, 16, 17)), (256, 1, (3, 11, 13)), (40, 2, (1, 9, 15))])
+def test_memory_topk_s16_row_tiles_agree_bit_for_bit(m, k, bhw):
+    """the 64-row form of the S16 memory kernel (8 waves, one slot tile per step; what 16384 rows and more take) against
+    the 32-row form on the same ragged inputs: every output identical (same accumulation order per distance, one
+    commit partial per 32 rows in both), and against the oracle with the gates of the test below"""
+    from test_gpu_parity import _check_quantize
+    lib = _lib.load()
+    embed = S.hashed_normal(f"gq2:64:{m}", (64, m), 0.9)
+    x = S.hashed_normal(f"gq2x:64:{m}", (*bhw, 64), 0.8)
+    outs = {}
+    try:
+        for rt in (1, 2):
+            assert lib.ammc_set_option(b"memory_rt", rt) == 0
+            outs[rt] = _memory_s16(embed, x, k)
+    finally:
+        lib.ammc_set_option(b"memory_rt", 0)
+    for a, b in zip(outs[1], outs[2]):
+        assert torch.equal(a, b)
+    _check_quantize(x, embed, k, *outs[2])
+    assert lib.ammc_set_option(b"memory_rt", 3) == -1
+
+
 @pytest.mark.parametrize("m,k,bhw", [(256, 2, (2, 8, 8)), (2000, 2, (3, 8, 8)), (256, 3, (1, 4, 8)), (256, 1, (1, 5, 7)),
                                      (5000, 2, (1, 3, 11)), (33, 4, (2, 2, 2))])
 def test_memory_topk_s16(m, k, bhw):
