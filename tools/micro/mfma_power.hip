@@ -147,16 +147,19 @@ int main(int argc, char** argv) {
   float* out;
   hipMalloc(&src, n * sizeof(f16x8));
   hipMalloc(&out, 256 * 512 * sizeof(float));
-  for (int mode = 0; mode < 3; ++mode) {
+  for (int mode = 0; mode < 5; ++mode) {
     srand(1234);
     for (size_t i = 0; i < n; ++i)
       for (int k = 0; k < 8; ++k) {
         float v = mode == 2 ? 0.5f : (float)rand() / RAND_MAX * 2.f - 1.f;
         if (mode == 1 && (i / 131072 == 0 || i / 131072 == 6) && (rand() & 1)) v = 0.f;    // the A fragments: half zeros
+        if (mode == 3 && (i / 131072 >= 2 && i / 131072 <= 5) && (rand() & 1)) v = 0.f;    // the B fragments: half zeros
+        if (mode == 4 && (rand() & 1)) v = 0.f;                                            // both
         h[i][k] = (_Float16)v;
       }
     hipMemcpy(src, h.data(), n * sizeof(f16x8), hipMemcpyHostToDevice);
-    const char* tag = mode == 0 ? "random operands" : mode == 1 ? "random, half of A zero" : "constant operands";
+    const char* tag = mode == 0 ? "random operands" : mode == 1 ? "random, half of A zero" : mode == 2 ? "constant operands"
+                      : mode == 3 ? "random, half of B zero" : "random, half of A and of B zero";
     char name[128];
     snprintf(name, sizeof name, "v_mfma_f32_32x32x16_f16, %s", tag);
     run_case<0>(name, src, out, seconds, hw);
