@@ -20,7 +20,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int SHAPE>
+template <int SHAPE, int ORDER = 0>
 __global__ __launch_bounds__(512, 2) void mfma_loop(const f16x8* __restrict__ src, float* __restrict__ out, int iters) {
   const int tid = threadIdx.x + blockIdx.x * 512;
   f16x8 a[2], b[4];
@@ -32,10 +32,18 @@ __global__ __launch_bounds__(512, 2) void mfma_loop(const f16x8* __restrict__ sr
       for (int j = 0; j < 4; ++j)
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     for (int it = 0; it < iters; ++it) {
+      if (ORDER == 0) {                                        // consecutive MFMAs share the A operand
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+      } else {                                                 // no operand shared between consecutive MFMAs
+        constexpr int si[8] = {0, 1, 0, 1, 0, 1, 0, 1}, sj[8] = {0, 1, 2, 3, 1, 0, 3, 2};
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          acc[si[q]][sj[q]] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[si[q]], b[sj[q]], acc[si[q]][sj[q]], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     float s = 0.f;
     for (int i = 0; i < 2; ++i)
@@ -95,10 +103,10 @@ static double read_num(const std::string& path) {
   return v;
 }
 
-template <int SHAPE>
+template <int SHAPE, int ORDER = 0>
 static void run_case(const char* name, const f16x8* src, float* out, double seconds, const std::string& hw) {
   const int blocks = 256, iters = 20000;                       // one 8-wave workgroup per CU = 2 waves per SIMD
-  hipLaunchKernelGGL(mfma_loop<SHAPE>, dim3(blocks), dim3(512), 0, 0, src, out, iters);
+  hipLaunchKernelGGL((mfma_loop<SHAPE, ORDER>), dim3(blocks), dim3(512), 0, 0, src, out, iters);
   hipDeviceSynchronize();
   std::atomic<bool> stop{false};
   std::vector<double> pw, fq;
@@ -118,7 +126,7 @@ static void run_case(const char* name, const f16x8* src, float* out, double seco
   long launches = 0;
   hipEventRecord(e0, 0);
   while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
-    for (int i = 0; i < 4; ++i) hipLaunchKernelGGL(mfma_loop<SHAPE>, dim3(blocks), dim3(512), 0, 0, src, out, iters);
+    for (int i = 0; i < 4; ++i) hipLaunchKernelGGL((mfma_loop<SHAPE, ORDER>), dim3(blocks), dim3(512), 0, 0, src, out, iters);
     launches += 4;
     hipDeviceSynchronize();
   }
@@ -165,6 +173,10 @@ int main(int argc, char** argv) {
     run_case<0>(name, src, out, seconds, hw);
     snprintf(name, sizeof name, "v_mfma_f32_16x16x32_f16, %s", tag);
     run_case<1>(name, src, out, seconds, hw);
+    if (mode == 0) {
+      snprintf(name, sizeof name, "32x32x16, %s, no operand shared", tag);
+      run_case<0, 1>(name, src, out, seconds, hw);
+    }
   }
   return 0;
 }
