@@ -68,6 +68,7 @@ class Act:
     def crop(self, H: int, W: int) -> "Act":
         """the top-left H x W pixels of the same buffer (strides unchanged)"""
         a = Act(self.buf, self.B, self.H, self.W, self.c, self.c_off, self.halo)
+        a.rs, a.bs = self.rs, self.bs           # a crop of a crop keeps the BUFFER's strides
         a.H, a.W = H, W
         return a
 

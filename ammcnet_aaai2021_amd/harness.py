@@ -189,11 +189,18 @@ class _FiniteWatch:
     weights for good.  The verdict on the loss is copied to pinned host memory right after the FORWARD (one 1-byte copy
     + an event, queued before the backward's kernels); `step` waits for that event only - by then the host has enqueued
     the whole backward, so the device keeps working while the host waits - and refuses the step loudly.  (The
-    BatchNorm / EMA buffers of the refused step were updated in place by its forward, as the reference's would be.)"""
+    BatchNorm / EMA buffers of the refused step were updated in place by its forward, as the reference's would be.)
+    Data parallel: the gradients are averaged across ranks INSIDE backward, so one rank's non-finite loss poisons every
+    rank's gradients; the verdict is therefore all-reduced (MIN) on the device before it is copied, and all ranks refuse
+    the step together (no rank steps on NaN gradients, none is left waiting in the next collective)."""
 
-    def __init__(self, *losses):
+    def __init__(self, *losses, group=None):
         self.flag = torch.empty(len(losses), dtype=torch.bool).pin_memory() if losses[0].is_cuda else None
         fin = torch.stack([torch.isfinite(v.detach()).all() for v in losses])
+        if parallel.dist.is_available() and parallel.dist.is_initialized() and parallel.dist.get_world_size(group) > 1:
+            vote = fin.to(torch.int32)
+            parallel.dist.all_reduce(vote, op=parallel.dist.ReduceOp.MIN, group=group)
+            fin = vote.to(torch.bool)
         if self.flag is not None:
             self.flag.copy_(fin, non_blocking=True)
             self.event = torch.cuda.Event()

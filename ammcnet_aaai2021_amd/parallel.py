@@ -81,11 +81,15 @@ class BucketedGradReducer:
 
     `push(tensors)` may be called many times during one backward; a bucket is flattened and
     all-reduced asynchronously as soon as it is full.  `finish()` flushes the tail, waits and
-    scatters the averaged values back IN PLACE into the pushed tensors."""
+    scatters the averaged values back IN PLACE into the pushed tensors.  `force`: take the collective path with ONE
+    rank too (an initialised process group is then required) - the one-GPU proof that the communicator, the
+    asynchronous all-reduce and its ordering against the raw-pointer kernels on torch's current stream work."""
 
-    def __init__(self, bucket_mb: float = 25.0, group=None):
+    def __init__(self, bucket_mb: float = 25.0, group=None, force: bool = False):
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.group = group
+        self.force = bool(force)
+        self._flats: Dict[int, torch.Tensor] = {}
         self._pending: List[torch.Tensor] = []
         self._pending_bytes = 0
         self._inflight: List[Tuple[torch.Tensor, List[torch.Tensor], object]] = []
@@ -95,8 +99,12 @@ class BucketedGradReducer:
     def world(self) -> int:
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
+    @property
+    def active(self) -> bool:
+        return self.world > 1 or (self.force and dist.is_initialized())
+
     def push(self, tensors: Iterable[torch.Tensor]) -> None:
-        if self.world == 1:
+        if not self.active:
             return
         for t in tensors:
             self._pending.append(t)
@@ -109,9 +117,7 @@ class BucketedGradReducer:
         (the backward pushes the same tensors in the same order), so the buffer is allocated once and only re-made
         when the total size or dtype / device changes - no `torch.cat` allocation per bucket per step"""
         n = sum(t.numel() for t in members)
-        flat = self._flats.get(slot) if hasattr(self, "_flats") else None
-        if not hasattr(self, "_flats"):
-            self._flats = {}
+        flat = self._flats.get(slot)
         if flat is None or flat.numel() != n or flat.dtype != members[0].dtype or flat.device != members[0].device:
             flat = torch.empty(n, dtype=members[0].dtype, device=members[0].device)
             self._flats[slot] = flat
@@ -134,7 +140,7 @@ class BucketedGradReducer:
         self.buckets_launched += 1
 
     def finish(self) -> None:
-        if self.world == 1:
+        if not self.active:
             return
         self._launch()
         inv = 1.0 / self.world
@@ -150,10 +156,11 @@ def attach_reducer(module: torch.nn.Module, reducer: Optional[BucketedGradReduce
     object.__setattr__(module, "_grad_reducer", reducer)
 
 
-def sync_statistics(module: torch.nn.Module, enabled: bool = True, group=None) -> None:
+def sync_statistics(module: torch.nn.Module, enabled: bool = True, group=None, force: bool = False) -> None:
     """Large-batch-exact data parallelism: BatchNorm batch statistics (forward sums and the
     two backward sums per layer, [2C] floats each) and the per-slot counts / feature sums of the EMA codebook
     update are all-reduced across ranks, so N ranks x B clips reproduce ONE step on N*B clips (running statistics
     and codebook identical on every rank).  Ranks must hold equal batch sizes.  Off by default: the stock
-    behaviour keeps statistics per rank."""
-    object.__setattr__(module, "_sync_stats", (bool(enabled), group))
+    behaviour keeps statistics per rank.  `force`: take the collective path with a world of one as well (one-GPU test of
+    the 33 collectives of a step over RCCL)."""
+    object.__setattr__(module, "_sync_stats", (bool(enabled), group, bool(force)))

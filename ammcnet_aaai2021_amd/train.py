@@ -45,10 +45,12 @@ class _WS:
 
     ZCHUNK = 16 << 20          # floats per chunk of the per-step-zeroed slab (64 MB)
 
-    def __init__(self, device):
+    def __init__(self, device, zchunk: Optional[int] = None):
         self.device = device
         self.lib = _lib.load()
         self.bytes = 0
+        if zchunk is not None:                  # stand-alone block engines: a handful of small accumulators
+            self.ZCHUNK = int(zchunk)
         self._zchunks: List[torch.Tensor] = []
         self._zfree = 0
 
@@ -82,6 +84,13 @@ class _WS:
         return Act(self.buf(B, H + 2 * halo, W + 2 * halo, c), B, H, W, c, 0, halo)
 
 
+def _check_embed_dim(d: int) -> None:
+    """the 1x1 `enc` weight / input gradients read the [rows][d] gradient of z in 32-channel tiles: a narrower or
+    ragged row would make them read the neighbouring pixels' values (and past the buffer at the last pixel)"""
+    if d % 32:
+        raise NotImplementedError(f"memory block in training mode: embed_dim {d} (multiples of 32; the reference uses 64)")
+
+
 def _stream(dev) -> int:
     return torch.cuda.current_stream(dev).cuda_stream
 
@@ -98,6 +107,7 @@ class _Ops:
         self.ws, self.lib, self.dev = ws, ws.lib, ws.device
         self.zeros = ws.buf(1024)
         self.sync_group = None          # set per step by TrainEngine: a process group, or False for "no sync"
+        self.sync_force = False         # parallel.sync_statistics(..., force=True): the collective path with one rank too
         self.s16 = (precision or TRAIN_PRECISION) == "s16"
         self._shadows: Dict[int, torch.Tensor] = {}
         self.amax = ws.buf(256, dtype=torch.int32)         # slots of ammc_absmax_bits_f32 / bn_bwd_apply
@@ -197,6 +207,12 @@ class _Ops:
         if self.sync_group is False or not dist.is_initialized():
             return 1
         return dist.get_world_size(self.sync_group)
+
+    @property
+    def sync_on(self) -> bool:
+        """the units take their all-reduce path: more than one rank, or one rank with `force` (the one-GPU RCCL test)"""
+        import torch.distributed as dist
+        return self.sync_world > 1 or (self.sync_force and self.sync_group is not False and dist.is_initialized())
 
     def all_reduce(self, t: torch.Tensor) -> None:
         import torch.distributed as dist
@@ -318,7 +334,7 @@ class _ConvBN:
         bn = self.bn
         part, nblk, count = self.partial, self.nblk, float(c.B * c.H * c.W)
         world = o.sync_world
-        if world > 1:
+        if o.sync_on:
             # synchronised statistics: [2C] sums of every rank are added, the finalizer sees the global batch
             tot = torch.empty(2 * self.cout, device=o.dev, dtype=torch.float32)
             _chk(lib.ammc_reduce_partials_f32(_ptr(self.partial), self.nblk, 2 * self.cout, 1.0, _ptr(tot), s), "reduce")
@@ -354,7 +370,7 @@ class _ConvBN:
         world = o.sync_world
         s16_wgrad = o.s16 and self.cin_p >= 8 and WGRAD_S16
         fused_amax = o.s16 and (da is not None or s16_wgrad)
-        if fused_amax and world == 1 and FUSE_BN_BWD:
+        if fused_amax and not o.sync_on and FUSE_BN_BWD:
             # one rank, S16 consumers: the reduction also bounds max |dc|, so the apply pass writes the S16 twin of dc
             # directly (fp32 dc only where the fp32 weight-gradient kernel still reads it)
             _chk(lib.ammc_bn_bwd_reduce_bound_f32(c.pix0(), *c.strides, dy.pix0(), *dy.strides, _ptr(self.mean),
@@ -381,7 +397,7 @@ class _ConvBN:
             _chk(lib.ammc_reduce_partials_f32(_ptr(self.partial), self.nblk, 2 * self.cout, 1.0, _ptr(sums), s), "reduce")
             grads[self.bn.bias] = sums[:self.cout]
             grads[self.bn.weight] = sums[self.cout:]
-            if world > 1:
+            if o.sync_on:
                 # the input gradient needs the sums over the GLOBAL batch; the kernel divides by the local pixel
                 # count, so hand it global_sums / world (equal batch per rank).  dgamma / dbeta stay local: the
                 # gradient all-reduce averages them like every other parameter.
@@ -462,6 +478,7 @@ class _Stream:
             self.d, self.m, self.k = q.quantize.dim, q.quantize.n_embed, q.quantize.k
             n = B * h * w
             self.n = n
+            _check_embed_dim(self.d)
             self.z = ws.act(B, h, w, self.d, halo=0)
             self.qk = ws.act(B, h, w, self.k * self.d, halo=0)
             self.q_one = ws.buf(B, h, w, self.d)
@@ -538,7 +555,7 @@ class _Stream:
              "diff")
         # EMA update AFTER the lookups (they use the pre-update codebook, unet.py:291-309); e_md keeps the
         # pre-update rows, which is what the backward's commit gradient needs
-        if o.sync_world > 1:
+        if o.sync_on:
             counts = torch.empty(self.m, device=o.dev, dtype=torch.float32)
             sums = torch.empty((self.d, self.m), device=o.dev, dtype=torch.float32)
             _chk(lib.ammc_codebook_count_f32(_ptr(self.z.buf), self.idx.data_ptr(), self.k, self.n, self.d, self.m,
@@ -716,6 +733,7 @@ class TrainEngine:
         st = self._get(B, H, W, x0.device)
         sync = getattr(self.module, "_sync_stats", None)          # parallel.sync_statistics(model, group)
         st["ops"].sync_group = sync[1] if sync and sync[0] else False
+        st["ops"].sync_force = bool(sync and sync[0] and len(sync) > 2 and sync[2])
         self.generation += 1
         st["generation"] = self.generation
         xs = [x.detach().float().contiguous() for x in inputs]
@@ -774,7 +792,7 @@ class TrainEngine:
             r, o = streams
             ops = st["ops"]
             douts = [dout if dout is not None else torch.zeros_like(s.out) for s, dout in ((r, d_rgb), (o, d_op))]
-            if ops.sync_world > 1:
+            if ops.sync_on:
                 _lockstep(ops, r.decode_backward_gen(douts[0], grads), o.decode_backward_gen(douts[1], grads))
                 stage_done()
             else:                                   # one stream after the other: its gradients leave for the all-reduce early
@@ -787,7 +805,7 @@ class TrainEngine:
             stage_done()
             dx4r = r.memory_backward(st["dzx"], g(dd_r), g(dq_r), grads)
             dx4o = o.memory_backward(st["dzy"], g(dd_o), g(dq_o), grads)
-            if ops.sync_world > 1:
+            if ops.sync_on:
                 _lockstep(ops, r.encode_backward_gen(dx4r, grads), o.encode_backward_gen(dx4o, grads))
             else:
                 _lockstep(ops, r.encode_backward_gen(dx4r, grads))
@@ -986,11 +1004,13 @@ class MemoryBlockEngine:
         st = self._ws.get(key)
         if st is not None:
             return st
-        ws = _WS(device)
+        ws = _WS(device, zchunk=1 << 18)            # 1 MB slabs: two 1x1 accumulators
         ops = _Ops(ws, "fp32")
         lib = ops.lib
         qz = self.module if self.kind == "quantize" else self.module.quantize
         d, m, k = qz.dim, qz.n_embed, qz.k
+        if self.kind != "quantize":
+            _check_embed_dim(d)
         st = dict(ops=ops, d=d, m=m, k=k)
         if self.kind == "quantize":
             B, h, w, dd = shape

@@ -43,7 +43,6 @@ PEAK_HBM_GBS = 8000.0
 POWER_CEILING_TFLOPS = {"32x32x16": 1675.0, "16x16x32": 1889.0}
 PARITY_TOL = 1e-4                 # BASELINE.json north_star: 1e-4 relative fp32
 PARITY_FIXTURE = os.path.join(ROOT, "tests", "golden", "twostream_256_b16_m2000_eval.npz")
-TRAIN_FIXTURE = os.path.join(ROOT, "tests", "golden", "twostream_256_b2_train.npz")
 S16_DTYPE = ("f32-equivalent: (hi,lo) f16 split, 3 fp16 MFMAs per product (v_mfma_f32_32x32x16_f16 in the 4-wave k-half-major "
              "kernels, 16x16x32 in the 8-wave / fused-decoder kernels), f32 accumulate")
 
@@ -112,27 +111,19 @@ def spawn_ranks(args) -> int:
     return rc
 
 
-def pin_to_gpu_numa_node(local_rank: int):
-    """Best effort, before anything touches the GPU: restrict this rank to the CPUs of the NUMA node its GPU hangs off
-    (sysfs only: the KFD topology lists the GPUs in enumeration order with their PCI location, the PCI device names its
-    NUMA node).  Host-side launch latency and the pinned-memory copies of a rank then stay on one socket instead of
-    wandering over both.  Returns a description for the JSON line, or None when the topology cannot be read."""
+def pin_to_gpu_numa_node(device_index: int):
+    """Best effort: restrict this rank to the CPUs of the NUMA node its GPU hangs off.  The PCI address comes from the
+    device the process actually got (`torch.cuda.get_device_properties`: correct under any combination of
+    HIP_ / ROCR_ / CUDA_VISIBLE_DEVICES and on cgroup-restricted boxes, where an index into the KFD topology is not),
+    the node from /sys/bus/pci/devices/<bdf>/numa_node.  Querying the properties touches the GPU, so this runs AFTER
+    device selection.  Host-side launch latency and the pinned-memory copies of a rank then stay on one socket.
+    Returns a description for the JSON line, or None (and pins nothing) when the address cannot be resolved."""
     try:
-        base = "/sys/class/kfd/kfd/topology/nodes"
-        gpus = []
-        for node in sorted(os.listdir(base), key=int):
-            props = dict(ln.split() for ln in open(f"{base}/{node}/properties") if len(ln.split()) == 2)
-            if int(props.get("simd_count", "0")) > 0:
-                gpus.append(props)
-        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
-        idx = local_rank
-        if vis:
-            ids = [int(v) for v in vis.split(",") if v.strip().isdigit()]
-            if local_rank < len(ids):
-                idx = ids[local_rank]
-        p = gpus[idx]
-        loc, dom = int(p["location_id"]), int(p.get("domain", "0"))
-        bdf = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7:x}"
+        pr = torch.cuda.get_device_properties(device_index)
+        stem = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+        bdf = next((d for d in sorted(os.listdir("/sys/bus/pci/devices")) if d.startswith(stem)), None)
+        if bdf is None:
+            return None
         node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
         if node < 0:
             return None
@@ -144,7 +135,7 @@ def pin_to_gpu_numa_node(local_rank: int):
         if not cpus:
             return None
         os.sched_setaffinity(0, cpus)
-        return {"gpu": idx, "pci": bdf, "numa_node": node, "cpus": len(cpus)}
+        return {"gpu": device_index, "pci": bdf, "numa_node": node, "cpus": len(cpus)}
     except Exception:
         return None
 
@@ -153,9 +144,6 @@ def init_ranks(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and os.environ.get("AMMC_BENCH_SHARE_GPU", "0") == "0" and os.environ.get("AMMC_BENCH_NUMA", "1") != "0":
-        global NUMA_PIN
-        NUMA_PIN = pin_to_gpu_numa_node(local_rank)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -167,6 +155,9 @@ def init_ranks(args):
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1 and not share and os.environ.get("AMMC_BENCH_NUMA", "1") != "0":
+        global NUMA_PIN
+        NUMA_PIN = pin_to_gpu_numa_node(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -228,7 +219,7 @@ def cpu_baseline(args):
     best = None
     pb = min(b, 4)                                   # the thread count is chosen on 4 clips, the baseline timed on all b
     with torch.no_grad():
-        for th in sorted({min(t, ncpu) for t in (8, 16, 32)}):
+        for th in sorted({min(t, ncpu) for t in (8, 16, 32, 64, 128, ncpu)}):
             torch.set_num_threads(th)
             O.twostream_forward(sd, rgb_x[:pb], op_x[:pb], 2)       # warm-up at this thread count
             t0 = time.perf_counter()
@@ -247,7 +238,7 @@ def cpu_baseline(args):
     med = times[len(times) // 2]
     return {"value": round(b / med, 4), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"{args.cpu_iters} timed forwards (median) of batch {b} at {args.size}x{args.size}, "
-                      f"n_embed {args.n_embed} (the headline workload's own batch), torch CPU fp32, best of 8/16/32 threads = "
+                      f"n_embed {args.n_embed} (the headline workload's own batch), torch CPU fp32, best of 8/16/32/64/128/{ncpu} threads = "
                       f"{threads} chosen on {pb} clips (host has {ncpu} logical CPUs)"}
 
 
@@ -301,43 +292,51 @@ def cpu_baseline_stress(d: int, m: int, k: int):
 
 # ---- configs[2] / configs[3]: training ---------------------------------------------------------------------------------------
 
-def train_parity(dev, size, precision):
-    """one training-mode forward + loss of the SAME network (synthetic parameters, 256 slots) on the two clips of the
-    reference-recorded fixture tests/golden/twostream_256_b2_train.npz (loss, outputs and gradients of the reference's
-    own autograd at 256x256): |loss - loss_ref| / loss_ref and the worst relative deviation of the strided frames.
-    None when the fixture is not this frame size.  Runs on its own model instance, outside every timed region."""
+GRAD_NORM_TOL = 2e-3              # per-tensor gradient norms (tests/test_gpu_train.py: the fixture's own fp32-vs-fp64 noise)
+
+
+def train_fixture_for(batch: int, size: int):
+    """the reference-recorded training vectors of this batch / frame size (tests/golden/twostream_<size>_b<batch>_train.npz:
+    loss, strided frames, gradient norms and post-forward buffers of the reference's own autograd), or None"""
     import numpy as np
-    import ammcnet_aaai2021_amd as A
-    from ammcnet_aaai2021_amd import harness, synthetic as S
-    if size != 256 or not os.path.exists(TRAIN_FIXTURE):
+    path = os.path.join(ROOT, "tests", "golden", f"twostream_{size}_b{batch}_train.npz")
+    if not os.path.exists(path):
         return None
-    d = np.load(TRAIN_FIXTURE)
-    cfg = json.loads(str(d["cfg"]))
-    net = A.get_twostream((12, 6), (3, 2), 64, cfg["n_embed"], cfg["k"])
-    net.load_state_dict(S.make_twostream_state())
-    net = net.to(dev).train()
-    net.train_precision = precision
-    rgb_x, op_x, rgb_t, op_t = (t.to(dev) for t in S.make_clips(cfg["batch"], cfg["hw"], cfg["hw"], tag=cfg["tag"]))
-    out = net(rgb_x, op_x)
-    loss = harness.generator_loss(out, rgb_t, op_t)
-    loss.backward()
+    d = np.load(path)
+    return path, d, json.loads(str(d["cfg"]))
+
+
+def train_parity(net, out, loss, fixture, with_grads: bool):
+    """the TIMED model's first optimisation step against the reference-recorded vectors of the same clips and
+    parameters: loss, strided frames of the recorded batch rows, per-tensor gradient norms (one rank only: with more the
+    gradients are already averaged over ranks that run other clips) and the BatchNorm / codebook buffers the forward
+    updated in place.  Called between backward and optimizer.step()."""
+    import numpy as np
+    path, d, cfg = fixture
     st = int(d["out_step"])
+    rows = [int(r) for r in d["rows"]] if "rows" in d.files else list(range(cfg["batch"]))
 
     def rel(a, b):
         a, b = a.detach().double().cpu(), torch.as_tensor(np.asarray(b)).double()
-        return float((a - b).abs().max() / b.abs().max())
+        return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
-    gn = []
-    for name, p in net.named_parameters():
-        want = float(d[f"gn.{name}"])
-        gn.append(abs(float(p.grad.double().norm()) - want) / max(want, 1e-30))
-    gn.sort()
-    res = {"fixture": os.path.relpath(TRAIN_FIXTURE, ROOT), "batch": cfg["batch"],
+    res = {"fixture": os.path.relpath(path, ROOT), "batch": cfg["batch"], "of": "the timed model's first step",
            "loss_rel": abs(float(loss.detach()) - float(d["loss"])) / abs(float(d["loss"])),
-           "frames_max_rel": max(rel(out[0][..., ::st, ::st], d["rgb"]), rel(out[1][..., ::st, ::st], d["op"])),
-           "grad_norm_rel_median": gn[len(gn) // 2], "grad_norm_rel_max": gn[-1]}
-    del net, out, loss
-    torch.cuda.empty_cache()
+           "frames_max_rel": max(rel(out[0][rows][..., ::st, ::st], d["rgb"]), rel(out[1][rows][..., ::st, ::st], d["op"])),
+           "commit_max_rel": max(rel(out[2][0], d["rgb_diff"]), rel(out[2][1], d["op_diff"]))}
+    sd = net.state_dict()
+    bufs = [rel(sd[k[4:]], d[k]) for k in d.files if k.startswith("buf.") and sd[k[4:]].is_floating_point()]
+    res["buffers_max_rel"] = max(bufs) if bufs else None
+    if with_grads:
+        gn = []
+        for name, p in net.named_parameters():
+            want = float(d[f"gn.{name}"])
+            gn.append(abs(float(p.grad.double().norm()) - want) / max(want, 1e-30))
+        gn.sort()
+        res["grad_norm_rel_median"], res["grad_norm_rel_max"] = gn[len(gn) // 2], gn[-1]
+    res["ok"] = bool(res["loss_rel"] <= PARITY_TOL and res["frames_max_rel"] <= PARITY_TOL and
+                     res["commit_max_rel"] <= PARITY_TOL and (res["buffers_max_rel"] or 0.0) <= PARITY_TOL and
+                     res.get("grad_norm_rel_max", 0.0) <= GRAD_NORM_TOL)
     return res
 
 
@@ -355,7 +354,11 @@ def run_train(args, rank, world, dev, dist, steps, warmup, with_cpu):
         parallel.broadcast_state(net)
         parallel.attach_reducer(net, parallel.BucketedGradReducer())
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
-    rgb_x, op_x, rgb_t, op_t = (t.to(dev) for t in S.make_clips(batch, args.size, args.size, tag=f"trainbench{rank}"))
+    # rank 0 trains on the clips of the reference-recorded fixture of this batch / frame size when there is one, so that
+    # the TIMED model's own first step is checked (as run_infer does); every other rank on its own clips (weak scaling)
+    fixture = train_fixture_for(batch, args.size) if rank == 0 else None
+    tag = fixture[2]["tag"] if fixture else f"trainbench{rank}"
+    rgb_x, op_x, rgb_t, op_t = (t.to(dev) for t in S.make_clips(batch, args.size, args.size, tag=tag))
     rgb = torch.cat([rgb_x.view(batch, 4, 3, args.size, args.size), rgb_t[:, None]], 1)
     op = torch.cat([op_x.view(batch, 3, 2, args.size, args.size), op_t[:, None]], 1)
     clock = Clock(dev, dist)
@@ -364,7 +367,18 @@ def run_train(args, rank, world, dev, dist, steps, warmup, with_cpu):
     def step():
         state["loss"] = harness.train_step(net, opt, rgb, op)
 
-    for _ in range(max(warmup, 1)):
+    # the first step, spelled out (harness.train_step's own lines) so that its outputs and gradients can be compared
+    # before the optimizer moves the parameters
+    opt.zero_grad(set_to_none=True)
+    out = net(rgb_x, op_x)
+    loss = harness.generator_loss(out, rgb_t, op_t)
+    watch = harness._FiniteWatch(loss)
+    loss.backward()
+    parity = train_parity(net, out, loss, fixture, with_grads=world == 1) if fixture else None
+    watch.step(opt)
+    state["loss"] = loss.detach()
+    del out, loss
+    for _ in range(max(warmup, 1) - 1):
         step()
     elapsed = clock.time(step, steps)
     if not bool(torch.isfinite(state["loss"])):
@@ -396,7 +410,6 @@ def run_train(args, rank, world, dev, dist, steps, warmup, with_cpu):
                     "launches_per_step": f["launches"], "share_of_step": round(f["ms"] / (1e3 * elapsed / steps), 4)}
     if rank != 0:
         return None
-    parity = train_parity(dev, args.size, net._train_engine.precision)
     value = batch * steps * world / elapsed
     flops = 3.0 * fwd_flops_per_clip(args.size, args.size)
     return {
@@ -411,7 +424,8 @@ def run_train(args, rank, world, dev, dist, steps, warmup, with_cpu):
                    "parallelism": f"dp{world} (bucketed RCCL all-reduce of 100 MB of fp32 gradients)" if world > 1 else "1 GPU",
                    "gflop_per_clip_fwd_bwd": round(flops / 1e9, 1)},
         "whole_path_tflops": round(value * flops / 1e12 / world, 2), "loss": float(state["loss"]),
-        "parity_loss_rel": parity["loss_rel"] if parity else None, "parity_tol": PARITY_TOL, "parity": parity,
+        "parity_loss_rel": parity["loss_rel"] if parity else None, "parity_tol": PARITY_TOL,
+        "grad_norm_tol": GRAD_NORM_TOL, "parity": parity,
         "roofline": roof,
         "kernels": {k: dict(launches_per_step=v["launches"], avg_us=round(1e3 * v["ms"] / v["launches"], 2),
                             tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)) for k, v in
@@ -434,7 +448,31 @@ def stress_traffic(n_rows):
     return None
 
 
-def stress_parity(ms, x, qk, idx, d, m, k, rows=4096):
+def stress_parity(ms, x, qk, idx, d, m, k, rows=32768, chunk=4096):
+    """`rows` rows of the launch, strided over ALL its row tiles, checked in chunks of `chunk` (one 4096 x 8192 distance
+    matrix in float64 at a time)"""
+    n = x.shape[0]
+    sel = torch.arange(0, n, max(1, n // rows), device=x.device)[:rows]
+    agg = None
+    for c in range(0, sel.numel(), chunk):
+        ii = sel[c:c + chunk]
+        r = _stress_parity_chunk(ms, x[ii], qk.reshape(n, -1)[ii], idx.reshape(n, -1)[ii], d, m, k)
+        if agg is None:
+            agg = dict(r, _same=r["index_agreement"] * r["rows_checked"])
+        else:
+            agg["rows_checked"] += r["rows_checked"]
+            agg["_same"] += r["index_agreement"] * r["rows_checked"]
+            agg["rows_with_resolvable_margin"] += r["rows_with_resolvable_margin"]
+            for key in ("agree_on_all_resolvable", "gather_bit_exact_where_agreed", "chosen_within_fp16_noise_of_true_neighbours"):
+                agg[key] = agg[key] and r[key]
+    agg["index_agreement"] = round(agg.pop("_same") / agg["rows_checked"], 6)
+    agg["rows_sampled"] = f"every {max(1, n // rows)}-th of the launch's {n} rows"
+    agg["ok"] = bool(agg["agree_on_all_resolvable"] and agg["gather_bit_exact_where_agreed"] and
+                     agg["chosen_within_fp16_noise_of_true_neighbours"] and agg["index_agreement"] > 0.9)
+    return agg
+
+
+def _stress_parity_chunk(ms, x, qk, idx, d, m, k, rows=1 << 30):
     """the bench's OWN launch against the CPU oracle (`Quantize_topk.forward`, fp32) on a slice of its rows: indices
     must agree wherever the distance margin exceeds what fp16 operands can resolve (4e-3 of the distance scale, the
     gate of tests/test_gpu_stress_f16.py), the gathered fp32 rows must be bit-exact where they agree, and every chosen
@@ -447,7 +485,7 @@ def stress_parity(ms, x, qk, idx, d, m, k, rows=4096):
     got = idx[:n].cpu().long().reshape(n, k)
     widx = widx.reshape(n, k)
     dist = (flat.double().pow(2).sum(1, keepdim=True) - 2 * flat.double() @ embed.double() + embed.double().pow(2).sum(0, keepdim=True))
-    srt = dist.sort(dim=1).values
+    srt = dist.topk(k + 1, dim=1, largest=False).values          # ascending: the k + 1 nearest
     margin = (srt[:, 1:k + 1] - srt[:, :k]).min(dim=1).values
     scale = flat.double().pow(2).sum(1) + embed.double().pow(2).sum(0).mean()
     safe = margin > 4e-3 * scale
@@ -752,9 +790,9 @@ def run_infer(args, rank, world, dev, dist):
         torch.cuda.empty_cache()
         t = run_train(args, 0, 1, dev, None, steps=5, warmup=2, with_cpu=False)
         line["train"] = {k: t[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config",
-                                           "whole_path_tflops", "loss", "parity_loss_rel", "parity_tol", "parity",
-                                           "roofline", "kernels")}
-        if t["parity_loss_rel"] is not None and t["parity_loss_rel"] > PARITY_TOL:
+                                           "whole_path_tflops", "loss", "parity_loss_rel", "parity_tol", "grad_norm_tol",
+                                           "parity", "roofline", "kernels")}
+        if t["parity"] is not None and not t["parity"]["ok"]:
             rc = 3
         torch.cuda.empty_cache()
         s = run_stress(args, 0, 1, dev, None, steps=10, warmup=2, with_cpu=False)
@@ -773,7 +811,7 @@ def main():
     rc = 0
     if args.mode == "train":
         line = run_train(args, rank, world, dev, dist, args.steps, args.warmup, world == 1 and not args.no_cpu_baseline)
-        if line is not None and line.get("parity_loss_rel") is not None and line["parity_loss_rel"] > PARITY_TOL:
+        if line is not None and line.get("parity") is not None and not line["parity"]["ok"]:
             rc = 3
     elif args.mode == "stress":
         line = run_stress(args, rank, world, dev, dist, args.steps, args.warmup, world == 1 and not args.no_cpu_baseline)

@@ -115,7 +115,9 @@ def twostream_eval(ref, hw, batch, n_embed, name, full, rows=None, q_step=1, gri
     print(name, {k: getattr(v, "shape", None) for k, v in list(out.items())[:8]})
 
 
-def twostream_train(ref, hw, batch, name, out_step=1):
+def twostream_train(ref, hw, batch, name, out_step=1, rows=None):
+    """`rows`: batch rows of the strided frames that are kept (all when None) - the batch-32 fixture of the training
+    benchmark's own shape stays a few hundred KB"""
     cfg = dict(in_channel=(12, 6), out_channel=(3, 2), embed_dim=64, n_embed=256, k=2)
     sd = S.make_twostream_state(**cfg)
     net = ref.get_twostream(cfg["in_channel"], cfg["out_channel"], 64, 256, 2)
@@ -127,8 +129,10 @@ def twostream_train(ref, hw, batch, name, out_step=1):
     # streams + the two commit terms; all lambdas 1.
     loss = torch.norm(rgb - rgb_t, p=2, dim=1).mean() + torch.norm(op - op_t, p=2, dim=1).mean() + (rd + od).sum()
     loss.backward()
-    out = {"loss": loss.detach().numpy(), "rgb": sub(rgb, out_step), "op": sub(op, out_step),
-           "rgb_diff": rd.detach().numpy(), "op_diff": od.detach().numpy(), "out_step": np.int64(out_step)}
+    keep = list(range(batch)) if rows is None else list(rows)
+    out = {"loss": loss.detach().numpy(), "rgb": sub(rgb[keep], out_step), "op": sub(op[keep], out_step),
+           "rgb_diff": rd.detach().numpy(), "op_diff": od.detach().numpy(), "out_step": np.int64(out_step),
+           "rows": np.array(keep, dtype=np.int64)}
     for k, p in net.named_parameters():
         g = p.grad.detach()
         out[f"gn.{k}"] = np.float64(g.double().norm().item())
@@ -348,6 +352,11 @@ def flownet2sd_golden(name="flownet2sd_eval"):
 def main():
     torch.set_num_threads(8)
     ref = load_ref_unet()
+    if len(sys.argv) > 1 and sys.argv[1] == "train_b32":
+        # the TIMED training batch of bench.py (BASELINE.json configs[2]: batch 32 at 256x256): ~30 GB of autograd state
+        # and a few minutes on 8 cores, so it is made on request only
+        twostream_train(ref, 256, 32, "twostream_256_b32_train", out_step=4, rows=(0, 31))
+        return
     param_counts(ref)
     shipped_record_structure()
     quantize_cases(ref)

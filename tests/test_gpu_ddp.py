@@ -138,3 +138,66 @@ def test_two_ranks_with_synchronised_statistics_equal_one_large_batch():
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] for r in res), res
+
+
+def _worker_rccl(port, q, sync):
+    """ONE rank on the one GPU with backend "nccl" (= RCCL): the communicator is built, every bucket all-reduce (and with
+    `sync` the 33 statistics collectives of the step) really runs on RCCL's stream beside the ctypes-launched kernels on
+    torch's current stream, and the step must come out as the step without any process group does."""
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    import ammcnet_aaai2021_amd as A
+    from ammcnet_aaai2021_amd import harness as Hn, parallel as P, synthetic as S
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    sd = S.make_twostream_state(tag="rccl1")
+    rgb_x, op_x, rgb_t, op_t = [t.to(dev) for t in S.make_clips(2, 64, 64, tag="rccl1clips")]
+
+    def step(with_group):
+        net = A.get_twostream((12, 6), (3, 2), 64, 256, 2)
+        net.load_state_dict(sd)
+        net = net.to(dev).train()
+        red = None
+        if with_group:
+            red = P.BucketedGradReducer(bucket_mb=8, force=True)
+            P.attach_reducer(net, red)
+            if sync:
+                P.sync_statistics(net, True, force=True)
+        Hn.generator_loss(net(rgb_x, op_x), rgb_t, op_t).backward()
+        torch.cuda.synchronize()
+        g = {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+        b = {n: v.detach().clone() for n, v in net.state_dict().items() if v.is_floating_point() and n not in g}
+        return g, b, red, net
+
+    g0, b0, _, _ = step(False)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    ok, detail = True, ""
+    try:
+        backend = dist.get_backend()
+        g1, b1, red, net = step(True)
+        ncoll = net._train_engine._last["ops"].collectives
+        gerr = max(float((g1[n] - g0[n]).norm() / g0[n].norm().clamp_min(1e-30)) for n in g0)
+        berr = max(float((b1[n] - b0[n]).abs().max() / b0[n].abs().max().clamp_min(1e-30)) for n in b0)
+        # per-rank mode: bit-identical (sum over one rank, times 1/1).  sync mode takes the unfused BatchNorm backward
+        # (fp32 dc re-encoded instead of the S16 twin written directly): same arithmetic to fp32 rounding
+        tol = 2e-4 if sync else 0.0
+        ok = backend == "nccl" and red.buckets_launched >= 3 and gerr <= tol and berr <= (1e-5 if sync else 0.0) and \
+            ncoll == (33 if sync else 0)
+        detail = f"backend {backend} buckets {red.buckets_launched} collectives {ncoll} grad {gerr:.2e} buffers {berr:.2e}"
+    finally:
+        dist.destroy_process_group()
+    q.put((0, ok, detail))
+
+
+@pytest.mark.parametrize("sync", [False, True], ids=["per_rank_stats", "sync_stats"])
+def test_rccl_world_of_one_runs_the_real_collectives(sync):
+    """RCCL itself executes - communicator, asynchronous bucket all-reduces during the hand-scheduled
+    backward, the lock-step statistics collectives - and the gradients / buffers are those of the step without it"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_rccl, args=(_free_port(), q, sync))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=60)
+    assert res[1], res

@@ -580,3 +580,40 @@ def test_twostream_train_step_256_vs_reference_vectors(train_precision):
     for key in d.files:
         if key.startswith("buf."):
             assert rel_err(nsd[key[4:]].cpu().double(), d[key].astype(np.float64)) <= 1e-4, key
+
+
+def test_twostream_train_step_256_batch32_vs_reference_vectors():
+    """The batch the training benchmark TIMES (BASELINE.json configs[2]: batch 32 at 256x256): 16x
+    the tiles per launch of the batch-2 fixture - several rounds per persistent grid, the split decisions of the weight
+    gradients at 32768 / 131072 pixels per channel block - against vectors recorded from the reference's own forward +
+    autograd on the same 32 clips (tests/golden/twostream_256_b32_train.npz: loss, strided frames of clips 0 and 31,
+    every gradient's norm and 64 samples, the buffers the forward updates; `make_golden.py train_b32`).  bench.py
+    computes the same comparison from its timed model's first step (`train.parity`)."""
+    d = np.load(os.path.join(GOLDEN, "twostream_256_b32_train.npz"))
+    cfg = json.loads(str(d["cfg"]))
+    assert (cfg["hw"], cfg["batch"], cfg["n_embed"]) == (256, 32, 256)
+    net = A.get_twostream((12, 6), (3, 2), 64, cfg["n_embed"], cfg["k"])
+    net.load_state_dict(S.make_twostream_state())
+    net = net.to(DEV).train()
+    rgb_x, op_x, rgb_t, op_t = (t.to(DEV) for t in S.make_clips(cfg["batch"], cfg["hw"], cfg["hw"], tag=cfg["tag"]))
+    out = net(rgb_x, op_x)
+    loss = O.generator_loss(out, rgb_t, op_t)
+    loss.backward()
+    st, rows = int(d["out_step"]), [int(r) for r in d["rows"]]
+    assert abs(float(loss.detach()) - float(d["loss"])) <= 1e-4 * abs(float(d["loss"]))
+    assert rel_err(out[0].detach().cpu()[rows][..., ::st, ::st], d["rgb"]) <= 1e-4
+    assert rel_err(out[1].detach().cpu()[rows][..., ::st, ::st], d["op"]) <= 1e-4
+    assert rel_err(out[2][0].detach().cpu(), d["rgb_diff"]) <= 1e-4 and rel_err(out[2][1].detach().cpu(), d["op_diff"]) <= 1e-4
+    errs = []
+    for name, p in net.named_parameters():
+        assert p.grad is not None, name
+        g = p.grad.detach().cpu()
+        gn = float(d[f"gn.{name}"])
+        assert abs(float(g.double().norm()) - gn) <= 2e-3 * gn + 1e-10, name
+        smp = g.flatten()[:: max(1, g.numel() // 64)][:64].double()
+        errs.append(_l2rel(smp, torch.as_tensor(d[f"gs.{name}"]).double()))
+    assert max(errs) <= 1e-2 and float(np.median(errs)) <= 2e-3, (max(errs), float(np.median(errs)))
+    nsd = net.state_dict()
+    for key in d.files:
+        if key.startswith("buf."):
+            assert rel_err(nsd[key[4:]].cpu().double(), d[key].astype(np.float64)) <= 1e-4, key

@@ -60,6 +60,21 @@ def _worker(rank, world, port, q):
     ref.load_state_dict(model.state_dict())
     ref(x).square().mean().backward()
     ok = ok and all(torch.allclose(p.grad, q_.grad, atol=1e-6) for p, q_ in zip(model.parameters(), ref.parameters()))
+    # --- the finite-loss verdict is collective: rank 1's loss is inf, BOTH ranks refuse the step (harness._FiniteWatch)
+    from ammcnet_aaai2021_amd import harness as H
+    w_ = torch.nn.Parameter(torch.ones(2))
+    opt = torch.optim.SGD([w_], lr=1.0)
+    w_.grad = torch.ones(2)
+    watch = H._FiniteWatch(torch.tensor(float("inf") if rank == 1 else 1.0))
+    try:
+        watch.step(opt)
+        refused = False
+    except FloatingPointError:
+        refused = True
+    ok = ok and refused and float(w_[0]) == 1.0
+    watch = H._FiniteWatch(torch.tensor(2.0), torch.tensor(3.0))       # all finite everywhere: the step is taken
+    watch.step(opt)
+    ok = ok and float(w_[0]) == 0.0
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
@@ -93,3 +108,19 @@ def test_single_process_reducer_is_a_no_op():
     red.push(g)
     red.finish()
     assert torch.equal(g[0], torch.ones(3)) and red.buckets_launched == 0
+
+
+def test_forced_reducer_runs_its_collectives_in_a_world_of_one():
+    """`force=True` takes the real path (flat bucket, async all-reduce, scatter back) with one rank: what the RCCL
+    world-size-1 GPU test relies on"""
+    port = _free_port()
+    dist.init_process_group("gloo", rank=0, world_size=1, init_method=f"tcp://127.0.0.1:{port}")
+    try:
+        g = [torch.arange(5.0), torch.ones(2, 3)]
+        red = P.BucketedGradReducer(bucket_mb=1e-5, force=True)
+        red.push(g)
+        red.finish()
+        assert red.buckets_launched == 2
+        assert torch.equal(g[0], torch.arange(5.0)) and torch.equal(g[1], torch.ones(2, 3))
+    finally:
+        dist.destroy_process_group()
