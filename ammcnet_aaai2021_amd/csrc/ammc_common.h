@@ -60,6 +60,10 @@ int ammc_opt_outc_stream();
 // dispatch option "memory_rt": rows per workgroup of memory_topk_s16, 0 = by size (default), 1 = 32, 2 = 64;
 // AMMC_MEMORY_RT / ammc_set_option
 int ammc_opt_memory_rt();
+// dispatch option "memory_split": ammc_memory_topk_fwd_f16 as one fused launch (0), or as contraction launches on the
+// caller's stream with the gather / commit of each chunk of rows on a second stream beside the next chunk's contraction
+// (1); -1 = by size (split from two rounds of workgroups up; default); AMMC_MEMORY_SPLIT / ammc_set_option
+int ammc_opt_memory_split();
 
 static inline int ammc_ilog2(int v) {
   int l = 0;

@@ -4,7 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-extern "C" int ammc_abi_version(void) { return 28; }
+extern "C" int ammc_abi_version(void) { return 29; }
 
 // dispatch options (ammc_common.h): initialised from the environment once, changed by ammc_set_option
 int g_ammc_s16_mf = -2;              // -2 = not read yet; -1 = auto (per variant); 0 / 1 = forced
@@ -30,6 +30,17 @@ int ammc_opt_memory_rt() {
   return g_ammc_memory_rt;
 }
 
+int g_ammc_memory_split = -2;      // -2 = not read yet; -1 = by size (default), 0 = fused launch, 1 = split contraction / gather
+
+int ammc_opt_memory_split() {
+  if (g_ammc_memory_split == -2) {
+    const char* e = getenv("AMMC_MEMORY_SPLIT");
+    const int v = e ? atoi(e) : -1;
+    g_ammc_memory_split = v == 0 || v == 1 ? v : -1;
+  }
+  return g_ammc_memory_split;
+}
+
 int ammc_opt_s16_mf() {
   if (g_ammc_s16_mf == -2) {
     const char* e = getenv("AMMC_S16_MF");
@@ -53,6 +64,11 @@ extern "C" int ammc_set_option(const char* key, int32_t value) {
   if (!strcmp(key, "memory_rt")) {
     if (value < 0 || value > 2) return AMMC_EINVAL;
     g_ammc_memory_rt = value;
+    return AMMC_OK;
+  }
+  if (!strcmp(key, "memory_split")) {
+    if (value < -1 || value > 1) return AMMC_EINVAL;
+    g_ammc_memory_split = value;
     return AMMC_OK;
   }
   return AMMC_EUNSUP;

@@ -143,6 +143,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN >= 1024 ? 1 : 2)) v
       int tap_ = k_ >> a.cin_log2;                                                                        \
       tap_ = tap_ < 3 ? tap_ : 3;                                                                         \
       toff_ = (int64_t)(tap_ >> 1) * d.x_rs + (int64_t)(tap_ & 1) * d.x_ps + (k_ & (d.cin - 1));          \
+    } else if (d.ntaps == 16) { /* 4x4 window (PixelDiscriminator, pix2pix_networks.py:604-628) */        \
+      int tap_ = k_ >> a.cin_log2;                                                                        \
+      tap_ = tap_ < 15 ? tap_ : 15;                                                                       \
+      toff_ = (int64_t)(tap_ >> 2) * d.x_rs + (int64_t)(tap_ & 3) * d.x_ps + (k_ & (d.cin - 1));          \
     } else {                                                                                              \
       toff_ = k_;                                                                                         \
     }                                                                                                     \
@@ -281,6 +285,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN >= 1024 ? 1 : 2)) v
           if (d.act == AMMC_ACT_RELU) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+          } else if (d.act == AMMC_ACT_LRELU) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : 0.1f * v[k];
           } else if (d.act == AMMC_ACT_TANH) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = tanhf(v[k]);
@@ -356,6 +363,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, (64 * WGM * WGN >= 1024 ? 1 : 2)) v
         if (d.act == AMMC_ACT_RELU) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+        } else if (d.act == AMMC_ACT_LRELU) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : 0.1f * v[k];
         }
         int co = c0, goff = 0;
         if (d.up == 2) {
@@ -450,6 +460,9 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(ConvArgs a) {
   if (d.act == AMMC_ACT_RELU) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+  } else if (d.act == AMMC_ACT_LRELU) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = v[i] > 0.f ? v[i] : 0.1f * v[i];
   }
   if (d.res) {
     const float* rp = d.res + ((int64_t)b * d.r_bs + (int64_t)y * d.r_rs + (int64_t)x * d.r_ps) + ncol0;
@@ -636,7 +649,7 @@ static int conv_gemm_s16_dispatch(const AmmcConvDesc* desc, void* stream, char* 
   if (!desc || !desc->x || !desc->w || !desc->y) return AMMC_EINVAL;
   const AmmcConvDesc& d = *desc;
   if (d.batch <= 0 || d.height <= 0 || d.width <= 0) return AMMC_EINVAL;
-  if (d.ntaps != 9 && d.ntaps != 1 && d.ntaps != 4) return AMMC_EINVAL;
+  if (d.ntaps != 9 && d.ntaps != 1 && d.ntaps != 4 && d.ntaps != 16) return AMMC_EINVAL;
   if (d.s16_mf < 0 || d.s16_mf > 2 || d.outc_stream < 0 || d.outc_stream > 2) return AMMC_EINVAL;
   if (d.ntaps != 1 && (d.cin < 8 || (d.cin & (d.cin - 1)))) return AMMC_EUNSUP;    // whole groups of 8
   if (d.x_step < 0 || d.x_step > 2) return AMMC_EINVAL;

@@ -953,6 +953,7 @@ int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream, char* 
   constexpr int TAP_SKIP = -12345;
   if (!mode) return TAP_SKIP;
   if (d.ntaps != 9 || d.up != 1 || d.x_step > 1) return TAP_SKIP;
+  if (d.act == AMMC_ACT_LRELU) return TAP_SKIP;           // (FlowNet2-SD / discriminator layers: the implicit-GEMM kernel's epilogue has it)
   if (d.cin % 32 || d.width % T_TW || d.height % T_TH) return TAP_SKIP;
   if (d.n != 32 && d.n != 64 && d.n % 128) return TAP_SKIP;
   if (d.n == 32 && !d.y_f32) return TAP_SKIP;

@@ -48,6 +48,31 @@ __global__ __launch_bounds__(256) void lrelu_kernel(float* __restrict__ y, int64
   *reinterpret_cast<f32x4*>(p) = v;
 }
 
+// the same on an S16 activation (groups of 8 channels: 16 B of hi halves, 16 B of lo halves)
+typedef _Float16 fl_h8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void lrelu_s16_kernel(float* __restrict__ y, int64_t y_bs, int64_t y_rs, int64_t y_ps, int B,
+                                                        int H, int W, int C8, float slope) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (int64_t)B * H * W * C8) return;
+  const int c8 = (int)(gid % C8);
+  int64_t t = gid / C8;
+  const int x = (int)(t % W);
+  t /= W;
+  const int yy = (int)(t % H), b = (int)(t / H);
+  float* p = y + b * y_bs + yy * y_rs + x * y_ps + c8 * 8;
+  const fl_h8 hi = *reinterpret_cast<const fl_h8*>(p), lo = *reinterpret_cast<const fl_h8*>(p + 4);
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float f = (float)hi[i] + (float)lo[i] * (1.f / 2048.f);
+    v[i] = f > 0.f ? f : f * slope;
+  }
+  ammc_u4 h, l;
+  ammc_s16_split8(v, h, l);
+  *reinterpret_cast<ammc_u4*>(p) = h;
+  *reinterpret_cast<ammc_u4*>(p + 4) = l;
+}
+
 // nn.Upsample(scale_factor=4, mode='bilinear') of (x * premul): NHWC channels [0, c) -> NCHW [B][c][4H][4W]
 // (align_corners=False: src = (dst + 0.5) / 4 - 0.5 clamped at 0; models.py:59, FlowNetSD.py:58)
 __global__ __launch_bounds__(256) void upsample4_kernel(const float* __restrict__ x, int64_t x_bs, int64_t x_rs, int64_t x_ps,
@@ -90,6 +115,16 @@ extern "C" int ammc_lrelu_f32(float* y, int64_t y_bs, int64_t y_rs, int64_t y_ps
   const int64_t total = (int64_t)batch * h * w * (c >> 2);
   hipLaunchKernelGGL(lrelu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, y_bs, y_rs,
                      y_ps, batch, h, w, c >> 2, slope);
+  return ammc_launch_status();
+}
+
+extern "C" int ammc_lrelu_s16(float* y, int64_t y_bs, int64_t y_rs, int64_t y_ps, int32_t batch, int32_t h, int32_t w,
+                              int32_t c, float slope, void* stream) {
+  if (!y || batch <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 7) || ((uintptr_t)y & 31) || ((y_bs | y_rs | y_ps) & 7))
+    return AMMC_EINVAL;
+  const int64_t total = (int64_t)batch * h * w * (c >> 3);
+  hipLaunchKernelGGL(lrelu_s16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, y_bs,
+                     y_rs, y_ps, batch, h, w, c >> 3, slope);
   return ammc_launch_status();
 }
 

@@ -21,6 +21,7 @@
 #include <hip/hip_fp16.h>
 #include <math.h>
 #include <algorithm>
+#include <mutex>
 
 namespace ammc_impl {
 
@@ -71,12 +72,19 @@ __device__ __forceinline__ void topk_insert16_ordered(float (&v)[K], int (&ix)[K
 
 // NSTEP = d / 16, a template argument: the k-loop is fully unrolled (across the back edge of a run-time loop the
 // compiler drains the register ring with vmcnt(0) every PF steps)
-template <int K, int NSTEP>
-__global__ __launch_bounds__(512, 1) void memory_topk_f16_kernel(
+// FUSED = 1: one launch does everything (contraction, merge, gather / commit).  FUSED = 0 (launches of more than one
+// round of workgroups): the kernel stops after writing the indices, and holds itself to SPLIT_VGPRS registers so that
+// the waves of memory_gather_f16_kernel - which does the gather / commit of an EARLIER chunk of rows on a second
+// stream - fit beside its two waves per SIMD (2 x 232 + 32 <= 512): the HBM-bound tail (3.2 GB per 262144 rows, 511 us
+// of the 2717-us launch when it ran serially behind every workgroup's contraction) then streams
+// while the matrix pipe works on the next rows.  `blk0`: first row block of this launch.
+constexpr int SPLIT_VGPRS = 232;
+template <int K, int NSTEP, int FUSED>
+__device__ __forceinline__ void memory_topk_f16_body(
     const float* __restrict__ x, const f16x8* __restrict__ e_kblk /* [d/8][mpad] */,
     const float* __restrict__ e_md, const float* __restrict__ enorm16, int n, int d, int m, int mpad,
     int* __restrict__ idx_out, float* __restrict__ q_topk, float* __restrict__ q_one,
-    float* __restrict__ diff_partial) {
+    float* __restrict__ diff_partial, int blk0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // region 0: the x tile [HBR][d] halfs (swizzled 16-B slots) during the contraction, then re-used for
   // the candidate lists [HBR][16][K] (value, index); region 1: |x|^2, final indices, reduction scratch
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(512, 1) void memory_topk_f16_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
-  const int r0 = blockIdx.x * HBR;
+  const int r0 = (blk0 + (int)blockIdx.x) * HBR;
   const int slots = d >> 3;                                             // 16-B slots (8 halfs) per row
 
   // ---- stage x as fp16 -----------------------------------------------------------------
@@ -254,6 +262,7 @@ __global__ __launch_bounds__(512, 1) void memory_topk_f16_kernel(
       if (r0 + tid < n) idx_out[(int64_t)(r0 + tid) * K + j] = ix[j];
     }
   }
+  if (!FUSED) return;                  // (the gather / commit of these rows is memory_gather_f16_kernel's)
   __syncthreads();
 
   // ---- gather (fp32 codebook) + commit distance (fp32 features re-read from HBM) ------------
@@ -285,7 +294,71 @@ __global__ __launch_bounds__(512, 1) void memory_topk_f16_kernel(
     if (tid < o) red[tid] += red[tid + o];
     __syncthreads();
   }
-  if (tid == 0) diff_partial[blockIdx.x] = red[0];
+  if (tid == 0) diff_partial[blk0 + blockIdx.x] = red[0];
+}
+
+// (the register cap is an attribute, which takes literals only: two entry points around one body.  On gfx90a and later
+// the backend DOUBLES the attribute's value - it budgets the unified file as architectural + accumulation registers - so
+// amdgpu_num_vgpr(116) is what yields "NumVgprs: 232, ScratchSize: 0" in the ISA, and (16) caps the gather kernel at 32)
+template <int K, int NSTEP>
+__global__ __launch_bounds__(512, 1) void memory_topk_f16_kernel(
+    const float* __restrict__ x, const f16x8* __restrict__ e_kblk, const float* __restrict__ e_md,
+    const float* __restrict__ enorm16, int n, int d, int m, int mpad, int* __restrict__ idx_out, float* __restrict__ q_topk,
+    float* __restrict__ q_one, float* __restrict__ diff_partial, int blk0) {
+  memory_topk_f16_body<K, NSTEP, 1>(x, e_kblk, e_md, enorm16, n, d, m, mpad, idx_out, q_topk, q_one, diff_partial, blk0);
+}
+template <int K, int NSTEP>
+__global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(116))) void memory_topk_f16_split_kernel(
+    const float* __restrict__ x, const f16x8* __restrict__ e_kblk, const float* __restrict__ e_md,
+    const float* __restrict__ enorm16, int n, int d, int m, int mpad, int* __restrict__ idx_out, float* __restrict__ q_topk,
+    float* __restrict__ q_one, float* __restrict__ diff_partial, int blk0) {
+  static_assert(SPLIT_VGPRS == 232, "the attribute above takes a literal");
+  memory_topk_f16_body<K, NSTEP, 0>(x, e_kblk, e_md, enorm16, n, d, m, mpad, idx_out, q_topk, q_one, diff_partial, blk0);
+}
+
+// The gather / commit phase as its own kernel (FUSED = 0 launches): one workgroup of 256 threads per 128-row block,
+// <= 32 VGPRs and no LDS to speak of, so that it co-resides with the contraction kernel.  Row block b = blk0 + blockIdx.x;
+// diff_partial[b] is summed in a fixed order (thread-strided partial sums, then a tree): deterministic.
+template <int K>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(16))) void memory_gather_f16_kernel(
+    const float* __restrict__ x, const float* __restrict__ e_md, const int* __restrict__ idx, int n, int d,
+    float* __restrict__ q_topk, float* __restrict__ q_one, float* __restrict__ diff_partial, int blk0) {
+  __shared__ float red[256];
+  __shared__ int best[HBR * K];
+  const int tid = threadIdx.x;
+  const int b = blk0 + (int)blockIdx.x;
+  const int r0 = b * HBR;
+  for (int i = tid; i < HBR * K; i += 256) best[i] = r0 + i / K < n ? idx[(int64_t)r0 * K + i] : 0;
+  __syncthreads();
+  float part = 0.f;
+  const int slots4 = d >> 2;
+  for (int p = tid; p < HBR * K * slots4; p += 256) {
+    const int sl = p % slots4;
+    const int rj = p / slots4;
+    const int j = rj % K, row = rj / K;
+    if (r0 + row >= n) continue;
+    const int s = best[row * K + j];
+    const f32x4 e = *reinterpret_cast<const f32x4*>(e_md + (int64_t)s * d + sl * 4);
+    *reinterpret_cast<f32x4*>(q_topk + ((int64_t)(r0 + row) * K + j) * d + sl * 4) = e;
+    if (j == 0) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (int64_t)(r0 + row) * d + sl * 4);
+      f32x4 q1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float df = e[i] - xv[i];
+        part += df * df;
+        q1[i] = xv[i] + df;
+      }
+      if (q_one) *reinterpret_cast<f32x4*>(q_one + (int64_t)(r0 + row) * d + sl * 4) = q1;
+    }
+  }
+  red[tid] = part;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) diff_partial[b] = red[0];
 }
 
 // [d][m] fp32 -> k-blocked fp16 [d/8][mpad][8] (slots >= m zero) and |half(E_s)|^2
@@ -307,22 +380,83 @@ __global__ __launch_bounds__(256) void pack_codebook_f16_kernel(const float* __r
   if (s < m) enorm16[s] = nrm;
 }
 
+// Second stream + events of the split form, made once per process (the only state the library keeps: a call that takes
+// the split path records / waits events on the caller's stream, allocates nothing and never synchronises the host).
+// Calls from several host threads serialise on the mutex for the few microseconds of their enqueue.
+constexpr int SPLIT_MAX_CHUNKS = 8;
+constexpr int SPLIT_ROUND_BLOCKS = 256;          // one workgroup per CU: a chunk is a whole number of rounds
+struct SplitState {
+  hipStream_t side = nullptr;
+  hipEvent_t chunk_done[SPLIT_MAX_CHUNKS];
+  hipEvent_t side_done = nullptr;
+  int device = -1;
+  bool ok = false;
+};
+static SplitState g_split;
+static std::mutex g_split_mu;
+
+static bool split_ready() {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  if (g_split.ok && g_split.device == dev) return true;
+  if (g_split.ok) return false;                   // made for another device: that process keeps the fused form here
+  if (hipStreamCreateWithFlags(&g_split.side, hipStreamNonBlocking) != hipSuccess) return false;
+  for (int i = 0; i < SPLIT_MAX_CHUNKS; ++i)
+    if (hipEventCreateWithFlags(&g_split.chunk_done[i], hipEventDisableTiming) != hipSuccess) return false;
+  if (hipEventCreateWithFlags(&g_split.side_done, hipEventDisableTiming) != hipSuccess) return false;
+  g_split.device = dev;
+  g_split.ok = true;
+  return true;
+}
+
 template <int K, int NSTEP>
 int launch_topk16n(const float* x, const void* e_kblk, const float* e_md, const float* enorm16, int n, int d, int m,
                    int* idx, float* q_topk, float* q_one, float* diff_partial, hipStream_t stream) {
   const size_t region0 = std::max((size_t)HBR * d * 2, (size_t)HBR * (16 * K + 1) * 8);
   const size_t lds = region0 + sizeof(float) * (HBR + HBR * K + 512 + HWAVES * TS * 32);
-  auto kern = memory_topk_f16_kernel<K, NSTEP>;
   if (lds > 160 * 1024) return AMMC_EUNSUP;
+  auto fused = memory_topk_f16_kernel<K, NSTEP>;
+  auto split = memory_topk_f16_split_kernel<K, NSTEP>;
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(split), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   const int mpad = (m + 31) / 32 * 32;
-  hipLaunchKernelGGL(kern, dim3((n + HBR - 1) / HBR), dim3(512), lds, stream, x,
-                     reinterpret_cast<const f16x8*>(e_kblk), e_md, enorm16, n, d, m, mpad, idx, q_topk, q_one,
-                     diff_partial);
+  const int nblk = (n + HBR - 1) / HBR;
+  // "memory_split" (AMMC_MEMORY_SPLIT): -1 = by size (split from two rounds of workgroups up), 0 = always fused, 1 = split
+  const int opt = ammc_opt_memory_split();
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(stream, &cap);
+  bool use_split = opt != 0 && (opt == 1 || nblk >= 2 * SPLIT_ROUND_BLOCKS) && cap == hipStreamCaptureStatusNone;
+  std::unique_lock<std::mutex> lock(g_split_mu, std::defer_lock);
+  if (use_split) {
+    lock.lock();
+    use_split = split_ready();
+  }
+  if (!use_split) {
+    hipLaunchKernelGGL(fused, dim3(nblk), dim3(512), lds, stream, x, reinterpret_cast<const f16x8*>(e_kblk), e_md, enorm16, n,
+                       d, m, mpad, idx, q_topk, q_one, diff_partial, 0);
+    return ammc_launch_status();
+  }
+  // chunks of whole rounds, at most SPLIT_MAX_CHUNKS: contraction of chunk c on the caller's stream, its gather / commit
+  // on the side stream behind an event - i.e. beside the contraction of chunk c + 1; the caller's stream finally waits
+  // for the side stream, so the call's outputs are complete for whatever the caller enqueues next
+  int rounds = (nblk + SPLIT_ROUND_BLOCKS - 1) / SPLIT_ROUND_BLOCKS;
+  int rounds_per_chunk = (rounds + SPLIT_MAX_CHUNKS - 1) / SPLIT_MAX_CHUNKS;
+  const int chunk_blocks = rounds_per_chunk * SPLIT_ROUND_BLOCKS;
+  int c = 0;
+  for (int b0 = 0; b0 < nblk; b0 += chunk_blocks, ++c) {
+    const int nb = std::min(chunk_blocks, nblk - b0);
+    hipLaunchKernelGGL(split, dim3(nb), dim3(512), lds, stream, x, reinterpret_cast<const f16x8*>(e_kblk), e_md, enorm16, n, d,
+                       m, mpad, idx, q_topk, q_one, diff_partial, b0);
+    if (hipEventRecord(g_split.chunk_done[c], stream) != hipSuccess) return ammc_launch_status();
+    if (hipStreamWaitEvent(g_split.side, g_split.chunk_done[c], 0) != hipSuccess) return ammc_launch_status();
+    hipLaunchKernelGGL(memory_gather_f16_kernel<K>, dim3(nb), dim3(256), 0, g_split.side, x, e_md, idx, n, d, q_topk, q_one,
+                       diff_partial, b0);
+  }
+  if (hipEventRecord(g_split.side_done, g_split.side) != hipSuccess) return ammc_launch_status();
+  if (hipStreamWaitEvent(stream, g_split.side_done, 0) != hipSuccess) return ammc_launch_status();
   return ammc_launch_status();
 }
 

@@ -13,6 +13,12 @@ as four 2x2-tap convolutions over the output gradient (one per input-pixel parit
 strides), of the stride-1 layer as one 16-tap convolution with the flipped filter.  `DiscFunction` exposes the pair
 as one autograd node, differentiable w.r.t. the frame (the generator's adversarial gradient) and the parameters.
 Every forward that may be differentiated takes its own workspace slot, so the three calls of a step coexist.
+
+Round 4 (`module.precision`, default "s16"): the FORWARD convolutions run on the split-fp16 kernel
+(`ammc_conv_gemm_s16`, ntaps 16: (hi, lo) half pairs, three fp16 MFMAs per product, fp32 accumulation - fp32-equivalent)
+with fp32 outputs; each activation is then re-encoded once into the S16 twin the next layer reads (the fp32 tensor stays
+for the weight gradient and the LeakyReLU mask of the backward, which remain on the exact-fp32 kernels).  "fp32" = the
+exact-fp32 MFMA kernels throughout, as in round 3.
 """
 from __future__ import annotations
 
@@ -28,6 +34,7 @@ from .engine import Act, _cin_pad, _kpad, _ptr
 
 SLOPE = 0.1          # nn.LeakyReLU(0.1, True), pix2pix_networks.py:606
 HALO = 2             # = the convs' padding
+DEFAULT_PRECISION = __import__("os").environ.get("AMMC_DISC_PRECISION", "s16")
 
 
 def _chk(rc, what):
@@ -40,9 +47,9 @@ def _out_hw(h: int, stride: int) -> int:
 
 
 class _Layer:
-    def __init__(self, cin: int, cout: int, stride: int):
+    def __init__(self, cin: int, cout: int, stride: int, s16: bool = False):
         self.cin, self.cout, self.stride = cin, cout, stride
-        self.cin_p = _cin_pad(cin)
+        self.cin_p = max(8, _cin_pad(cin)) if s16 else _cin_pad(cin)       # S16 operands: whole groups of 8 channels
         self.n = cout if cout % 64 == 0 else 32            # GEMM columns (the 1-channel head pads to a 32 tile)
         self.kpad = _kpad(16 * self.cin_p)
         self.rows = self.cin_p if self.cin_p % 64 == 0 else 32        # columns of the input-gradient GEMM
@@ -68,6 +75,9 @@ class _Slot:
         self.bp = [torch.zeros(L.n, device=dev) for L in eng.layers]
         self.wd = [torch.zeros((4 if L.stride == 2 else 1) * L.rows * L.dkpad, device=dev) for L in eng.layers]
         self.has_dgrad = False
+        # split-fp16 forward: the S16 twins of the layer inputs and of the packed filters
+        self.acts16 = [Act(torch.zeros_like(a.buf), a.B, a.H, a.W, a.c, 0, HALO) for a in self.acts] if eng.s16 else None
+        self.w16 = [torch.zeros_like(w) for w in self.wp] if eng.s16 else None
 
 
 class _Lease:
@@ -81,15 +91,18 @@ class _Lease:
 
 
 class DiscEngine:
-    def __init__(self, module: "PixelDiscriminator"):
+    def __init__(self, module: "PixelDiscriminator", precision: str = "s16"):
+        if precision not in ("s16", "fp32"):
+            raise ValueError("PixelDiscriminator.precision must be 's16' or 'fp32'")
         self.module = module
+        self.s16 = precision == "s16"
         self.lib = _lib.load()
         self.device = None
         self.layers: List[_Layer] = []
         chans = [module.input_nc] + list(module.num_filters[:-1])
         for i in range(len(chans) - 1):
-            self.layers.append(_Layer(chans[i], chans[i + 1], 2))
-        self.layers.append(_Layer(module.num_filters[-1], 1, 1))
+            self.layers.append(_Layer(chans[i], chans[i + 1], 2, self.s16))
+        self.layers.append(_Layer(module.num_filters[-1], 1, 1, self.s16))
         self._pools: Dict[Tuple[int, int, int], list] = {}
         self._grads: Dict[Tuple[int, int, int], List[Act]] = {}
         self._scratch: Optional[torch.Tensor] = None
@@ -131,7 +144,7 @@ class DiscEngine:
         return self._grads[key]
 
     def _conv(self, x_ptr: int, x_strides, w: torch.Tensor, y_ptr: int, y_strides, *, batch, height, width, cin, ntaps,
-              n, shift=None, act=ACT_NONE, x_step=1, n_store=0, y_cs=0, what="conv"):
+              n, shift=None, act=ACT_NONE, x_step=1, n_store=0, y_cs=0, what="conv", s16=False):
         d = AmmcConvDesc()
         d.x, d.w, d.y = x_ptr, _ptr(w), y_ptr
         d.scale, d.shift, d.res = None, (_ptr(shift) if shift is not None else None), None
@@ -140,7 +153,11 @@ class DiscEngine:
         d.n_store, d.y_cs = n_store, y_cs
         d.x_bs, d.x_rs, d.x_ps = x_strides
         d.y_bs, d.y_rs, d.y_ps = y_strides
-        _chk(self.lib.ammc_conv_gemm_f32(C.byref(d), self.s), what)
+        if s16:                                     # S16 operands, fp32 output
+            d.y_f32 = 1
+            _chk(self.lib.ammc_conv_gemm_s16(C.byref(d), self.s), what)
+        else:
+            _chk(self.lib.ammc_conv_gemm_f32(C.byref(d), self.s), what)
 
     # ---- forward ---------------------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, params: Sequence[torch.Tensor], keep: bool, need_dx: bool):
@@ -165,18 +182,30 @@ class DiscEngine:
         slot.has_dgrad = keep
         oh, ow = slot.out_hw
         out = torch.empty(B, 1, oh, ow, device=x.device, dtype=torch.float32)
+        s16 = self.s16
+
+        def twin(t32: torch.Tensor, t16: torch.Tensor):
+            _chk(lib.ammc_split_rows_f32(_ptr(t32), t32.numel(), _ptr(t16), s), "split_rows")
+
+        if s16:
+            twin(a0.buf, slot.acts16[0].buf)
+            for i in range(len(self.layers)):
+                twin(slot.wp[i], slot.w16[i])
         for i, L in enumerate(self.layers):
-            a = slot.acts[i]
+            a = slot.acts16[i] if s16 else slot.acts[i]
+            wts = slot.w16 if s16 else slot.wp
             x_origin = _ptr(a.buf)                                     # window corner of output pixel (0,0)
             if i + 1 < len(self.layers):
                 y = slot.acts[i + 1]
-                self._conv(x_origin, a.strides, slot.wp[i], y.pix0(), y.strides, batch=B, height=y.H, width=y.W,
+                self._conv(x_origin, a.strides, wts[i], y.pix0(), y.strides, batch=B, height=y.H, width=y.W,
                            cin=L.cin_p, ntaps=16, n=L.n, shift=slot.bp[i], act=ACT_LRELU, x_step=L.stride,
-                           what=f"disc.conv{i}")
+                           what=f"disc.conv{i}", s16=s16)
+                if s16:
+                    twin(y.buf, slot.acts16[i + 1].buf)                # what the next layer reads
             else:
-                self._conv(x_origin, a.strides, slot.wp[i], _ptr(out), (oh * ow, ow, 1), batch=B, height=oh, width=ow,
+                self._conv(x_origin, a.strides, wts[i], _ptr(out), (oh * ow, ow, 1), batch=B, height=oh, width=ow,
                            cin=L.cin_p, ntaps=16, n=L.n, shift=slot.bp[i], act=ACT_NONE, x_step=1, n_store=1,
-                           y_cs=oh * ow, what="disc.head")
+                           y_cs=oh * ow, what="disc.head", s16=s16)
         if not keep:
             pool.append(slot)
             return None, out
@@ -293,6 +322,7 @@ class PixelDiscriminator(nn.Module):
             net.extend([nn.Conv2d(num_filters[i - 1], num_filters[i], 4, 2, 2, bias=True), nn.LeakyReLU(SLOPE, True)])
         net.append(nn.Conv2d(num_filters[-1], 1, 4, 1, 2))
         self.net = nn.Sequential(*net)                     # parameter holders; never called
+        self.precision = DEFAULT_PRECISION
         object.__setattr__(self, "_engine", None)
 
     def _params(self) -> List[torch.Tensor]:
@@ -305,8 +335,8 @@ class PixelDiscriminator(nn.Module):
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         if not input.is_cuda:
             raise _lib.AmmcHipError("PixelDiscriminator runs on the HIP kernels only: input must be a GPU tensor")
-        if self._engine is None:
-            object.__setattr__(self, "_engine", DiscEngine(self))
+        if self._engine is None or self._engine.s16 != (self.precision == "s16"):
+            object.__setattr__(self, "_engine", DiscEngine(self, self.precision))
         params = self._params()
         if torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in params)):
             return DiscFunction.apply(self._engine, input, *params)

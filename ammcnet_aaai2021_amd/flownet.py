@@ -9,7 +9,13 @@ every ConvTranspose2d(k 4, s 2, p 1) is four 2x2-tap parity convolutions through
 transposed conv IS the input gradient of a conv: the filters come from `ammc_pack_conv4_dgrad_weight_f32`, pad 1).
 Concatenations (`torch.cat`, models.py:35-52) are channel slices of one buffer; a layer that READS a concatenation runs
 once per part (channel counts 1026 / 770 / 386 / 194 are not what the kernel tiles; their parts 512+512+2 ... are) and
-accumulates through the epilogue's residual input.  Exact fp32 MFMA throughout (flows reach tens of pixels).
+accumulates through the epilogue's residual input.
+
+Two arithmetic forms (`net.precision`): "s16" (default, round 4) = the split-fp16 kernels the generator runs on
+(`ammc_conv_gemm_s16`: (hi, lo) half pairs, three fp16 MFMAs per product, fp32 accumulation - fp32-equivalent; flows of
+tens of pixels are far inside the half range), activations and packed filters kept as S16; the 2-channel flow heads and
+their 2 -> 2 up-convolutions stay fp32 (their outputs enter the concatenations as 8-channel S16 parts).  "fp32" = the
+exact-fp32 MFMA kernels throughout (round 3: 13.5 ms per batch-32 forward against ~3 for S16).
 """
 from __future__ import annotations
 
@@ -24,6 +30,7 @@ from ._lib import ACT_LRELU, ACT_NONE, AmmcConvDesc
 from .engine import Act, _cin_pad, _kpad, _ptr
 
 SLOPE = 0.1
+DEFAULT_PRECISION = __import__("os").environ.get("AMMC_FLOWNET_PRECISION", "s16")
 
 
 def _chk(rc, what):
@@ -36,8 +43,11 @@ def _ncols(c: int) -> int:
 
 
 class _Engine:
-    def __init__(self, module: "FlowNet2SD"):
+    def __init__(self, module: "FlowNet2SD", precision: str = "s16"):
+        if precision not in ("s16", "fp32"):
+            raise ValueError("FlowNet2SD.precision must be 's16' or 'fp32'")
         self.m = module
+        self.s16 = precision == "s16"
         self.lib = _lib.load()
         self.ws: Dict[Tuple, dict] = {}
         self.packs: Optional[dict] = None
@@ -48,26 +58,40 @@ class _Engine:
         ps = list(self.m.parameters())
         return (sum(p._version for p in ps), ps[0].device, ps[0].data_ptr())
 
-    def _pack_conv(self, w: torch.Tensor, b: torch.Tensor, parts: Sequence[int]):
-        """3x3 conv over a (possibly concatenated) input: one packed filter per part, bias padded to the column count"""
+    def _cp(self, c: int, fp32_layer: bool = False) -> int:
+        """padded channel count of an input part: S16 operands come in whole groups of 8"""
+        return max(8, _cin_pad(c)) if (self.s16 and not fp32_layer) else _cin_pad(c)
+
+    def _w16(self, wp: torch.Tensor, fp32_layer: bool = False) -> torch.Tensor:
+        """the packed filter as the layer's kernel reads it: S16 for the split-fp16 layers"""
+        if not self.s16 or fp32_layer:
+            return wp
+        w16 = torch.empty_like(wp)
+        _chk(self.lib.ammc_split_rows_f32(_ptr(wp), wp.numel(), _ptr(w16), torch.cuda.current_stream(wp.device).cuda_stream), "split_rows")
+        return w16
+
+    def _pack_conv(self, w: torch.Tensor, b: torch.Tensor, parts: Sequence[int], head: bool = False):
+        """3x3 conv over a (possibly concatenated) input: one packed filter per part, bias padded to the column count.
+        `head`: a layer that stays on the fp32 kernels in both forms (never set for convs: the flow heads READ S16)"""
         lib, dev = self.lib, w.device
         s = torch.cuda.current_stream(dev).cuda_stream
         co = w.shape[0]
         n = _ncols(co)
         out, c0 = [], 0
         for c in parts:
-            cp = _cin_pad(c)
+            cp = self._cp(c, head)
             wp = torch.zeros(n, _kpad(9 * cp), device=dev)
             ws = w.detach()[:, c0:c0 + c].contiguous()
             _chk(lib.ammc_pack_conv_weight_f32(_ptr(ws), co, c, 3, cp, _ptr(wp), s), "pack_conv")
-            out.append((wp, cp))
+            out.append((self._w16(wp, head), cp))
             c0 += c
         bias = torch.zeros(n, device=dev)
         bias[:co].copy_(b.detach())
         return dict(w=out, bias=bias, n=n, co=co)
 
-    def _pack_deconv(self, w: torch.Tensor, b: torch.Tensor, parts: Sequence[int]):
-        """ConvTranspose2d(k 4, s 2, p 1), weight [Cin, Cout, 4, 4]: per input part four parity filters [rows][4*cin_p]"""
+    def _pack_deconv(self, w: torch.Tensor, b: torch.Tensor, parts: Sequence[int], head: bool = False):
+        """ConvTranspose2d(k 4, s 2, p 1), weight [Cin, Cout, 4, 4]: per input part four parity filters [rows][4*cin_p].
+        `head`: the 2 -> 2 up-convolution of a flow estimate (fp32 kernels in both forms)"""
         lib, dev = self.lib, w.device
         s = torch.cuda.current_stream(dev).cuda_stream
         co = w.shape[1]
@@ -75,16 +99,16 @@ class _Engine:
         out, c0 = [], 0
         wd = w.detach().contiguous()
         for c in parts:
-            cp = _cin_pad(c)
+            cp = self._cp(c, head)
             kp = _kpad(4 * cp)
             wp = torch.zeros(4 * rows * kp, device=dev)
             _chk(lib.ammc_pack_conv4_dgrad_weight_f32(_ptr(wd, c0 * co * 16), c, co, cp, rows, 2, 1, _ptr(wp), s),
                  "pack_deconv")
-            out.append((wp, cp, rows * kp))
+            out.append((self._w16(wp, head), cp, rows * kp))
             c0 += c
         bias = torch.zeros(rows, device=dev)
         bias[:co].copy_(b.detach())
-        return dict(w=out, bias=bias, n=rows, co=co)
+        return dict(w=out, bias=bias, n=rows, co=co, head=head)
 
     def _ensure_packs(self):
         v = self._version()
@@ -109,7 +133,7 @@ class _Engine:
             pk[f"predict_flow{lvl}"] = self._pack_conv(pf.weight, pf.bias, [pf.weight.shape[1]])
         for a, b in ((6, 5), (5, 4), (4, 3), (3, 2)):
             up = getattr(m, f"upsampled_flow{a}_to_{b}")
-            pk[f"up{a}"] = self._pack_deconv(up.weight, up.bias, (2,))
+            pk[f"up{a}"] = self._pack_deconv(up.weight, up.bias, (2,), head=True)
         self.packs, self.pack_version = pk, v
 
     # ---- workspace -------------------------------------------------------------------------------------------
@@ -125,15 +149,24 @@ class _Engine:
 
         ws = dict(x0=act(1, 8), c0=act(1, 64), t1=act(2, 64), c1=act(2, 128), t2=act(4, 128), t3=act(8, 256),
                   t4=act(16, 512), t5=act(32, 512), t6=act(64, 1024), c6=act(64, 1024),
-                  cat2=act(4, 196), cat3=act(8, 388), cat4=act(16, 772), cat5=act(32, 1028),
+                  # (S16: pixel strides are whole groups of 8 channels - the 2-channel flow part of a concatenation lives in
+                  # its own 8-channel buffer, u*, below)
+                  cat2=act(4, 192 if self.s16 else 196), cat3=act(8, 384 if self.s16 else 388),
+                  cat4=act(16, 768 if self.s16 else 772), cat5=act(32, 1024 if self.s16 else 1028),
                   ic5=act(32, 512), ic4=act(16, 256), ic3=act(8, 128), ic2=act(4, 64),
                   f6=act(64, 4), f5=act(32, 4), f4=act(16, 4), f3=act(8, 4), f2=act(4, 4))
+        if self.s16:
+            # the up-sampled flow estimates: fp32 from their 2 -> 2 transposed conv (uf*), then the 8-channel S16 part
+            # of the concatenation (u*: channels 2..7 zero); the prepared frame pair likewise (x0 fp32 -> x0s)
+            ws.update(uf6=act(32, 8), uf5=act(16, 8), uf4=act(8, 8), uf3=act(4, 8),
+                      u6=act(32, 8), u5=act(16, 8), u4=act(8, 8), u3=act(4, 8), x0s=act(1, 8))
         self.ws[key] = ws
         return ws
 
     # ---- launches --------------------------------------------------------------------------------------------
-    def _conv(self, x: Act, pk: dict, y: Act, stride=1, act=ACT_LRELU, n_store=0):
-        """3x3 conv of `x` (one Act, or the list of parts of a concatenation) into y"""
+    def _conv(self, x: Act, pk: dict, y: Act, stride=1, act=ACT_LRELU, n_store=0, y_f32=False):
+        """3x3 conv of `x` (one Act, or the list of parts of a concatenation) into y (`y_f32`: an fp32 output from S16
+        operands - the flow heads)"""
         parts = x if isinstance(x, (list, tuple)) else [x]
         s = torch.cuda.current_stream(y.buf.device).cuda_stream
         for i, (xp, (wp, cp)) in enumerate(zip(parts, pk["w"])):
@@ -148,7 +181,11 @@ class _Engine:
             d.x_bs, d.x_rs, d.x_ps = xp.strides
             d.y_bs, d.y_rs, d.y_ps = y.strides
             d.r_bs, d.r_rs, d.r_ps = y.strides
-            _chk(self.lib.ammc_conv_gemm_f32(C.byref(d), s), "flownet.conv")
+            if self.s16:
+                d.y_f32 = 1 if y_f32 else 0
+                _chk(self.lib.ammc_conv_gemm_s16(C.byref(d), s), "flownet.conv(s16)")
+            else:
+                _chk(self.lib.ammc_conv_gemm_f32(C.byref(d), s), "flownet.conv")
         assert len(parts) == 1 or act == ACT_NONE, "a multi-part conv carries no activation in this network"
 
     def _deconv(self, x, pk: dict, y: Act, lrelu: bool):
@@ -172,9 +209,13 @@ class _Engine:
                 d.x_bs, d.x_rs, d.x_ps = xp.strides
                 d.y_bs, d.y_rs, d.y_ps = y.bs, 2 * y.rs, 2 * y.ps
                 d.r_bs, d.r_rs, d.r_ps = y.bs, 2 * y.rs, 2 * y.ps
-                _chk(self.lib.ammc_conv_gemm_f32(C.byref(d), s), "flownet.deconv")
+                if self.s16 and not pk.get("head"):
+                    _chk(self.lib.ammc_conv_gemm_s16(C.byref(d), s), "flownet.deconv(s16)")
+                else:
+                    _chk(self.lib.ammc_conv_gemm_f32(C.byref(d), s), "flownet.deconv")
         if lrelu and len(parts) > 1:
-            _chk(self.lib.ammc_lrelu_f32(y.pix0(), *y.strides, y.B, y.H, y.W, y.c, SLOPE, s), "flownet.lrelu")
+            fn = self.lib.ammc_lrelu_s16 if self.s16 else self.lib.ammc_lrelu_f32
+            _chk(fn(y.pix0(), *y.strides, y.B, y.H, y.W, y.c, SLOPE, s), "flownet.lrelu")
 
     def forward(self, inputs: torch.Tensor) -> torch.Tensor:
         if not inputs.is_cuda:
@@ -192,10 +233,28 @@ class _Engine:
         x0 = ws["x0"]
         _chk(lib.ammc_flownet_prep_f32(_ptr(x), B, H, W, x0.pix0(), *x0.strides, float(self.m.rgb_max), s), "prep")
         cat2, cat3, cat4, cat5 = ws["cat2"], ws["cat3"], ws["cat4"], ws["cat5"]
-        c2, d2, u3 = cat2.slice(0, 128), cat2.slice(128, 64), cat2.slice(192, 4)
-        c3, d3, u4 = cat3.slice(0, 256), cat3.slice(256, 128), cat3.slice(384, 4)
-        c4, d4, u5 = cat4.slice(0, 512), cat4.slice(512, 256), cat4.slice(768, 4)
-        c5, d5, u6 = cat5.slice(0, 512), cat5.slice(512, 512), cat5.slice(1024, 4)
+        c2, d2 = cat2.slice(0, 128), cat2.slice(128, 64)
+        c3, d3 = cat3.slice(0, 256), cat3.slice(256, 128)
+        c4, d4 = cat4.slice(0, 512), cat4.slice(512, 256)
+        c5, d5 = cat5.slice(0, 512), cat5.slice(512, 512)
+        if self.s16:
+            u3, u4, u5, u6 = ws["u3"], ws["u4"], ws["u5"], ws["u6"]
+            x0s = ws["x0s"]
+            _chk(lib.ammc_split_rows_f32(_ptr(x0.buf), x0.buf.numel(), _ptr(x0s.buf), s), "split_rows(x0)")
+            x0 = x0s
+        else:
+            u3, u4, u5, u6 = cat2.slice(192, 4), cat3.slice(384, 4), cat4.slice(768, 4), cat5.slice(1024, 4)
+
+        def upflow(f: Act, name: str, u: Act):
+            """the 2 -> 2 transposed conv of a flow estimate (fp32 kernels); S16 form: into the fp32 staging buffer, then
+            re-encoded as the 8-channel S16 part of the concatenation"""
+            if not self.s16:
+                self._deconv(f, pk[name], u, lrelu=False)
+                return
+            uf = ws["uf" + name[2]]
+            self._deconv(f, pk[name], uf, lrelu=False)
+            _chk(lib.ammc_split_rows_f32(_ptr(uf.buf), uf.buf.numel(), _ptr(u.buf), s), "split_rows(flow)")
+
         self._conv(x0, pk["conv0"], ws["c0"])
         self._conv(ws["c0"], pk["conv1"], ws["t1"], stride=2)
         self._conv(ws["t1"], pk["conv1_1"], ws["c1"])
@@ -210,28 +269,28 @@ class _Engine:
         self._conv(c5, pk["conv6"], ws["t6"], stride=2)
         self._conv(ws["t6"], pk["conv6_1"], ws["c6"])
         # decoder (models.py:31-54)
-        self._conv(ws["c6"], pk["predict_flow6"], ws["f6"], act=ACT_NONE)
-        self._deconv(ws["f6"], pk["up6"], u6, lrelu=False)
+        self._conv(ws["c6"], pk["predict_flow6"], ws["f6"], act=ACT_NONE, y_f32=True)
+        upflow(ws["f6"], "up6", u6)
         self._deconv(ws["c6"], pk["deconv5"], d5, lrelu=True)
         p5 = [c5, d5, u6]
         self._conv(p5, pk["inter_conv5"], ws["ic5"], act=ACT_NONE)
-        self._conv(ws["ic5"], pk["predict_flow5"], ws["f5"], act=ACT_NONE)
-        self._deconv(ws["f5"], pk["up5"], u5, lrelu=False)
+        self._conv(ws["ic5"], pk["predict_flow5"], ws["f5"], act=ACT_NONE, y_f32=True)
+        upflow(ws["f5"], "up5", u5)
         self._deconv(p5, pk["deconv4"], d4, lrelu=True)
         p4 = [c4, d4, u5]
         self._conv(p4, pk["inter_conv4"], ws["ic4"], act=ACT_NONE)
-        self._conv(ws["ic4"], pk["predict_flow4"], ws["f4"], act=ACT_NONE)
-        self._deconv(ws["f4"], pk["up4"], u4, lrelu=False)
+        self._conv(ws["ic4"], pk["predict_flow4"], ws["f4"], act=ACT_NONE, y_f32=True)
+        upflow(ws["f4"], "up4", u4)
         self._deconv(p4, pk["deconv3"], d3, lrelu=True)
         p3 = [c3, d3, u4]
         self._conv(p3, pk["inter_conv3"], ws["ic3"], act=ACT_NONE)
-        self._conv(ws["ic3"], pk["predict_flow3"], ws["f3"], act=ACT_NONE)
-        self._deconv(ws["f3"], pk["up3"], u3, lrelu=False)
+        self._conv(ws["ic3"], pk["predict_flow3"], ws["f3"], act=ACT_NONE, y_f32=True)
+        upflow(ws["f3"], "up3", u3)
         self._deconv(p3, pk["deconv2"], d2, lrelu=True)
         p2 = [c2, d2, u3]
         self._conv(p2, pk["inter_conv2"], ws["ic2"], act=ACT_NONE)
         f2 = ws["f2"]
-        self._conv(ws["ic2"], pk["predict_flow2"], f2, act=ACT_NONE)
+        self._conv(ws["ic2"], pk["predict_flow2"], f2, act=ACT_NONE, y_f32=True)
         out = torch.empty(B, 2, H, W, device=dev, dtype=torch.float32)
         _chk(lib.ammc_upsample4_bilinear_f32(f2.pix0(), *f2.strides, B, f2.H, f2.W, 2, float(self.m.div_flow), _ptr(out), s),
              "upsample")
@@ -259,6 +318,7 @@ class FlowNet2SD(nn.Module):
             raise NotImplementedError("FlowNet2SD(batchNorm=True) is not built; the reference constructs it with "
                                       "batchNorm=False (models/__init__.py:126, flownet2/models.py:10)")
         self.batchNorm, self.rgb_max, self.div_flow = False, 255.0, div_flow
+        self.precision = DEFAULT_PRECISION
         self.conv0 = _conv(6, 64)
         self.conv1, self.conv1_1 = _conv(64, 64, 2), _conv(64, 128)
         self.conv2, self.conv2_1 = _conv(128, 128, 2), _conv(128, 128)
@@ -282,7 +342,7 @@ class FlowNet2SD(nn.Module):
     def forward(self, inputs: torch.Tensor) -> torch.Tensor:
         if self.training:
             raise NotImplementedError("FlowNet2SD is a frozen estimator here: call .eval() (train_helper.py:284)")
-        if self._engine is None:
-            object.__setattr__(self, "_engine", _Engine(self))
+        if self._engine is None or self._engine.s16 != (self.precision == "s16"):
+            object.__setattr__(self, "_engine", _Engine(self, self.precision))
         with torch.no_grad():
             return self._engine.forward(inputs)

@@ -35,7 +35,12 @@ TRAIN_PRECISION = os.environ.get("AMMC_TRAIN_PRECISION", "s16")
 WGRAD_S16 = os.environ.get("AMMC_WGRAD_S16", "1") != "0"          # the 3x3 weight gradients as well (wgrad_s16.hip)
 # ConvTranspose forward / input gradient on the S16 kernels too: opt-in - its short-K GEMMs gain less than the operand
 # re-encoding costs (74.9 ms/step without, 75.5 with)
-CONVT_S16 = os.environ.get("AMMC_CONVT_S16", "0") != "0"
+CONVT_S16 = os.environ.get("AMMC_CONVT_S16", "0") != "0"          # ConvTranspose input gradient too (re-encodes its operand)
+# Round 4: every activation that only split-fp16 kernels read again is written as its S16 twin BY ITS PRODUCER (the
+# BatchNorm apply pass stores the fp32 tensor and the twin in one sweep, the max-pool runs on twins, the ConvTranspose
+# forward runs on conv_gemm_s16 with an S16 output): no fp32 -> S16 re-encoding pass of an activation is left in the
+# forward (they were 2.4 ms of the 70-ms step), and the ConvTranspose forward leaves the fp32 MFMA pipe.
+TWIN_S16 = os.environ.get("AMMC_TWIN_S16", "1") != "0"
 MID_S16 = os.environ.get("AMMC_MID_S16", "1") != "0"              # double_conv middle activations exist as S16 only
 FUSE_BN_BWD = os.environ.get("AMMC_FUSE_BN_BWD", "1") != "0"      # BN backward writes the S16 twin of dc (one rank)
 
@@ -174,10 +179,10 @@ class _Ops:
                           what)
 
     def conv_s16(self, x: Act, w: torch.Tensor, y: Act, *, ntaps, cin, n, res: Optional[Act] = None, what="conv",
-                 rescale: bool = False, pre=None, shift=None, up=1, cgroup=None, x_step=1):
+                 rescale: bool = False, pre=None, shift=None, up=1, cgroup=None, x_step=1, y_s16: bool = False):
         """3x3 conv on the split-fp16 MFMA kernels: x (fp32, any channel slice of its buffer) is re-encoded into its S16
-        twin (or `pre` = what `to_s16` returned for it), the packed filter likewise; fp32 output (+ fp32 residual).
-        ammc_conv_gemm_s16 picks the kernel."""
+        twin (or `pre` = what `to_s16` returned for it), the packed filter likewise; fp32 output (+ fp32 residual), or -
+        `y_s16`: y is the S16 twin itself - an S16 output.  ammc_conv_gemm_s16 picks the kernel."""
         lib, s = self.lib, self.s
         xs, inv = pre if pre is not None else self.to_s16(x, rescale)
         w16 = torch.empty_like(w)
@@ -189,7 +194,7 @@ class _Ops:
         d.scale = _ptr(inv) if inv is not None else None
         d.shift = _ptr(shift) if shift is not None else None
         d.batch, d.height, d.width = y.B, y.H // up, y.W // up
-        d.cin, d.ntaps, d.n, d.up, d.act, d.y_f32, d.x_step = cin, ntaps, n, up, ACT_NONE, 1, x_step
+        d.cin, d.ntaps, d.n, d.up, d.act, d.y_f32, d.x_step = cin, ntaps, n, up, ACT_NONE, 0 if y_s16 else 1, x_step
         d.cgroup = cgroup if cgroup is not None else n
         d.x_bs, d.x_rs, d.x_ps = xs.strides
         d.y_bs, d.y_rs, d.y_ps = y.strides
@@ -298,6 +303,7 @@ class _ConvBN:
         ws = ops.ws
         self.ops, self.conv, self.bn, self.x, self.y, self.res, self.name = ops, conv, bn, x, y, res, name
         self.y_s16_only = False       # set by _DoubleConv: y is read by split-fp16 convolutions only -> written as S16, never as fp32
+        self.y_s16_too = False        # set by _Stream / TrainEngine: y has fp32 AND S16 readers -> the apply pass writes both
         self.x_is_s16 = False         # ... and its consumer finds the twin of x ready
         self.cout, self.cin = conv.weight.shape[0], conv.weight.shape[1]
         self.cin_p = _cin_pad(self.cin)
@@ -347,10 +353,11 @@ class _ConvBN:
                                       _ptr(self.invstd), _ptr(self.scale), _ptr(self.shift), s), "bn_finalize")
         bn.num_batches_tracked += 1
         r = self.res
-        if self.y_s16_only:
+        if self.y_s16_only or self.y_s16_too:
             _chk(lib.ammc_scale_shift_act_s16_f32(c.pix0(), *c.strides, _ptr(self.scale), _ptr(self.shift),
                                                   r.pix0() if r is not None else None,
-                                                  *(r.strides if r is not None else (0, 0, 0)), None,
+                                                  *(r.strides if r is not None else (0, 0, 0)),
+                                                  None if self.y_s16_only else self.y.pix0(),
                                                   o.shadow(self.y).pix0(), *self.y.strides, 1, c.B, c.H, c.W, self.cout, s),
                  "bn_apply_s16")
             return
@@ -440,6 +447,14 @@ class _DoubleConv:
             self.u0.y_s16_only = self.u1.x_is_s16 = True
         self.dmid = ops.ws.act(x.B, x.H, x.W, seq[0].weight.shape[0])
 
+    def emit_twin(self) -> None:
+        """the block's output gets its S16 twin from the block's own apply pass"""
+        self.u1.y_s16_too = True
+
+    def input_has_twin(self) -> None:
+        """the S16 twin of the block's input is complete when the block runs (its producers wrote it)"""
+        self.u0.x_is_s16 = True
+
     def forward_gen(self):
         yield from self.u0.forward_gen()
         yield from self.u1.forward_gen()
@@ -526,6 +541,20 @@ class _Stream:
         self.outc_amax = ws.zbuf(256, dtype=torch.int32)
         self.outc_wdp = ws.buf(64, _kpad(9 * 64))
         self.scratch = ws.buf(lib.ammc_chan_reduce_blocks(B * H * W) * 512 + 1024)
+        # S16 twins written by their producers (TWIN_S16): skips and decoder outputs by the BatchNorm apply pass, pooled
+        # tensors by the S16 max-pool, the up half of the concat buffers by the ConvTranspose on conv_gemm_s16
+        self.twins = bool(ops.s16 and WGRAD_S16 and TWIN_S16)
+        self.bottom_twin = False                    # the decoder input's twin is written by ITS producer (set by the owner)
+        if self.twins:
+            for blk in (self.inc, self.down[0], self.down[1]):
+                blk.emit_twin()                     # skip[0..2]: read by the pool and by the decoder's first conv
+            for blk in self.down + self.up_dc:
+                blk.input_has_twin()                # pooled[i] / cat[lvl]
+            for blk in self.up_dc:
+                blk.emit_twin()                     # read by the next ConvTranspose / the output layer
+            if not has_vq:
+                self.down[2].emit_twin()            # x4 is the decoder's input
+                self.bottom_twin = True
 
     # ---- forward pieces -------------------------------------------------------------
     def encode_gen(self, x: torch.Tensor):
@@ -535,7 +564,11 @@ class _Stream:
         yield from self.inc.forward_gen()
         for i in range(3):
             p, sk = self.pooled[i], self.skip[i]
-            _chk(lib.ammc_maxpool2x2_f32(sk.pix0(), *sk.strides, p.pix0(), *p.strides, p.B, p.H, p.W, p.c, s), "pool")
+            if self.twins:                          # twin -> twin: the fp32 pooled tensor has no reader left
+                p16, sk16 = o.shadow(p), o.shadow(sk)
+                _chk(lib.ammc_maxpool2x2_s16(sk16.pix0(), *sk16.strides, p16.pix0(), *p16.strides, p.B, p.H, p.W, p.c, s), "pool_s16")
+            else:
+                _chk(lib.ammc_maxpool2x2_f32(sk.pix0(), *sk.strides, p.pix0(), *p.strides, p.B, p.H, p.W, p.c, s), "pool")
             yield from self.down[i].forward_gen()
 
     def memory_gen(self):
@@ -582,8 +615,16 @@ class _Stream:
             m = self.up_mods[j]
             _chk(lib.ammc_pack_convt_weight_f32(_ptr(m.up.weight.detach()), 2 * c, c, _ptr(self.up_wp[j]), s), "pack")
             self.up_b4[j].copy_(m.up.bias.detach().repeat(4))
-            (o.conv_s16 if o.s16 and CONVT_S16 else o.conv)(y, self.up_wp[j], self.cat[lvl].slice(c, c), ntaps=1, cin=2 * c,
-                                                          n=4 * c, shift=self.up_b4[j], up=2, cgroup=c, what=f"up{j + 1}.up")
+            dst = self.cat[lvl].slice(c, c)
+            if self.twins:
+                # S16 in (the producer's twin), S16 out (the up half of the concat buffer's twin: its only readers are the
+                # first conv of the block and that conv's weight gradient, both on the split-fp16 kernels)
+                has = self.bottom_twin if j == 0 else True
+                o.conv_s16(y, self.up_wp[j], o.shadow(dst), ntaps=1, cin=2 * c, n=4 * c, shift=self.up_b4[j], up=2, cgroup=c,
+                           what=f"up{j + 1}.up", pre=(o.shadow(y), None) if has else None, y_s16=True)
+            else:
+                (o.conv_s16 if o.s16 and CONVT_S16 else o.conv)(y, self.up_wp[j], dst, ntaps=1, cin=2 * c,
+                                                              n=4 * c, shift=self.up_b4[j], up=2, cgroup=c, what=f"up{j + 1}.up")
             yield from self.up_dc[j].forward_gen()
             y = self.up_out[j]
         net = self.net
@@ -598,7 +639,7 @@ class _Stream:
         d.cin, d.ntaps, d.n, d.up, d.cgroup, d.act, d.n_store = 64, 9, 32, 1, 32, ACT_TANH, self.cout
         d.y_bs, d.y_rs, d.y_ps, d.y_cs = self.cout * self.H * self.W, self.W, 1, self.H * self.W
         if o.s16:
-            u16, _ = o.to_s16(u3)                          # also the A operand of the weight gradient later
+            u16 = o.shadow(u3) if self.twins else o.to_s16(u3)[0]       # also the A operand of the weight gradient later
             w16 = torch.empty_like(self.outc_wp)
             _chk(lib.ammc_split_rows_f32(_ptr(self.outc_wp), self.outc_wp.numel(), _ptr(w16), s), "split_rows(w)")
             d.x, d.w, d.y_f32 = u16.tap0(), _ptr(w16), 1
@@ -716,6 +757,10 @@ class TrainEngine:
                 xb, yb = ws.act(B, h, w, 512), ws.act(B, h, w, 512)
                 o2f = _DoubleConv(ops, m.bridge.O2F, o.x4q, xb, r.x4q, "bridge.O2F")
                 f2o = _DoubleConv(ops, m.bridge.F20, r.x4q, yb, o.x4q, "bridge.F20")
+                if r.twins:
+                    o2f.emit_twin()                 # xb / yb feed the first ConvTranspose of their stream
+                    f2o.emit_twin()
+                    r.bottom_twin = o.bottom_twin = True
                 st = dict(ops=ops, streams=[r, o], o2f=o2f, f2o=f2o, xb=xb, yb=yb,
                           dzx=ws.act(B, h, w, 512), dzy=ws.act(B, h, w, 512))
             else:

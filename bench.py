@@ -17,6 +17,7 @@ Besides the contract fields the JSON line carries
 and, at N = 1 (each outside the headline's timed region; --no-secondary skips them):
   fp32_exact      the same workload on the exact-fp32 MFMA kernels (`model.precision = "fp32"`)
   train           BASELINE.json configs[2]: batch 32, forward + backward + Adam           (alone: --mode train)
+  train_gan       the reference's whole joint G / D iteration with FlowNet2-SD, batch 32   (alone: --mode train_gan)
   stress_memory   BASELINE.json configs[4]: 8192 slots x 512-d memory addressing, fp16 MFMA (alone: --mode stress)
 """
 from __future__ import annotations
@@ -59,10 +60,11 @@ def parse():
     p.add_argument("--precision", choices=("fp32", "s16"), default=os.environ.get("AMMC_PRECISION", "s16"),
                    help="s16 (the package default) = split-fp16 MFMA with fp32 accumulation, fp32-equivalent; "
                         "fp32 = exact fp32 MFMA")
-    p.add_argument("--mode", choices=("infer", "train", "stress"), default="infer",
+    p.add_argument("--mode", choices=("infer", "train", "stress", "train_gan"), default="infer",
                    help="infer = the headline metric (BASELINE.json configs[1]); train = configs[2]/[3]: fwd+bwd+Adam, "
                         "batch 32 per GPU, data parallel with a bucketed RCCL gradient all-reduce when --gpus > 1; "
-                        "stress = configs[4]: the fp16 memory-addressing kernel alone, rows sharded over the GPUs")
+                        "stress = configs[4]: the fp16 memory-addressing kernel alone, rows sharded over the GPUs; "
+                        "train_gan = the reference's whole joint G / D iteration with FlowNet2-SD (one GPU)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-secondary", action="store_true", help="headline only (profiling runs)")
     p.add_argument("--cpu-sample-batch", type=int, default=16, help="clips of the CPU baseline's forwards (the workload's own batch)")
@@ -313,7 +315,7 @@ def train_parity(net, out, loss, fixture, with_grads: bool):
     updated in place.  Called between backward and optimizer.step()."""
     import numpy as np
     path, d, cfg = fixture
-    st = int(d["out_step"])
+    st = int(d["out_step"]) if "out_step" in d.files else 1            # (the 64x64 fixture stores whole frames)
     rows = [int(r) for r in d["rows"]] if "rows" in d.files else list(range(cfg["batch"]))
 
     def rel(a, b):
@@ -325,15 +327,17 @@ def train_parity(net, out, loss, fixture, with_grads: bool):
            "frames_max_rel": max(rel(out[0][rows][..., ::st, ::st], d["rgb"]), rel(out[1][rows][..., ::st, ::st], d["op"])),
            "commit_max_rel": max(rel(out[2][0], d["rgb_diff"]), rel(out[2][1], d["op_diff"]))}
     sd = net.state_dict()
-    bufs = [rel(sd[k[4:]], d[k]) for k in d.files if k.startswith("buf.") and sd[k[4:]].is_floating_point()]
-    res["buffers_max_rel"] = max(bufs) if bufs else None
+    bufs = sorted((rel(sd[k[4:]], d[k]), k[4:]) for k in d.files if k.startswith("buf.") and sd[k[4:]].is_floating_point())
+    res["buffers_max_rel"] = bufs[-1][0] if bufs else None
+    res["buffers_worst"] = [f"{n} {e:.2e}" for e, n in bufs[-3:][::-1]]
     if with_grads:
         gn = []
         for name, p in net.named_parameters():
             want = float(d[f"gn.{name}"])
-            gn.append(abs(float(p.grad.double().norm()) - want) / max(want, 1e-30))
+            gn.append((abs(float(p.grad.double().norm()) - want) / max(want, 1e-30), name))
         gn.sort()
-        res["grad_norm_rel_median"], res["grad_norm_rel_max"] = gn[len(gn) // 2], gn[-1]
+        res["grad_norm_rel_median"], res["grad_norm_rel_max"] = gn[len(gn) // 2][0], gn[-1][0]
+        res["grad_norm_worst"] = [f"{n} {e:.2e}" for e, n in gn[-3:][::-1]]
     res["ok"] = bool(res["loss_rel"] <= PARITY_TOL and res["frames_max_rel"] <= PARITY_TOL and
                      res["commit_max_rel"] <= PARITY_TOL and (res["buffers_max_rel"] or 0.0) <= PARITY_TOL and
                      res.get("grad_norm_rel_max", 0.0) <= GRAD_NORM_TOL)
@@ -432,6 +436,95 @@ def run_train(args, rank, world, dev, dist, steps, warmup, with_cpu):
                     sorted(fams.items(), key=lambda kv: -kv[1]["ms"])},
         "cpu_baseline": cpu_baseline_train(args.size) if with_cpu else None,
         **backend_info(dist, world)}
+
+
+def run_train_gan(args, dev, steps, warmup):
+    """The reference's WHOLE joint-training iteration (run_helper/train_helper.py:296-339; BASELINE.json configs[2]
+    says "joint-training"): generator forward, two FlowNet2-SD forwards (flow-consistency term), three PixelDiscriminator
+    forwards, D backward + Adam, G backward through D + Adam - `harness.train_step_gan`, batch 32, one GPU.  The first
+    iteration runs on the clips of the reference-recorded fixture of this batch (tests/golden/gan_256_b<batch>_iteration.npz)
+    and its two losses and the gradient norms of both networks are compared with it."""
+    import numpy as np
+    import ammcnet_aaai2021_amd as A
+    from ammcnet_aaai2021_amd import harness, synthetic as S
+    batch = args.batch if (args.batch and args.mode == "train_gan") else 32
+    size = args.size
+    G = A.get_twostream((12, 6), (3, 2), 64, 256, 2)
+    G.load_state_dict(S.make_twostream_state())
+    G = G.to(dev).train()
+    D = A.PixelDiscriminator(3, [128, 256, 512, 512])
+    D.load_state_dict(S.make_discriminator_state())
+    D = D.to(dev).train()
+    F2 = A.FlowNet2SD()
+    F2.load_state_dict(S.make_flownet2sd_state())
+    F2 = F2.to(dev).eval()
+    flow_fn = harness.flownet_flow_fn(F2)
+    opt_g = torch.optim.Adam(G.parameters(), lr=2e-4)
+    opt_d = torch.optim.Adam(D.parameters(), lr=2e-5)
+    path = os.path.join(ROOT, "tests", "golden", f"gan_{size}_b{batch}_iteration.npz")
+    fx = np.load(path) if os.path.exists(path) else None
+    cfg = json.loads(str(fx["cfg"])) if fx is not None else None
+    lams = cfg["lams"] if cfg else harness.LAMS_ANOPRED
+    rgb_x, op_x, rgb_t, op_t = (t.to(dev) for t in S.make_clips(batch, size, size, tag=cfg["tag"] if cfg else "ganbench"))
+    rgb = torch.cat([rgb_x.view(batch, 4, 3, size, size), rgb_t[:, None]], 1)
+    op = torch.cat([op_x.view(batch, 3, 2, size, size), op_t[:, None]], 1)
+    state = {}
+
+    def it():
+        state["g"], state["d"] = harness.train_step_gan(G, D, opt_g, opt_d, rgb, op, flow_fn, **lams)
+
+    it()                                                   # the first iteration: the one that is compared
+    parity = None
+    if fx is not None:
+        gl, dl = float(state["g"]), float(state["d"])
+        dgn = sorted(abs(float(p.grad.double().norm()) - float(fx["dgn." + n])) / float(fx["dgn." + n]) for n, p in D.named_parameters())
+        ggn = sorted(abs(float(p.grad.double().norm()) - float(fx["ggn." + n])) / max(float(fx["ggn." + n]), 1e-30)
+                     for n, p in G.named_parameters())
+        parity = {"fixture": os.path.relpath(path, ROOT), "batch": batch, "of": "the timed models' first iteration",
+                  "g_loss_rel": abs(gl - float(fx["g_loss"])) / abs(float(fx["g_loss"])),
+                  "d_loss_rel": abs(dl - float(fx["d_loss"])) / abs(float(fx["d_loss"])),
+                  "d_grad_norm_rel_max": dgn[-1], "g_grad_norm_rel_median": ggn[len(ggn) // 2], "g_grad_norm_rel_max": ggn[-1]}
+        parity["ok"] = bool(parity["g_loss_rel"] <= PARITY_TOL and parity["d_loss_rel"] <= PARITY_TOL and
+                            dgn[-1] <= 1e-3 and ggn[-1] <= 1e-2 and ggn[len(ggn) // 2] <= GRAD_NORM_TOL)
+    for _ in range(max(warmup, 1) - 1):
+        it()
+    clock = Clock(dev, None)
+    elapsed = clock.time(it, steps)
+    if not (bool(torch.isfinite(state["g"])) and bool(torch.isfinite(state["d"]))):
+        raise SystemExit("joint-training iteration produced a non-finite loss")
+    # where the iteration's time goes: each piece alone, event-bracketed (outside the timed region)
+    def timed(fn, n=3):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return round(e0.elapsed_time(e1) / n, 2)
+
+    with torch.no_grad():
+        fake = (rgb_t * 0.9).contiguous()
+    parts = {"flownet2sd_forward_x2_ms": timed(lambda: (flow_fn(rgb_t, fake), flow_fn(rgb_t, rgb_t))),
+             "generator_step_ms (fwd + bwd + Adam, no D / flow terms)": timed(lambda: harness.train_step(G, opt_g, rgb, op))}
+
+    def d_only():
+        dl_ = harness.discriminate_loss(D(rgb_t), D(fake))
+        opt_d.zero_grad(set_to_none=True)
+        dl_.backward()
+        opt_d.step()
+    parts["discriminator_update_ms (2 fwd + bwd + Adam)"] = timed(d_only)
+    return {
+        "metric": "clips/sec, one joint G / D training iteration (train_helper.py:296-339): G fwd, 2x FlowNet2-SD fwd, 3x D fwd, "
+                  "D bwd + Adam, G bwd through D + Adam",
+        "value": round(batch * steps / elapsed, 2), "unit": "clips/s", "n_gpus": 1, "steps": steps, "warmup": max(warmup, 1),
+        "ms_per_step": round(1e3 * elapsed / steps, 3),
+        "dtype": "f32-equivalent: (hi,lo) f16 split MFMA for the generator's 3x3 convolutions and FlowNet2-SD "
+                 f"(precision {F2.precision}); PixelDiscriminator on exact-f32 MFMA",
+        "config": {"workload": "Avenue-shaped dual-stream generator + 256-slot memory + AMFT, PixelDiscriminator, frozen FlowNet2-SD, "
+                               "batch 32: the reference's joint-training iteration (BASELINE.json configs[2])",
+                   "batch_per_gpu": batch, "frame": f"{size}x{size}", "lams": lams},
+        "g_loss": float(state["g"]), "d_loss": float(state["d"]), "parity": parity, "parity_tol": PARITY_TOL, "pieces": parts}
 
 
 # ---- configs[4]: the memory-addressing kernel alone ------------------------------------------------------------------------
@@ -794,6 +887,13 @@ def run_infer(args, rank, world, dev, dist):
                                            "parity", "roofline", "kernels")}
         if t["parity"] is not None and not t["parity"]["ok"]:
             rc = 3
+        del t
+        torch.cuda.empty_cache()
+        gan = run_train_gan(args, dev, steps=5, warmup=2)
+        line["train_gan"] = gan
+        if gan["parity"] is not None and not gan["parity"]["ok"]:
+            rc = 3
+        del gan
         torch.cuda.empty_cache()
         s = run_stress(args, 0, 1, dev, None, steps=10, warmup=2, with_cpu=False)
         line["stress_memory"] = {k: s[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype",
@@ -815,6 +915,12 @@ def main():
             rc = 3
     elif args.mode == "stress":
         line = run_stress(args, rank, world, dev, dist, args.steps, args.warmup, world == 1 and not args.no_cpu_baseline)
+    elif args.mode == "train_gan":
+        if world != 1:
+            raise SystemExit("--mode train_gan is a one-GPU leg")
+        line = run_train_gan(args, dev, args.steps, args.warmup)
+        if line["parity"] is not None and not line["parity"]["ok"]:
+            rc = 3
     else:
         if args.batch is None:
             args.batch = 16

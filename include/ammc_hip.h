@@ -48,6 +48,10 @@ const char* ammc_error_string(int code);
  *             (default), 0 = on the halo-patch kernel.  Initial value: AMMC_OUTC_STREAM.
  *   "memory_rt"  feature rows per workgroup of ammc_memory_topk_fwd_s16: 0 = by size (64 from 16384 rows up, k <= 2,
  *             m <= 2048; default), 1 = 32, 2 = 64.  Results are bit-identical.  Initial value: AMMC_MEMORY_RT.
+ *   "memory_split"  ammc_memory_topk_fwd_f16: -1 = by size (default: from 65536 rows up the contraction runs in chunks of
+ *             whole rounds of workgroups on the caller's stream and the HBM-bound gather / commit of each chunk on a
+ *             second, library-owned stream beside the next chunk's contraction; the caller's stream waits for it before
+ *             the call's successors run), 0 = one fused launch, 1 = split at any size.  Initial value: AMMC_MEMORY_SPLIT.
  * Returns AMMC_EUNSUP for an unknown key, AMMC_EINVAL for a value out of range.  These are PROCESS defaults
  * (not thread safe against concurrent launches); a caller that needs a per-call choice sets the descriptor fields
  * `s16_mf` / `outc_stream` instead, which take precedence and touch no global state. */
@@ -84,7 +88,7 @@ typedef struct AmmcConvDesc {
   const float* res;      /* residual added after the activation, or NULL (S16 kernels: S16, or fp32 NHWC when y_f32) */
   int32_t batch, height, width;        /* pixel space of m                               */
   int32_t cin;           /* channels per tap: power of two >= 4                           */
-  int32_t ntaps;         /* 9 (3x3, pad 1 via the halo), 4 (2x2, see x_step) or 1         */
+  int32_t ntaps;         /* 9 (3x3, pad 1 via the halo), 4 (2x2, see x_step), 16 (4x4) or 1 */
   int32_t n;             /* GEMM N: 32, or a multiple of 64                               */
   int32_t up;            /* 1, or 2 for the ConvTranspose scatter                         */
   int32_t cgroup;        /* channels per (dy,dx) group when up=2 (multiple of 32); else n */
@@ -298,6 +302,9 @@ int ammc_flownet_prep_f32(const float* in /* [B][3][2][H][W], 0..rgb_max */, int
                           float* y /* NHWC, 8 channels */, int64_t y_bs, int64_t y_rs, int64_t y_ps, float rgb_max,
                           void* stream);
 int ammc_lrelu_f32(float* y, int64_t y_bs, int64_t y_rs, int64_t y_ps, int32_t batch, int32_t h, int32_t w, int32_t c,
+                   float slope, void* stream);
+/* the same LeakyReLU in place on an S16 activation (c % 8 == 0): the split-fp16 form of the FlowNet2-SD forward */
+int ammc_lrelu_s16(float* y, int64_t y_bs, int64_t y_rs, int64_t y_ps, int32_t batch, int32_t h, int32_t w, int32_t c,
                    float slope, void* stream);
 int ammc_upsample4_bilinear_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, int32_t batch, int32_t h,
                                 int32_t w, int32_t c, float premul, float* out /* NCHW [B][c][4h][4w] */, void* stream);

@@ -349,9 +349,67 @@ def flownet2sd_golden(name="flownet2sd_eval"):
     print(name, {k: getattr(v, "shape", v) for k, v in out.items() if k != "state_keys"})
 
 
+def gan_iteration(ref, batch, name):
+    """One iteration of the reference's joint loop (run_helper/train_helper.py:296-339) from the reference's OWN classes:
+    generator (`twostream`, train mode), `PixelDiscriminator`, frozen `FlowNet2SD`, the loss classes of
+    losses_utils.py combined as `Twostream_vq_Loss.forward` (loss_zoo.py:323-336; the latent term is the sum of the two
+    commit values) with the ano_pred lambdas.  Stores the two losses, every term, and the norm of every
+    gradient the two backward passes leave (D's from d_loss, G's from g_loss through D and the loss terms)."""
+    p2p, lu = load_ref_losses_and_d()
+    flow_models = load_ref_flownet()
+    lam = dict(lam_adv=0.05, lam_gdl=1.0, lam_flow=2.0, lam_lp=1.0, lam_lp_op=1.0, lam_latent=1.0)
+    cfg = dict(in_channel=(12, 6), out_channel=(3, 2), embed_dim=64, n_embed=256, k=2)
+    G = ref.get_twostream(cfg["in_channel"], cfg["out_channel"], 64, 256, 2)
+    G.load_state_dict(S.make_twostream_state(**cfg), strict=True)
+    G.train()
+    D = p2p.PixelDiscriminator(3, [128, 256, 512, 512], use_norm=False)
+    D.load_state_dict(S.make_discriminator_state(), strict=True)
+    D.train()
+    F2 = flow_models.FlowNet2SD().eval()
+    F2.load_state_dict(S.make_flownet2sd_state(), strict=True)
+    rgb_x, op_x, rgb_t, op_t = S.make_clips(batch, 256, 256, tag=name)
+    rgb_out, op_out, (rd, od), _ = G(rgb_x, op_x)
+    last = rgb_t                                     # `rgb_input_last = rgb[:, -1]` IS the target frame (train_helper.py:299)
+    with torch.no_grad():
+        fp = F2((torch.cat([last.unsqueeze(2), rgb_out.detach().unsqueeze(2)], 2) * 0.5 + 0.5) * 255.0) / 255.0
+        fg = F2((torch.cat([last.unsqueeze(2), rgb_t.unsqueeze(2)], 2) * 0.5 + 0.5) * 255.0) / 255.0
+    d_gen = D(rgb_out)
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self       # Gradient_Loss.forward puts its filters on the GPU
+    try:
+        gdl = lu.Gradient_Loss(1, 3)(rgb_out, rgb_t)
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    terms = dict(adv=lu.Adversarial_Loss()(d_gen), gdl=gdl, flow=lu.Flow_Loss()(fp, fg), int_rgb=lu.L2()(rgb_out, rgb_t),
+                 int_op=lu.L2()(op_out, op_t), latent=(rd + od).sum())
+    g_loss = lam["lam_adv"] * terms["adv"] + lam["lam_gdl"] * terms["gdl"] + lam["lam_flow"] * terms["flow"] + \
+        lam["lam_lp"] * terms["int_rgb"] + lam["lam_latent"] * terms["latent"] + lam["lam_lp_op"] * terms["int_op"]
+    d_loss = lu.Discriminate_Loss()(D(rgb_t), D(rgb_out.detach()))
+    D.zero_grad()
+    d_loss.backward()
+    out = {"g_loss": np.float64(g_loss.item()), "d_loss": np.float64(d_loss.item())}
+    out.update({"term." + k: np.float64(v.item()) for k, v in terms.items()})
+    for k, p in D.named_parameters():
+        out["dgn." + k] = np.float64(p.grad.double().norm().item())
+    G.zero_grad()
+    g_loss.backward()
+    for k, p in G.named_parameters():
+        out["ggn." + k] = np.float64(p.grad.double().norm().item())
+    out["flow_pred_absmax"] = np.float64(fp.abs().max().item())
+    out["cfg"] = np.array(json.dumps(dict(hw=256, batch=batch, tag=name, lams=lam, **cfg)))
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    print(name, {k: float(v) for k, v in out.items() if k.endswith("loss") or k.startswith("term.")})
+
+
 def main():
     torch.set_num_threads(8)
     ref = load_ref_unet()
+    if len(sys.argv) > 1 and sys.argv[1] == "gan":
+        # the joint G / D iteration at the training benchmark's frame size: batch 2 (the -m gpu test) or 32 (what
+        # bench.py's train_gan leg times; ~35 GB, several minutes)
+        b = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+        gan_iteration(ref, b, f"gan_256_b{b}_iteration")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "train_b32":
         # the TIMED training batch of bench.py (BASELINE.json configs[2]: batch 32 at 256x256): ~30 GB of autograd state
         # and a few minutes on 8 cores, so it is made on request only

@@ -25,17 +25,20 @@ def _l2rel(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
-def _disc(sd=None, filters=(128, 256, 512, 512), cin=3):
+def _disc(sd=None, filters=(128, 256, 512, 512), cin=3, precision=None):
     sd = sd or S.make_discriminator_state(cin, filters)
     net = A.PixelDiscriminator(cin, list(filters), use_norm=False)
     net.load_state_dict(sd, strict=True)
+    if precision is not None:
+        net.precision = precision          # "s16" (default): split-fp16 forward convolutions; "fp32": exact-fp32 MFMA
     return net.to(DEV).train(), sd
 
 
-def test_discriminator_golden_forward_and_adversarial_gradients():
+@pytest.mark.parametrize("precision", ["s16", "fp32"])
+def test_discriminator_golden_forward_and_adversarial_gradients(precision):
     name = "discriminator_64_b2"
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
-    net, sd = _disc()
+    net, sd = _disc(precision=precision)
     _, _, real, _ = S.make_clips(2, 64, 64, tag=name)
     fake = (real + 0.3 * S.hashed_uniform(name + ":fake", tuple(real.shape))).clamp(-1, 1)
     fk = fake.to(DEV).requires_grad_(True)
@@ -78,9 +81,10 @@ def test_discriminator_golden_forward_and_adversarial_gradients():
 
 @pytest.mark.parametrize("b,h,w,filters", [(1, 256, 256, (128, 256, 512, 512)), (3, 40, 72, (128, 256, 512, 512)),
                                             (2, 34, 50, (64, 128, 128)), (1, 8, 8, (128, 256, 512, 512))])
-def test_discriminator_shapes_vs_oracle(b, h, w, filters):
+@pytest.mark.parametrize("precision", ["s16", "fp32"])
+def test_discriminator_shapes_vs_oracle(b, h, w, filters, precision):
     """the harness size (256x256 -> 34x34), non-square / odd intermediate sizes, a shallower filter list"""
-    net, sd = _disc(filters=filters)
+    net, sd = _disc(filters=filters, precision=precision)
     x = S.hashed_uniform(f"disc-x-{b}-{h}-{w}", (b, 3, h, w))
     xg = x.to(DEV).requires_grad_(True)
     y = net(xg)

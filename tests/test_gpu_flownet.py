@@ -24,9 +24,13 @@ def _net():
     return net.to(DEV).eval(), sd
 
 
-def test_flownet2sd_golden_and_oracle():
+@pytest.mark.parametrize("precision", ["s16", "fp32"])
+def test_flownet2sd_golden_and_oracle(precision):
+    """both arithmetic forms: the split-fp16 kernels (default: S16 activations and filters, fp32 flow heads) and the
+    exact-fp32 kernels, same gates"""
     g = np.load(os.path.join(GOLDEN, "flownet2sd_eval.npz"))
     net, sd = _net()
+    net.precision = precision
     assert sum(p.numel() for p in net.parameters()) == int(g["param_count"])
     for tag in ("a", "b"):
         shape = tuple(int(v) for v in g["shape_" + tag])
@@ -37,6 +41,7 @@ def test_flownet2sd_golden_and_oracle():
     x = (S.hashed_uniform("flow-other", (1, 3, 2, 128, 192)) + 1) * 127.5
     want = O.flownet2sd_forward(sd, x)
     assert rel_err(net(x.to(DEV)).cpu(), want) <= 2e-5
+    assert net._engine.s16 == (precision == "s16")
 
 
 def test_flownet2sd_interface():

@@ -68,3 +68,32 @@ def test_memory_topk_f16_65536_rows_chunked_oracle():
         sq += float((wq1.reshape(chunk, d).double() - flat.double()).pow(2).sum())
     assert agree_all / n > 0.9, agree_all / n
     assert abs(float(diff) - sq / (n * d)) <= 5e-3 * sq / (n * d)
+
+
+@pytest.mark.parametrize("n", [65536, 65536 + 128 * 300 + 57, 1024])
+def test_split_contraction_and_gather_equal_the_fused_launch(n):
+    """`memory_split`: contraction in chunks of whole rounds on the caller's stream, gather / commit of every chunk on
+    the library's second stream beside the next chunk's contraction (the default from two rounds of workgroups up).  Same
+    indices, same gathered fp32 rows and q_one bit for bit as ONE fused launch; the commit sum to summation order.  The
+    ragged size ends in a partial chunk and a partial row block; 1024 rows force the split form below its default size.
+    Successors on the caller's stream must see complete outputs: they are read right after the call, without a device
+    synchronisation in between."""
+    from ammcnet_aaai2021_amd import _lib
+    lib = _lib.load()
+    d, m, k = 512, 8192, 2
+    embed = S.hashed_normal("s16:split:e", (d, m), 0.9).to(DEV)
+    g = torch.Generator().manual_seed(n)
+    x = (torch.randn(n, d, generator=g) * 0.8).view(1, 1, n, d).to(DEV)
+    res = {}
+    try:
+        for mode in (0, 1):
+            assert lib.ammc_set_option(b"memory_split", mode) == 0
+            for _ in range(2):                                     # the second call re-uses the events of the first
+                qk, diff, q1, idx = ops.quantize_topk_f16(embed, x, k)
+            res[mode] = (qk.clone(), diff.clone(), q1.clone(), idx.clone())        # (clone: enqueued on the caller's stream)
+    finally:
+        lib.ammc_set_option(b"memory_split", -1)
+    torch.cuda.synchronize()
+    assert torch.equal(res[0][3], res[1][3]) and torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2])
+    assert rel_err(res[1][1].cpu(), res[0][1].cpu()) <= 1e-6
+    assert lib.ammc_set_option(b"memory_split", 2) == -1              # AMMC_EINVAL
