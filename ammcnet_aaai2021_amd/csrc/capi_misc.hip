@@ -30,7 +30,7 @@ int ammc_opt_memory_rt() {
   return g_ammc_memory_rt;
 }
 
-int g_ammc_memory_split = -2;      // -2 = not read yet; -1 = by size (default), 0 = fused launch, 1 = split contraction / gather
+int g_ammc_memory_split = -2;      // -2 = not read yet; -1 / 0 = fused launch (default), 1 = split contraction / gather
 
 int ammc_opt_memory_split() {
   if (g_ammc_memory_split == -2) {

@@ -424,11 +424,16 @@ int launch_topk16n(const float* x, const void* e_kblk, const float* e_md, const 
   }
   const int mpad = (m + 31) / 32 * 32;
   const int nblk = (n + HBR - 1) / HBR;
-  // "memory_split" (AMMC_MEMORY_SPLIT): -1 = by size (split from two rounds of workgroups up), 0 = always fused, 1 = split
+  // "memory_split" (AMMC_MEMORY_SPLIT): 1 = split, else ONE fused launch (the default).  Measured at 262144 rows (round 4,
+  // profiles/r04_stress_split_trace.txt): the trace shows the gather of chunk c running beside the contraction of chunk
+  // c + 1 as designed, but the contraction of a chunk then takes 295 us instead of 282 (it shares L2 / HBM and the power
+  // budget with the gather, which itself stretches from 154 to 240 us at the one wave per SIMD the register file leaves
+  // it) and the last chunk's gather is exposed: 2560 us per call against 2580 fused - 1 %, not worth a second stream
+  // by default.
   const int opt = ammc_opt_memory_split();
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(stream, &cap);
-  bool use_split = opt != 0 && (opt == 1 || nblk >= 2 * SPLIT_ROUND_BLOCKS) && cap == hipStreamCaptureStatusNone;
+  bool use_split = opt == 1 && cap == hipStreamCaptureStatusNone;
   std::unique_lock<std::mutex> lock(g_split_mu, std::defer_lock);
   if (use_split) {
     lock.lock();

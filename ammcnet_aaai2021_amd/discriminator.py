@@ -17,8 +17,11 @@ Every forward that may be differentiated takes its own workspace slot, so the th
 Round 4 (`module.precision`, default "s16"): the FORWARD convolutions run on the split-fp16 kernel
 (`ammc_conv_gemm_s16`, ntaps 16: (hi, lo) half pairs, three fp16 MFMAs per product, fp32 accumulation - fp32-equivalent)
 with fp32 outputs; each activation is then re-encoded once into the S16 twin the next layer reads (the fp32 tensor stays
-for the weight gradient and the LeakyReLU mask of the backward, which remain on the exact-fp32 kernels).  "fp32" = the
-exact-fp32 MFMA kernels throughout, as in round 3.
+for the weight gradient and the LeakyReLU mask of the backward).  The INPUT-GRADIENT convolutions run on the same kernel:
+the gradient of a layer's output is brought into the half range by a power of two found on the device
+(`ammc_absmax_bits_f32` + `ammc_split_rows_scaled_f32`, as the generator's gradients are), re-encoded once, and the
+scale is undone in the epilogue; fp32 outputs.  Weight gradients stay on `ammc_conv_wgrad_f32`.  "fp32" = the exact-fp32
+MFMA kernels throughout, as in round 3.
 """
 from __future__ import annotations
 
@@ -78,6 +81,7 @@ class _Slot:
         # split-fp16 forward: the S16 twins of the layer inputs and of the packed filters
         self.acts16 = [Act(torch.zeros_like(a.buf), a.B, a.H, a.W, a.c, 0, HALO) for a in self.acts] if eng.s16 else None
         self.w16 = [torch.zeros_like(w) for w in self.wp] if eng.s16 else None
+        self.wd16 = [torch.zeros_like(w) for w in self.wd] if eng.s16 else None
 
 
 class _Lease:
@@ -105,6 +109,7 @@ class DiscEngine:
         self.layers.append(_Layer(module.num_filters[-1], 1, 1, self.s16))
         self._pools: Dict[Tuple[int, int, int], list] = {}
         self._grads: Dict[Tuple[int, int, int], List[Act]] = {}
+        self._grads16: Dict[Tuple[int, int, int], List[Act]] = {}
         self._scratch: Optional[torch.Tensor] = None
         self._zeros: Optional[torch.Tensor] = None
         self.slots_created = 0
@@ -119,6 +124,7 @@ class DiscEngine:
             self.device = device
             self._pools.clear()
             self._grads.clear()
+            self._grads16.clear()
             self._zeros = torch.zeros(1024, device=device)
             self._scratch = None
 
@@ -141,13 +147,16 @@ class DiscEngine:
                     h, w = slot.out_hw
                 gs.append(Act(torch.zeros(slot.B, h + 2, w + 2, L.gc, device=self.device), slot.B, h, w, L.gc, 0, 1))
             self._grads[key] = gs
+            if self.s16:                           # S16 twins of the gradients + the slots / scale of their rescaling
+                self._grads16[key] = [Act(torch.zeros_like(g.buf), g.B, g.H, g.W, g.c, 0, 1) for g in gs]
         return self._grads[key]
 
     def _conv(self, x_ptr: int, x_strides, w: torch.Tensor, y_ptr: int, y_strides, *, batch, height, width, cin, ntaps,
-              n, shift=None, act=ACT_NONE, x_step=1, n_store=0, y_cs=0, what="conv", s16=False):
+              n, shift=None, act=ACT_NONE, x_step=1, n_store=0, y_cs=0, what="conv", s16=False, scale=None):
         d = AmmcConvDesc()
         d.x, d.w, d.y = x_ptr, _ptr(w), y_ptr
-        d.scale, d.shift, d.res = None, (_ptr(shift) if shift is not None else None), None
+        d.scale = _ptr(scale) if scale is not None else None
+        d.shift, d.res = (_ptr(shift) if shift is not None else None), None
         d.batch, d.height, d.width = batch, height, width
         d.cin, d.ntaps, d.n, d.up, d.cgroup, d.act, d.x_step = cin, ntaps, n, 1, n, act, x_step
         d.n_store, d.y_cs = n_store, y_cs
@@ -179,6 +188,8 @@ class DiscEngine:
             if keep and (i > 0 or need_dx):
                 _chk(lib.ammc_pack_conv4_dgrad_weight_f32(_ptr(w), L.cout, L.cin, L.gc, L.rows, L.stride, 2,
                                                           _ptr(slot.wd[i]), s), "pack_dgrad")
+                if self.s16:
+                    _chk(lib.ammc_split_rows_f32(_ptr(slot.wd[i]), slot.wd[i].numel(), _ptr(slot.wd16[i]), s), "split_rows(wd)")
         slot.has_dgrad = keep
         oh, ow = slot.out_hw
         out = torch.empty(B, 1, oh, ow, device=x.device, dtype=torch.float32)
@@ -262,11 +273,21 @@ class DiscEngine:
                 dx = torch.empty(B, L.cin, slot.H, slot.W, device=self.device, dtype=torch.float32)
                 y0, ybs, yrs, yps = _ptr(dx), L.cin * slot.H * slot.W, slot.W, 1
                 ycs, nstore, esz = slot.H * slot.W, L.cin, 4
+            gsrc, wdi, inv = g, slot.wd[i], None
+            if self.s16:
+                # the gradient as an S16 operand: max |g| on the device -> a power of two that puts it at 2^10 -> the
+                # re-encoding; 2^-k comes back through the epilogue's per-column scale
+                gsrc, wdi = self._grads16[(slot.B, slot.H, slot.W)][i], slot.wd16[i]
+                amax = torch.zeros(256, device=self.device, dtype=torch.int32)
+                inv = torch.empty(1024, device=self.device, dtype=torch.float32)
+                _chk(lib.ammc_absmax_bits_f32(_ptr(g.buf), g.buf.numel(), amax.data_ptr(), s), "absmax(g)")
+                _chk(lib.ammc_split_rows_scaled_f32(_ptr(g.buf), g.buf.numel(), _ptr(gsrc.buf), amax.data_ptr(), _ptr(inv),
+                                                    1024, s), "split_rows_scaled(g)")
             if L.stride == 1:
                 # dA[q] = sum_r g[q + 2 - r] W[r]: a 16-tap window starting at g(q - 1) with the flipped filter
-                self._conv(g.pix0() - esz * (g.rs + g.ps), g.strides, slot.wd[i], y0, (ybs, yrs, yps), batch=B,
+                self._conv(gsrc.pix0() - esz * (g.rs + g.ps), g.strides, wdi, y0, (ybs, yrs, yps), batch=B,
                            height=a.H, width=a.W, cin=g.c, ntaps=16, n=L.rows, n_store=nstore, y_cs=ycs,
-                           what=f"disc.dgrad{i}")
+                           what=f"disc.dgrad{i}", s16=self.s16, scale=inv)
             else:
                 per = L.rows * L.dkpad
                 for ph in range(4):
@@ -274,9 +295,10 @@ class DiscEngine:
                     hh, ww = (a.H - py + 1) // 2, (a.W - px + 1) // 2
                     if hh <= 0 or ww <= 0:
                         continue
-                    self._conv(g.pix0(), g.strides, slot.wd[i][ph * per:(ph + 1) * per],
+                    self._conv(gsrc.pix0(), g.strides, wdi[ph * per:(ph + 1) * per],
                                y0 + esz * (py * yrs + px * yps), (ybs, 2 * yrs, 2 * yps), batch=B, height=hh, width=ww,
-                               cin=g.c, ntaps=4, n=L.rows, n_store=nstore, y_cs=ycs, what=f"disc.dgrad{i}.{ph}")
+                               cin=g.c, ntaps=4, n=L.rows, n_store=nstore, y_cs=ycs, what=f"disc.dgrad{i}.{ph}",
+                               s16=self.s16, scale=inv)
         return dx, grads
 
 

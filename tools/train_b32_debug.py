@@ -30,7 +30,8 @@ for prec in ("s16", "fp32"):
     torch.cuda.synchronize()
     sd = {k: v.detach().double().cpu() for k, v in net.state_dict().items() if v.is_floating_point()}
     gn = {n: float(p.grad.double().norm()) for n, p in net.named_parameters()}
-    res[prec] = (sd, gn, float(loss))
+    gs = {n: p.grad.detach().flatten()[:: max(1, p.grad.numel() // 64)][:64].double().cpu() for n, p in net.named_parameters()}
+    res[prec] = (sd, gn, float(loss.detach()), gs)
     if prec == "s16":
         st = net._train_engine._last
         for si, name in ((0, "rgb"), (1, "op")):
@@ -67,3 +68,20 @@ rows.sort(reverse=True)
 print("gradient norms: s16-vs-fixture  fp32-vs-fixture  s16-vs-fp32")
 for r in rows[:12]:
     print("  %.2e  %.2e  %.2e  %s" % r)
+
+
+def l2rel(a, b):
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+for prec in ("s16", "fp32"):
+    e = sorted(l2rel(res[prec][3][n], torch.as_tensor(d[f"gs.{n}"]).double()) for n in res[prec][3])
+    print(f"64-sample L2 per gradient tensor, {prec} vs fixture: max {e[-1]:.2e}  p90 {e[int(0.9 * len(e))]:.2e}  median {e[len(e) // 2]:.2e}")
+e = sorted(l2rel(res["s16"][3][n], res["fp32"][3][n]) for n in res["s16"][3])
+print(f"64-sample L2 per gradient tensor, s16 vs fp32 engine: max {e[-1]:.2e}  p90 {e[int(0.9 * len(e))]:.2e}  median {e[len(e) // 2]:.2e}")
+for stream in ("rgb", "op"):
+    k = f"{stream}.vq_down3.quan.quantize.cluster_size"
+    w = torch.as_tensor(np.asarray(d["buf." + k])).double()
+    for prec in ("s16", "fp32"):
+        moved = float((res[prec][0][k] - w).abs().sum()) / 0.01 / 2          # rows whose nearest slot differs (decay 0.99)
+        print(f"{k} {prec}: {moved:.2f} re-routed rows of {B * 32 * 32}")
