@@ -355,6 +355,32 @@ def train_parity(net, out, loss, fixture, with_grads: bool):
     return res
 
 
+def train_traffic(kernel: str, batch: int, size: int):
+    """HBM-side bytes per launch of the training step's dominant kernel family from the committed PMC passes of
+    `bench.py --mode train` (tools/profile_round.sh <tag> train -> profiles/rNN_train_pmc_traffic.json): the weight-gradient
+    family is the dispatch-weighted mean over its wgrad_tap*_s16 instances.  (None, None) when no profile of this batch /
+    frame size is committed."""
+    for path in _profiles(["train_pmc_traffic.json"]):
+        with open(path) as fp:
+            prof = json.load(fp)
+        wl = prof.get("workload", {})
+        if (wl.get("batch"), wl.get("size")) != (batch, size):
+            continue
+        rows = prof.get("kernels", {})
+        if kernel.startswith("conv_wgrad_s16"):
+            sel = [v for k, v in rows.items() if k.startswith(("wgrad_tap3_s16", "wgrad_tap_s16", "wgrad_s16"))]
+        else:
+            sel = [v for k, v in rows.items() if _norm_kernel(k) == _norm_kernel(kernel)]
+        sel = [v for v in sel if v.get("traffic_bytes_per_launch") is not None and v.get("dispatches")]
+        if not sel:
+            continue
+        n = sum(v["dispatches"] for v in sel)
+        return (sum(v["dispatches"] * v["traffic_bytes_per_launch"] for v in sel) / n,
+                {"file": os.path.relpath(path, ROOT), "command": prof.get("source"), "workload": wl, "commit": prof.get("commit"),
+                 "averaged_over_launches": n})
+    return None, None
+
+
 def run_train(args, rank, world, dev, dist, steps, warmup, with_cpu):
     """one optimisation step of the shipped network (256 slots) per "step", batch 32 per GPU (weak scaling), gradients
     averaged over RCCL inside backward (parallel.BucketedGradReducer).  Returns the JSON object (rank 0) or None."""
@@ -418,8 +444,10 @@ def run_train(args, rank, world, dev, dist, steps, warmup, with_cpu):
             s16 = net._train_engine.precision == "s16"
             peak = PEAK_F16_MFMA_TFLOPS if s16 else PEAK_F32_MFMA_TFLOPS
             ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
+            traffic, tsrc = train_traffic(name, batch, args.size)
             roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None, "mfma_issue_frac": round((3.0 if s16 else 1.0) * ach / peak, 4),
+                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc,
+                    "mfma_issue_frac": round((3.0 if s16 else 1.0) * ach / peak, 4),
                     "power_ceiling": power_ceiling("wgrad_tap3_s16", 3.0 * ach) if s16 else None,
                     "flops_per_launch": f["flops"] / f["launches"], "avg_launch_us": round(1e3 * f["ms"] / f["launches"], 2),
                     "launches_per_step": f["launches"], "share_of_step": round(f["ms"] / (1e3 * elapsed / steps), 4)}
