@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # AMMC_LIB: another build of the SAME library (A/B measurements: `python -m ammcnet_aaai2021_amd.build --variant x`)
 LIB_PATH = os.environ.get("AMMC_LIB") or os.path.join(HERE, "libammc_hip.so")
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU = 0, 1, 2, 3
 
@@ -92,7 +92,8 @@ SIGNATURES = {
     "ammc_pack_conv_dgrad_weight_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
     "ammc_transpose_pad_f32": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "ammc_pack_conv4_dgrad_weight_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
-    "ammc_flownet_prep_f32": (C.c_int, [_p, _i32, _i32, _i32, _p] + _s3 + [_f32, _p]),
+    "ammc_flownet_prep_scratch_doubles": (C.c_int, [_i32]),
+    "ammc_flownet_prep_f32": (C.c_int, [_p, _i32, _i32, _i32, _p] + _s3 + [_f32, _p, _p]),
     "ammc_lrelu_f32": (C.c_int, [_p] + _s3 + [_i32, _i32, _i32, _i32, _f32, _p]),
     "ammc_lrelu_s16": (C.c_int, [_p] + _s3 + [_i32, _i32, _i32, _i32, _f32, _p]),
     "ammc_upsample4_bilinear_f32": (C.c_int, [_p] + _s3 + [_i32, _i32, _i32, _i32, _f32, _p, _p]),

@@ -5,24 +5,42 @@
 namespace ammc_impl {
 
 // inputs [B][3][2][H][W] in 0..rgb_max  ->  NHWC activation with 8 channels: (x - mean over (frame, H, W)) / rgb_max,
-// channel order frame-major (models.py:16-18); channels 6, 7 are zero.  One workgroup per (sample, colour).
-__global__ __launch_bounds__(256) void flownet_prep_kernel(const float* __restrict__ in, int H, int W,
-                                                           float* __restrict__ y, int64_t y_bs, int64_t y_rs, int64_t y_ps,
-                                                           float rgb_max) {
+// channel order frame-major (models.py:16-18); channels 6, 7 are zero.  Two kernels (round 4: one workgroup per (sample,
+// colour) doing both halves took 306 us at batch 32, 96 workgroups on 256 CUs): PREP_SLICES workgroups per (sample,
+// colour) sum their slice in double, then every workgroup of the second kernel adds the slices' sums in a fixed order
+// (the mean is the same bits everywhere, run to run) and writes its share of the pixels.
+constexpr int PREP_SLICES = 32;
+__global__ __launch_bounds__(256) void flownet_prep_sum_kernel(const float* __restrict__ in, int H, int W, double* __restrict__ part) {
   __shared__ double red[256];
-  const int b = blockIdx.x / 3, c = blockIdx.x % 3;
+  const int bc = blockIdx.x / PREP_SLICES, sl = blockIdx.x % PREP_SLICES;
   const int64_t n = (int64_t)2 * H * W;
-  const float* src = in + ((int64_t)b * 3 + c) * n;
+  const int64_t per = (n + PREP_SLICES - 1) / PREP_SLICES;
+  const int64_t lo = sl * per, hi = lo + per < n ? lo + per : n;
+  const float* src = in + (int64_t)bc * n;
   double s = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += 256) s += (double)src[i];
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) s += (double)src[i];
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  const float mean = (float)(red[0] / (double)n);
-  for (int64_t i = threadIdx.x; i < n; i += 256) {
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void flownet_prep_kernel(const float* __restrict__ in, int H, int W,
+                                                           float* __restrict__ y, int64_t y_bs, int64_t y_rs, int64_t y_ps,
+                                                           float rgb_max, const double* __restrict__ part) {
+  const int bc = blockIdx.x / PREP_SLICES, sl = blockIdx.x % PREP_SLICES;
+  const int b = bc / 3, c = bc % 3;
+  const int64_t n = (int64_t)2 * H * W;
+  const float* src = in + (int64_t)bc * n;
+  double tot = 0.0;
+  for (int i = 0; i < PREP_SLICES; ++i) tot += part[bc * PREP_SLICES + i];
+  const float mean = (float)(tot / (double)n);
+  const int64_t per = (n + PREP_SLICES - 1) / PREP_SLICES;
+  const int64_t lo = sl * per, hi = lo + per < n ? lo + per : n;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
     const int f = (int)(i / ((int64_t)H * W));
     const int64_t r = i - (int64_t)f * H * W;
     const int yy = (int)(r / W), xx = (int)(r - (int64_t)yy * W);
@@ -100,11 +118,17 @@ __global__ __launch_bounds__(256) void upsample4_kernel(const float* __restrict_
 }  // namespace ammc_impl
 using namespace ammc_impl;
 
+extern "C" int ammc_flownet_prep_scratch_doubles(int32_t batch) { return batch > 0 ? batch * 3 * PREP_SLICES : 0; }
+
 extern "C" int ammc_flownet_prep_f32(const float* in, int32_t batch, int32_t h, int32_t w, float* y, int64_t y_bs,
-                                     int64_t y_rs, int64_t y_ps, float rgb_max, void* stream) {
+                                     int64_t y_rs, int64_t y_ps, float rgb_max, double* scratch, void* stream) {
   if (!in || !y || batch <= 0 || h <= 0 || w <= 0 || !(rgb_max > 0.f)) return AMMC_EINVAL;
-  hipLaunchKernelGGL(flownet_prep_kernel, dim3(batch * 3), dim3(256), 0, (hipStream_t)stream, in, h, w, y, y_bs, y_rs, y_ps,
-                     rgb_max);
+  if (!scratch || ((uintptr_t)scratch & 7)) return AMMC_EINVAL;
+  double* part = scratch;
+  const int need = batch * 3 * PREP_SLICES;
+  hipLaunchKernelGGL(flownet_prep_sum_kernel, dim3(need), dim3(256), 0, (hipStream_t)stream, in, h, w, part);
+  hipLaunchKernelGGL(flownet_prep_kernel, dim3(need), dim3(256), 0, (hipStream_t)stream, in, h, w, y, y_bs, y_rs, y_ps,
+                     rgb_max, part);
   return ammc_launch_status();
 }
 

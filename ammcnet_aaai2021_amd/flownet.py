@@ -160,10 +160,20 @@ class _Engine:
             # of the concatenation (u*: channels 2..7 zero); the prepared frame pair likewise (x0 fp32 -> x0s)
             ws.update(uf6=act(32, 8), uf5=act(16, 8), uf4=act(8, 8), uf3=act(4, 8),
                       u6=act(32, 8), u5=act(16, 8), u4=act(8, 8), u3=act(4, 8), x0s=act(1, 8))
+            # split-K workspace of ammc_conv_gemm_s16: the layers below 1/16 resolution have 4-64 output tiles for 256
+            # CUs and K up to 9216 - one workgroup per tile walks 288 chunks alone (conv5_1: 306 us for 32 workgroups);
+            # with the workspace the kernel cuts K into up to 16 slices per tile and a streaming kernel finishes
+            # (largest user: [16 slices][B * 8 * 8 pixels of conv5_1 at 256x256][512]; 32 M floats cover batch 64)
+            ws["splitk"] = torch.empty(max(1 << 22, 16 * B * (H // 32) * (W // 32) * 512), device=dev)
         self.ws[key] = ws
         return ws
 
     # ---- launches --------------------------------------------------------------------------------------------
+    def _splitk(self, d: AmmcConvDesc, dev) -> None:
+        """hand the call the split-K workspace (the library uses it only where a layer cannot fill the chip)"""
+        wk = self._cur_ws["splitk"]
+        d.splitk_ws, d.splitk_ws_floats = _ptr(wk), wk.numel()
+
     def _conv(self, x: Act, pk: dict, y: Act, stride=1, act=ACT_LRELU, n_store=0, y_f32=False):
         """3x3 conv of `x` (one Act, or the list of parts of a concatenation) into y (`y_f32`: an fp32 output from S16
         operands - the flow heads)"""
@@ -183,6 +193,7 @@ class _Engine:
             d.r_bs, d.r_rs, d.r_ps = y.strides
             if self.s16:
                 d.y_f32 = 1 if y_f32 else 0
+                self._splitk(d, y.buf.device)
                 _chk(self.lib.ammc_conv_gemm_s16(C.byref(d), s), "flownet.conv(s16)")
             else:
                 _chk(self.lib.ammc_conv_gemm_f32(C.byref(d), s), "flownet.conv")
@@ -210,6 +221,7 @@ class _Engine:
                 d.y_bs, d.y_rs, d.y_ps = y.bs, 2 * y.rs, 2 * y.ps
                 d.r_bs, d.r_rs, d.r_ps = y.bs, 2 * y.rs, 2 * y.ps
                 if self.s16 and not pk.get("head"):
+                    self._splitk(d, y.buf.device)
                     _chk(self.lib.ammc_conv_gemm_s16(C.byref(d), s), "flownet.deconv(s16)")
                 else:
                     _chk(self.lib.ammc_conv_gemm_f32(C.byref(d), s), "flownet.deconv")
@@ -229,9 +241,13 @@ class _Engine:
         dev = x.device
         self._ensure_packs()
         ws, pk, lib = self._workspace(B, H, W, dev), self.packs, self.lib
+        self._cur_ws = ws
         s = torch.cuda.current_stream(dev).cuda_stream
         x0 = ws["x0"]
-        _chk(lib.ammc_flownet_prep_f32(_ptr(x), B, H, W, x0.pix0(), *x0.strides, float(self.m.rgb_max), s), "prep")
+        if "prep" not in ws:
+            ws["prep"] = torch.empty(lib.ammc_flownet_prep_scratch_doubles(B), device=dev, dtype=torch.float64)
+        _chk(lib.ammc_flownet_prep_f32(_ptr(x), B, H, W, x0.pix0(), *x0.strides, float(self.m.rgb_max),
+                                       ws["prep"].data_ptr(), s), "prep")
         cat2, cat3, cat4, cat5 = ws["cat2"], ws["cat3"], ws["cat4"], ws["cat5"]
         c2, d2 = cat2.slice(0, 128), cat2.slice(128, 64)
         c3, d3 = cat3.slice(0, 256), cat3.slice(256, 128)

@@ -298,9 +298,12 @@ int ammc_pack_conv4_dgrad_weight_f32(const float* w_oihw, int32_t cout, int32_t 
  * stride 1|2) + LeakyReLU(0.1) layers are ammc_conv_gemm_f32 (ntaps 9, x_step = stride, AMMC_ACT_LRELU); its
  * ConvTranspose2d(k 4, s 2, p 1) layers are the four 2x2-tap parity convolutions of ammc_pack_conv4_dgrad_weight_f32
  * (pad 1); layers whose input is a concatenation run once per part and accumulate through `res`. */
+/* scratch: ammc_flownet_prep_scratch_doubles(batch) doubles of device memory (per (sample, colour) slice sums of the mean:
+ * summed by 32 workgroups each, combined in a fixed order) */
+int ammc_flownet_prep_scratch_doubles(int32_t batch);
 int ammc_flownet_prep_f32(const float* in /* [B][3][2][H][W], 0..rgb_max */, int32_t batch, int32_t h, int32_t w,
                           float* y /* NHWC, 8 channels */, int64_t y_bs, int64_t y_rs, int64_t y_ps, float rgb_max,
-                          void* stream);
+                          double* scratch, void* stream);
 int ammc_lrelu_f32(float* y, int64_t y_bs, int64_t y_rs, int64_t y_ps, int32_t batch, int32_t h, int32_t w, int32_t c,
                    float slope, void* stream);
 /* the same LeakyReLU in place on an S16 activation (c % 8 == 0): the split-fp16 form of the FlowNet2-SD forward */
