@@ -1,5 +1,6 @@
-// Weight gradient of the 3x3 convolutions with S16 operands on the fp16 MFMA pipe (training, see wgrad_f32.hip for
-// the fp32 form and the GEMM view):
+// Weight gradient of the convolutions with S16 operands on the fp16 MFMA pipe (training, see wgrad_f32.hip for
+// the fp32 form and the GEMM view; 3x3 windows, and - round 4, this im2col form only - the 4x4 stride-1|2 windows of
+// PixelDiscriminator and the 2x2 stride-2 window of a ConvTranspose's weight gradient):
 //
 //   dWp[n][k] += sum over pixels m of  G[m][n] * A[m + tap(k)][c(k)]          k = tap * Cin + c
 //
@@ -31,6 +32,7 @@ struct WgradS16Args {
   const float* g_inv_scale;
   int M, kpad, cin_log2;
   int row_tiles, col_tiles, msplit, chunks_per_block, nchunks;
+  int tap_w, a_step;             // window width (3, 4 or 2) and the stride of the window origin in `a` (1 or 2)
 };
 
 constexpr int WS_BR = 128, WS_BC = 128;         // tile of dWp: rows (n) x columns (k)
@@ -78,8 +80,8 @@ __global__ __launch_bounds__(WS_NT, 2) void wgrad_s16_kernel(WgradS16Args a) {
     int k = col0 + 4 * ls;
     k = k < a.kpad ? k : a.kpad - 4;
     int tap = k >> a.cin_log2;
-    tap = tap < 8 ? tap : 8;
-    const int r = (tap * 11) >> 5, s = tap - 3 * r;
+    tap = tap < d.ntaps - 1 ? tap : d.ntaps - 1;           // K padding: any valid address (those columns are never stored)
+    const int r = a.tap_w == 3 ? (tap * 11) >> 5 : (a.tap_w == 4 ? tap >> 2 : tap >> 1), s = tap - a.tap_w * r;
     a_toff[j] = (int64_t)r * d.a_rs + (int64_t)s * d.a_ps + (k & (d.cin - 1));
   }
   int g_px[WS_GJ], g_col[WS_GJ];
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(WS_NT, 2) void wgrad_s16_kernel(WgradS16Args a) {
       m = m < a.M ? m : a.M - 1;                                                                        \
       const int x = m % W, t = m / W;                                                                   \
       const int y = t % H, b = t / H;                                                                   \
-      const float* src = d.a + ((int64_t)b * d.a_bs + (int64_t)y * d.a_rs + (int64_t)x * d.a_ps) + a_toff[j]; \
+      const float* src = d.a + ((int64_t)b * d.a_bs + (int64_t)(y * a.a_step) * d.a_rs + (int64_t)(x * a.a_step) * d.a_ps) + a_toff[j]; \
       __builtin_amdgcn_global_load_lds(src, adst + j * (WS_NT * 4), 16, 0, 0);                                 \
     }                                                                                                   \
   }
@@ -227,7 +229,7 @@ extern "C" int ammc_conv_wgrad_s16(const AmmcWgradDesc* desc, const float* g_inv
   if (!desc || !desc->g || !desc->a || !desc->dw || !desc->zeros) return AMMC_EINVAL;
   const AmmcWgradDesc& d = *desc;
   if (d.batch <= 0 || d.height <= 0 || d.width <= 0 || d.n <= 0 || (d.n % 32)) return AMMC_EINVAL;
-  if (d.ntaps != 9 || d.a_step > 1) return AMMC_EUNSUP;                       // the 3x3 layers only
+  if ((d.ntaps != 9 && d.ntaps != 16 && d.ntaps != 4) || d.a_step < 0 || d.a_step > 2) return AMMC_EUNSUP;
   if (d.cin < 8 || (d.cin & (d.cin - 1))) return AMMC_EUNSUP;
   if (((uintptr_t)d.g | (uintptr_t)d.a | (uintptr_t)d.zeros) & 31) return AMMC_EINVAL;
   if ((d.g_bs | d.g_rs | d.g_ps | d.a_bs | d.a_rs | d.a_ps) & 7) return AMMC_EINVAL;
@@ -237,9 +239,11 @@ extern "C" int ammc_conv_wgrad_s16(const AmmcWgradDesc* desc, const float* g_inv
   a.d = d;
   a.g_inv_scale = g_inv_scale;
   a.M = (int)M;
-  a.kpad = ((9 * d.cin + 31) / 32) * 32;
+  a.kpad = ((d.ntaps * d.cin + 31) / 32) * 32;
   a.cin_log2 = ammc_ilog2(d.cin);
-  {
+  a.tap_w = d.ntaps == 9 ? 3 : (d.ntaps == 16 ? 4 : 2);
+  a.a_step = d.a_step > 1 ? d.a_step : 1;
+  if (d.ntaps == 9 && a.a_step == 1) {                    // the halo-patch forms: stride-1 3x3 layers
     const int rc = wgrad_tap_s16_try(d, g_inv_scale, a.kpad, (hipStream_t)stream);
     if (rc != -12345) return rc;
   }

@@ -20,8 +20,9 @@ with fp32 outputs; each activation is then re-encoded once into the S16 twin the
 for the weight gradient and the LeakyReLU mask of the backward).  The INPUT-GRADIENT convolutions run on the same kernel:
 the gradient of a layer's output is brought into the half range by a power of two found on the device
 (`ammc_absmax_bits_f32` + `ammc_split_rows_scaled_f32`, as the generator's gradients are), re-encoded once, and the
-scale is undone in the epilogue; fp32 outputs.  Weight gradients stay on `ammc_conv_wgrad_f32`.  "fp32" = the exact-fp32
-MFMA kernels throughout, as in round 3.
+scale is undone in the epilogue; fp32 outputs.  The weight gradients read the same two twins (`ammc_conv_wgrad_s16`,
+4x4 windows, stride 1 | 2: the im2col form of wgrad_s16.hip).  "fp32" = the exact-fp32 MFMA kernels throughout, as in
+round 3.
 """
 from __future__ import annotations
 
@@ -249,16 +250,31 @@ class DiscEngine:
                 y = slot.acts[i + 1]
                 _chk(lib.ammc_lrelu_bwd_f32(y.pix0(), *y.strides, g.pix0(), *g.strides, B, g.H, g.W, g.c, SLOPE, s),
                      "lrelu_bwd")
+            g16 = inv = None
+            if self.s16 and (need_dw or i > 0 or need_dx):
+                # the gradient as an S16 operand (shared by the weight- and the input-gradient kernels): max |g| on the
+                # device -> a power of two that puts it at 2^10 -> the re-encoding; 2^-k comes back through the epilogues
+                g16 = self._grads16[(slot.B, slot.H, slot.W)][i]
+                amax = torch.zeros(256, device=self.device, dtype=torch.int32)
+                inv = torch.empty(1024, device=self.device, dtype=torch.float32)
+                _chk(lib.ammc_absmax_bits_f32(_ptr(g.buf), g.buf.numel(), amax.data_ptr(), s), "absmax(g)")
+                _chk(lib.ammc_split_rows_scaled_f32(_ptr(g.buf), g.buf.numel(), _ptr(g16.buf), amax.data_ptr(), _ptr(inv),
+                                                    1024, s), "split_rows_scaled(g)")
             if need_dw:
                 grads[2 * i + 1] = self._chan_sum(g, g.c if L.cout > 1 else 4)[:L.cout].clone()
                 dwp = torch.zeros(L.n, L.kpad, device=self.device)
                 d = AmmcWgradDesc()
-                d.g, d.a, d.dw, d.zeros = g.pix0(), _ptr(a.buf), _ptr(dwp), _ptr(self._zeros)
+                d.dw, d.zeros = _ptr(dwp), _ptr(self._zeros)
                 d.batch, d.height, d.width = B, g.H, g.W
                 d.n, d.cin, d.ntaps, d.a_step = L.n, L.cin_p, 16, L.stride
                 d.g_bs, d.g_rs, d.g_ps = g.strides
                 d.a_bs, d.a_rs, d.a_ps = a.strides
-                _chk(lib.ammc_conv_wgrad_f32(C.byref(d), s), f"disc.wgrad{i}")
+                if self.s16:                       # S16 twins of the gradient and of the layer input (written by the forward)
+                    d.g, d.a = g16.pix0(), _ptr(slot.acts16[i].buf)
+                    _chk(lib.ammc_conv_wgrad_s16(C.byref(d), _ptr(inv), s), f"disc.wgrad{i}(s16)")
+                else:
+                    d.g, d.a = g.pix0(), _ptr(a.buf)
+                    _chk(lib.ammc_conv_wgrad_f32(C.byref(d), s), f"disc.wgrad{i}")
                 dw = torch.empty(L.cout, L.cin, 4, 4, device=self.device)
                 _chk(lib.ammc_unpack_conv_wgrad_f32(_ptr(dwp), L.cout, L.cin, 4, L.cin_p, _ptr(dw), s), "unpack_wgrad")
                 grads[2 * i] = dw
@@ -273,16 +289,7 @@ class DiscEngine:
                 dx = torch.empty(B, L.cin, slot.H, slot.W, device=self.device, dtype=torch.float32)
                 y0, ybs, yrs, yps = _ptr(dx), L.cin * slot.H * slot.W, slot.W, 1
                 ycs, nstore, esz = slot.H * slot.W, L.cin, 4
-            gsrc, wdi, inv = g, slot.wd[i], None
-            if self.s16:
-                # the gradient as an S16 operand: max |g| on the device -> a power of two that puts it at 2^10 -> the
-                # re-encoding; 2^-k comes back through the epilogue's per-column scale
-                gsrc, wdi = self._grads16[(slot.B, slot.H, slot.W)][i], slot.wd16[i]
-                amax = torch.zeros(256, device=self.device, dtype=torch.int32)
-                inv = torch.empty(1024, device=self.device, dtype=torch.float32)
-                _chk(lib.ammc_absmax_bits_f32(_ptr(g.buf), g.buf.numel(), amax.data_ptr(), s), "absmax(g)")
-                _chk(lib.ammc_split_rows_scaled_f32(_ptr(g.buf), g.buf.numel(), _ptr(gsrc.buf), amax.data_ptr(), _ptr(inv),
-                                                    1024, s), "split_rows_scaled(g)")
+            gsrc, wdi = (g16, slot.wd16[i]) if self.s16 else (g, slot.wd[i])
             if L.stride == 1:
                 # dA[q] = sum_r g[q + 2 - r] W[r]: a 16-tap window starting at g(q - 1) with the flipped filter
                 self._conv(gsrc.pix0() - esz * (g.rs + g.ps), g.strides, wdi, y0, (ybs, yrs, yps), batch=B,

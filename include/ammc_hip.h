@@ -270,9 +270,10 @@ typedef struct AmmcWgradDesc {
   int64_t a_bs, a_rs, a_ps;
 } AmmcWgradDesc;
 int ammc_conv_wgrad_f32(const AmmcWgradDesc* desc, void* stream);
-/* the same for the 3x3 layers with S16 operands (g, a: the S16 twins of the fp32 tensors, same strides): fp16 MFMA with
- * transposed LDS fragment reads; g_inv_scale (device, may be NULL): the power-of-two that ammc_split_rows_scaled_f32
- * left in g, divided out of the result */
+/* the same with S16 operands (g, a: the S16 twins of the fp32 tensors, same strides): fp16 MFMA with transposed LDS
+ * fragment reads; g_inv_scale (device, may be NULL): the power-of-two that ammc_split_rows_scaled_f32 left in g (or in
+ * a: it is one scalar on the result), divided out.  ntaps 9 (the stride-1 3x3 layers: halo-patch kernels), 16 (4x4,
+ * a_step 1 | 2: PixelDiscriminator) or 4 (2x2, a_step 2: ConvTranspose); cin a power of two >= 8, n % 32 == 0. */
 int ammc_conv_wgrad_s16(const AmmcWgradDesc* desc, const float* g_inv_scale, void* stream);
 /* packed gradient -> the module's parameter layout */
 int ammc_unpack_conv_wgrad_f32(const float* packed, int32_t cout, int32_t cin, int32_t ksize, int32_t cin_p,
