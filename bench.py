@@ -65,6 +65,9 @@ def parse():
                         "batch 32 per GPU, data parallel with a bucketed RCCL gradient all-reduce when --gpus > 1; "
                         "stress = configs[4]: the fp16 memory-addressing kernel alone, rows sharded over the GPUs; "
                         "train_gan = the reference's whole joint G / D iteration with FlowNet2-SD (one GPU)")
+    p.add_argument("--sync-stats", action="store_true",
+                   help="--mode train with --gpus N: BatchNorm batch statistics and the EMA codebook counts all-reduced across "
+                        "the ranks (parallel.sync_statistics: N ranks x B clips = one step on N*B clips; 33 collectives per step)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-secondary", action="store_true", help="headline only (profiling runs)")
     p.add_argument("--cpu-sample-batch", type=int, default=16, help="clips of the CPU baseline's forwards (the workload's own batch)")
@@ -394,6 +397,8 @@ def run_train(args, rank, world, dev, dist, steps, warmup, with_cpu):
     if world > 1:
         parallel.broadcast_state(net)
         parallel.attach_reducer(net, parallel.BucketedGradReducer())
+        if getattr(args, "sync_stats", False):
+            parallel.sync_statistics(net, True)
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
     # rank 0 trains on the clips of the reference-recorded fixture of this batch / frame size when there is one, so that
     # the TIMED model's own first step is checked (as run_infer does); every other rank on its own clips (weak scaling)
@@ -464,7 +469,10 @@ def run_train(args, rank, world, dev, dist, steps, warmup, with_cpu):
         "config": {"workload": "Ped2 dual-stream + 256-slot memory + AMFT, batch 32 per GPU, fwd+bwd+Adam "
                                "(BASELINE.json configs[2]; configs[3] with --gpus 8)",
                    "batch_per_gpu": batch, "frame": f"{args.size}x{args.size}",
-                   "parallelism": f"dp{world} (bucketed RCCL all-reduce of 100 MB of fp32 gradients)" if world > 1 else "1 GPU",
+                   "parallelism": (f"dp{world} (bucketed RCCL all-reduce of 100 MB of fp32 gradients" +
+                                   (", synchronised BatchNorm / EMA statistics: 33 collectives per step)" if getattr(args, "sync_stats", False) else ")"))
+                   if world > 1 else "1 GPU",
+                   "statistics_collectives_per_step": (ops.collectives // max(steps + max(warmup, 1) + 1, 1)) if world > 1 else 0,
                    "gflop_per_clip_fwd_bwd": round(flops / 1e9, 1)},
         "whole_path_tflops": round(value * flops / 1e12 / world, 2), "loss": float(state["loss"]),
         "parity_loss_rel": parity["loss_rel"] if parity else None, "parity_tol": PARITY_TOL,

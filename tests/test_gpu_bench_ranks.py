@@ -55,6 +55,7 @@ def test_bench_two_ranks(mode, extra, launcher):
 
 @pytest.mark.parametrize("mode,extra,units", [("infer", ["--batch", "1", "--size", "64", "--no-cpu-baseline"], 1),
                                                ("train", ["--batch", "1", "--size", "64"], 1),
+                                               ("train", ["--batch", "1", "--size", "64", "--sync-stats"], 1),
                                                ("stress", ["--batch", "1"], 1024)])
 def test_bench_eight_ranks_self_spawned(mode, extra, units):
     """the shape of the driver's 8-GPU run on the one test GPU: `python bench.py --gpus 8` starts eight ranks itself
@@ -71,6 +72,8 @@ def test_bench_eight_ranks_self_spawned(mode, extra, units):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 8 and rec["rccl_ranks"] == 8 and rec["scaling"] == "weak"
     assert abs(rec["value"] - 8 * units / (rec["ms_per_step"] * 1e-3)) <= 0.02 * rec["value"]
+    if mode == "train":                                              # the lock-step statistics collectives of 8 ranks
+        assert rec["config"]["statistics_collectives_per_step"] == (33 if "--sync-stats" in extra else 0)
 
 
 def test_bench_refuses_more_ranks_than_gpus():
