@@ -36,12 +36,15 @@ __host__ __device__ inline int red_pix_for(int M) {
 // MODE 1: sum(g), sum(g * xhat), g = dy * [pre>0]  (BN backward), xhat = (c - mean) * invstd
 // MODE 2: sum(x)                                   (bias gradients)
 // MODE 3: MODE 1 + max|g|, max|xhat| per channel    (Q = 4: bounds max|dc| before dc exists, bn_bwd_finalize_kernel)
+// MODE 4: MODE 2 + max|x| of the whole tensor into the 256 `amax_bits` slots (as ammc_absmax_bits_f32 leaves it): the
+//         bias-gradient pass of a ConvTranspose also finds the power of two for the S16 re-encoding of its gradient
 // Layout: thread = (channel group of 4, pixel lane); partial[block][q][C].
 template <int MODE>
 __global__ __launch_bounds__(256) void chan_reduce_kernel(
     const float* __restrict__ x, Tensor3 xt, const float* __restrict__ dy, Tensor3 dt,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
-    const float* __restrict__ beta, int relu, int M, int H, int W, int C, float* __restrict__ partial) {
+    const float* __restrict__ beta, int relu, int M, int H, int W, int C, float* __restrict__ partial,
+    int* __restrict__ amax_bits = nullptr) {
   __shared__ f32x4 red[MODE == 3 ? 4 : 2][256];
   const int C4 = C >> 2;
   const int tx = threadIdx.x % C4;
@@ -92,6 +95,9 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(
         } else if (MODE == 2) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) s0[i] += v[u][i];
+        } else if (MODE == 4) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { s0[i] += v[u][i]; m0v[i] = fmaxf(m0v[i], fabsf(v[u][i])); }
         } else {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(
     }
   }
   red[0][threadIdx.x] = s0;
-  red[1][threadIdx.x] = s1;
+  red[1][threadIdx.x] = MODE == 4 ? m0v : s1;
   if (MODE == 3) {
     red[2][threadIdx.x] = m0v;
     red[3][threadIdx.x] = m1v;
@@ -125,16 +131,24 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(
     for (int j = 1; j < PY; ++j) {
       const f32x4 a0 = red[0][j * C4 + tx], a1 = red[1][j * C4 + tx];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { s0[i] += a0[i]; s1[i] += a1[i]; }
+      for (int i = 0; i < 4; ++i) {
+        s0[i] += a0[i];
+        if (MODE == 4) m0v[i] = fmaxf(m0v[i], a1[i]);
+        else s1[i] += a1[i];
+      }
       if (MODE == 3) {
         const f32x4 b0 = red[2][j * C4 + tx], b1 = red[3][j * C4 + tx];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { m0v[i] = fmaxf(m0v[i], b0[i]); m1v[i] = fmaxf(m1v[i], b1[i]); }
       }
     }
-    float* p = partial + (int64_t)blockIdx.x * (MODE == 2 ? 1 : (MODE == 3 ? 4 : 2)) * C;
+    float* p = partial + (int64_t)blockIdx.x * ((MODE == 2 || MODE == 4) ? 1 : (MODE == 3 ? 4 : 2)) * C;
     *reinterpret_cast<f32x4*>(p + tx * 4) = s0;
-    if (MODE != 2) *reinterpret_cast<f32x4*>(p + C + tx * 4) = s1;
+    if (MODE != 2 && MODE != 4) *reinterpret_cast<f32x4*>(p + C + tx * 4) = s1;
+    if (MODE == 4) {                       // (ty == 0: threads 0 .. C4 - 1; one atomic per thread is a few dozen per workgroup)
+      const float m = fmaxf(fmaxf(m0v[0], m0v[1]), fmaxf(m0v[2], m0v[3]));
+      if (amax_bits && m > 0.f && m < INFINITY) atomicMax(amax_bits + (blockIdx.x & 255), __float_as_int(m));
+    }
     if (MODE == 3) {
       *reinterpret_cast<f32x4*>(p + 2 * C + tx * 4) = m0v;
       *reinterpret_cast<f32x4*>(p + 3 * C + tx * 4) = m1v;
@@ -385,6 +399,38 @@ __device__ __forceinline__ float tk_pow2_to_1024(int amax_bits) {      // as pow
   int fe = 10 - e;
   fe = fe < -60 ? -60 : (fe > 60 ? 60 : fe);
   return __int_as_float((fe + 127) << 23);
+}
+
+// fp32 NHWC channel slice -> its S16 twin, scaled by the power of two that brings max |x| (the 256 slots of MODE 4 /
+// ammc_absmax_bits_f32) to 2^10; 2^-k goes to inv_scale[0..n) for the consumers' epilogues.  The strided form of
+// ammc_split_rows_scaled_f32: the gradient of a ConvTranspose's output is one half of a concat buffer.
+__global__ __launch_bounds__(256) void split_scaled_strided_kernel(const float* __restrict__ x, Tensor3 xt, float* __restrict__ y16,
+                                                                   Tensor3 yt, int M, int H, int W, int C8,
+                                                                   const int* __restrict__ amax_bits, float* __restrict__ inv_scale, int n) {
+  __shared__ int red[256];
+  red[threadIdx.x] = amax_bits[threadIdx.x];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] = max(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  const float f = tk_pow2_to_1024(red[0]);
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < n; i += 256) inv_scale[i] = 1.f / f;        // a power of two: exact
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (int64_t)M * C8) return;
+  const int c8 = (int)(gid % C8);
+  const int m = (int)(gid / C8);
+  const float* xp = x + pix_off(m, H, W, xt) + c8 * 8;
+  const f32x4 a0 = *reinterpret_cast<const f32x4*>(xp), a1 = *reinterpret_cast<const f32x4*>(xp + 4);
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[i] = a0[i] * f; v[4 + i] = a1[i] * f; }
+  ammc_u4 hi, lo;
+  ammc_s16_split8(v, hi, lo);
+  float* yp = y16 + pix_off(m, H, W, yt) + c8 * 8;
+  *reinterpret_cast<ammc_u4*>(yp) = hi;
+  *reinterpret_cast<ammc_u4*>(yp + 4) = lo;
 }
 
 // bn_bwd_apply with the S16 twin as output: one thread per (pixel, group of 8 channels); dc * f with the power of
@@ -865,6 +911,28 @@ int ammc_chan_sum_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, 
   Tensor3 xt{x_bs, x_rs, x_ps}, none{0, 0, 0};
   hipLaunchKernelGGL(chan_reduce_kernel<2>, dim3(ammc_chan_reduce_blocks(M)), dim3(256), 0, (hipStream_t)stream,
                      x, xt, nullptr, none, nullptr, nullptr, nullptr, nullptr, 0, M, h, w, c, partial);
+  return ammc_launch_status();
+}
+
+int ammc_chan_sum_absmax_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, int32_t batch, int32_t h, int32_t w,
+                             int32_t c, float* partial, int32_t* amax_bits, void* stream) {
+  if (check_nhwc(x, batch, h, w, c) || !partial || !amax_bits) return AMMC_EINVAL;
+  const int M = batch * h * w;
+  Tensor3 xt{x_bs, x_rs, x_ps}, none{0, 0, 0};
+  hipLaunchKernelGGL(chan_reduce_kernel<4>, dim3(ammc_chan_reduce_blocks(M)), dim3(256), 0, (hipStream_t)stream,
+                     x, xt, nullptr, none, nullptr, nullptr, nullptr, nullptr, 0, M, h, w, c, partial, amax_bits);
+  return ammc_launch_status();
+}
+
+int ammc_split_scaled_strided_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, float* y16, int64_t y_bs,
+                                  int64_t y_rs, int64_t y_ps, int32_t batch, int32_t h, int32_t w, int32_t c,
+                                  const int32_t* amax_bits, float* inv_scale, int32_t n, void* stream) {
+  if (check_nhwc(x, batch, h, w, c) || !y16 || !amax_bits || !inv_scale || n <= 0 || (c & 7)) return AMMC_EINVAL;
+  if (((uintptr_t)y16 & 31) || ((y_bs | y_rs | y_ps) & 7) || ((uintptr_t)x & 15) || ((x_bs | x_rs | x_ps) & 3)) return AMMC_EINVAL;
+  const int M = batch * h * w;
+  Tensor3 xt{x_bs, x_rs, x_ps}, yt{y_bs, y_rs, y_ps};
+  hipLaunchKernelGGL(split_scaled_strided_kernel, dim3(nblk((int64_t)M * (c >> 3))), dim3(256), 0, (hipStream_t)stream, x, xt,
+                     y16, yt, M, h, w, c >> 3, amax_bits, inv_scale, n);
   return ammc_launch_status();
 }
 

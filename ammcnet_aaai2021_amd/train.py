@@ -41,6 +41,11 @@ CONVT_S16 = os.environ.get("AMMC_CONVT_S16", "0") != "0"          # ConvTranspos
 # forward runs on conv_gemm_s16 with an S16 output): no fp32 -> S16 re-encoding pass of an activation is left in the
 # forward (they were 2.4 ms of the 70-ms step), and the ConvTranspose forward leaves the fp32 MFMA pipe.
 TWIN_S16 = os.environ.get("AMMC_TWIN_S16", "1") != "0"
+# ... and in the backward the gradient of a ConvTranspose's output is re-encoded ONCE (its max |g| comes out of the
+# bias-gradient pass that reads it anyway, the re-encoding touches its half of the concat buffer only) for BOTH of the
+# layer's gradient kernels: weight gradient on ammc_conv_wgrad_s16 (2x2 window, stride 2), input gradient on
+# ammc_conv_gemm_s16.  (AMMC_CONVT_S16 alone re-encoded the whole concat buffer for the input gradient only: no gain.)
+CONVT_GRADS_S16 = os.environ.get("AMMC_CONVT_GRADS_S16", "1") != "0"
 MID_S16 = os.environ.get("AMMC_MID_S16", "1") != "0"              # double_conv middle activations exist as S16 only
 FUSE_BN_BWD = os.environ.get("AMMC_FUSE_BN_BWD", "1") != "0"      # BN backward writes the S16 twin of dc (one rank)
 
@@ -163,18 +168,20 @@ class _Ops:
             _chk(lib.ammc_split_rows_f32(_ptr(x.buf), x.buf.numel(), _ptr(xs.buf), s), "split_rows(x)")
         return xs, inv
 
-    def wgrad_s16(self, g16: Act, a16: Act, dw: torch.Tensor, inv, *, n, cin, what="wgrad", true_nc=None):
-        """3x3 weight gradient from the S16 twins of the output gradient and of the layer input"""
+    def wgrad_s16(self, g16: Act, a16: Act, dw: torch.Tensor, inv, *, n, cin, what="wgrad", true_nc=None, ntaps=9, a_step=1):
+        """weight gradient from the S16 twins of the output gradient and of the layer input (3x3; ntaps 4 / a_step 2: the
+        ConvTranspose form of ammc_conv_wgrad_f32 - g = the layer input, a = the output gradient at twice the resolution)"""
         if not getattr(dw, "_ammc_zslab", False):          # slab buffers were cleared by `_WS.zero_step` (backward start)
             dw.zero_()
         d = AmmcWgradDesc()
-        d.g, d.a, d.dw, d.zeros = g16.pix0(), a16.tap0(), _ptr(dw), _ptr(self.zeros)
+        d.g, d.a, d.dw, d.zeros = g16.pix0(), (a16.tap0() if ntaps == 9 else a16.pix0()), _ptr(dw), _ptr(self.zeros)
         d.batch, d.height, d.width = g16.B, g16.H, g16.W
-        d.n, d.cin, d.ntaps, d.a_step = n, cin, 9, 1
+        d.n, d.cin, d.ntaps, d.a_step = n, cin, ntaps, a_step
         d.g_bs, d.g_rs, d.g_ps = g16.strides
         d.a_bs, d.a_rs, d.a_ps = a16.strides
-        self._mfma_launch("conv_wgrad_s16 (3x3 weight gradients: wgrad_tap3_s16 / wgrad_tap_s16 instances)",
-                          2.0 * g16.B * g16.H * g16.W * 9 * (true_nc if true_nc is not None else n * cin),   # unpadded channels
+        self._mfma_launch("conv_wgrad_s16 (3x3 weight gradients: wgrad_tap3_s16 / wgrad_tap_s16 instances)" if ntaps == 9 else
+                          "conv_wgrad_s16 (ConvTranspose weight gradients: wgrad_s16)",
+                          2.0 * g16.B * g16.H * g16.W * ntaps * (true_nc if true_nc is not None else n * cin),   # unpadded channels
                           lambda: self.lib.ammc_conv_wgrad_s16(C.byref(d), _ptr(inv) if inv is not None else None, self.s),
                           what)
 
@@ -514,7 +521,7 @@ class _Stream:
         self.up_mods = (net.up1, net.up2, net.up3)
         self.up_dc: List[_DoubleConv] = []
         self.up_out: List[Act] = []
-        self.up_wp, self.up_b4, self.up_dwp, self.up_wT = [], [], [], []
+        self.up_wp, self.up_b4, self.up_dwp, self.up_wT, self.up_amax = [], [], [], [], []
         for j, lvl in enumerate((2, 1, 0)):
             c = CHANS[lvl]
             out = ws.act(B, H >> lvl, W >> lvl, c)
@@ -523,6 +530,7 @@ class _Stream:
             self.up_wp.append(ws.buf(4 * c, 2 * c))
             self.up_b4.append(ws.buf(4 * c))
             self.up_dwp.append(ws.zbuf(2 * c, 4 * c))
+            self.up_amax.append(ws.zbuf(256, dtype=torch.int32))
             self.up_wT.append(ws.buf(2 * c, 4 * c))
         self.u3 = self.up_out[2]
         self.outc_wp = ws.buf(32, 576)
@@ -685,14 +693,35 @@ class _Stream:
             # gradient of the ConvTranspose output: the top-left 2h x 2w of the skip-sized tensor (`up.forward` pads an
             # odd level on the right / bottom, models/unet_parts.py; the pad's gradient is dropped)
             dys = self.dcat[lvl].slice(c, c).crop(2 * x_in.H, 2 * x_in.W)
-            grads[m.up.bias] = o.chan_sum(dys, c, self.scratch)
-            o.wgrad(x_in, dys, self.up_dwp[j], n=2 * c, cin=c, ntaps=4, a_step=2, what=f"up{j + 1}.up.wgrad")
+            both16 = self.twins and CONVT_GRADS_S16 and (self.bottom_twin if j == 0 else True)
+            pre = None
+            if both16:
+                # one pass: bias gradient + max |g| of the slice; one strided re-encoding; both gradient kernels read it
+                amax = self.up_amax[j]
+                nb = lib.ammc_chan_reduce_blocks(dys.B * dys.H * dys.W)
+                _chk(lib.ammc_chan_sum_absmax_f32(dys.pix0(), *dys.strides, dys.B, dys.H, dys.W, c, _ptr(self.scratch),
+                                                  amax.data_ptr(), s), "chan_sum_absmax")
+                bsum = torch.empty(c, device=o.dev, dtype=torch.float32)
+                _chk(lib.ammc_reduce_partials_f32(_ptr(self.scratch), nb, c, 1.0, _ptr(bsum), s), "reduce_partials")
+                grads[m.up.bias] = bsum
+                dys16 = o.shadow(dys)
+                inv = torch.empty(1024, device=o.dev, dtype=torch.float32)
+                _chk(lib.ammc_split_scaled_strided_f32(dys.pix0(), *dys.strides, dys16.pix0(), *dys16.strides, dys.B, dys.H,
+                                                       dys.W, c, amax.data_ptr(), _ptr(inv), 1024, s), "split_scaled_strided")
+                pre = (dys16, inv)
+                o.wgrad_s16(o.shadow(x_in), dys16, self.up_dwp[j], inv, n=2 * c, cin=c, ntaps=4, a_step=2,
+                            what=f"up{j + 1}.up.wgrad")
+            else:
+                grads[m.up.bias] = o.chan_sum(dys, c, self.scratch)
+                o.wgrad(x_in, dys, self.up_dwp[j], n=2 * c, cin=c, ntaps=4, a_step=2, what=f"up{j + 1}.up.wgrad")
             dwt = torch.empty_like(m.up.weight)
             _chk(lib.ammc_unpack_convt_wgrad_f32(_ptr(self.up_dwp[j]), 2 * c, c, _ptr(dwt), s), "unpack_convt")
             grads[m.up.weight] = dwt
             _chk(lib.ammc_transpose_pad_f32(_ptr(self.up_wp[j]), 4 * c, 2 * c, 4 * c, _ptr(self.up_wT[j]), s), "transpose")
             dst = self.dbottom if j == 0 else self.du[j - 1]
-            if o.s16 and CONVT_S16:
+            if both16:
+                o.conv_s16(dys, self.up_wT[j], dst, ntaps=4, cin=c, n=2 * c, x_step=2, what=f"up{j + 1}.up.dgrad", pre=pre)
+            elif o.s16 and CONVT_S16:
                 o.conv_s16(dys, self.up_wT[j], dst, ntaps=4, cin=c, n=2 * c, x_step=2, rescale=True,
                            what=f"up{j + 1}.up.dgrad")
             else:

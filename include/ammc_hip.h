@@ -379,6 +379,14 @@ int ammc_bn_bwd_apply_s16_f32(const float* c_raw, int64_t c_bs, int64_t c_rs, in
 /* per-channel sum over pixels (bias gradients): partial Q=1 */
 int ammc_chan_sum_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, int32_t batch, int32_t h, int32_t w,
                       int32_t c, float* partial, void* stream);
+/* the same pass with max |x| of the whole tensor left in the [256] amax slots (zeroed by the caller; as
+ * ammc_absmax_bits_f32): the bias-gradient pass of a ConvTranspose also finds the power of two of its gradient's S16
+ * re-encoding; then that re-encoding for a channel SLICE (strided form of ammc_split_rows_scaled_f32; c % 8 == 0) */
+int ammc_chan_sum_absmax_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, int32_t batch, int32_t h, int32_t w,
+                             int32_t c, float* partial, int32_t* amax_bits, void* stream);
+int ammc_split_scaled_strided_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, float* y16, int64_t y_bs,
+                                  int64_t y_rs, int64_t y_ps, int32_t batch, int32_t h, int32_t w, int32_t c,
+                                  const int32_t* amax_bits, float* inv_scale, int32_t n, void* stream);
 int ammc_reduce_partials_f32(const float* partial, int32_t nblocks, int32_t qc, float scale, float* out, void* stream);
 /* nn.MaxPool2d(2) backward (+ `add`, the gradient reaching the same tensor through the skip).  h, w: the pooled size;
  * in_h, in_w: the size of x / add / dx (2h or 2h+1: the last row / column of an odd size is in no window and gets `add`
