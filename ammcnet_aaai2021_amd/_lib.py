@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # AMMC_LIB: another build of the SAME library (A/B measurements: `python -m ammcnet_aaai2021_amd.build --variant x`)
 LIB_PATH = os.environ.get("AMMC_LIB") or os.path.join(HERE, "libammc_hip.so")
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU = 0, 1, 2, 3
 
@@ -91,6 +91,8 @@ SIGNATURES = {
     "ammc_unpack_convt_wgrad_f32": (C.c_int, [_p, _i32, _i32, _p, _p]),
     "ammc_pack_conv_dgrad_weight_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
     "ammc_transpose_pad_f32": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
+    "ammc_pack_filters_item_bytes": (C.c_int, []),
+    "ammc_pack_filters_s16": (C.c_int, [_p, _i32, _i64, _p]),
     "ammc_pack_conv4_dgrad_weight_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     "ammc_flownet_prep_scratch_doubles": (C.c_int, [_i32]),
     "ammc_flownet_prep_f32": (C.c_int, [_p, _i32, _i32, _i32, _p] + _s3 + [_f32, _p, _p]),

@@ -719,6 +719,49 @@ __global__ __launch_bounds__(256) void pack_conv_dgrad_weight_kernel(const float
   out[gid] = v;
 }
 
+// All 3x3 filters of a training step in ONE launch, straight to their S16 images (round 4: the step issued ~140 launches
+// of 5-8 us for this - a pack and a split per layer and direction).  items: device table, one entry per filter image;
+// group_end = running total of 8-element output groups (a thread takes one group = one 32-byte S16 store, finds its
+// item by binary search).  kind 0: forward filter [cout][kpad], k = tap * cin_p + c (ammc_pack_conv_weight_f32);
+// kind 1: input-gradient filter [rows][kpad], k = tap * cout_p + n, value W[n][c][2-r][2-s] (ammc_pack_conv_dgrad_weight_f32).
+struct PackItem {
+  const float* w;        // OIHW [cout][cin][3][3]
+  float* out16;          // S16 image
+  int32_t cout, cin, inner_p, kpad, kind, rows;     // inner_p = cin_p (kind 0) or cout_p (kind 1); rows of the image
+  int64_t group_end;
+};
+__global__ __launch_bounds__(256) void pack_filters_s16_kernel(const PackItem* __restrict__ items, int n_items, int64_t total) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  int lo = 0, hi = n_items - 1;
+  while (lo < hi) {                                   // first item whose group_end > gid
+    const int mid = (lo + hi) >> 1;
+    if (items[mid].group_end > gid) hi = mid; else lo = mid + 1;
+  }
+  const PackItem it = items[lo];
+  const int64_t g = gid - (lo ? items[lo - 1].group_end : 0);
+  const int k8 = it.kpad >> 3;
+  const int row = (int)(g / k8), k0 = (int)(g % k8) * 8;
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = k0 + i;
+    const int tap = k / it.inner_p, in = k % it.inner_p;
+    float t = 0.f;
+    if (it.kind == 0) {
+      if (tap < 9 && in < it.cin && row < it.cout) t = it.w[((int64_t)row * it.cin + in) * 9 + tap];
+    } else {
+      if (tap < 9 && in < it.cout && row < it.cin) t = it.w[((int64_t)in * it.cin + row) * 9 + (8 - tap)];
+    }
+    v[i] = t;
+  }
+  ammc_u4 h, l;
+  ammc_s16_split8(v, h, l);
+  float* op = it.out16 + ((int64_t)row * it.kpad + k0);
+  *reinterpret_cast<ammc_u4*>(op) = h;
+  *reinterpret_cast<ammc_u4*>(op + 4) = l;
+}
+
 // [rows][cols] -> [cols][rows_p] zero padded (1x1 conv input-gradient filter)
 __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ w, int rows, int cols,
                                                             int rows_p, float* __restrict__ out) {
@@ -1012,6 +1055,15 @@ int ammc_pack_conv_dgrad_weight_f32(const float* w_oihw, int32_t cout, int32_t c
   const int kpad = ((9 * cout_p + 31) / 32) * 32;
   hipLaunchKernelGGL(pack_conv_dgrad_weight_kernel, dim3(nblk((int64_t)rows * kpad)), dim3(256), 0,
                      (hipStream_t)stream, w_oihw, cout, cin, cout_p, kpad, rows, out);
+  return ammc_launch_status();
+}
+
+int ammc_pack_filters_item_bytes(void) { return (int)sizeof(PackItem); }
+
+int ammc_pack_filters_s16(const void* items_dev, int32_t n_items, int64_t total_groups, void* stream) {
+  if (!items_dev || n_items <= 0 || total_groups <= 0 || ((uintptr_t)items_dev & 7)) return AMMC_EINVAL;
+  hipLaunchKernelGGL(pack_filters_s16_kernel, dim3(nblk(total_groups)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const PackItem*>(items_dev), n_items, total_groups);
   return ammc_launch_status();
 }
 

@@ -46,6 +46,9 @@ TWIN_S16 = os.environ.get("AMMC_TWIN_S16", "1") != "0"
 # layer's gradient kernels: weight gradient on ammc_conv_wgrad_s16 (2x2 window, stride 2), input gradient on
 # ammc_conv_gemm_s16.  (AMMC_CONVT_S16 alone re-encoded the whole concat buffer for the input gradient only: no gain.)
 CONVT_GRADS_S16 = os.environ.get("AMMC_CONVT_GRADS_S16", "1") != "0"
+# all 3x3 filters of a step packed to their S16 images by ONE launch per direction (ammc_pack_filters_s16) instead of a
+# pack and a split launch per layer and direction (~140 launches of 5-8 us per step)
+PACK_BATCH = os.environ.get("AMMC_PACK_BATCH", "1") != "0"
 MID_S16 = os.environ.get("AMMC_MID_S16", "1") != "0"              # double_conv middle activations exist as S16 only
 FUSE_BN_BWD = os.environ.get("AMMC_FUSE_BN_BWD", "1") != "0"      # BN backward writes the S16 twin of dc (one rank)
 
@@ -125,6 +128,10 @@ class _Ops:
         # collects (kernel label, algorithmic flops, start event, end event)
         self.timing: Optional[list] = None
         self.collectives = 0            # statistics all-reduces issued (tests: the streams share them)
+        self.pack_items = {"fwd": [], "bwd": []}      # (weight, out16, cout, cin, inner_p, kpad, kind, rows) of every 3x3 unit
+        self._pack_tables: Dict[str, tuple] = {}
+        self.packed = {"fwd": False, "bwd": False}    # this step's batched pack has run (TrainEngine sets / clears)
+        self.nbt: Optional[list] = None  # TrainEngine.forward: the BatchNorm step counters of this forward (32 one-element adds -> one launch)
 
     def _mfma_launch(self, label, flops: float, call, what: str):
         if self.timing is None:
@@ -135,6 +142,30 @@ class _Ops:
         _chk(call(), what)
         e1.record()
         self.timing.append((label() if callable(label) else label, flops, e0, e1))
+
+    def run_pack(self, which: str) -> None:
+        """every registered 3x3 filter of one direction -> its S16 image, one launch.  The device table is rebuilt when a
+        parameter's storage moved (`.to()`, re-assignment); in-place updates (optimizers, load_state_dict) keep it."""
+        items = self.pack_items[which]
+        if not items:
+            return
+        import numpy as np
+        ptrs = tuple(it[0].data_ptr() for it in items)
+        tab = self._pack_tables.get(which)
+        if tab is None or tab[0] != ptrs:
+            dt = np.dtype([("w", "u8"), ("out", "u8"), ("cout", "i4"), ("cin", "i4"), ("inner_p", "i4"), ("kpad", "i4"),
+                           ("kind", "i4"), ("rows", "i4"), ("group_end", "i8")])
+            assert dt.itemsize == self.lib.ammc_pack_filters_item_bytes()
+            arr = np.zeros(len(items), dtype=dt)
+            total = 0
+            for i, (w, out16, cout, cin, inner_p, kpad, kind, rows) in enumerate(items):
+                total += rows * kpad // 8
+                arr[i] = (w.data_ptr(), out16.data_ptr(), cout, cin, inner_p, kpad, kind, rows, total)
+            dev = torch.from_numpy(arr.view(np.uint8).copy()).to(self.dev)
+            tab = (ptrs, dev, len(items), total)
+            self._pack_tables[which] = tab
+        _chk(self.lib.ammc_pack_filters_s16(tab[1].data_ptr(), tab[2], tab[3], self.s), f"pack_filters({which})")
+        self.packed[which] = True
 
     def shadow(self, a: Act) -> Act:
         """the S16 twin of an fp32 NHWC buffer (same geometry, allocated once per underlying buffer)"""
@@ -186,14 +217,16 @@ class _Ops:
                           what)
 
     def conv_s16(self, x: Act, w: torch.Tensor, y: Act, *, ntaps, cin, n, res: Optional[Act] = None, what="conv",
-                 rescale: bool = False, pre=None, shift=None, up=1, cgroup=None, x_step=1, y_s16: bool = False):
+                 rescale: bool = False, pre=None, shift=None, up=1, cgroup=None, x_step=1, y_s16: bool = False,
+                 w16: Optional[torch.Tensor] = None):
         """3x3 conv on the split-fp16 MFMA kernels: x (fp32, any channel slice of its buffer) is re-encoded into its S16
         twin (or `pre` = what `to_s16` returned for it), the packed filter likewise; fp32 output (+ fp32 residual), or -
         `y_s16`: y is the S16 twin itself - an S16 output.  ammc_conv_gemm_s16 picks the kernel."""
         lib, s = self.lib, self.s
         xs, inv = pre if pre is not None else self.to_s16(x, rescale)
-        w16 = torch.empty_like(w)
-        _chk(lib.ammc_split_rows_f32(_ptr(w), w.numel(), _ptr(w16), s), "split_rows(w)")
+        if w16 is None:                              # (else: the S16 image is already there - the step's batched pack)
+            w16 = torch.empty_like(w)
+            _chk(lib.ammc_split_rows_f32(_ptr(w), w.numel(), _ptr(w16), s), "split_rows(w)")
         d = AmmcConvDesc()
         d.x = xs.tap0() if ntaps == 9 else xs.pix0()
         d.w, d.y = _ptr(w16), y.pix0()
@@ -328,6 +361,15 @@ class _ConvBN:
         self.amax = ws.zbuf(256, dtype=torch.int32)                  # max |dc| slots of this unit (see _Ops.to_s16)
         self.rows = max(64, (self.cin + 63) // 64 * 64) if self.cin >= 32 else 0   # dgrad filter rows
         self.wdp = ws.buf(self.rows, _kpad(9 * self.cout)) if self.rows else None
+        self.w16 = self.wd16 = None
+        if ops.s16 and self.cin_p >= 8 and PACK_BATCH:
+            # S16 images of the forward / input-gradient filters, written by the step's batched pack (TrainEngine)
+            self.w16 = ws.buf(self.cout, self.kpad)
+            ops.pack_items["fwd"].append((conv.weight, self.w16, self.cout, self.cin, self.cin_p, self.kpad, 0, self.cout))
+            if self.rows:
+                self.wd16 = ws.buf(self.rows, _kpad(9 * self.cout))
+                ops.pack_items["bwd"].append((conv.weight, self.wd16, self.cout, self.cin, self.cout, _kpad(9 * self.cout), 1,
+                                              self.rows))
 
     def forward(self):
         for _ in self.forward_gen():
@@ -336,10 +378,12 @@ class _ConvBN:
     def forward_gen(self):
         o, lib, s = self.ops, self.ops.lib, self.ops.s
         w = self.conv.weight.detach()
-        _chk(lib.ammc_pack_conv_weight_f32(_ptr(w), self.cout, self.cin, 3, self.cin_p, _ptr(self.wp), s), "pack")
+        batched = self.w16 is not None and o.packed["fwd"]
+        if not batched:
+            _chk(lib.ammc_pack_conv_weight_f32(_ptr(w), self.cout, self.cin, 3, self.cin_p, _ptr(self.wp), s), "pack")
         if o.s16 and self.cin_p >= 8:
             o.conv_s16(self.x, self.wp, self.craw, ntaps=9, cin=self.cin_p, n=self.cout, what=self.name,
-                       pre=(o.shadow(self.x), None) if self.x_is_s16 else None)
+                       pre=(o.shadow(self.x), None) if self.x_is_s16 else None, w16=self.w16 if batched else None)
         else:
             o.conv(self.x, self.wp, self.craw, ntaps=9, cin=self.cin_p, n=self.cout, what=self.name)
         c = self.craw
@@ -358,7 +402,10 @@ class _ConvBN:
                                       float(bn.momentum if bn.momentum is not None else BN_MOMENTUM),
                                       _ptr(bn.running_mean), _ptr(bn.running_var), _ptr(self.mean),
                                       _ptr(self.invstd), _ptr(self.scale), _ptr(self.shift), s), "bn_finalize")
-        bn.num_batches_tracked += 1
+        if o.nbt is None:
+            bn.num_batches_tracked += 1
+        else:
+            o.nbt.append(bn.num_batches_tracked)              # one fused increment at the end of the forward (TrainEngine)
         r = self.res
         if self.y_s16_only or self.y_s16_too:
             _chk(lib.ammc_scale_shift_act_s16_f32(c.pix0(), *c.strides, _ptr(self.scale), _ptr(self.shift),
@@ -434,11 +481,13 @@ class _ConvBN:
         grads[self.conv.weight] = dw
         if da is not None:
             w = self.conv.weight.detach()
-            _chk(lib.ammc_pack_conv_dgrad_weight_f32(_ptr(w), self.cout, self.cin, self.cout, self.rows,
-                                                     _ptr(self.wdp), s), "pack_dgrad")
+            batched = self.wd16 is not None and o.packed["bwd"]
+            if not batched:
+                _chk(lib.ammc_pack_conv_dgrad_weight_f32(_ptr(w), self.cout, self.cin, self.cout, self.rows,
+                                                         _ptr(self.wdp), s), "pack_dgrad")
             if o.s16:
                 o.conv_s16(self.dc, self.wdp, da, ntaps=9, cin=self.cout, n=self.rows, res=da_res,
-                           what=self.name + ".dgrad", rescale=True, pre=pre)
+                           what=self.name + ".dgrad", rescale=True, pre=pre, w16=self.wd16 if batched else None)
             else:
                 o.conv(self.dc, self.wdp, da, ntaps=9, cin=self.cout, n=self.rows, res=da_res, what=self.name + ".dgrad")
 
@@ -818,6 +867,10 @@ class TrainEngine:
         # (with synchronised statistics the two streams advance layer by layer and share each collective, `_lockstep`;
         # their buffers are disjoint, so the order between the streams does not matter - within a stream it is kept)
         ops = st["ops"]
+        ops.nbt = []
+        ops.packed["fwd"] = ops.packed["bwd"] = False
+        if ops.s16 and PACK_BATCH:
+            ops.run_pack("fwd")                    # every 3x3 forward filter of the step -> S16, one launch
         _lockstep(ops, *[s.encode_gen(x) for s, x in zip(streams, xs)])
         vq = [s for s in streams if s.has_vq]
         _lockstep(ops, *[s.memory_gen() for s in vq])
@@ -830,6 +883,9 @@ class TrainEngine:
         else:
             bottoms = [streams[0].bottom]
         _lockstep(ops, *[s.decode_gen(b) for s, b in zip(streams, bottoms)])
+        if ops.nbt:
+            torch._foreach_add_(ops.nbt, 1)
+        ops.nbt = None
         outs = [s.out for s in streams]
         self._last = st
         if hasattr(self.module, "_param_epoch"):
@@ -848,6 +904,8 @@ class TrainEngine:
         streams: List[_Stream] = st["streams"]
         grads: Dict = {}
         st["ops"].ws.zero_step()            # weight-gradient accumulators and max-|g| slots: one memset per 64-MB chunk
+        if st["ops"].s16 and PACK_BATCH:
+            st["ops"].run_pack("bwd")           # every input-gradient filter -> S16, one launch
         reducer = getattr(self.module, "_grad_reducer", None)     # parallel.BucketedGradReducer or None
         sent = set()
 

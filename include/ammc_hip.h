@@ -285,6 +285,15 @@ int ammc_pack_conv_dgrad_weight_f32(const float* w_oihw, int32_t cout, int32_t c
                                     float* out, void* stream);
 int ammc_transpose_pad_f32(const float* w, int32_t rows, int32_t cols, int32_t rows_p, float* out, void* stream);
 
+/* All 3x3 filters of a training step packed in ONE launch, straight to the S16 images the split-fp16 kernels read
+ * (= ammc_pack_conv_weight_f32 / ammc_pack_conv_dgrad_weight_f32 followed by ammc_split_rows_f32, per layer).  items_dev: a
+ * device array of n_items records of ammc_pack_filters_item_bytes() bytes each:
+ *   { const float* w_oihw; float* out16; int32 cout, cin, inner_p, kpad, kind, rows; int64 group_end; }
+ * kind 0 = forward filter [rows = cout][kpad], k = tap * inner_p + c (inner_p = cin_p); kind 1 = input-gradient filter
+ * [rows >= cin][kpad], k = tap * inner_p + n (inner_p = cout_p); group_end = running total of rows * kpad / 8. */
+int ammc_pack_filters_item_bytes(void);
+int ammc_pack_filters_s16(const void* items_dev, int32_t n_items, int64_t total_groups, void* stream);
+
 /* PixelDiscriminator (Code/models/pix2pix_networks.py:580-631): Conv2d(k 4, padding 2, stride 2|1, bias) + LeakyReLU(0.1).
  * Forward and weight gradient run through ammc_conv_gemm_f32 / ammc_conv_wgrad_f32 with ntaps 16 (x_step / a_step =
  * the stride, x / a = the corner of a 2-pixel halo).  Input gradient: stride 1 = one 16-tap conv with the flipped
