@@ -1,0 +1,195 @@
+"""The C-ABI entry points added in round 4, each against an fp64 / composition reference through ctypes:
+  * `ammc_conv_wgrad_s16` with 4x4 windows at stride 1 | 2 (PixelDiscriminator) and the 2x2 stride-2 window of a
+    ConvTranspose's weight gradient (the generalised im2col form of csrc/wgrad_s16.hip);
+  * `ammc_conv_gemm_s16` with a 4x4 window, stride 2 and the LeakyReLU epilogue, S16 and fp32 outputs;
+  * `ammc_pack_filters_s16` = pack + split of every layer, bit for bit, from one launch;
+  * `ammc_chan_sum_absmax_f32` + `ammc_split_scaled_strided_f32` on a channel slice of a wider buffer;
+  * `ammc_lrelu_s16`."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ammcnet_aaai2021_amd import _lib, synthetic as S
+from ammcnet_aaai2021_amd._lib import ACT_LRELU, AmmcConvDesc, AmmcWgradDesc
+from ammcnet_aaai2021_amd.engine import Act, _kpad, _ptr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _s16(lib, t):
+    out = torch.empty_like(t)
+    _lib.check(lib.ammc_split_rows_f32(_ptr(t), t.numel(), _ptr(out), torch.cuda.current_stream().cuda_stream), "split")
+    return out
+
+
+def _decode(buf, c):
+    h = buf.contiguous().view(torch.float16).reshape(*buf.shape[:-1], c // 8, 2, 8).double()
+    return (h[..., 0, :] + h[..., 1, :] / 2048.0).reshape(*buf.shape[:-1], c)
+
+
+@pytest.mark.parametrize("B,H,W,cin,n,stride,gmag", [(2, 20, 28, 8, 128, 2, 1e-6), (3, 17, 13, 128, 256, 2, 1.0),
+                                                      (2, 9, 11, 256, 32, 1, 3e-4), (1, 33, 33, 64, 64, 2, 1e-2)])
+def test_wgrad_s16_4x4_windows(B, H, W, cin, n, stride, gmag):
+    """dW[n][c][r][s] = sum_m G[m][n] A[stride * m + (r, s)][c] over a 2-pixel zero halo (Conv2d(k 4, padding 2))"""
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    oh, ow = (H + 4 - 4) // stride + 1, (W + 4 - 4) // stride + 1
+    tag = f"w4-{B}-{H}-{W}-{cin}-{n}-{stride}"
+    a = S.hashed_uniform(tag + "a", (B, H, W, cin)).to(DEV)
+    g = (S.hashed_uniform(tag + "g", (B, oh, ow, n)) * gmag).to(DEV)
+    A32 = Act(torch.zeros(B, H + 4, W + 4, cin, device=DEV), B, H, W, cin, 0, 2)
+    A32.interior().copy_(a)
+    G32 = Act(torch.zeros(B, oh + 2, ow + 2, n, device=DEV), B, oh, ow, n, 0, 1)
+    G32.interior().copy_(g)
+    A16 = _s16(lib, A32.buf)
+    G16 = Act(torch.empty_like(G32.buf), B, oh, ow, n, 0, 1)
+    amax = torch.zeros(256, dtype=torch.int32, device=DEV)
+    inv = torch.empty(8, device=DEV)
+    _lib.check(lib.ammc_absmax_bits_f32(_ptr(G32.buf), G32.buf.numel(), amax.data_ptr(), s), "absmax")
+    _lib.check(lib.ammc_split_rows_scaled_f32(_ptr(G32.buf), G32.buf.numel(), _ptr(G16.buf), amax.data_ptr(), _ptr(inv), 8, s), "split g")
+    kpad = _kpad(16 * cin)
+    dwp = torch.zeros(max(n, 32), kpad, device=DEV)
+    zeros = torch.zeros(1024, device=DEV)
+    d = AmmcWgradDesc()
+    d.g, d.a, d.dw, d.zeros = G16.pix0(), _ptr(A16), _ptr(dwp), _ptr(zeros)         # a: the corner of the 2-pixel halo
+    d.batch, d.height, d.width, d.n, d.cin, d.ntaps, d.a_step = B, oh, ow, n, cin, 16, stride
+    d.g_bs, d.g_rs, d.g_ps = G16.strides
+    d.a_bs, d.a_rs, d.a_ps = A32.strides
+    _lib.check(lib.ammc_conv_wgrad_s16(C.byref(d), _ptr(inv), s), "wgrad_s16(4x4)")
+    dw = torch.empty(n, cin, 4, 4, device=DEV)
+    _lib.check(lib.ammc_unpack_conv_wgrad_f32(_ptr(dwp), n, cin, 4, cin, _ptr(dw), s), "unpack")
+    w = torch.zeros(n, cin, 4, 4, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(a.double().cpu().permute(0, 3, 1, 2), w, stride=stride, padding=2) * g.double().cpu().permute(0, 3, 1, 2)).sum().backward()
+    err = float((dw.double().cpu() - w.grad).abs().max() / w.grad.abs().max())
+    assert err <= 3e-6, err
+
+
+@pytest.mark.parametrize("B,h,w,c,gmag", [(2, 8, 16, 64, 1e-5), (3, 5, 7, 128, 1.0)])
+def test_wgrad_s16_convtranspose_window(B, h, w, c, gmag):
+    """ConvTranspose2d(2c, c, 2, stride 2): dW[ci][co][dy][dx] = sum_m X[m][ci] dY[2m + (dy, dx)][co]; rows = input channels,
+    k = (dy * 2 + dx) * c + co (the layout `ammc_unpack_convt_wgrad_f32` reads); the SCALE sits on the `a` operand here"""
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    tag = f"wt-{B}-{h}-{w}-{c}"
+    x = S.hashed_uniform(tag + "x", (B, h, w, 2 * c)).to(DEV)
+    dy = (S.hashed_uniform(tag + "dy", (B, 2 * h, 2 * w, c)) * gmag).to(DEV)
+    X32 = Act(torch.zeros(B, h + 2, w + 2, 2 * c, device=DEV), B, h, w, 2 * c, 0, 1)
+    X32.interior().copy_(x)
+    # the gradient lives in the upper half of a 2c-channel concat buffer: strided operands
+    D32 = Act(torch.zeros(B, 2 * h + 2, 2 * w + 2, 2 * c, device=DEV), B, 2 * h, 2 * w, c, c, 1)
+    D32.interior().copy_(dy)
+    X16 = Act(_s16(lib, X32.buf), B, h, w, 2 * c, 0, 1)
+    D16 = Act(torch.zeros_like(D32.buf), B, 2 * h, 2 * w, c, c, 1)
+    amax = torch.zeros(256, dtype=torch.int32, device=DEV)
+    inv = torch.empty(16, device=DEV)
+    nb = lib.ammc_chan_reduce_blocks(B * 4 * h * w)
+    part = torch.zeros(nb * c + 64, device=DEV)
+    _lib.check(lib.ammc_chan_sum_absmax_f32(D32.pix0(), *D32.strides, B, 2 * h, 2 * w, c, _ptr(part), amax.data_ptr(), s), "chan_sum_absmax")
+    bsum = torch.empty(c, device=DEV)
+    _lib.check(lib.ammc_reduce_partials_f32(_ptr(part), nb, c, 1.0, _ptr(bsum), s), "reduce")
+    _lib.check(lib.ammc_split_scaled_strided_f32(D32.pix0(), *D32.strides, D16.pix0(), *D16.strides, B, 2 * h, 2 * w, c,
+                                                 amax.data_ptr(), _ptr(inv), 16, s), "split_scaled_strided")
+    assert float((bsum.double().cpu() - dy.double().cpu().sum((0, 1, 2))).abs().max()) <= 1e-5 * float(dy.abs().sum((0, 1, 2)).max())
+    factor = 1.0 / float(inv[0])
+    assert 1024.0 <= float(dy.abs().max()) * factor < 2048.0
+    got = _decode(D16.buf, 2 * c)[:, 1:-1, 1:-1, c:] / factor                      # the re-encoded slice, scale undone
+    assert float((got.cpu() - dy.double().cpu()).abs().max()) <= 3e-7 * float(dy.abs().max())
+    assert float(_decode(D16.buf, 2 * c)[..., :c].abs().max()) == 0.0             # the other half of the twin is untouched
+    dwp = torch.zeros(2 * c, 4 * c, device=DEV)
+    zeros = torch.zeros(1024, device=DEV)
+    d = AmmcWgradDesc()
+    d.g, d.a, d.dw, d.zeros = X16.pix0(), D16.pix0(), _ptr(dwp), _ptr(zeros)
+    d.batch, d.height, d.width, d.n, d.cin, d.ntaps, d.a_step = B, h, w, 2 * c, c, 4, 2
+    d.g_bs, d.g_rs, d.g_ps = X16.strides
+    d.a_bs, d.a_rs, d.a_ps = D16.strides
+    _lib.check(lib.ammc_conv_wgrad_s16(C.byref(d), _ptr(inv), s), "wgrad_s16(convT)")
+    dwt = torch.empty(2 * c, c, 2, 2, device=DEV)
+    _lib.check(lib.ammc_unpack_convt_wgrad_f32(_ptr(dwp), 2 * c, c, _ptr(dwt), s), "unpack_convt")
+    wt = torch.zeros(2 * c, c, 2, 2, dtype=torch.float64, requires_grad=True)
+    (F.conv_transpose2d(x.double().cpu().permute(0, 3, 1, 2), wt, stride=2) * dy.double().cpu().permute(0, 3, 1, 2)).sum().backward()
+    err = float((dwt.double().cpu() - wt.grad).abs().max() / wt.grad.abs().max())
+    assert err <= 3e-6, err
+
+
+@pytest.mark.parametrize("y_f32", [0, 1])
+def test_conv_gemm_s16_4x4_stride2_lrelu(y_f32):
+    """Conv2d(k 4, stride 2, padding 2) + bias + LeakyReLU(0.1) (pix2pix_networks.py:604-606) on the split-fp16 kernel"""
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    B, H, W, cin, n = 2, 21, 30, 64, 128
+    oh, ow = (H + 4 - 4) // 2 + 1, (W + 4 - 4) // 2 + 1
+    x = S.hashed_uniform("c4x", (B, H, W, cin)).to(DEV)
+    w = (S.hashed_uniform("c4w", (n, cin, 4, 4)) * 0.05).to(DEV)
+    bias = S.hashed_uniform("c4b", (n,)).to(DEV)
+    X32 = Act(torch.zeros(B, H + 4, W + 4, cin, device=DEV), B, H, W, cin, 0, 2)
+    X32.interior().copy_(x)
+    X16 = _s16(lib, X32.buf)
+    wp = torch.zeros(n, _kpad(16 * cin), device=DEV)
+    _lib.check(lib.ammc_pack_conv_weight_f32(_ptr(w), n, cin, 4, cin, _ptr(wp), s), "pack")
+    w16 = _s16(lib, wp)
+    Y = Act(torch.zeros(B, oh + 2, ow + 2, n, device=DEV), B, oh, ow, n, 0, 1)
+    d = AmmcConvDesc()
+    d.x, d.w, d.y, d.shift = _ptr(X16), _ptr(w16), Y.pix0(), _ptr(bias)
+    d.batch, d.height, d.width, d.cin, d.ntaps, d.n, d.up, d.cgroup, d.act, d.x_step, d.y_f32 = B, oh, ow, cin, 16, n, 1, n, ACT_LRELU, 2, y_f32
+    d.x_bs, d.x_rs, d.x_ps = X32.strides
+    d.y_bs, d.y_rs, d.y_ps = Y.strides
+    _lib.check(lib.ammc_conv_gemm_s16(C.byref(d), s), "conv_gemm_s16(4x4)")
+    want = F.leaky_relu(F.conv2d(x.double().cpu().permute(0, 3, 1, 2), w.double().cpu(), bias.double().cpu(), stride=2, padding=2), 0.1)
+    got = (Y.interior().double() if y_f32 else _decode(Y.buf, n)[:, 1:-1, 1:-1]).cpu().permute(0, 3, 1, 2)
+    assert float((got - want).abs().max() / want.abs().max()) <= 3e-6
+
+
+def test_pack_filters_s16_equals_pack_then_split():
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    shapes = [(64, 12, 16), (64, 64, 64), (128, 64, 64), (256, 128, 128), (512, 512, 512), (64, 128, 128)]     # (cout, cin, cin_p)
+    dt = np.dtype([("w", "u8"), ("out", "u8"), ("cout", "i4"), ("cin", "i4"), ("inner_p", "i4"), ("kpad", "i4"),
+                   ("kind", "i4"), ("rows", "i4"), ("group_end", "i8")])
+    assert dt.itemsize == lib.ammc_pack_filters_item_bytes()
+    items, want, keep, total = [], [], [], 0
+    for i, (cout, cin, cin_p) in enumerate(shapes):
+        w = S.hashed_normal(f"pk{i}", (cout, cin, 3, 3), 0.05).to(DEV)
+        kpad = _kpad(9 * cin_p)
+        wp = torch.zeros(cout, kpad, device=DEV)
+        _lib.check(lib.ammc_pack_conv_weight_f32(_ptr(w), cout, cin, 3, cin_p, _ptr(wp), s), "pack")
+        out = torch.full((cout, kpad), 7.0, device=DEV)
+        total += cout * kpad // 8
+        items.append((w.data_ptr(), out.data_ptr(), cout, cin, cin_p, kpad, 0, cout, total))
+        want.append(_s16(lib, wp))
+        keep.append((w, out))
+        if cin >= 32:                                  # the flipped / transposed input-gradient filter of the same layer
+            rows, kd = max(64, (cin + 63) // 64 * 64), _kpad(9 * cout)
+            wd = torch.zeros(rows, kd, device=DEV)
+            _lib.check(lib.ammc_pack_conv_dgrad_weight_f32(_ptr(w), cout, cin, cout, rows, _ptr(wd), s), "pack_dgrad")
+            out = torch.full((rows, kd), 7.0, device=DEV)
+            total += rows * kd // 8
+            items.append((w.data_ptr(), out.data_ptr(), cout, cin, cout, kd, 1, rows, total))
+            want.append(_s16(lib, wd))
+            keep.append((w, out))
+    table = torch.from_numpy(np.array(items, dtype=dt).view(np.uint8).copy()).to(DEV)
+    _lib.check(lib.ammc_pack_filters_s16(table.data_ptr(), len(items), total, s), "pack_filters_s16")
+    for (w, out), ref in zip(keep, want):
+        assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+
+
+def test_lrelu_s16_in_place_on_a_channel_slice():
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    B, H, W, ctot, c0, c = 2, 5, 7, 96, 32, 40
+    x = (S.hashed_normal("lr16", (B, H + 2, W + 2, ctot), 3.0)).to(DEV)
+    x16 = _s16(lib, x)
+    a = Act(x16, B, H, W, c, c0, 1)
+    _lib.check(lib.ammc_lrelu_s16(a.pix0(), *a.strides, B, H, W, c, 0.1, s), "lrelu_s16")
+    got = _decode(x16, ctot)
+    ref = _decode(_s16(lib, x), ctot)
+    want = ref.clone()
+    sl = want[:, 1:-1, 1:-1, c0:c0 + c]
+    want[:, 1:-1, 1:-1, c0:c0 + c] = torch.where(sl > 0, sl, 0.1 * sl)
+    assert float((got - want).abs().max()) <= 3e-7 * float(want.abs().max())
+    mask = torch.ones_like(want, dtype=torch.bool)
+    mask[:, 1:-1, 1:-1, c0:c0 + c] = False
+    assert torch.equal(got[mask], ref[mask])                      # everything outside the slice's interior is untouched
