@@ -47,7 +47,6 @@ struct WgradTap3Args {
 };
 
 constexpr int W3_PW = 32, W3_HW = W3_PW + 2;                           // patch width, halo width
-constexpr int W3_NT = 512;
 // slot swizzle by pixel row m & 3: rows of 256 / 512 bytes are bank aligned (16 slots of 16 B = all banks) - toggle the
 // plane bit for odd rows and the next 128 B for rows 2, 3; rows of 128 bytes alternate bank halves by themselves, so
 // only rows two apart have to part: toggle the plane bit by bit 1 of the row
@@ -71,11 +70,16 @@ __device__ __forceinline__ f16x8u w3_frag(u32x2u a, u32x2u b) {
 // patch (waves of different groups add their parts to the same outputs).  PH = 4 with one row per wave serves the thin
 // operands: 32 gradient channels (the output layer) or 16 / 8 input channels (the first layers; channels beyond Cin
 // are read from the caller's zero buffer).
-template <int NG, int NA, int NP, int PH>
-__global__ __launch_bounds__(W3_NT, 2) void wgrad_tap3_s16_kernel(WgradTap3Args a) {
-  static_assert(NG * NA * NP == 8 && (PH == 2 || PH == 4) && PH % NP == 0, "8 waves");
+// GW = 2 (round 4, four waves, ONE per SIMD with the whole 512-register file): a wave owns TWO 32-channel blocks of the
+// gradient, so a transposed A fragment - four of the 4.7 LDS reads a step costs - feeds six MFMAs instead of three:
+// 0.9 reads per MFMA instead of 1.4 (the kernel runs at 0.52 of the matrix pipe with its LDS reads at ~80 % of the MFMA
+// time).  288 accumulator registers per lane; the same 128 x 64 channel workgroup tile as <4, 2, 1, 2>.
+template <int NG, int NA, int NP, int PH, int GW = 1>
+__global__ __launch_bounds__(64 * NG * NA * NP, (GW == 2 ? 1 : 2)) void wgrad_tap3_s16_kernel(WgradTap3Args a) {
+  static_assert((NG * NA * NP == 8 || (GW == 2 && NG * NA * NP == 4)) && (PH == 2 || PH == 4) && PH % NP == 0, "8 (4) waves");
+  constexpr int W3_NT = 64 * NG * NA * NP;
   constexpr int W3_PH = PH, W3_PX = PH * W3_PW, W3_HPX = (PH + 2) * W3_HW, RPW = PH / NP;
-  constexpr int W3_TN = 32 * NG, W3_TC = 32 * NA;
+  constexpr int W3_TN = 32 * NG * GW, W3_TC = 32 * NA;
   constexpr int W3_GRB = W3_TN * 4, W3_ARB = W3_TC * 4;                  // row bytes
   constexpr int W3_GSLOTS = W3_TN / 4, W3_ASLOTS = W3_TC / 4;            // 16-byte slots per row
   constexpr int W3_GJ = W3_PX * W3_GSLOTS / W3_NT;                       // DMA rounds
@@ -140,16 +144,18 @@ __global__ __launch_bounds__(W3_NT, 2) void wgrad_tap3_s16_kernel(WgradTap3Args 
     }                                                                                                     \
   }
 
-  f32x16 acc[9];
+  f32x16 acc[GW][9];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int b = 0; b < GW; ++b)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[b][t][r] = 0.f;
 
   // transposed-read lane roles: lane 4q+p of a 16-lane group supplies pixel row q; p >> 1 picks the S16 group of the
   // pair, p & 1 the 8-byte half of its 16 plane bytes
   const int l16 = lane & 15, q = l16 >> 2, p = l16 & 3, gi = l31 >> 4;
-  const int sg = 8 * wg + 4 * gi + 2 * (p >> 1);                // logical slot of this lane's hi bytes in a G row
+  const int sg = 8 * (wg * GW) + 4 * gi + 2 * (p >> 1);         // logical slot of this lane's hi bytes in a G row (block 0 of the wave)
   const int sa = 8 * wa + 4 * gi + 2 * (p >> 1);                // ... in an A row
   // G pixel rows of a read are y*32 + x16 + 4j + q: row & 3 == q, one swizzle per lane.  Fragments per lane half h:
   //   G_hi = GH[8h .. 8h+7]                                   A_x1 = (h ? AL : AH)[0-7]      A_x2 = (h ? AH : AL)[8-15]
@@ -158,9 +164,14 @@ __global__ __launch_bounds__(W3_NT, 2) void wgrad_tap3_s16_kernel(WgradTap3Args 
   // K order is free as long as both operands agree: the hi*hi MFMA takes its A fragment from the halves of the two
   // cross fragments that hold hi, so a tap costs FOUR transposed reads, not six.  The 2^-11 of the cross terms goes on
   // the whole G cross fragments (hi and lo halves alike), once per k-step.
-  const uint32_t g_lane_hi = (uint32_t)(((sg + 0) ^ w3_swz<W3_GRB>(q)) * 16 + (p & 1) * 8 + q * W3_GRB + h * (8 * W3_GRB));
-  const uint32_t g_lane_x1 = (uint32_t)(((sg + (1 - h)) ^ w3_swz<W3_GRB>(q)) * 16 + (p & 1) * 8 + q * W3_GRB);
-  const uint32_t g_lane_x2 = (uint32_t)(((sg + h) ^ w3_swz<W3_GRB>(q)) * 16 + (p & 1) * 8 + q * W3_GRB);
+  uint32_t g_lane_hi[GW], g_lane_x1[GW], g_lane_x2[GW];       // (per block: the swizzle XORs a bit that adding 8 slots carries into)
+#pragma unroll
+  for (int b = 0; b < GW; ++b) {
+    const int sb = sg + 8 * b;
+    g_lane_hi[b] = (uint32_t)(((sb + 0) ^ w3_swz<W3_GRB>(q)) * 16 + (p & 1) * 8 + q * W3_GRB + h * (8 * W3_GRB));
+    g_lane_x1[b] = (uint32_t)(((sb + (1 - h)) ^ w3_swz<W3_GRB>(q)) * 16 + (p & 1) * 8 + q * W3_GRB);
+    g_lane_x2[b] = (uint32_t)(((sb + h) ^ w3_swz<W3_GRB>(q)) * 16 + (p & 1) * 8 + q * W3_GRB);
+  }
   // A rows start anywhere: (row & 3) = (q + 2 (y + r) + s) & 3 for tap (r, s); the four possible swizzled slot offsets,
   // rotated by q, so that the index below is a compile-time constant
   uint32_t a_sw_x1[4], a_sw_x2[4];
@@ -182,8 +193,8 @@ __global__ __launch_bounds__(W3_NT, 2) void wgrad_tap3_s16_kernel(WgradTap3Args 
   // a full LDS round trip, four times per patch).  Waits are counted: LDS reads return in order, so step U needs
   // everything issued up to A(U) and tolerates what was issued after it.  Issue order around a boundary:
   //   ... A(t7) [step t5, before its wait], G(next) [step t5, after it], A(t8) [t6], A(next t0) [t7], A(next t1) [t8] ...
-  u32x2u ar[3][4], graw[2][6];
-  f16x8u gf_hi, gf_x1, gf_x2;
+  u32x2u ar[3][4], graw[GW][2][6];
+  f16x8u gf_hi[GW], gf_x1[GW], gf_x2[GW];
 #define W3_AREAD(Y0, U, S)                                                                                    \
   {                                                                                                           \
     constexpr int y_ = (Y0) + (U) / 18, xh_ = ((U) / 9) & 1, t_ = (U) % 9;                                    \
@@ -200,32 +211,39 @@ __global__ __launch_bounds__(W3_NT, 2) void wgrad_tap3_s16_kernel(WgradTap3Args 
   {                                                                                                           \
     constexpr int gp_ = (((Y0) + (HH) / 2) * 32 + 16 * ((HH) & 1)) * W3_GRB;                                  \
     static_assert(gp_ + 12 * W3_GRB < 65536, "ds offset");                                                    \
-    graw[S][0] = w3_read_tr16<gp_>(ghi);                                                                      \
-    graw[S][1] = w3_read_tr16<gp_ + 4 * W3_GRB>(ghi);                                                         \
-    graw[S][2] = w3_read_tr16<gp_>(g1);                                                                       \
-    graw[S][3] = w3_read_tr16<gp_ + 4 * W3_GRB>(g1);                                                          \
-    graw[S][4] = w3_read_tr16<gp_ + 8 * W3_GRB>(g2);                                                          \
-    graw[S][5] = w3_read_tr16<gp_ + 12 * W3_GRB>(g2);                                                         \
+    _Pragma("unroll") for (int b_ = 0; b_ < GW; ++b_) {                                                       \
+      graw[b_][S][0] = w3_read_tr16<gp_>(ghi[b_]);                                                            \
+      graw[b_][S][1] = w3_read_tr16<gp_ + 4 * W3_GRB>(ghi[b_]);                                               \
+      graw[b_][S][2] = w3_read_tr16<gp_>(g1[b_]);                                                             \
+      graw[b_][S][3] = w3_read_tr16<gp_ + 4 * W3_GRB>(g1[b_]);                                                \
+      graw[b_][S][4] = w3_read_tr16<gp_ + 8 * W3_GRB>(g2[b_]);                                                \
+      graw[b_][S][5] = w3_read_tr16<gp_ + 12 * W3_GRB>(g2[b_]);                                               \
+    }                                                                                                         \
   }
 #define W3_STEP(Y0, U)                                                                                        \
   {                                                                                                           \
     constexpr int t_ = (U) % 9, hh_ = (U) / 9;                                                                \
     constexpr bool nxt_ = hh_ + 1 < NH;                                                                       \
     if ((U) + 2 < NU) W3_AREAD(Y0, ((U) + 2 < NU ? (U) + 2 : 0), (((U) + 2) % 3))                             \
-    constexpr int cnt_ = ((U) + 1 < NU ? 4 : 0) + ((U) + 2 < NU ? 4 : 0) + (((t_ == 6 || t_ == 7) && nxt_) ? 6 : 0); \
-    __builtin_amdgcn_s_waitcnt(0xC07F | (cnt_ << 8));                                                         \
+    constexpr int cnt_ = ((U) + 1 < NU ? 4 : 0) + ((U) + 2 < NU ? 4 : 0) + (((t_ == 6 || t_ == 7) && nxt_) ? 6 * GW : 0); \
+    __builtin_amdgcn_s_waitcnt(0xC07F | ((cnt_ < 15 ? cnt_ : 15) << 8));    /* (lgkmcnt is a 4-bit field: 15 = the most it can tolerate) */ \
     __builtin_amdgcn_sched_barrier(0);                                                                        \
     if (t_ == 0) {                                                                                            \
-      gf_hi = w3_frag(graw[hh_ & 1][0], graw[hh_ & 1][1]);                                                    \
-      gf_x1 = w3_frag(graw[hh_ & 1][2], graw[hh_ & 1][3]) * cg;                                               \
-      gf_x2 = w3_frag(graw[hh_ & 1][4], graw[hh_ & 1][5]) * cg;                                               \
+      _Pragma("unroll") for (int b_ = 0; b_ < GW; ++b_) {                                                     \
+        gf_hi[b_] = w3_frag(graw[b_][hh_ & 1][0], graw[b_][hh_ & 1][1]);                                      \
+        gf_x1[b_] = w3_frag(graw[b_][hh_ & 1][2], graw[b_][hh_ & 1][3]) * cg;                                 \
+        gf_x2[b_] = w3_frag(graw[b_][hh_ & 1][4], graw[b_][hh_ & 1][5]) * cg;                                 \
+      }                                                                                                       \
     }                                                                                                         \
     if (t_ == 5 && nxt_) W3_GREAD(Y0, (nxt_ ? hh_ + 1 : 0), ((hh_ + 1) & 1))                                  \
     const f16x8u ax1_ = w3_frag(ar[(U) % 3][0], ar[(U) % 3][1]), ax2_ = w3_frag(ar[(U) % 3][2], ar[(U) % 3][3]); \
     const f16x8u ahi_ = upper ? ax2_ : ax1_;                                                                  \
-    acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf_hi, ahi_, acc[t_], 0, 0, 0);                          \
-    acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf_x1, ax1_, acc[t_], 0, 0, 0);                          \
-    acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf_x2, ax2_, acc[t_], 0, 0, 0);                          \
+    _Pragma("unroll") for (int b_ = 0; b_ < GW; ++b_)                                                         \
+      acc[b_][t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf_hi[b_], ahi_, acc[b_][t_], 0, 0, 0);            \
+    _Pragma("unroll") for (int b_ = 0; b_ < GW; ++b_)                                                         \
+      acc[b_][t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf_x1[b_], ax1_, acc[b_][t_], 0, 0, 0);            \
+    _Pragma("unroll") for (int b_ = 0; b_ < GW; ++b_)                                                         \
+      acc[b_][t_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf_x2[b_], ax2_, acc[b_][t_], 0, 0, 0);            \
     __builtin_amdgcn_sched_barrier(0);                                                                        \
   }
 #define W3_STEP9(Y0, U) W3_STEP(Y0, U) W3_STEP(Y0, (U) + 1) W3_STEP(Y0, (U) + 2) W3_STEP(Y0, (U) + 3) W3_STEP(Y0, (U) + 4) \
@@ -250,7 +268,9 @@ __global__ __launch_bounds__(W3_NT, 2) void wgrad_tap3_s16_kernel(WgradTap3Args 
     if (pt + 1 < p_end) W3_ISSUE(pt + 1, stage ^ 1);
     const uint32_t gst = g_base + (uint32_t)(stage * W3_GSTAGE * 4);
     const uint32_t abase = a_base + (uint32_t)(stage * W3_ASTAGE * 4) + a_lane;
-    const uint32_t ghi = gst + g_lane_hi, g1 = gst + g_lane_x1, g2 = gst + g_lane_x2;
+    uint32_t ghi[GW], g1[GW], g2[GW];
+#pragma unroll
+    for (int b = 0; b < GW; ++b) { ghi[b] = gst + g_lane_hi[b]; g1[b] = gst + g_lane_x1[b]; g2[b] = gst + g_lane_x2[b]; }
     if (0 == wp) { W3_SEQ(0) }                           // (uniform per wave; the rows are literals in the offsets)
     if (NP >= 2 && 1 == wp) { W3_SEQ((NP >= 2 ? RPW : 0)) }
     if (NP == 4) {
@@ -271,23 +291,26 @@ __global__ __launch_bounds__(W3_NT, 2) void wgrad_tap3_s16_kernel(WgradTap3Args 
   const float inv = a.g_inv_scale ? a.g_inv_scale[0] : 1.f;
   const int c = c0 + 32 * wa + l31;
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const int col = t * d.cin + c;
+  for (int b = 0; b < GW; ++b)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = row0 + 32 * wg + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (row < d.n && c < d.cin) unsafeAtomicAdd(d.dw + (int64_t)row * a.kpad + col, acc[t][r] * inv);
+    for (int t = 0; t < 9; ++t) {
+      const int col = t * d.cin + c;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + 32 * (wg * GW + b) + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < d.n && c < d.cin) unsafeAtomicAdd(d.dw + (int64_t)row * a.kpad + col, acc[b][t][r] * inv);
+      }
     }
-  }
 }
 
-template <int NG, int NA, int NP, int PH>
+template <int NG, int NA, int NP, int PH, int GW = 1>
 static int launch_wgrad_tap3(WgradTap3Args a, hipStream_t stream) {
-  constexpr int TN = 32 * NG, TC = 32 * NA;
+  constexpr int W3_NT = 64 * NG * NA * NP;
+  constexpr int TN = 32 * NG * GW, TC = 32 * NA;
   constexpr int AJ = ((PH + 2) * W3_HW * (TC / 4) + W3_NT - 1) / W3_NT;
   constexpr size_t lds = (size_t)(2 * PH * W3_PW * TN + 2 * AJ * W3_NT * 4) * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = wgrad_tap3_s16_kernel<NG, NA, NP, PH>;
+  auto kern = wgrad_tap3_s16_kernel<NG, NA, NP, PH, GW>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) return (int)e;
@@ -318,6 +341,9 @@ int wgrad_tap3_s16_try(const AmmcWgradDesc& d, const float* g_inv_scale, int kpa
   a.tiles_x = d.width / W3_PW;
   a.tiles_y = a.npatch = 0;                                       // set by the launcher (patch height)
   if (d.cin % 64 == 0) {
+    // AMMC_WGRAD_GW: 2 = the four-wave form with two gradient blocks per wave (A/B; round 4)
+    static const int gw = getenv("AMMC_WGRAD_GW") ? atoi(getenv("AMMC_WGRAD_GW")) : 1;
+    if (d.n % 128 == 0 && gw == 2) return launch_wgrad_tap3<2, 2, 1, 2, 2>(a, stream);
     if (d.n % 128 == 0) return launch_wgrad_tap3<4, 2, 1, 2>(a, stream);
     if (d.n % 64 == 0) return launch_wgrad_tap3<2, 2, 2, 2>(a, stream);
     if (d.n == 32 && d.height % 4 == 0) return launch_wgrad_tap3<1, 2, 4, 4>(a, stream);    // the output layer
