@@ -282,8 +282,11 @@ def train_step_gan(generator: torch.nn.Module, discriminator: torch.nn.Module, o
     if flow_fn is not None:
         with torch.no_grad():
             # the reference pairs BOTH frames with `rgb_input_last = rgb[:, -1]`, i.e. with the target frame itself
-            # (train_helper.py:299, 309-312), not with the frame before it: followed as written
-            flow_pred, flow_gt = flow_fn(rgb[:, -1], out[0].detach()), flow_fn(rgb[:, -1], rgb_t)
+            # (train_helper.py:299, 309-312), not with the frame before it: followed as written.  The two FlowNet2-SD
+            # forwards run as ONE batch of 2 b pairs (every sample is independent in that network - its mean subtraction
+            # is per sample - so the flows are the same; the layers below 1/16 resolution fill the chip twice as well)
+            both = flow_fn(torch.cat([rgb[:, -1], rgb[:, -1]]), torch.cat([out[0].detach(), rgb_t]))
+            flow_pred, flow_gt = both[:b], both[b:]
     d_params = [p for p in discriminator.parameters() if p.requires_grad]
     for p in d_params:                 # the G step needs dL/d(frame) through D, not D's weight gradients
         p.requires_grad_(False)
@@ -293,7 +296,10 @@ def train_step_gan(generator: torch.nn.Module, discriminator: torch.nn.Module, o
         for p in d_params:
             p.requires_grad_(True)
     g_loss = generator_loss_full(out, rgb_t, op_t, d_gen, flow_pred, flow_gt, **lams)
-    d_loss = discriminate_loss(discriminator(rgb_t), discriminator(out[0].detach()))
+    # D(real) and D(fake.detach()) (train_helper.py:326-327) as one call on 2 b frames: the discriminator has no
+    # batch-coupled layer, the patch maps and every gradient are those of the two calls
+    d_both = discriminator(torch.cat([rgb_t, out[0].detach()]))
+    d_loss = discriminate_loss(d_both[:b], d_both[b:])
     watch = _FiniteWatch(d_loss, g_loss)
     optimizer_D.zero_grad(set_to_none=True)
     d_loss.backward()

@@ -552,11 +552,12 @@ def run_train_gan(args, dev, steps, warmup):
 
     with torch.no_grad():
         fake = (rgb_t * 0.9).contiguous()
-    parts = {"flownet2sd_forward_x2_ms": timed(lambda: (flow_fn(rgb_t, fake), flow_fn(rgb_t, rgb_t))),
+    parts = {"flownet2sd_forward_x2_ms": timed(lambda: flow_fn(torch.cat([rgb_t, rgb_t]), torch.cat([fake, rgb_t]))),
              "generator_step_ms (fwd + bwd + Adam, no D / flow terms)": timed(lambda: harness.train_step(G, opt_g, rgb, op))}
 
     def d_only():
-        dl_ = harness.discriminate_loss(D(rgb_t), D(fake))
+        d_both = D(torch.cat([rgb_t, fake]))
+        dl_ = harness.discriminate_loss(d_both[:batch], d_both[batch:])
         opt_d.zero_grad(set_to_none=True)
         dl_.backward()
         opt_d.step()
