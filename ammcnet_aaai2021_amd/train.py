@@ -609,6 +609,10 @@ class _Stream:
                 blk.input_has_twin()                # pooled[i] / cat[lvl]
             for blk in self.up_dc:
                 blk.emit_twin()                     # read by the next ConvTranspose / the output layer
+                if CONVT_GRADS_S16:
+                    # ... and by nothing else: the next ConvTranspose's forward AND weight gradient, the output layer and
+                    # its weight gradient all read the twin - the fp32 tensor would be written for nobody
+                    blk.u1.y_s16_only = True
             if not has_vq:
                 self.down[2].emit_twin()            # x4 is the decoder's input
                 self.bottom_twin = True
@@ -839,6 +843,8 @@ class TrainEngine:
                     o2f.emit_twin()                 # xb / yb feed the first ConvTranspose of their stream
                     f2o.emit_twin()
                     r.bottom_twin = o.bottom_twin = True
+                    if CONVT_GRADS_S16:             # (forward and weight gradient of that ConvTranspose: twin readers both)
+                        o2f.u1.y_s16_only = f2o.u1.y_s16_only = True
                 st = dict(ops=ops, streams=[r, o], o2f=o2f, f2o=f2o, xb=xb, yb=yb,
                           dzx=ws.act(B, h, w, 512), dzy=ws.act(B, h, w, 512))
             else:
