@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # AMMC_LIB: another build of the SAME library (A/B measurements: `python -m ammcnet_aaai2021_amd.build --variant x`)
 LIB_PATH = os.environ.get("AMMC_LIB") or os.path.join(HERE, "libammc_hip.so")
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU = 0, 1, 2, 3
 
@@ -117,6 +117,7 @@ SIGNATURES = {
     "ammc_split_scaled_strided_f32": (C.c_int, [_p] + _s3 + [_p] + _s3 + [_i32, _i32, _i32, _i32, _p, _p, _i32, _p]),
     "ammc_reduce_partials_f32": (C.c_int, [_p, _i32, _i32, _f32, _p, _p]),
     "ammc_maxpool2x2_bwd_f32": (C.c_int, [_p] + _s3 + [_p] + _s3 + [_p] + _s3 + [_p] + _s3 + [_i32] * 6 + [_p]),
+    "ammc_maxpool2x2_bwd_s16x_f32": (C.c_int, [_p] + _s3 + [_p] + _s3 + [_p] + _s3 + [_p] + _s3 + [_i32] * 6 + [_p]),
     "ammc_tanh_bwd_nhwc_f32": (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _p] + _s3 + [_i32, _p]),
     "ammc_commit_bwd_f32": (C.c_int, [_p, _p, _p, _i32, _p, _p, _p, _i32, _i32, _p]),
     "ammc_codebook_count_f32": (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _p, _p, _p]),

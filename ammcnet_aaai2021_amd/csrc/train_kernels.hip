@@ -500,6 +500,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_s16_kernel(
 // dx[2y+i][2x+j] = add[2y+i][2x+j] + (first max position in row-major window order ? dp[y][x] : 0)
 // x / add / dx are fh x fw (fh = 2h or 2h+1): the last row / column of an odd size belongs to no window (MaxPool2d floors)
 // and receives only `add` (or zero); the grid covers ceil(fh/2) x ceil(fw/2) window positions.
+// XS16: x is the S16 twin of the pooled tensor (what the forward's ammc_maxpool2x2_s16 compared: v = hi + lo 2^-11) -
+// the fp32 tensor then has no reader left in the step and is not written at all.
+template <bool XS16>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(
     const float* __restrict__ x, Tensor3 xt, const float* __restrict__ dp, Tensor3 pt,
     const float* __restrict__ add, Tensor3 at, float* __restrict__ dx, Tensor3 ot, int M, int h, int w, int fh, int fw,
@@ -515,10 +518,23 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(
     const float* s = x + (int64_t)b * xt.bs + (int64_t)(2 * yy) * xt.rs + (int64_t)(2 * xx) * xt.ps + c4 * 4;
     const f32x4 g = *reinterpret_cast<const f32x4*>(dp + (int64_t)b * pt.bs + (int64_t)yy * pt.rs + (int64_t)xx * pt.ps + c4 * 4);
     f32x4 v[4];
-    v[0] = *reinterpret_cast<const f32x4*>(s);
-    v[1] = *reinterpret_cast<const f32x4*>(s + xt.ps);
-    v[2] = *reinterpret_cast<const f32x4*>(s + xt.rs);
-    v[3] = *reinterpret_cast<const f32x4*>(s + xt.rs + xt.ps);
+    if (XS16) {
+      // channels 4 c4 .. + 3 of S16 group c4 >> 1: four hi halves at byte 8 (c4 & 1) of the group, their lo halves 16 bytes on
+      typedef _Float16 mp_h4 __attribute__((ext_vector_type(4)));
+      const float* sg = x + (int64_t)b * xt.bs + (int64_t)(2 * yy) * xt.rs + (int64_t)(2 * xx) * xt.ps + (c4 >> 1) * 8 + (c4 & 1) * 2;
+      const int64_t offs[4] = {0, xt.ps, xt.rs, xt.rs + xt.ps};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const mp_h4 hv = *reinterpret_cast<const mp_h4*>(sg + offs[j]), lv = *reinterpret_cast<const mp_h4*>(sg + offs[j] + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[j][i] = (float)hv[i] + (float)lv[i] * (1.f / 2048.f);
+      }
+    } else {
+      v[0] = *reinterpret_cast<const f32x4*>(s);
+      v[1] = *reinterpret_cast<const f32x4*>(s + xt.ps);
+      v[2] = *reinterpret_cast<const f32x4*>(s + xt.rs);
+      v[3] = *reinterpret_cast<const f32x4*>(s + xt.rs + xt.ps);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int arg = 0;
@@ -994,7 +1010,21 @@ int ammc_maxpool2x2_bwd_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t 
   if ((in_h >> 1) != h || (in_w >> 1) != w) return AMMC_EINVAL;
   const int M = batch * ((in_h + 1) >> 1) * ((in_w + 1) >> 1);
   Tensor3 xt{x_bs, x_rs, x_ps}, pt{p_bs, p_rs, p_ps}, at{a_bs, a_rs, a_ps}, ot{o_bs, o_rs, o_ps};
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblk((int64_t)M * (c >> 2))), dim3(256), 0, (hipStream_t)stream, x, xt,
+  hipLaunchKernelGGL(maxpool_bwd_kernel<false>, dim3(nblk((int64_t)M * (c >> 2))), dim3(256), 0, (hipStream_t)stream, x, xt,
+                     dp, pt, add, at, dx, ot, M, h, w, in_h, in_w, c >> 2);
+  return ammc_launch_status();
+}
+
+int ammc_maxpool2x2_bwd_s16x_f32(const float* x16, int64_t x_bs, int64_t x_rs, int64_t x_ps, const float* dp, int64_t p_bs,
+                                 int64_t p_rs, int64_t p_ps, const float* add, int64_t a_bs, int64_t a_rs, int64_t a_ps,
+                                 float* dx, int64_t o_bs, int64_t o_rs, int64_t o_ps, int32_t batch, int32_t h, int32_t w,
+                                 int32_t in_h, int32_t in_w, int32_t c, void* stream) {
+  if (!x16 || !dp || !dx || batch <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 7)) return AMMC_EINVAL;
+  if (((uintptr_t)x16 & 31) || ((x_bs | x_rs | x_ps) & 7)) return AMMC_EINVAL;
+  if ((in_h >> 1) != h || (in_w >> 1) != w) return AMMC_EINVAL;
+  const int M = batch * ((in_h + 1) >> 1) * ((in_w + 1) >> 1);
+  Tensor3 xt{x_bs, x_rs, x_ps}, pt{p_bs, p_rs, p_ps}, at{a_bs, a_rs, a_ps}, ot{o_bs, o_rs, o_ps};
+  hipLaunchKernelGGL(maxpool_bwd_kernel<true>, dim3(nblk((int64_t)M * (c >> 2))), dim3(256), 0, (hipStream_t)stream, x16, xt,
                      dp, pt, add, at, dx, ot, M, h, w, in_h, in_w, c >> 2);
   return ammc_launch_status();
 }

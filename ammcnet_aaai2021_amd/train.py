@@ -605,6 +605,9 @@ class _Stream:
         if self.twins:
             for blk in (self.inc, self.down[0], self.down[1]):
                 blk.emit_twin()                     # skip[0..2]: read by the pool and by the decoder's first conv
+                # ... as twins; the max-pool backward finds its arg-max on the twin as well (the values the forward's
+                # pool compared), so the fp32 skip tensor has no reader and is not written
+                blk.u1.y_s16_only = True
             for blk in self.down + self.up_dc:
                 blk.input_has_twin()                # pooled[i] / cat[lvl]
             for blk in self.up_dc:
@@ -808,8 +811,14 @@ class _Stream:
         for i in (2, 1, 0):
             yield from self.down[i].backward_gen(dy, self.dpooled[i], None, grads)
             sk, dpo, add, out = self.skip[i], self.dpooled[i], self.dcat[i].slice(0, CHANS[i]), self.dskip_tot[i]
-            _chk(lib.ammc_maxpool2x2_bwd_f32(sk.pix0(), *sk.strides, dpo.pix0(), *dpo.strides, add.pix0(), *add.strides,
-                                             out.pix0(), *out.strides, dpo.B, dpo.H, dpo.W, sk.H, sk.W, dpo.c, s), "maxpool_bwd")
+            if self.twins:
+                sk16 = o.shadow(sk)
+                _chk(lib.ammc_maxpool2x2_bwd_s16x_f32(sk16.pix0(), *sk16.strides, dpo.pix0(), *dpo.strides, add.pix0(),
+                                                      *add.strides, out.pix0(), *out.strides, dpo.B, dpo.H, dpo.W, sk.H, sk.W,
+                                                      dpo.c, s), "maxpool_bwd(s16)")
+            else:
+                _chk(lib.ammc_maxpool2x2_bwd_f32(sk.pix0(), *sk.strides, dpo.pix0(), *dpo.strides, add.pix0(), *add.strides,
+                                                 out.pix0(), *out.strides, dpo.B, dpo.H, dpo.W, sk.H, sk.W, dpo.c, s), "maxpool_bwd")
             dy = out
         yield from self.inc.backward_gen(dy, None, None, grads)
 

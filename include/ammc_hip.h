@@ -404,6 +404,12 @@ int ammc_maxpool2x2_bwd_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t 
                             int64_t p_rs, int64_t p_ps, const float* add, int64_t a_bs, int64_t a_rs, int64_t a_ps,
                             float* dx, int64_t o_bs, int64_t o_rs, int64_t o_ps, int32_t batch, int32_t h, int32_t w,
                             int32_t in_h, int32_t in_w, int32_t c, void* stream);
+/* the same with the S16 twin of x as the pooled tensor (what ammc_maxpool2x2_s16 compared in the forward; c % 8 == 0): the
+ * fp32 x then has no reader in the training step and is never written */
+int ammc_maxpool2x2_bwd_s16x_f32(const float* x16, int64_t x_bs, int64_t x_rs, int64_t x_ps, const float* dp, int64_t p_bs,
+                                 int64_t p_rs, int64_t p_ps, const float* add, int64_t a_bs, int64_t a_rs, int64_t a_ps,
+                                 float* dx, int64_t o_bs, int64_t o_rs, int64_t o_ps, int32_t batch, int32_t h, int32_t w,
+                                 int32_t in_h, int32_t in_w, int32_t c, void* stream);
 /* torch.tanh backward at the module boundary: NCHW (dout, out) -> NHWC d(pre-tanh), cp channels */
 int ammc_tanh_bwd_nhwc_f32(const float* dout_nchw, const float* out_nchw, int32_t batch, int32_t c, int32_t h,
                            int32_t w, float* y, int64_t y_bs, int64_t y_rs, int64_t y_ps, int32_t cp, void* stream);
