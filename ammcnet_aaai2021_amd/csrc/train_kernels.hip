@@ -26,9 +26,12 @@ __device__ __forceinline__ int64_t pix_off(int m, int H, int W, const Tensor3& t
 // Pixels per workgroup in the per-channel reductions: about 2048 workgroups whatever the level (a fixed 2048 pixels
 // left the 32x32 level with 16 workgroups on a 256-CU chip and the average of these kernels at 2.2 TB/s).  A function
 // of the pixel count alone, so the partial sums - and the results - are the same on every launch.
+// (Round 4: ~1024 workgroups instead of ~2048 - four workgroups of 256 threads per CU keep 64-128 KB of loads in flight,
+// as many as eight did, and the finalizers that combine the partial rows - 64 launches of 8-64 workgroups per training
+// step, pure latency - walk half as many.)
 __host__ __device__ inline int red_pix_for(int M) {
-  int p = ((M + 2047) / 2048 + 63) & ~63;
-  return p < 64 ? 64 : (p > 2048 ? 2048 : p);
+  int p = ((M + 1023) / 1024 + 63) & ~63;
+  return p < 64 ? 64 : (p > 4096 ? 4096 : p);
 }
 
 // ---- per-channel reductions ---------------------------------------------------------
@@ -168,8 +171,9 @@ __device__ __forceinline__ void column_sums(const float* __restrict__ partial, i
   const int cl = threadIdx.x % RP_COLS, sl = threadIdx.x / RP_COLS;
   double a = 0.0, b = 0.0;
   if (valid) {
-    // eight rows per trip, loads first (one dependent load per row left this latency-bound); the sums keep row order
-    constexpr int U = 4;
+    // eight rows (sixteen loads) per trip, loads first (one dependent load per row left this latency-bound); the sums
+    // keep row order whatever U is
+    constexpr int U = 8;
     for (int r0 = sl; r0 < nblk; r0 += U * RP_SLICES) {
       float va[U], vb[U];
 #pragma unroll
@@ -370,11 +374,21 @@ __global__ __launch_bounds__(RP_THREADS) void bn_bwd_finalize_kernel(const float
   double s, ss;
   column_sums(partial, nblk, (int64_t)4 * C, c, c < C, C, red, s, ss);
   float mg = 0.f, mx = 0.f;
-  if (c < C)
-    for (int r = sl; r < nblk; r += RP_SLICES) {
-      mg = fmaxf(mg, partial[(int64_t)r * 4 * C + 2 * C + c]);
-      mx = fmaxf(mx, partial[(int64_t)r * 4 * C + 3 * C + c]);
+  if (c < C) {
+    constexpr int U = 8;                              // loads first, as column_sums
+    for (int r0 = sl; r0 < nblk; r0 += U * RP_SLICES) {
+      float vg[U], vx[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int r = r0 + u * RP_SLICES;
+        const bool ok = r < nblk;
+        vg[u] = ok ? partial[(int64_t)r * 4 * C + 2 * C + c] : 0.f;
+        vx[u] = ok ? partial[(int64_t)r * 4 * C + 3 * C + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) mg = fmaxf(mg, vg[u]), mx = fmaxf(mx, vx[u]);
     }
+  }
   redm[0][sl][cl] = mg;
   redm[1][sl][cl] = mx;
   __syncthreads();
