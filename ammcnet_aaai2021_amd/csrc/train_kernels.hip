@@ -8,6 +8,8 @@
 // variance to normalise, unbiased for the running estimate, momentum 0.1), nn.MaxPool2d(2)
 // (:36), torch.tanh (:1007), `diff` (:310), EMA update (:298-309).
 #include "ammc_common.h"
+#include <type_traits>
+#include <stdlib.h>
 
 namespace ammc_impl {
 
@@ -42,6 +44,15 @@ __host__ __device__ inline int red_pix_for(int M) {
 // MODE 4: MODE 2 + max|x| of the whole tensor into the 256 `amax_bits` slots (as ammc_absmax_bits_f32 leaves it): the
 //         bias-gradient pass of a ConvTranspose also finds the power of two for the S16 re-encoding of its gradient
 // Layout: thread = (channel group of 4, pixel lane); partial[block][q][C].
+// Workgroup b sums every gridDim.x-th chunk of U * PY pixels (a function of the shape alone: the same partial sums on
+// every launch); a thread walks U pixel streams whose coordinates AND element offsets advance by additions and two
+// carries per trip, and a trip issues all its loads before its first sum.  (Round 4.  The first form recomputed
+// b * bs + y * rs + x * ps per load - 36 quarter-rate integer multiplies per trip of four loads - and guarded each load
+// by a branch, which made hipcc wait for the loads in pairs.  Removing both did not move the kernel: on the 537-MB
+// tensors of the 256x256 level it reads at 4.2-4.6 TB/s because the convolution that has just written the tensor
+// left ~256 MB of it dirty in the Infinity Cache, and those lines go out to HBM under this kernel's loads - read plus
+// write-back is the 6.1 TB/s HBM streams at.  Walking the tensor back to front, or as eight runs side by side the
+// way the convolution's XCDs wrote it, to hit those lines instead of evicting them: measured, no gain.)
 template <int MODE>
 __global__ __launch_bounds__(256) void chan_reduce_kernel(
     const float* __restrict__ x, Tensor3 xt, const float* __restrict__ dy, Tensor3 dt,
@@ -49,79 +60,98 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(
     const float* __restrict__ beta, int relu, int M, int H, int W, int C, float* __restrict__ partial,
     int* __restrict__ amax_bits = nullptr) {
   __shared__ f32x4 red[MODE == 3 ? 4 : 2][256];
+  constexpr bool BWD = MODE == 1 || MODE == 3;
+  constexpr int U = BWD ? 4 : 8;                     // 16-byte loads in flight per thread: 8 either way
   const int C4 = C >> 2;
   const int tx = threadIdx.x % C4;
   const int ty = threadIdx.x / C4;
   const int PY = 256 / C4;
-  const int red_pix = red_pix_for(M);
-  const int m0 = blockIdx.x * red_pix;
-  const int m1 = min(m0 + red_pix, M);
+  const int step = U * PY;
+  const int stride = (int)gridDim.x * step;
+  const int sx = stride % W, sy = (stride / W) % H, sb = stride / (W * H);
+  const int64_t x_adv = (int64_t)sb * xt.bs + (int64_t)sy * xt.rs + (int64_t)sx * xt.ps;
+  const int64_t x_row = xt.rs - (int64_t)W * xt.ps, x_img = xt.bs - (int64_t)H * xt.rs;      // carries
+  const int64_t d_adv = BWD ? (int64_t)sb * dt.bs + (int64_t)sy * dt.rs + (int64_t)sx * dt.ps : 0;
+  const int64_t d_row = BWD ? dt.rs - (int64_t)W * dt.ps : 0, d_img = BWD ? dt.bs - (int64_t)H * dt.rs : 0;
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f}, m0v = {0.f, 0.f, 0.f, 0.f}, m1v = {0.f, 0.f, 0.f, 0.f};
   f32x4 mu, is, ga, be;
-  if ((MODE == 1 || MODE == 3) && ty < PY) {
+  if (BWD && ty < PY) {
     mu = *reinterpret_cast<const f32x4*>(mean + tx * 4);
     is = *reinterpret_cast<const f32x4*>(invstd + tx * 4);
     ga = *reinterpret_cast<const f32x4*>(gamma + tx * 4);
     be = *reinterpret_cast<const f32x4*>(beta + tx * 4);
   }
   if (ty < PY) {
-    // four pixels per iteration, all loads first: a single 16-byte load in flight per thread left these kernels at
-    // ~1 TB/s (latency-bound); the pixel coordinates advance incrementally instead of two divisions per load
-    constexpr int U = 4;
-    int px[U], py[U], pb[U];
+    int px[U], py[U];
+    int64_t ox[U], od[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int m = m0 + ty + u * PY;
+      const int m = blockIdx.x * step + ty + u * PY;
       px[u] = m % W;
       const int q = m / W;
       py[u] = q % H;
-      pb[u] = q / H;
+      ox[u] = (int64_t)(q / H) * xt.bs + (int64_t)py[u] * xt.rs + (int64_t)px[u] * xt.ps + tx * 4;
+      od[u] = BWD ? (int64_t)(q / H) * dt.bs + (int64_t)py[u] * dt.rs + (int64_t)px[u] * dt.ps + tx * 4 : 0;
     }
-    const int step = U * PY;
-    for (int mb = m0 + ty; mb < m1; mb += step) {
+    // one trip: all loads first, then the sums; GUARD = the last, partial trip (loads of the pixels past the end are
+    // redirected to stream 0's pixel, which is in range, and their values dropped)
+    auto trip = [&](const int mb, auto guard) {
+      constexpr bool GUARD = decltype(guard)::value;
       f32x4 v[U], g[U];
+      bool ok[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const bool ok = mb + u * PY < m1;
-        const int64_t ox = (int64_t)pb[u] * xt.bs + (int64_t)py[u] * xt.rs + (int64_t)px[u] * xt.ps;
-        v[u] = ok ? *reinterpret_cast<const f32x4*>(x + ox + tx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        if (MODE == 1 || MODE == 3) {
-          const int64_t od = (int64_t)pb[u] * dt.bs + (int64_t)py[u] * dt.rs + (int64_t)px[u] * dt.ps;
-          g[u] = ok ? *reinterpret_cast<const f32x4*>(dy + od + tx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        ok[u] = !GUARD || mb + u * PY < M;
+        v[u] = *reinterpret_cast<const f32x4*>(x + (ok[u] ? ox[u] : ox[0]));
+        if (BWD) g[u] = *reinterpret_cast<const f32x4*>(dy + (ok[u] ? od[u] : od[0]));
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (MODE == 0) {
+        if (!GUARD || ok[u]) {
+          if (MODE == 0) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) { s0[i] += v[u][i]; s1[i] += v[u][i] * v[u][i]; }
-        } else if (MODE == 2) {
+            for (int i = 0; i < 4; ++i) { s0[i] += v[u][i]; s1[i] += v[u][i] * v[u][i]; }
+          } else if (MODE == 2) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) s0[i] += v[u][i];
-        } else if (MODE == 4) {
+            for (int i = 0; i < 4; ++i) s0[i] += v[u][i];
+          } else if (MODE == 4) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) { s0[i] += v[u][i]; m0v[i] = fmaxf(m0v[i], fabsf(v[u][i])); }
-        } else {
+            for (int i = 0; i < 4; ++i) { s0[i] += v[u][i]; m0v[i] = fmaxf(m0v[i], fabsf(v[u][i])); }
+          } else {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float xh = (v[u][i] - mu[i]) * is[i];
-            const float pre = v[u][i] * ga[i] + be[i];      // ga = folded scale, be = folded shift: the forward's expression
-            const float gi = (!relu || pre > 0.f) ? g[u][i] : 0.f;
-            s0[i] += gi;
-            s1[i] += gi * xh;
-            if (MODE == 3) {                       // (out-of-range pixels load zeros: xh = -mean * invstd, a real value
-              m0v[i] = fmaxf(m0v[i], fabsf(gi));   //  of the bound's domain only if the channel has such a pixel - it
-              m1v[i] = fmaxf(m1v[i], fabsf(xh));   //  can only loosen the bound)
+            for (int i = 0; i < 4; ++i) {
+              const float xh = (v[u][i] - mu[i]) * is[i];
+              const float pre = v[u][i] * ga[i] + be[i];      // ga = folded scale, be = folded shift: the forward's expression
+              const float gi = (!relu || pre > 0.f) ? g[u][i] : 0.f;
+              s0[i] += gi;
+              s1[i] += gi * xh;
+              if (MODE == 3) {
+                m0v[i] = fmaxf(m0v[i], fabsf(gi));
+                m1v[i] = fmaxf(m1v[i], fabsf(xh));
+              }
             }
           }
         }
-        px[u] += step;                                       // next pixel of this stream
-        while (px[u] >= W) {
+        px[u] += sx;                                         // next chunk of this stream: + stride, two carries
+        py[u] += sy;
+        ox[u] += x_adv;
+        if (BWD) od[u] += d_adv;
+        if (px[u] >= W) {
           px[u] -= W;
-          if (++py[u] == H) { py[u] = 0; ++pb[u]; }
+          ++py[u];
+          ox[u] += x_row;
+          if (BWD) od[u] += d_row;
+        }
+        if (py[u] >= H) {
+          py[u] -= H;
+          ox[u] += x_img;
+          if (BWD) od[u] += d_img;
         }
       }
-    }
+    };
+    int mb = blockIdx.x * step + ty;
+    for (; mb + (U - 1) * PY < M; mb += stride) trip(mb, std::false_type{});
+    if (mb < M) trip(mb, std::true_type{});
   }
   red[0][threadIdx.x] = s0;
   red[1][threadIdx.x] = MODE == 4 ? m0v : s1;
@@ -863,6 +893,176 @@ __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* __restrict_
 
 inline unsigned nblk(int64_t total) { return (unsigned)((total + 255) / 256); }
 
+// ---- row forms of the two big elementwise passes (round 4) ---------------------------------------------------------
+// One workgroup per image row, thread = (pixel lane, group of 8 channels) walking the row in steps of 256 items: the
+// row base is uniform (scalar arithmetic), a thread's channel group never changes (256 is a multiple of C8), so the
+// per-channel constants are loaded ONCE per thread and an item's offsets are the previous item's plus a constant.
+// The one-item-per-thread forms above pay, per 32-48 bytes of traffic, four integer divisions, nine 64-bit multiplies
+// and twelve 16-byte loads of per-channel constants (and bn_bwd_apply_s16 an eight-barrier LDS reduction of the 256
+// amax slots in front of its first load).  Need C8 = 2^csh <= 256 and pixel strides below 2^24; else the forms above.
+// Measured in the batch-32 training step: bn_bwd_apply_s16 150 -> 129 us per launch on average (1.6 GB in 270 us =
+// 5.9 TB/s on the 256x256 level), scale_shift_act_s16 unchanged (it already ran at 5.8-6.2 TB/s).
+__global__ __launch_bounds__(256) void scale_shift_act_s16_rows_kernel(
+    const float* __restrict__ x, Tensor3 xt, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ res, Tensor3 rt, float* __restrict__ y32, float* __restrict__ y16, Tensor3 yt, int relu,
+    int H, int W, int csh) {
+  constexpr int U = 4;
+  const int row = blockIdx.x, b = row / H, yy = row - b * H;
+  const float* xr = x + (int64_t)b * xt.bs + (int64_t)yy * xt.rs;
+  const float* rr = res ? res + (int64_t)b * rt.bs + (int64_t)yy * rt.rs : nullptr;
+  const int64_t yrow = (int64_t)b * yt.bs + (int64_t)yy * yt.rs;
+  const int n = W << csh;
+  const int c8 = threadIdx.x & ((1 << csh) - 1), px0 = threadIdx.x >> csh, dpx = 256 >> csh;
+  const f32x4 sc0 = *reinterpret_cast<const f32x4*>(scale + c8 * 8), sc1 = *reinterpret_cast<const f32x4*>(scale + c8 * 8 + 4);
+  const f32x4 sh0 = *reinterpret_cast<const f32x4*>(shift + c8 * 8), sh1 = *reinterpret_cast<const f32x4*>(shift + c8 * 8 + 4);
+  int xo = px0 * (int)xt.ps + c8 * 8, ro = px0 * (int)rt.ps + c8 * 8, yo = px0 * (int)yt.ps + c8 * 8;
+  const int xd = dpx * (int)xt.ps, rd = dpx * (int)rt.ps, yd = dpx * (int)yt.ps;
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  for (int e = threadIdx.x; e < n; e += 256 * U) {
+    f32x4 v[U][2], r[U][2];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {                     // (items past the end of the row re-load item 0 and are dropped)
+      ok[u] = e + u * 256 < n;
+      const float* p = xr + (ok[u] ? xo + u * xd : xo);
+      v[u][0] = *reinterpret_cast<const f32x4*>(p);
+      v[u][1] = *reinterpret_cast<const f32x4*>(p + 4);
+      if (rr) {
+        const float* q = rr + (ok[u] ? ro + u * rd : ro);
+        r[u][0] = *reinterpret_cast<const f32x4*>(q);
+        r[u][1] = *reinterpret_cast<const f32x4*>(q + 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!ok[u]) continue;
+      float o[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float t0 = v[u][0][i] * sc0[i] + sh0[i], t1 = v[u][1][i] * sc1[i] + sh1[i];
+        if (relu) { t0 = t0 > 0.f ? t0 : 0.f; t1 = t1 > 0.f ? t1 : 0.f; }
+        if (rr) { t0 += r[u][0][i]; t1 += r[u][1][i]; }
+        o[i] = t0;
+        o[4 + i] = t1;
+      }
+      const int64_t oo = yrow + yo + u * yd;
+      if (y32) {
+        *reinterpret_cast<f32x4*>(y32 + oo) = f32x4{o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<f32x4*>(y32 + oo + 4) = f32x4{o[4], o[5], o[6], o[7]};
+      }
+      f16x8 hi, lo;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const _Float16 hv = (_Float16)o[i];
+        hi[i] = hv;
+        lo[i] = (_Float16)((o[i] - (float)hv) * 2048.f);
+      }
+      *reinterpret_cast<f16x8*>(y16 + oo) = hi;
+      *reinterpret_cast<f16x8*>(y16 + oo + 4) = lo;
+    }
+    xo += U * xd;
+    ro += U * rd;
+    yo += U * yd;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_s16_rows_kernel(
+    const float* __restrict__ c, Tensor3 ct, const float* __restrict__ dy, Tensor3 dt,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ sums, float inv_count, int relu,
+    float* __restrict__ dc16, float* __restrict__ dc32, Tensor3 ot, int H, int W, int csh,
+    const int* __restrict__ amax_bits, float* __restrict__ inv_scale, int n_inv) {
+  constexpr int U = 4;
+  __shared__ int red[4];
+  const int row = blockIdx.x, b = row / H, yy = row - b * H;
+  const float* cr = c + (int64_t)b * ct.bs + (int64_t)yy * ct.rs;
+  const float* gr = dy + (int64_t)b * dt.bs + (int64_t)yy * dt.rs;
+  const int64_t orow = (int64_t)b * ot.bs + (int64_t)yy * ot.rs;
+  const int n = W << csh;
+  const int C = 8 << csh;
+  const int c8 = threadIdx.x & ((1 << csh) - 1), px0 = threadIdx.x >> csh, dpx = 256 >> csh;
+  int co = px0 * (int)ct.ps + c8 * 8, go = px0 * (int)dt.ps + c8 * 8, oo = px0 * (int)ot.ps + c8 * 8;
+  const int cd = dpx * (int)ct.ps, gd = dpx * (int)dt.ps, od = dpx * (int)ot.ps;
+  // the power of two from the 256 amax slots: one slot per thread, a maximum per wave by shuffles, four values through LDS
+  int am = amax_bits[threadIdx.x];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) am = max(am, __shfl_xor(am, off));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = am;
+  // per-channel constants, loaded once (the arithmetic below is the one-item form's, operation for operation)
+  f32x4 mu[2], is[2], ga[2], be[2], sg[2], sgx[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int cc = c8 * 8 + h * 4;
+    mu[h] = *reinterpret_cast<const f32x4*>(mean + cc);
+    is[h] = *reinterpret_cast<const f32x4*>(invstd + cc);
+    ga[h] = *reinterpret_cast<const f32x4*>(gamma + cc);
+    be[h] = *reinterpret_cast<const f32x4*>(beta + cc);
+    sg[h] = *reinterpret_cast<const f32x4*>(sums + cc);
+    sgx[h] = *reinterpret_cast<const f32x4*>(sums + C + cc);
+  }
+  __syncthreads();
+  const float f = tk_pow2_to_1024(max(max(red[0], red[1]), max(red[2], red[3])));
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < n_inv; i += 256) inv_scale[i] = 1.f / f;
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  for (int e = threadIdx.x; e < n; e += 256 * U) {
+    f32x4 v[U][2], g[U][2];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ok[u] = e + u * 256 < n;
+      const float* p = cr + (ok[u] ? co + u * cd : co);
+      const float* q = gr + (ok[u] ? go + u * gd : go);
+      v[u][0] = *reinterpret_cast<const f32x4*>(p);
+      v[u][1] = *reinterpret_cast<const f32x4*>(p + 4);
+      g[u][0] = *reinterpret_cast<const f32x4*>(q);
+      g[u][1] = *reinterpret_cast<const f32x4*>(q + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!ok[u]) continue;
+      float o[8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float xh = (v[u][h][i] - mu[h][i]) * is[h][i];
+          const float pre = v[u][h][i] * ga[h][i] + be[h][i];
+          const float gi = (!relu || pre > 0.f) ? g[u][h][i] : 0.f;
+          o[h * 4 + i] = ga[h][i] * (gi - sg[h][i] * inv_count - xh * sgx[h][i] * inv_count);
+        }
+      const int64_t op = orow + oo + u * od;
+      if (dc32) {
+        *reinterpret_cast<f32x4*>(dc32 + op) = f32x4{o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<f32x4*>(dc32 + op + 4) = f32x4{o[4], o[5], o[6], o[7]};
+      }
+      f16x8 hi, lo;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float w = o[i] * f;
+        const _Float16 hv = (_Float16)w;
+        hi[i] = hv;
+        lo[i] = (_Float16)((w - (float)hv) * 2048.f);
+      }
+      *reinterpret_cast<f16x8*>(dc16 + op) = hi;
+      *reinterpret_cast<f16x8*>(dc16 + op + 4) = lo;
+    }
+    co += U * cd;
+    go += U * gd;
+    oo += U * od;
+  }
+}
+
+// csh = log2(C8) when the row forms apply (AMMC_ROW_KERNELS=0 switches them off for A/Bs), else -1
+static int rows_csh(int c8, int64_t ps_a, int64_t ps_b, int64_t ps_c, int w) {
+  static const int on = getenv("AMMC_ROW_KERNELS") ? atoi(getenv("AMMC_ROW_KERNELS")) != 0 : 1;
+  if (!on || c8 <= 0 || (c8 & (c8 - 1)) || c8 > 256) return -1;
+  const int64_t lim = 1 << 24;
+  if (ps_a >= lim || ps_b >= lim || ps_c >= lim || ps_a < 0 || ps_b < 0 || ps_c < 0) return -1;
+  if ((int64_t)w * (ps_a > ps_b ? (ps_a > ps_c ? ps_a : ps_c) : (ps_b > ps_c ? ps_b : ps_c)) >= (1LL << 31)) return -1;
+  return __builtin_ctz((unsigned)c8);
+}
+
 }  // namespace ammc_impl
 using namespace ammc_impl;
 
@@ -916,8 +1116,13 @@ int ammc_scale_shift_act_s16_f32(const float* x, int64_t x_bs, int64_t x_rs, int
     return AMMC_EINVAL;
   const int M = batch * h * w;
   Tensor3 xt{x_bs, x_rs, x_ps}, rt{r_bs, r_rs, r_ps}, yt{y_bs, y_rs, y_ps};
-  hipLaunchKernelGGL(scale_shift_act_s16_kernel, dim3(nblk((int64_t)M * (c >> 3))), dim3(256), 0, (hipStream_t)stream,
-                     x, xt, scale, shift, res, rt, y32, y16, yt, relu, M, h, w, c >> 3);
+  const int csh = rows_csh(c >> 3, x_ps, res ? r_ps : 0, y_ps, w);
+  if (csh >= 0)
+    hipLaunchKernelGGL(scale_shift_act_s16_rows_kernel, dim3(batch * h), dim3(256), 0, (hipStream_t)stream, x, xt, scale, shift,
+                       res, rt, y32, y16, yt, relu, h, w, csh);
+  else
+    hipLaunchKernelGGL(scale_shift_act_s16_kernel, dim3(nblk((int64_t)M * (c >> 3))), dim3(256), 0, (hipStream_t)stream,
+                       x, xt, scale, shift, res, rt, y32, y16, yt, relu, M, h, w, c >> 3);
   return ammc_launch_status();
 }
 
@@ -977,9 +1182,14 @@ int ammc_bn_bwd_apply_s16_f32(const float* c_raw, int64_t c_bs, int64_t c_rs, in
     return AMMC_EINVAL;
   const int M = batch * h * w;
   Tensor3 ct{c_bs, c_rs, c_ps}, dt{d_bs, d_rs, d_ps}, ot{o_bs, o_rs, o_ps};
-  hipLaunchKernelGGL(bn_bwd_apply_s16_kernel, dim3(nblk((int64_t)M * (c >> 3))), dim3(256), 0, (hipStream_t)stream, c_raw,
-                     ct, dy, dt, mean, invstd, gamma, beta, sums, 1.f / (float)M, relu, dc16, dc32, ot, M, h, w, c >> 3,
-                     amax_bits, inv_scale, n_inv);
+  const int csh = rows_csh(c >> 3, c_ps, d_ps, o_ps, w);
+  if (csh >= 0)
+    hipLaunchKernelGGL(bn_bwd_apply_s16_rows_kernel, dim3(batch * h), dim3(256), 0, (hipStream_t)stream, c_raw, ct, dy, dt, mean,
+                       invstd, gamma, beta, sums, 1.f / (float)M, relu, dc16, dc32, ot, h, w, csh, amax_bits, inv_scale, n_inv);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_s16_kernel, dim3(nblk((int64_t)M * (c >> 3))), dim3(256), 0, (hipStream_t)stream, c_raw,
+                       ct, dy, dt, mean, invstd, gamma, beta, sums, 1.f / (float)M, relu, dc16, dc32, ot, M, h, w, c >> 3,
+                       amax_bits, inv_scale, n_inv);
   return ammc_launch_status();
 }
 
