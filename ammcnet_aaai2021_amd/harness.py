@@ -165,6 +165,15 @@ def generator_loss(out, rgb_t: torch.Tensor, op_t: torch.Tensor, lam_lp: float =
     return lam_lp * l_rgb + lam_lp_op * l_op + lam_latent * (rd + od).sum()
 
 
+def adam(params, lr: float, **kw) -> torch.optim.Adam:
+    """the reference's optimizer (`torch.optim.Adam(params, lr=...)`, optimizer/__init__.py:39-49) - the same update
+    rule in torch's FUSED form when the parameters live on the GPU: one multi-tensor launch per ~chunk of parameters
+    instead of the ~17 elementwise launches of the default foreach form (0.48 -> ~0.15 ms per batch-32 step)"""
+    params = list(params)
+    fused = bool(params) and all(p.is_cuda for p in params)
+    return torch.optim.Adam(params, lr=lr, fused=fused, **kw)
+
+
 def train_step(model: torch.nn.Module, optimizer: torch.optim.Optimizer, rgb: torch.Tensor, op: torch.Tensor,
                **lams) -> torch.Tensor:
     """one G step of the joint training loop (train_helper.py:296-339 without D / FlowNet terms).

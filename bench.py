@@ -399,7 +399,7 @@ def run_train(args, rank, world, dev, dist, steps, warmup, with_cpu):
         parallel.attach_reducer(net, parallel.BucketedGradReducer())
         if getattr(args, "sync_stats", False):
             parallel.sync_statistics(net, True)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    opt = harness.adam(net.parameters(), lr=1e-4)
     # rank 0 trains on the clips of the reference-recorded fixture of this batch / frame size when there is one, so that
     # the TIMED model's own first step is checked (as run_infer does); every other rank on its own clips (weak scaling)
     fixture = train_fixture_for(batch, args.size) if rank == 0 else None
@@ -506,8 +506,8 @@ def run_train_gan(args, dev, steps, warmup):
     F2.load_state_dict(S.make_flownet2sd_state())
     F2 = F2.to(dev).eval()
     flow_fn = harness.flownet_flow_fn(F2)
-    opt_g = torch.optim.Adam(G.parameters(), lr=2e-4)
-    opt_d = torch.optim.Adam(D.parameters(), lr=2e-5)
+    opt_g = harness.adam(G.parameters(), lr=2e-4)
+    opt_d = harness.adam(D.parameters(), lr=2e-5)
     path = os.path.join(ROOT, "tests", "golden", f"gan_{size}_b{batch}_iteration.npz")
     fx = np.load(path) if os.path.exists(path) else None
     cfg = json.loads(str(fx["cfg"])) if fx is not None else None

@@ -212,6 +212,29 @@ def test_unetmem_and_unet_train_step():
     assert not bad, bad
 
 
+def test_harness_adam_is_torch_adam_in_fused_form():
+    """`harness.adam` (what the bench's training legs step with) = the reference's `torch.optim.Adam(params, lr)`:
+    same parameters after three steps as the default (foreach) form, up to fp32 rounding of the reordered update"""
+    from ammcnet_aaai2021_amd import harness
+    g = torch.Generator().manual_seed(5)
+    shapes = [(64, 12, 3, 3), (64,), (128, 64, 3, 3), (256, 512), (3,)]
+    init = [torch.randn(sh, generator=g) for sh in shapes]
+    grads = [[torch.randn(sh, generator=g) * 10.0 ** (-k) for sh in shapes] for k in range(3)]
+    outs = []
+    for make in (lambda ps: harness.adam(ps, lr=1e-3), lambda ps: torch.optim.Adam(ps, lr=1e-3)):
+        ps = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+        opt = make(ps)
+        for gs in grads:
+            for p_, g_ in zip(ps, gs):
+                p_.grad = g_.clone().to(DEV)
+            opt.step()
+        outs.append([p_.detach().cpu() for p_ in ps])
+    assert harness.adam([torch.nn.Parameter(init[0].clone().to(DEV))], lr=1e-3).defaults["fused"] is True
+    for a, b, t0 in zip(outs[0], outs[1], init):
+        assert float((a - b).abs().max()) <= 5e-7 * max(1.0, float(t0.abs().max())), float((a - b).abs().max())
+        assert float((a - t0).abs().max()) > 1e-4            # (the steps did move the parameters)
+
+
 def test_adam_steps_track_the_oracle():
     """three optimiser steps end to end (weights change -> filters are re-packed every step)"""
     sd = S.make_twostream_state()

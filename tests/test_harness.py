@@ -140,3 +140,13 @@ def test_checkpoint_tooling_follows_the_reference_conventions(tmp_path):
     for k, v in got.items():
         src = want if k.startswith("bridge.") else sa
         assert torch.equal(v, src[k]), k
+
+
+def test_adam_helper_on_cpu_parameters_is_plain_adam():
+    from ammcnet_aaai2021_amd import harness
+    p = torch.nn.Parameter(torch.ones(4))
+    opt = harness.adam([p], lr=1e-2)
+    assert isinstance(opt, torch.optim.Adam) and not opt.defaults["fused"] and opt.defaults["lr"] == 1e-2
+    p.grad = torch.ones(4)
+    opt.step()
+    assert torch.allclose(p.detach(), torch.full((4,), 0.99), atol=1e-6)
