@@ -22,6 +22,7 @@
 // tile in LDS).  fp32 outputs (`y_f32`: the encoder output that feeds the memory kernel, the NCHW `outc` frames, the
 // training path) store two fp32 quads per 8 channels, or one pixel per lane along an NCHW row.
 #include "ammc_common.h"
+#include <string.h>
 #include <hip/hip_fp16.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -685,7 +686,7 @@ static int conv_gemm_s16_dispatch(const AmmcConvDesc* desc, void* stream, char* 
     const int rc = conv_tap_s16_try(d, a.kpad, s, label, label_len);
     if (rc != -12345) return rc;
   }
-  if (d.pool_y) return AMMC_EUNSUP;                 // the fused max-pool output exists in the halo-patch kernel only
+  if (d.pool_y || d.stats) return AMMC_EUNSUP;      // the fused max-pool / statistics outputs exist in the halo-patch kernel only
   // split-K for layers that cannot fill the chip (small batch: 32x32 / 64x64 levels with K up to 4608): each K
   // slice is its own workgroup writing an fp32 partial tile; a streaming kernel sums the slices and finishes
   if (d.splitk_ws && !d.y_f32 && d.up == 1 && d.n % 128 == 0 && a.nchunks >= 16) {
@@ -719,6 +720,21 @@ extern "C" int ammc_conv_gemm_s16_variant(const AmmcConvDesc* desc, char* out, i
   if (!out || out_len < 48) return AMMC_EINVAL;
   out[0] = 0;
   return conv_gemm_s16_dispatch(desc, nullptr, out, out_len);
+}
+
+namespace ammc_s16 {
+int conv_tap_s16_stat_rows(const AmmcConvDesc& d);       // conv_tap_s16.hip
+}
+
+extern "C" int ammc_conv_gemm_s16_stats_rows(const AmmcConvDesc* desc) {
+  if (!desc) return 0;
+  AmmcConvDesc d = *desc;
+  static float dummy[8];
+  d.stats = dummy;                                   // never written: the dispatch below only produces the label
+  char label[96];
+  label[0] = 0;
+  if (conv_gemm_s16_dispatch(&d, nullptr, label, (int)sizeof(label)) != AMMC_OK) return 0;
+  return strstr(label, "+stats") ? conv_tap_s16_stat_rows(d) : 0;
 }
 
 extern "C" int ammc_split_rows_f32(const float* src, int64_t count, float* dst, void* stream) {

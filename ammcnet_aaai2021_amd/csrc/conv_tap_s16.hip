@@ -90,6 +90,31 @@ constexpr int T_APIECES = T_HP * 8;                                             
 // class that runs at the higher wave priority (see below).
 //
 // KH = 1 (4-wave, one patch stage, 32x32x16): the k-half-major software pipeline, see "KH" below.
+// Sums of eight registers over the 32 lanes of each half of the wave (an accumulator register holds 32 pixels of one
+// channel), valid in lanes 31 and 63: four row_shr steps leave each 16-lane row's total in its lane 15, row_bcast15
+// adds it into the next row.  v_add_f32 with DPP modifiers - no LDS crossbar traffic, unlike __shfl - written in asm,
+// one step of all eight registers after the other: from __builtin_amdgcn_update_dpp hipcc makes a v_mov_b32_dpp AND an
+// add per step, and a DPP read needs two wait states behind the VALU write of its source, which eight independent
+// chains hide (the s_nop covers the writes in front of the block).
+__device__ __forceinline__ void tap_half_sums32(f32x4& a, f32x4& b) {
+  float v0 = a[0], v1 = a[1], v2 = a[2], v3 = a[3], v4 = b[0], v5 = b[1], v6 = b[2], v7 = b[3];
+#define TAP_DPP_STEP(mod_)                                                                                            \
+  "v_add_f32_dpp %0, %0, %0 " mod_ "\n v_add_f32_dpp %1, %1, %1 " mod_ "\n v_add_f32_dpp %2, %2, %2 " mod_              \
+  "\n v_add_f32_dpp %3, %3, %3 " mod_ "\n v_add_f32_dpp %4, %4, %4 " mod_ "\n v_add_f32_dpp %5, %5, %5 " mod_          \
+  "\n v_add_f32_dpp %6, %6, %6 " mod_ "\n v_add_f32_dpp %7, %7, %7 " mod_ "\n"
+  asm volatile("s_nop 1\n"
+               TAP_DPP_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+               TAP_DPP_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+               TAP_DPP_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+               TAP_DPP_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+               TAP_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+               "s_nop 1"
+               : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));
+#undef TAP_DPP_STEP
+  a = f32x4{v0, v1, v2, v3};
+  b = f32x4{v4, v5, v6, v7};
+}
+
 template <int WGM, int WGN, int TM, int TN, int AS, int MF, int KH = 0>
 __device__ __forceinline__ void conv_tap_s16_tile(const TapArgs& a, const int vb, const int nvb, const bool hiprio) {
   static_assert((WGM * WGN == 8 || WGM * WGN == 4) && WGM * TM == T_TH, "4 or 8 waves, 8 image rows");
@@ -774,6 +799,16 @@ __device__ __forceinline__ void conv_tap_s16_tile(const TapArgs& a, const int vb
     const int nstore = d.n_store > 0 ? d.n_store : d.n;
     const int64_t ycs = d.y_cs > 0 ? d.y_cs : 1;
     float sq0 = 0.f;
+    // d.stats (training-mode BatchNorm): per-channel sum / sum of squares of the values this workgroup stores, so that
+    // no pass re-reads the tensor for them.  A register is 32 pixels of one channel: the rows of the wave are added
+    // in the lane, the lanes by DPP (tap_half_sum32), lanes 31 / 63 park the wave's totals in LDS - the stages are
+    // dead by now: every wave has waited for its last DMA and is past its last fragment read once the barrier falls -
+    // and after a second barrier the waves' rows are added in a fixed order and leave as one row of stats[patch][2][n].
+    float* const St = smem;                                     // [WGM][2][BN]
+    if (d.stats) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -782,6 +817,7 @@ __device__ __forceinline__ void conv_tap_s16_tile(const TapArgs& a, const int vb
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
         if (d.scale) sc = *reinterpret_cast<const f32x4*>(SCs + c0 - n0);
         if (d.shift) sh = *reinterpret_cast<const f32x4*>(SCs + BN + c0 - n0);
+        f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           f32x4 v;
@@ -791,6 +827,8 @@ __device__ __forceinline__ void conv_tap_s16_tile(const TapArgs& a, const int vb
             if (d.act == AMMC_ACT_RELU) t = t > 0.f ? t : 0.f;
             else if (d.act == AMMC_ACT_TANH) t = tanhf(t);
             v[k] = t;
+            st1[k] += t;
+            st2[k] += t * t;
           }
           if (d.res) {                                          // fp32 outputs take an fp32 NHWC residual
             const f32x4 rv = *reinterpret_cast<const f32x4*>(d.res + r_pix[i] + c0);
@@ -813,12 +851,30 @@ __device__ __forceinline__ void conv_tap_s16_tile(const TapArgs& a, const int vb
               }
           }
         }
+        if (d.stats) {
+          tap_half_sums32(st1, st2);
+          if (l31 == 31) {
+            *reinterpret_cast<f32x4*>(St + (wm * 2) * BN + (c0 - n0)) = st1;
+            *reinterpret_cast<f32x4*>(St + (wm * 2 + 1) * BN + (c0 - n0)) = st2;
+          }
+        }
       }
     }
     if (d.sq_target) {
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) sq0 += __shfl_xor(sq0, off);
       if (lane == 0) unsafeAtomicAdd(d.sq_acc + b, sq0);
+    }
+    if (d.stats) {
+      __syncthreads();
+      float* const row = d.stats + (int64_t)(logical / a.n_tiles) * 2 * d.n + n0;
+      for (int t = tid; t < 2 * BN; t += NT) {
+        const int which = t / BN, cl = t - which * BN;
+        float acc = St[which * BN + cl];
+#pragma unroll
+        for (int w = 1; w < WGM; ++w) acc += St[(w * 2 + which) * BN + cl];
+        row[(int64_t)which * d.n + cl] = acc;
+      }
     }
     return;
   }
@@ -917,9 +973,12 @@ __global__ TAP_BOUNDS void conv_tap_s16_kernel(TapArgs a) {
 
 template <int WGM, int WGN, int TM, int TN, int AS = 2, int MF = 0, int KH = 0>
 static int launch_tap(const TapArgs& a, hipStream_t stream, char* label, int label_len) {
+  // the statistics epilogue exists in the 32x32x16 form's fp32 store of plain layers (what a training forward launches)
+  if (a.d.stats && (MF != 0 || !a.d.y_f32 || a.d.act != AMMC_ACT_NONE || a.d.res || a.d.sq_target || a.d.n_store || a.d.y_cs > 1))
+    return AMMC_EUNSUP;
   if (label) {                                     // the name rocprofv3 prints for this instance
-    if (KH) snprintf(label, label_len, "conv_tap_s16<%d, %d, %d, %d, %d, %d, %d>", WGM, WGN, TM, TN, AS, MF, KH);
-    else snprintf(label, label_len, "conv_tap_s16<%d, %d, %d, %d, %d, %d>", WGM, WGN, TM, TN, AS, MF);
+    if (KH) snprintf(label, label_len, "conv_tap_s16<%d, %d, %d, %d, %d, %d, %d>%s", WGM, WGN, TM, TN, AS, MF, KH, a.d.stats ? "+stats" : "");
+    else snprintf(label, label_len, "conv_tap_s16<%d, %d, %d, %d, %d, %d>%s", WGM, WGN, TM, TN, AS, MF, a.d.stats ? "+stats" : "");
     return AMMC_OK;
   }
   constexpr int BN = WGN * TN * 32;
@@ -944,6 +1003,9 @@ static int launch_tap(const TapArgs& a, hipStream_t stream, char* label, int lab
 }
 
 int conv_outc_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream, char* label, int label_len);
+
+// rows of AmmcConvDesc::stats: one per output patch
+int conv_tap_s16_stat_rows(const AmmcConvDesc& d) { return d.batch * (d.height / T_TH) * (d.width / T_TW); }
 
 // Called by ammc_conv_gemm_s16 (conv_gemm_s16.hip) after its argument checks.  Returns TAP_SKIP when the descriptor is
 // not this kernel's case (the caller then runs the implicit-GEMM kernel), else the launch status.
@@ -985,7 +1047,7 @@ int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream, char* 
   const int mf = mfo < 0 ? (wide4 ? 0 : 1) : mfo;
   // the output layer (2-3 filters, fp32 NCHW + tanh): 4 waves, 52 KB of LDS, THREE workgroups per CU (124 us against
   // 128 for the 8-wave form at two per CU; the layer waits for its 45-KB patches, not for the matrix pipe)
-  if (d.n == 32) {
+  if (d.n == 32 && !d.stats) {
     const int rc = conv_outc_s16_try(d, kpad, stream, label, label_len);      // the streaming form (conv_outc_s16.hip)
     if (rc != TAP_SKIP) return rc;
   }

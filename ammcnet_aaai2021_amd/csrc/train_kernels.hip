@@ -234,9 +234,17 @@ __device__ __forceinline__ void column_sums(const float* __restrict__ partial, i
   ss = red[1][0][cl];
 }
 
+// seg_rows > 0: blockIdx.y = a run of seg_rows rows -> out[blockIdx.y][QC] (the first of two stages when a convolution's
+// statistics epilogue leaves thousands of rows: with QC / 8 workgroups alone, 8192 rows took 58 us)
 __global__ __launch_bounds__(RP_THREADS) void reduce_partials_kernel(const float* __restrict__ partial, int nblk, int QC,
-                                                              float scale, float* __restrict__ out) {
+                                                              float scale, float* __restrict__ out, int seg_rows) {
   __shared__ double red[2][RP_SLICES][RP_COLS];
+  if (seg_rows > 0) {
+    const int r0 = blockIdx.y * seg_rows;
+    partial += (int64_t)r0 * QC;
+    out += (int64_t)blockIdx.y * QC;
+    nblk = min(seg_rows, nblk - r0);
+  }
   const int i = blockIdx.x * RP_COLS + threadIdx.x % RP_COLS;
   double s, ss;
   column_sums(partial, nblk, QC, i, i < QC, 0, red, s, ss);
@@ -1228,7 +1236,16 @@ int ammc_split_scaled_strided_f32(const float* x, int64_t x_bs, int64_t x_rs, in
 int ammc_reduce_partials_f32(const float* partial, int32_t nblocks, int32_t qc, float scale, float* out, void* stream) {
   if (!partial || !out || nblocks <= 0 || qc <= 0) return AMMC_EINVAL;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((qc + RP_COLS - 1) / RP_COLS), dim3(RP_THREADS), 0, (hipStream_t)stream, partial, nblocks, qc,
-                     scale, out);
+                     scale, out, 0);
+  return ammc_launch_status();
+}
+
+int ammc_reduce_partials_seg_f32(const float* partial, int32_t nblocks, int32_t qc, int32_t seg_rows, float* out, void* stream) {
+  if (!partial || !out || nblocks <= 0 || qc <= 0 || seg_rows <= 0) return AMMC_EINVAL;
+  const int nseg = (nblocks + seg_rows - 1) / seg_rows;
+  if (nseg > 65535) return AMMC_EUNSUP;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((qc + RP_COLS - 1) / RP_COLS, nseg), dim3(RP_THREADS), 0, (hipStream_t)stream, partial,
+                     nblocks, qc, 1.f, out, seg_rows);
   return ammc_launch_status();
 }
 

@@ -49,6 +49,10 @@ CONVT_GRADS_S16 = os.environ.get("AMMC_CONVT_GRADS_S16", "1") != "0"
 # all 3x3 filters of a step packed to their S16 images by ONE launch per direction (ammc_pack_filters_s16) instead of a
 # pack and a split launch per layer and direction (~140 launches of 5-8 us per step)
 PACK_BATCH = os.environ.get("AMMC_PACK_BATCH", "1") != "0"
+# BatchNorm batch statistics as a second output of the convolution that produces the tensor (AmmcConvDesc.stats: one
+# partial row per 8 x 32 output patch, from the accumulators) instead of a pass that re-reads it
+FUSE_BN_STATS = os.environ.get("AMMC_FUSE_BN_STATS", "1") != "0"
+STAT_SEG = 128
 MID_S16 = os.environ.get("AMMC_MID_S16", "1") != "0"              # double_conv middle activations exist as S16 only
 FUSE_BN_BWD = os.environ.get("AMMC_FUSE_BN_BWD", "1") != "0"      # BN backward writes the S16 twin of dc (one rank)
 
@@ -218,7 +222,7 @@ class _Ops:
 
     def conv_s16(self, x: Act, w: torch.Tensor, y: Act, *, ntaps, cin, n, res: Optional[Act] = None, what="conv",
                  rescale: bool = False, pre=None, shift=None, up=1, cgroup=None, x_step=1, y_s16: bool = False,
-                 w16: Optional[torch.Tensor] = None):
+                 w16: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None):
         """3x3 conv on the split-fp16 MFMA kernels: x (fp32, any channel slice of its buffer) is re-encoded into its S16
         twin (or `pre` = what `to_s16` returned for it), the packed filter likewise; fp32 output (+ fp32 residual), or -
         `y_s16`: y is the S16 twin itself - an S16 output.  ammc_conv_gemm_s16 picks the kernel."""
@@ -240,10 +244,22 @@ class _Ops:
         d.y_bs, d.y_rs, d.y_ps = y.strides
         if res is not None:
             d.r_bs, d.r_rs, d.r_ps = res.strides
+        d.stats = _ptr(stats) if stats is not None else None
         # (fp32 outputs: no S16 range flag here - an operand beyond the half range becomes inf in `to_s16` and the
         # loss turns non-finite, which the training loop sees)
-        self._mfma_launch(lambda: s16_variant(d), 2.0 * d.batch * d.height * d.width * ntaps * cin * n,
+        self._mfma_launch(lambda: s16_variant(d).replace("+stats", ""), 2.0 * d.batch * d.height * d.width * ntaps * cin * n,
                           lambda: lib.ammc_conv_gemm_s16(C.byref(d), s), what)
+
+    def conv_s16_stats_rows(self, x: Act, w: torch.Tensor, y: Act, *, cin, n) -> int:
+        """rows of the statistics output (`AmmcConvDesc.stats`) of the kernel `conv_s16` would launch for this 3x3 layer
+        with an fp32 output, 0 when that kernel has no statistics epilogue"""
+        d = AmmcConvDesc()
+        d.x, d.w, d.y = x.tap0(), _ptr(w), y.pix0()           # (addresses are only checked for alignment)
+        d.batch, d.height, d.width = y.B, y.H, y.W
+        d.cin, d.ntaps, d.n, d.up, d.act, d.y_f32, d.x_step, d.cgroup = cin, 9, n, 1, ACT_NONE, 1, 1, n
+        d.x_bs, d.x_rs, d.x_ps = x.strides
+        d.y_bs, d.y_rs, d.y_ps = y.strides
+        return int(self.lib.ammc_conv_gemm_s16_stats_rows(C.byref(d)))
 
     @property
     def sync_world(self) -> int:
@@ -355,6 +371,12 @@ class _ConvBN:
         self.scale, self.shift = ws.buf(self.cout), ws.buf(self.cout)
         self.nblk = ops.lib.ammc_chan_reduce_blocks(x.B * x.H * x.W)
         self.partial = ws.buf(self.nblk, 4, self.cout)               # Q = 2 sums (+ 2 maxima in the fused S16 backward)
+        # forward statistics from the convolution's own epilogue where its kernel has one (FUSE_BN_STATS)
+        self.stat_rows = (ops.conv_s16_stats_rows(x, self.wp, self.craw, cin=self.cin_p, n=self.cout)
+                          if ops.s16 and self.cin_p >= 8 and FUSE_BN_STATS else 0)
+        self.stat_partial = ws.buf(self.stat_rows, 2, self.cout) if self.stat_rows else None
+        # thousands of rows (8192 at batch 32, 256x256) are first combined in runs of STAT_SEG by many workgroups
+        self.stat_seg = ws.buf((self.stat_rows + STAT_SEG - 1) // STAT_SEG, 2, self.cout) if self.stat_rows > 1024 else None
         # backward
         self.dc = ws.act(x.B, x.H, x.W, self.cout)
         self.dwp = ws.zbuf(self.cout, self.kpad)
@@ -383,18 +405,25 @@ class _ConvBN:
             _chk(lib.ammc_pack_conv_weight_f32(_ptr(w), self.cout, self.cin, 3, self.cin_p, _ptr(self.wp), s), "pack")
         if o.s16 and self.cin_p >= 8:
             o.conv_s16(self.x, self.wp, self.craw, ntaps=9, cin=self.cin_p, n=self.cout, what=self.name,
-                       pre=(o.shadow(self.x), None) if self.x_is_s16 else None, w16=self.w16 if batched else None)
+                       pre=(o.shadow(self.x), None) if self.x_is_s16 else None, w16=self.w16 if batched else None,
+                       stats=self.stat_partial)
         else:
             o.conv(self.x, self.wp, self.craw, ntaps=9, cin=self.cin_p, n=self.cout, what=self.name)
         c = self.craw
-        _chk(lib.ammc_bn_stats_f32(c.pix0(), *c.strides, c.B, c.H, c.W, self.cout, _ptr(self.partial), s), "bn_stats")
         bn = self.bn
         part, nblk, count = self.partial, self.nblk, float(c.B * c.H * c.W)
+        if self.stat_rows:
+            part, nblk = self.stat_partial, self.stat_rows          # written by the convolution
+            if self.stat_seg is not None:
+                _chk(lib.ammc_reduce_partials_seg_f32(_ptr(part), nblk, 2 * self.cout, STAT_SEG, _ptr(self.stat_seg), s), "reduce_seg")
+                part, nblk = self.stat_seg, self.stat_seg.shape[0]
+        else:
+            _chk(lib.ammc_bn_stats_f32(c.pix0(), *c.strides, c.B, c.H, c.W, self.cout, _ptr(self.partial), s), "bn_stats")
         world = o.sync_world
         if o.sync_on:
             # synchronised statistics: [2C] sums of every rank are added, the finalizer sees the global batch
             tot = torch.empty(2 * self.cout, device=o.dev, dtype=torch.float32)
-            _chk(lib.ammc_reduce_partials_f32(_ptr(self.partial), self.nblk, 2 * self.cout, 1.0, _ptr(tot), s), "reduce")
+            _chk(lib.ammc_reduce_partials_f32(_ptr(part), nblk, 2 * self.cout, 1.0, _ptr(tot), s), "reduce")
             yield tot                                           # summed over the ranks by `_lockstep`
             part, nblk, count = tot, 1, count * world
         _chk(lib.ammc_bn_finalize_f32(_ptr(part), nblk, self.cout, count,

@@ -112,6 +112,10 @@ typedef struct AmmcConvDesc {
   int64_t pool_bs, pool_rs, pool_ps; /* == 0, H % 8 == 0, >= 192 patches; no residual), may be NULL: also store the 2x2   */
                           /* max-pooled output (nn.MaxPool2d(2) of the `down` block that follows, unet.py:36) at half     */
                           /* resolution; AMMC_EUNSUP when the layer is not that kernel's                                  */
+  float* stats;           /* ammc_conv_gemm_s16, fp32 outputs, may be NULL: per-channel sum and sum of squares of the STORED    */
+                          /* values of every output patch, stats[patch][2][n] - the partial rows ammc_bn_finalize_f32 combines */
+                          /* (training-mode BatchNorm2d statistics, models/unet.py:12,15, without re-reading the tensor);      */
+                          /* rows = ammc_conv_gemm_s16_stats_rows(desc), AMMC_EUNSUP when that is 0                            */
 } AmmcConvDesc;
 
 int ammc_conv_gemm_f32(const AmmcConvDesc* desc, void* stream);
@@ -212,6 +216,10 @@ int ammc_conv_first_s16(const float* x_nchw, int32_t batch, int32_t c, int32_t h
  * argument checks and the same dispatch code run with the launch replaced by the label.  Tests pin kernel coverage on
  * it and bench.py labels its per-kernel timings with it. */
 int ammc_conv_gemm_s16_variant(const AmmcConvDesc* desc, char* out, int32_t out_len);
+/* Rows of `desc->stats` the kernel ammc_conv_gemm_s16 would launch for this descriptor writes (one per 8 x 32 output
+ * patch), or 0 when that kernel has no statistics epilogue (the caller then runs ammc_bn_stats_f32 on the output as
+ * before).  `desc->stats` itself is ignored here.  Same argument checks and dispatch code as the launch. */
+int ammc_conv_gemm_s16_stats_rows(const AmmcConvDesc* desc);
 /* fp32 -> S16, count elements (multiple of 8): packed filters, gathered codebook rows */
 int ammc_split_rows_f32(const float* src, int64_t count, float* dst, void* stream);
 /* Gradient tensors as S16 operands (what autograd derives for the 3x3 convs, train_helper.py:337-339): the largest
@@ -397,6 +405,9 @@ int ammc_split_scaled_strided_f32(const float* x, int64_t x_bs, int64_t x_rs, in
                                   int64_t y_rs, int64_t y_ps, int32_t batch, int32_t h, int32_t w, int32_t c,
                                   const int32_t* amax_bits, float* inv_scale, int32_t n, void* stream);
 int ammc_reduce_partials_f32(const float* partial, int32_t nblocks, int32_t qc, float scale, float* out, void* stream);
+/* the same per run of seg_rows rows: out[ceil(nblocks / seg_rows)][qc] - a first stage in front of ammc_bn_finalize_f32 /
+ * ammc_reduce_partials_f32 when a convolution's statistics output (AmmcConvDesc.stats) has thousands of rows */
+int ammc_reduce_partials_seg_f32(const float* partial, int32_t nblocks, int32_t qc, int32_t seg_rows, float* out, void* stream);
 /* nn.MaxPool2d(2) backward (+ `add`, the gradient reaching the same tensor through the skip).  h, w: the pooled size;
  * in_h, in_w: the size of x / add / dx (2h or 2h+1: the last row / column of an odd size is in no window and gets `add`
  * alone, as MaxPool2d's floor does) */

@@ -101,6 +101,27 @@ def _fake_desc(B, H, W, cin, n, ntaps=9, up=1, y_f32=0):
     return d
 
 
+def test_statistics_rows_of_the_training_forward_layers():
+    """which 3x3 layers of the timed training step (batch 32, 256x256: BASELINE.json configs[2]) get their BatchNorm
+    statistics from the convolution's own epilogue (`AmmcConvDesc.stats`): the k-half-major halo-patch kernels of the
+    256x256, 128x128 and 64x64 levels; the 16x16x32 kernel of the 32x32 level and the implicit-GEMM kernel of the first
+    layer report 0 rows"""
+    from ammcnet_aaai2021_amd.engine import s16_variant
+    lib = _lib.load()
+    B = 32
+    for (hw, cin, n), rows in {(256, 64, 64): B * 32 * 8, (256, 128, 64): B * 32 * 8, (128, 64, 128): B * 16 * 4,
+                               (128, 256, 128): B * 16 * 4, (64, 128, 256): B * 8 * 2, (32, 512, 512): 0, (256, 16, 64): 0}.items():
+        d = _fake_desc(B, hw, hw, cin, n, y_f32=1)
+        assert lib.ammc_conv_gemm_s16_stats_rows(C.byref(d)) == rows, (hw, cin, n)
+        d.stats = 0x500000
+        if rows:
+            assert s16_variant(d).endswith(", 0, 1>+stats")
+        else:
+            assert lib.ammc_conv_gemm_s16_variant(C.byref(d), C.create_string_buffer(96), 96) == -2      # AMMC_EUNSUP
+    d = _fake_desc(B, 256, 256, 64, 64, y_f32=0)                 # an S16 output has no statistics epilogue
+    assert lib.ammc_conv_gemm_s16_stats_rows(C.byref(d)) == 0
+
+
 def test_s16_dispatch_of_the_benchmark_shapes():
     """which kernel each layer of the benchmark's workload (batch 16, 256x256: BASELINE.json configs[1]) gets - the
     variants named here are the ones tests/test_gpu_conv_tap.py and the batch-16 golden test must reach"""

@@ -193,3 +193,75 @@ def test_lrelu_s16_in_place_on_a_channel_slice():
     mask = torch.ones_like(want, dtype=torch.bool)
     mask[:, 1:-1, 1:-1, c0:c0 + c] = False
     assert torch.equal(got[mask], ref[mask])                      # everything outside the slice's interior is untouched
+
+
+@pytest.mark.parametrize("B,H,W,cin,n,want", [(3, 128, 128, 64, 64, "conv_tap_s16<4, 1, 2, 2, 1, 0, 1>+stats"),
+                                              (4, 256, 256, 32, 128, "conv_tap_s16<4, 1, 2, 4, 1, 0, 1>+stats"),
+                                              (2, 64, 64, 64, 256, None)])
+def test_conv_s16_statistics_output_is_the_channel_sums_of_what_it_stored(B, H, W, cin, n, want):
+    """AmmcConvDesc.stats (training-mode BatchNorm statistics as a second output of the convolution, csrc/conv_tap_s16.hip):
+    one row per 8 x 32 output patch = that patch's per-channel sum and sum of squares of the fp32 values the kernel
+    stored, and `ammc_bn_finalize_f32` over the rows = mean / biased variance of the tensor.  A kernel without the
+    epilogue reports 0 rows and refuses a descriptor that asks for it."""
+    from ammcnet_aaai2021_amd.engine import s16_variant
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    tag = f"cstat-{B}-{H}-{W}-{cin}-{n}"
+    X = Act(torch.zeros(B, H + 2, W + 2, cin, device=DEV), B, H, W, cin, 0, 1)
+    X.interior().copy_(S.hashed_uniform(tag + "x", (B, H, W, cin)).to(DEV) + 0.25)       # non-zero mean
+    w = (S.hashed_uniform(tag + "w", (n, 9 * cin)) * (2.0 / (9 * cin)) ** 0.5).to(DEV)
+    X16, w16 = Act(_s16(lib, X.buf), B, H, W, cin, 0, 1), _s16(lib, w)
+    Y = Act(torch.zeros(B, H + 2, W + 2, n, device=DEV), B, H, W, n, 0, 1)
+    d = AmmcConvDesc()
+    d.x, d.w, d.y = X16.tap0(), _ptr(w16), Y.pix0()
+    d.batch, d.height, d.width, d.cin, d.ntaps, d.n, d.up, d.cgroup, d.act, d.y_f32, d.x_step = B, H, W, cin, 9, n, 1, n, 0, 1, 1
+    d.x_bs, d.x_rs, d.x_ps = X16.strides
+    d.y_bs, d.y_rs, d.y_ps = Y.strides
+    rows = lib.ammc_conv_gemm_s16_stats_rows(C.byref(d))
+    if want is None:
+        assert rows == 0
+        d.stats = _ptr(torch.zeros(8, device=DEV))
+        assert lib.ammc_conv_gemm_s16(C.byref(d), s) == -2                      # AMMC_EUNSUP, nothing launched
+        return
+    assert rows == B * (H // 8) * (W // 32)
+    stats = torch.full((rows, 2, n), float("nan"), device=DEV)
+    d.stats = _ptr(stats)
+    assert s16_variant(d) == want
+    _lib.check(lib.ammc_conv_gemm_s16(C.byref(d), s), "conv+stats")
+    torch.cuda.synchronize()
+    y = Y.interior().double()                                                        # what the kernel stored
+    patches = y.reshape(B, H // 8, 8, W // 32, 32, n).permute(0, 1, 3, 2, 4, 5).reshape(rows, 256, n)
+    ref1, ref2 = patches.sum(1), (patches * patches).sum(1)
+    got = stats.double()
+    assert bool(torch.isfinite(got).all())
+    e1 = float((got[:, 0] - ref1).abs().max() / ref1.abs().max())
+    e2 = float((got[:, 1] - ref2).abs().max() / ref2.abs().max())
+    assert e1 <= 2e-6 and e2 <= 2e-6, (e1, e2)                                      # fp32 sums of 256 values
+    # the same output without statistics is bit-identical (the epilogue only adds a second output)
+    Y2 = Act(torch.zeros_like(Y.buf), B, H, W, n, 0, 1)
+    d.y, d.stats = Y2.pix0(), None
+    _lib.check(lib.ammc_conv_gemm_s16(C.byref(d), s), "conv")
+    assert torch.equal(Y2.buf, Y.buf)
+    # ... and the finalizer over the rows gives the tensor's batch statistics
+    gamma, beta = torch.ones(n, device=DEV), torch.zeros(n, device=DEV)
+    rm, rv = torch.zeros(n, device=DEV), torch.ones(n, device=DEV)
+    mean, invstd, scale, shift = (torch.empty(n, device=DEV) for _ in range(4))
+    _lib.check(lib.ammc_bn_finalize_f32(_ptr(stats), rows, n, float(B * H * W), _ptr(gamma), _ptr(beta), 1e-5, 0.1, _ptr(rm),
+                                        _ptr(rv), _ptr(mean), _ptr(invstd), _ptr(scale), _ptr(shift), s), "bn_finalize")
+    flat = y.reshape(-1, n)
+    assert float((mean.double() - flat.mean(0)).abs().max()) <= 1e-6 * float(flat.abs().max())
+    ref_is = 1.0 / torch.sqrt(flat.var(0, unbiased=False) + 1e-5)
+    assert float(((invstd.double() - ref_is) / ref_is).abs().max()) <= 1e-5
+
+
+def test_reduce_partials_in_segments():
+    """`ammc_reduce_partials_seg_f32`: out[s] = the sum of rows [s * seg, (s + 1) * seg) (the last run may be short)"""
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    rows, qc, seg = 1000, 136, 128
+    part = S.hashed_uniform("rpseg", (rows, qc)).to(DEV)
+    nseg = (rows + seg - 1) // seg
+    out = torch.full((nseg, qc), float("nan"), device=DEV)
+    _lib.check(lib.ammc_reduce_partials_seg_f32(_ptr(part), rows, qc, seg, _ptr(out), s), "reduce_seg")
+    ref = torch.stack([part[i * seg:(i + 1) * seg].double().sum(0) for i in range(nseg)])
+    assert float((out.double() - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
