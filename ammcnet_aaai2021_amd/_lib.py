@@ -83,6 +83,7 @@ SIGNATURES = {
     "ammc_nchw_to_s16_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _i64, _i64, _i64, _i32, _p]),
     "ammc_s16_to_nchw_f32": (C.c_int, [_p, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _p, _p]),
     "ammc_maxpool2x2_s16": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _p]),
+    "ammc_maxpool2x2_s16_idx": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _p, _i32, _i32, _i32, _i32, _p]),
     "ammc_pack_codebook_f16": (C.c_int, [_p, _i32, _i32, _p, _p, _p]),
     "ammc_memory_topk_f16_blocks": (C.c_int, [_i32]),
     "ammc_memory_topk_fwd_f16": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
@@ -120,6 +121,7 @@ SIGNATURES = {
     "ammc_reduce_partials_seg_f32": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "ammc_maxpool2x2_bwd_f32": (C.c_int, [_p] + _s3 + [_p] + _s3 + [_p] + _s3 + [_p] + _s3 + [_i32] * 6 + [_p]),
     "ammc_maxpool2x2_bwd_s16x_f32": (C.c_int, [_p] + _s3 + [_p] + _s3 + [_p] + _s3 + [_p] + _s3 + [_i32] * 6 + [_p]),
+    "ammc_maxpool2x2_bwd_idx_f32": (C.c_int, [_p, _p] + _s3 + [_p] + _s3 + [_p] + _s3 + [_i32] * 6 + [_p]),
     "ammc_tanh_bwd_nhwc_f32": (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _p] + _s3 + [_i32, _p]),
     "ammc_commit_bwd_f32": (C.c_int, [_p, _p, _p, _i32, _p, _p, _p, _i32, _i32, _p]),
     "ammc_codebook_count_f32": (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _p, _p, _p]),

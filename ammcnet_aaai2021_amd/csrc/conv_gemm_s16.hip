@@ -605,7 +605,8 @@ __global__ __launch_bounds__(256) void s16_to_nchw_kernel(const float* __restric
 // MaxPool2d(2) on S16: compare the decoded values, copy the winner's (hi, lo) bits
 __global__ __launch_bounds__(256) void maxpool2x2_s16_kernel(const float* __restrict__ x, int64_t x_bs, int64_t x_rs,
                                                              int64_t x_ps, float* __restrict__ y, int64_t y_bs,
-                                                             int64_t y_rs, int64_t y_ps, int B, int h, int w, int G) {
+                                                             int64_t y_rs, int64_t y_ps, int B, int h, int w, int G,
+                                                             unsigned char* __restrict__ idx) {
   const int64_t total = (int64_t)B * h * w * G;
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (gid >= total) return;
@@ -624,21 +625,25 @@ __global__ __launch_bounds__(256) void maxpool2x2_s16_kernel(const float* __rest
     lo[p] = *reinterpret_cast<const f16x8*>(s + offs[p] + 4);
   }
   f16x8 oh, ol;
+  unsigned long long args = 0;                       // window position (row-major, first maximum) of each channel, a byte each
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     float best = (float)hi[0][i] + (float)lo[0][i] * LO_INV;
     _Float16 bh = hi[0][i], bl = lo[0][i];
+    unsigned arg = 0;
 #pragma unroll
     for (int p = 1; p < 4; ++p) {
       const float v = (float)hi[p][i] + (float)lo[p][i] * LO_INV;
-      if (v > best) { best = v; bh = hi[p][i]; bl = lo[p][i]; }
+      if (v > best) { best = v; bh = hi[p][i]; bl = lo[p][i]; arg = p; }
     }
     oh[i] = bh;
     ol[i] = bl;
+    args |= (unsigned long long)arg << (8 * i);
   }
   float* dst = y + (int64_t)b * y_bs + (int64_t)yy * y_rs + (int64_t)xx * y_ps + g * 8;
   *reinterpret_cast<f16x8*>(dst) = oh;
   *reinterpret_cast<f16x8*>(dst + 4) = ol;
+  if (idx) *reinterpret_cast<unsigned long long*>(idx + gid * 8) = args;      // dense [B][h][w][C]
 }
 
 inline unsigned nblk(int64_t total) { return (unsigned)((total + 255) / 256); }
@@ -787,6 +792,17 @@ extern "C" int ammc_maxpool2x2_s16(const float* x, int64_t x_bs, int64_t x_rs, i
   if ((x_bs | x_rs | x_ps | y_bs | y_rs | y_ps) & 7) return AMMC_EINVAL;
   const int64_t total = (int64_t)batch * h * w * (c >> 3);
   hipLaunchKernelGGL(maxpool2x2_s16_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, x, x_bs, x_rs, x_ps,
-                     y, y_bs, y_rs, y_ps, batch, h, w, c >> 3);
+                     y, y_bs, y_rs, y_ps, batch, h, w, c >> 3, nullptr);
+  return ammc_launch_status();
+}
+
+extern "C" int ammc_maxpool2x2_s16_idx(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, float* y, int64_t y_bs,
+                                       int64_t y_rs, int64_t y_ps, uint8_t* idx, int32_t batch, int32_t h, int32_t w,
+                                       int32_t c, void* stream) {
+  if (!x || !y || !idx || batch <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 7) || ((uintptr_t)idx & 7)) return AMMC_EINVAL;
+  if ((x_bs | x_rs | x_ps | y_bs | y_rs | y_ps) & 7) return AMMC_EINVAL;
+  const int64_t total = (int64_t)batch * h * w * (c >> 3);
+  hipLaunchKernelGGL(maxpool2x2_s16_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, x, x_bs, x_rs, x_ps,
+                     y, y_bs, y_rs, y_ps, batch, h, w, c >> 3, idx);
   return ammc_launch_status();
 }

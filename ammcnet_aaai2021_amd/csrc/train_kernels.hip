@@ -615,6 +615,53 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(
   }
 }
 
+// The same from the window positions the forward recorded (ammc_maxpool2x2_s16_idx: a byte per pooled element, dense
+// [B][h][w][C]) instead of the pooled tensor itself: 1 byte read per 16 that maxpool_bwd_kernel<true> reads to find the
+// maxima again.  Thread = (window, 8 channels).
+__global__ __launch_bounds__(256) void maxpool_bwd_idx_kernel(
+    const unsigned char* __restrict__ idx, const float* __restrict__ dp, Tensor3 pt, const float* __restrict__ add,
+    Tensor3 at, float* __restrict__ dx, Tensor3 ot, int M, int h, int w, int fh, int fw, int C8) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (int64_t)M * C8) return;
+  const int hh = (fh + 1) >> 1, ww = (fw + 1) >> 1;
+  const int c8 = (int)(gid % C8);
+  const int m = (int)(gid / C8);
+  const int xx = m % ww, q = m / ww, yy = q % hh, b = q / hh;
+  const bool win = yy < h && xx < w;
+  unsigned long long args = 0;
+  f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
+  if (win) {
+    args = *reinterpret_cast<const unsigned long long*>(idx + ((((int64_t)b * h + yy) * w + xx) * C8 + c8) * 8);
+    const float* gp = dp + (int64_t)b * pt.bs + (int64_t)yy * pt.rs + (int64_t)xx * pt.ps + c8 * 8;
+    g0 = *reinterpret_cast<const f32x4*>(gp);
+    g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+  }
+  f32x4 a[4][2];
+  bool in[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    in[j] = 2 * yy + (j >> 1) < fh && 2 * xx + (j & 1) < fw;
+    a[j][0] = a[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (in[j] && add) {
+      const float* ap = add + (int64_t)b * at.bs + (int64_t)(2 * yy + (j >> 1)) * at.rs + (int64_t)(2 * xx + (j & 1)) * at.ps + c8 * 8;
+      a[j][0] = *reinterpret_cast<const f32x4*>(ap);
+      a[j][1] = *reinterpret_cast<const f32x4*>(ap + 4);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (!in[j]) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (win && (unsigned)((args >> (8 * i)) & 0xff) == (unsigned)j) a[j][0][i] += g0[i];
+      if (win && (unsigned)((args >> (8 * (4 + i))) & 0xff) == (unsigned)j) a[j][1][i] += g1[i];
+    }
+    float* op = dx + (int64_t)b * ot.bs + (int64_t)(2 * yy + (j >> 1)) * ot.rs + (int64_t)(2 * xx + (j & 1)) * ot.ps + c8 * 8;
+    *reinterpret_cast<f32x4*>(op) = a[j][0];
+    *reinterpret_cast<f32x4*>(op + 4) = a[j][1];
+  }
+}
+
 // d(pre-tanh) = dout * (1 - out^2), NCHW -> NHWC (channels >= C written as zero up to Cp)
 __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                        int B, int C, int H, int W, float* __restrict__ y, Tensor3 yt,
@@ -1273,6 +1320,20 @@ int ammc_maxpool2x2_bwd_s16x_f32(const float* x16, int64_t x_bs, int64_t x_rs, i
   Tensor3 xt{x_bs, x_rs, x_ps}, pt{p_bs, p_rs, p_ps}, at{a_bs, a_rs, a_ps}, ot{o_bs, o_rs, o_ps};
   hipLaunchKernelGGL(maxpool_bwd_kernel<true>, dim3(nblk((int64_t)M * (c >> 2))), dim3(256), 0, (hipStream_t)stream, x16, xt,
                      dp, pt, add, at, dx, ot, M, h, w, in_h, in_w, c >> 2);
+  return ammc_launch_status();
+}
+
+int ammc_maxpool2x2_bwd_idx_f32(const uint8_t* idx, const float* dp, int64_t p_bs, int64_t p_rs, int64_t p_ps, const float* add,
+                                int64_t a_bs, int64_t a_rs, int64_t a_ps, float* dx, int64_t o_bs, int64_t o_rs, int64_t o_ps,
+                                int32_t batch, int32_t h, int32_t w, int32_t in_h, int32_t in_w, int32_t c, void* stream) {
+  if (!idx || !dp || !dx || batch <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 7) || ((uintptr_t)idx & 7)) return AMMC_EINVAL;
+  if ((in_h >> 1) != h || (in_w >> 1) != w) return AMMC_EINVAL;
+  if (((uintptr_t)dp | (uintptr_t)dx | (uintptr_t)add) & 15) return AMMC_EINVAL;
+  if ((p_bs | p_rs | p_ps | o_bs | o_rs | o_ps | (add ? (a_bs | a_rs | a_ps) : 0)) & 3) return AMMC_EINVAL;
+  const int M = batch * ((in_h + 1) >> 1) * ((in_w + 1) >> 1);
+  Tensor3 pt{p_bs, p_rs, p_ps}, at{a_bs, a_rs, a_ps}, ot{o_bs, o_rs, o_ps};
+  hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3(nblk((int64_t)M * (c >> 3))), dim3(256), 0, (hipStream_t)stream, idx, dp, pt,
+                     add, at, dx, ot, M, h, w, in_h, in_w, c >> 3);
   return ammc_launch_status();
 }
 

@@ -53,6 +53,9 @@ PACK_BATCH = os.environ.get("AMMC_PACK_BATCH", "1") != "0"
 # partial row per 8 x 32 output patch, from the accumulators) instead of a pass that re-reads it
 FUSE_BN_STATS = os.environ.get("AMMC_FUSE_BN_STATS", "1") != "0"
 STAT_SEG = 128
+# max-pool backward from the window positions recorded by the forward (a byte per pooled element) instead of finding the
+# maxima again from the pooled tensor's S16 twin
+POOL_IDX = os.environ.get("AMMC_POOL_IDX", "1") != "0"
 MID_S16 = os.environ.get("AMMC_MID_S16", "1") != "0"              # double_conv middle activations exist as S16 only
 FUSE_BN_BWD = os.environ.get("AMMC_FUSE_BN_BWD", "1") != "0"      # BN backward writes the S16 twin of dc (one rank)
 
@@ -630,6 +633,7 @@ class _Stream:
         # S16 twins written by their producers (TWIN_S16): skips and decoder outputs by the BatchNorm apply pass, pooled
         # tensors by the S16 max-pool, the up half of the concat buffers by the ConvTranspose on conv_gemm_s16
         self.twins = bool(ops.s16 and WGRAD_S16 and TWIN_S16)
+        self.pool_idx = None          # per level: window positions of the pooled maxima (twins: encode_gen)
         self.bottom_twin = False                    # the decoder input's twin is written by ITS producer (set by the owner)
         if self.twins:
             for blk in (self.inc, self.down[0], self.down[1]):
@@ -659,7 +663,13 @@ class _Stream:
             p, sk = self.pooled[i], self.skip[i]
             if self.twins:                          # twin -> twin: the fp32 pooled tensor has no reader left
                 p16, sk16 = o.shadow(p), o.shadow(sk)
-                _chk(lib.ammc_maxpool2x2_s16(sk16.pix0(), *sk16.strides, p16.pix0(), *p16.strides, p.B, p.H, p.W, p.c, s), "pool_s16")
+                if self.pool_idx is None and POOL_IDX:      # window positions of the maxima: what the backward routes by
+                    self.pool_idx = [torch.empty(q.B, q.H, q.W, q.c, dtype=torch.uint8, device=o.dev) for q in self.pooled]
+                if POOL_IDX:
+                    _chk(lib.ammc_maxpool2x2_s16_idx(sk16.pix0(), *sk16.strides, p16.pix0(), *p16.strides,
+                                                     self.pool_idx[i].data_ptr(), p.B, p.H, p.W, p.c, s), "pool_s16")
+                else:
+                    _chk(lib.ammc_maxpool2x2_s16(sk16.pix0(), *sk16.strides, p16.pix0(), *p16.strides, p.B, p.H, p.W, p.c, s), "pool_s16")
             else:
                 _chk(lib.ammc_maxpool2x2_f32(sk.pix0(), *sk.strides, p.pix0(), *p.strides, p.B, p.H, p.W, p.c, s), "pool")
             yield from self.down[i].forward_gen()
@@ -840,7 +850,11 @@ class _Stream:
         for i in (2, 1, 0):
             yield from self.down[i].backward_gen(dy, self.dpooled[i], None, grads)
             sk, dpo, add, out = self.skip[i], self.dpooled[i], self.dcat[i].slice(0, CHANS[i]), self.dskip_tot[i]
-            if self.twins:
+            if self.twins and POOL_IDX:
+                _chk(lib.ammc_maxpool2x2_bwd_idx_f32(self.pool_idx[i].data_ptr(), dpo.pix0(), *dpo.strides, add.pix0(),
+                                                     *add.strides, out.pix0(), *out.strides, dpo.B, dpo.H, dpo.W, sk.H, sk.W,
+                                                     dpo.c, s), "maxpool_bwd(idx)")
+            elif self.twins:
                 sk16 = o.shadow(sk)
                 _chk(lib.ammc_maxpool2x2_bwd_s16x_f32(sk16.pix0(), *sk16.strides, dpo.pix0(), *dpo.strides, add.pix0(),
                                                       *add.strides, out.pix0(), *out.strides, dpo.B, dpo.H, dpo.W, sk.H, sk.W,

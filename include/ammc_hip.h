@@ -239,6 +239,12 @@ int ammc_s16_to_nchw_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_p
 int ammc_maxpool2x2_s16(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, float* y, int64_t y_bs,
                         int64_t y_rs, int64_t y_ps, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream);
 
+/* ... that also records, for every pooled element, which of the four window positions (row-major, the first maximum)
+ * it came from: idx[batch][h][w][c], a byte each (8-byte aligned) - what ammc_maxpool2x2_bwd_idx_f32 routes gradients by */
+int ammc_maxpool2x2_s16_idx(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, float* y, int64_t y_bs,
+                            int64_t y_rs, int64_t y_ps, uint8_t* idx, int32_t batch, int32_t h, int32_t w, int32_t c,
+                            void* stream);
+
 /* fp16-operand form of the memory addressing for large memories (BASELINE.json config 5: 8192
  * slots x 512-d): distance GEMM on v_mfma_f32_32x32x16_f16 with fp32 accumulation, everything
  * else as ammc_memory_topk_fwd_f32 (gather / q_one / commit distance from the fp32 codebook).
@@ -421,6 +427,11 @@ int ammc_maxpool2x2_bwd_s16x_f32(const float* x16, int64_t x_bs, int64_t x_rs, i
                                  int64_t p_rs, int64_t p_ps, const float* add, int64_t a_bs, int64_t a_rs, int64_t a_ps,
                                  float* dx, int64_t o_bs, int64_t o_rs, int64_t o_ps, int32_t batch, int32_t h, int32_t w,
                                  int32_t in_h, int32_t in_w, int32_t c, void* stream);
+/* the same from the window positions recorded by ammc_maxpool2x2_s16_idx in the forward (c % 8 == 0): the pooled tensor is
+ * not read at all */
+int ammc_maxpool2x2_bwd_idx_f32(const uint8_t* idx, const float* dp, int64_t p_bs, int64_t p_rs, int64_t p_ps, const float* add,
+                                int64_t a_bs, int64_t a_rs, int64_t a_ps, float* dx, int64_t o_bs, int64_t o_rs, int64_t o_ps,
+                                int32_t batch, int32_t h, int32_t w, int32_t in_h, int32_t in_w, int32_t c, void* stream);
 /* torch.tanh backward at the module boundary: NCHW (dout, out) -> NHWC d(pre-tanh), cp channels */
 int ammc_tanh_bwd_nhwc_f32(const float* dout_nchw, const float* out_nchw, int32_t batch, int32_t c, int32_t h,
                            int32_t w, float* y, int64_t y_bs, int64_t y_rs, int64_t y_ps, int32_t cp, void* stream);

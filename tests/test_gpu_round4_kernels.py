@@ -265,3 +265,53 @@ def test_reduce_partials_in_segments():
     _lib.check(lib.ammc_reduce_partials_seg_f32(_ptr(part), rows, qc, seg, _ptr(out), s), "reduce_seg")
     ref = torch.stack([part[i * seg:(i + 1) * seg].double().sum(0) for i in range(nseg)])
     assert float((out.double() - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("B,fh,fw,c", [(2, 16, 24, 64), (3, 9, 13, 16), (1, 64, 64, 128)])
+def test_maxpool_index_map_routes_like_the_recomputed_maxima(B, fh, fw, c):
+    """`ammc_maxpool2x2_s16_idx` = `ammc_maxpool2x2_s16` + a byte per pooled element (the window position of the first
+    maximum); `ammc_maxpool2x2_bwd_idx_f32` from those bytes = `ammc_maxpool2x2_bwd_s16x_f32`, which finds the maxima
+    again from the pooled tensor - bit for bit, odd sizes (a last row / column outside every window) included"""
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    h, w = fh // 2, fw // 2
+    tag = f"mpidx-{B}-{fh}-{fw}-{c}"
+    x = S.hashed_uniform(tag + "x", (B, fh, fw, c))
+    x[:, 0:2, 0:2, :8] = 0.5                                    # a tie in the first window: the first position wins
+    X = Act(torch.zeros(B, fh + 2, fw + 2, c, device=DEV), B, fh, fw, c, 0, 1)
+    X.interior().copy_(x.to(DEV))
+    X16 = Act(_s16(lib, X.buf), B, fh, fw, c, 0, 1)
+    P_a = Act(torch.zeros(B, h + 2, w + 2, c, device=DEV), B, h, w, c, 0, 1)
+    P_b = Act(torch.zeros_like(P_a.buf), B, h, w, c, 0, 1)
+    idx = torch.full((B, h, w, c), 255, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.ammc_maxpool2x2_s16(X16.pix0(), *X16.strides, P_a.pix0(), *P_a.strides, B, h, w, c, s), "pool")
+    _lib.check(lib.ammc_maxpool2x2_s16_idx(X16.pix0(), *X16.strides, P_b.pix0(), *P_b.strides, idx.data_ptr(), B, h, w, c, s), "pool+idx")
+    assert torch.equal(P_a.buf, P_b.buf)
+    xd = _decode(X16.buf, c)[:, 1:-1, 1:-1][:, :2 * h, :2 * w]
+    win = xd.reshape(B, h, 2, w, 2, c).permute(0, 1, 3, 2, 4, 5).reshape(B, h, w, 4, c)
+    assert torch.equal(idx.long(), win.argmax(3)) or torch.equal(win.gather(3, idx.long()[:, :, :, None]).squeeze(3), win.max(3).values)
+    assert int(idx[:, 0, 0, :8].max()) == 0
+    dp = Act(torch.zeros(B, h + 2, w + 2, c, device=DEV), B, h, w, c, 0, 1)
+    dp.interior().copy_(S.hashed_uniform(tag + "g", (B, h, w, c)).to(DEV))
+    add = Act(torch.zeros(B, fh + 2, fw + 2, c, device=DEV), B, fh, fw, c, 0, 1)
+    add.interior().copy_(S.hashed_uniform(tag + "a", (B, fh, fw, c)).to(DEV))
+    outs = []
+    for which in range(2):
+        out = Act(torch.full((B, fh + 2, fw + 2, c), 7.0, device=DEV), B, fh, fw, c, 0, 1)
+        if which == 0:
+            _lib.check(lib.ammc_maxpool2x2_bwd_s16x_f32(X16.pix0(), *X16.strides, dp.pix0(), *dp.strides, add.pix0(), *add.strides,
+                                                        out.pix0(), *out.strides, B, h, w, fh, fw, c, s), "bwd s16x")
+        else:
+            _lib.check(lib.ammc_maxpool2x2_bwd_idx_f32(idx.data_ptr(), dp.pix0(), *dp.strides, add.pix0(), *add.strides,
+                                                       out.pix0(), *out.strides, B, h, w, fh, fw, c, s), "bwd idx")
+        outs.append(out.buf.clone())
+    assert torch.equal(outs[0], outs[1])
+    # ... and it is MaxPool2d's gradient plus `add`
+    xt = xd.permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    F.max_pool2d(xt, 2).backward(dp.interior().double().permute(0, 3, 1, 2))
+    ref = add.interior().double().clone()
+    ref[:, :2 * h, :2 * w] += xt.grad.permute(0, 2, 3, 1)
+    got = outs[1][:, 1:-1, 1:-1].double()
+    mism = (got - ref).abs() > 1e-6
+    mism[:, 0:2, 0:2, :8] = False                               # (the planted tie: whichever position torch picks)
+    assert not bool(mism.any()), int(mism.sum())
