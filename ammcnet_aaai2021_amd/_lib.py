@@ -109,6 +109,7 @@ SIGNATURES = {
     "ammc_bn_finalize_f32": (C.c_int, [_p, _i32, _i32, _f32, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _p]),
     "ammc_scale_shift_act_f32": (C.c_int, [_p] + _s3 + [_p, _p, _p] + _s3 + [_p] + _s3 + [_i32] * 5 + [_p]),
     "ammc_scale_shift_act_s16_f32": (C.c_int, [_p] + _s3 + [_p, _p, _p] + _s3 + [_p, _p] + _s3 + [_i32] * 5 + [_p]),
+    "ammc_scale_shift_act_s16_pool_f32": (C.c_int, [_p] + _s3 + [_p, _p, _p, _p] + _s3 + [_p] + _s3 + [_p] + [_i32] * 5 + [_p]),
     "ammc_bn_bwd_reduce_f32": (C.c_int, [_p] + _s3 + [_p] + _s3 + [_p, _p, _p, _p] + [_i32] * 5 + [_p, _p]),
     "ammc_bn_bwd_apply_f32": (C.c_int, [_p] + _s3 + [_p] + _s3 + [_p, _p, _p, _p, _p, _i32, _p] + _s3 + [_i32] * 4 + [_p, _p]),
     "ammc_bn_bwd_reduce_bound_f32": (C.c_int, [_p] + _s3 + [_p] + _s3 + [_p, _p, _p, _p] + [_i32] * 5 + [_p, _p]),

@@ -1108,6 +1108,98 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_s16_rows_kernel(
   }
 }
 
+// scale_shift_act_s16 of a tensor that a MaxPool2d(2) follows (the second unit of `inconv` / `down`, models/unet.py:23-37):
+// one workgroup per PAIR of rows, thread = (window, group of 8 channels): the four activations of the window are written
+// as S16 (and fp32 when asked), and so are their 2x2 maximum - the winner's (hi, lo) pair by the decoded values, the first
+// maximum in row-major order: ammc_maxpool2x2_s16_idx's rule, bit for bit - and its window position, without the pass
+// that would read the full-resolution S16 tensor back (537 MB of the 671 MB that pass moves on the 256x256 level).
+__global__ __launch_bounds__(256) void scale_shift_act_s16_pool_rows_kernel(
+    const float* __restrict__ x, Tensor3 xt, const float* __restrict__ scale, const float* __restrict__ shift,
+    float* __restrict__ y32, float* __restrict__ y16, Tensor3 yt, float* __restrict__ p16, Tensor3 pt,
+    unsigned char* __restrict__ idx, int relu, int H2, int W2, int csh) {
+  constexpr int U = 2;
+  const int row = blockIdx.x, b = row / H2, yy = row - b * H2;              // pooled row yy of sample b
+  const float* xr = x + (int64_t)b * xt.bs + (int64_t)(2 * yy) * xt.rs;
+  const int64_t yrow = (int64_t)b * yt.bs + (int64_t)(2 * yy) * yt.rs;
+  float* pr = p16 + (int64_t)b * pt.bs + (int64_t)yy * pt.rs;
+  unsigned char* ir = idx + (((int64_t)b * H2 + yy) * W2 << csh) * 8;
+  const int n = W2 << csh;
+  const int c8 = threadIdx.x & ((1 << csh) - 1), px0 = threadIdx.x >> csh, dpx = 256 >> csh;
+  const f32x4 sc0 = *reinterpret_cast<const f32x4*>(scale + c8 * 8), sc1 = *reinterpret_cast<const f32x4*>(scale + c8 * 8 + 4);
+  const f32x4 sh0 = *reinterpret_cast<const f32x4*>(shift + c8 * 8), sh1 = *reinterpret_cast<const f32x4*>(shift + c8 * 8 + 4);
+  int xo = 2 * px0 * (int)xt.ps + c8 * 8, yo = 2 * px0 * (int)yt.ps + c8 * 8, po = px0 * (int)pt.ps + c8 * 8;
+  const int xd = 2 * dpx * (int)xt.ps, yd = 2 * dpx * (int)yt.ps, pd = dpx * (int)pt.ps;
+  const int xw[4] = {0, (int)xt.ps, (int)xt.rs, (int)xt.rs + (int)xt.ps};   // the window, row-major
+  const int yw[4] = {0, (int)yt.ps, (int)yt.rs, (int)yt.rs + (int)yt.ps};
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  for (int e = threadIdx.x; e < n; e += 256 * U) {
+    f32x4 v[U][4][2];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ok[u] = e + u * 256 < n;
+      const float* p = xr + (ok[u] ? xo + u * xd : xo);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[u][j][0] = *reinterpret_cast<const f32x4*>(p + xw[j]);
+        v[u][j][1] = *reinterpret_cast<const f32x4*>(p + xw[j] + 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!ok[u]) continue;
+      f16x8 hi[4], lo[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float t0 = v[u][j][0][i] * sc0[i] + sh0[i], t1 = v[u][j][1][i] * sc1[i] + sh1[i];
+          if (relu) { t0 = t0 > 0.f ? t0 : 0.f; t1 = t1 > 0.f ? t1 : 0.f; }
+          o[i] = t0;
+          o[4 + i] = t1;
+        }
+        const int64_t oo = yrow + yo + u * yd + yw[j];
+        if (y32) {
+          *reinterpret_cast<f32x4*>(y32 + oo) = f32x4{o[0], o[1], o[2], o[3]};
+          *reinterpret_cast<f32x4*>(y32 + oo + 4) = f32x4{o[4], o[5], o[6], o[7]};
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const _Float16 hv = (_Float16)o[i];
+          hi[j][i] = hv;
+          lo[j][i] = (_Float16)((o[i] - (float)hv) * 2048.f);
+        }
+        *reinterpret_cast<f16x8*>(y16 + oo) = hi[j];
+        *reinterpret_cast<f16x8*>(y16 + oo + 4) = lo[j];
+      }
+      f16x8 oh, ol;
+      unsigned long long args = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float best = (float)hi[0][i] + (float)lo[0][i] * (1.f / 2048.f);
+        _Float16 bh = hi[0][i], bl = lo[0][i];
+        unsigned arg = 0;
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+          const float d = (float)hi[j][i] + (float)lo[j][i] * (1.f / 2048.f);
+          if (d > best) { best = d; bh = hi[j][i]; bl = lo[j][i]; arg = j; }
+        }
+        oh[i] = bh;
+        ol[i] = bl;
+        args |= (unsigned long long)arg << (8 * i);
+      }
+      float* pp = pr + po + u * pd;
+      *reinterpret_cast<f16x8*>(pp) = oh;
+      *reinterpret_cast<f16x8*>(pp + 4) = ol;
+      *reinterpret_cast<unsigned long long*>(ir + (int64_t)(e + u * 256) * 8) = args;
+    }
+    xo += U * xd;
+    yo += U * yd;
+    po += U * pd;
+  }
+}
+
 // csh = log2(C8) when the row forms apply (AMMC_ROW_KERNELS=0 switches them off for A/Bs), else -1
 static int rows_csh(int c8, int64_t ps_a, int64_t ps_b, int64_t ps_c, int w) {
   static const int on = getenv("AMMC_ROW_KERNELS") ? atoi(getenv("AMMC_ROW_KERNELS")) != 0 : 1;
@@ -1178,6 +1270,22 @@ int ammc_scale_shift_act_s16_f32(const float* x, int64_t x_bs, int64_t x_rs, int
   else
     hipLaunchKernelGGL(scale_shift_act_s16_kernel, dim3(nblk((int64_t)M * (c >> 3))), dim3(256), 0, (hipStream_t)stream,
                        x, xt, scale, shift, res, rt, y32, y16, yt, relu, M, h, w, c >> 3);
+  return ammc_launch_status();
+}
+
+int ammc_scale_shift_act_s16_pool_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, const float* scale,
+                                      const float* shift, float* y32, float* y16, int64_t y_bs, int64_t y_rs, int64_t y_ps,
+                                      float* pool16, int64_t p_bs, int64_t p_rs, int64_t p_ps, uint8_t* idx, int32_t relu,
+                                      int32_t batch, int32_t h, int32_t w, int32_t c, void* stream) {
+  if (check_nhwc(x, batch, h, w, c) || !scale || !shift || !y16 || !pool16 || !idx || (c & 7) || ((uintptr_t)y16 & 31) ||
+      ((uintptr_t)pool16 & 31) || ((uintptr_t)idx & 7) || ((y_bs | y_rs | y_ps | p_bs | p_rs | p_ps) & 7))
+    return AMMC_EINVAL;
+  if ((h | w) & 1) return AMMC_EUNSUP;               // MaxPool2d floors: an odd size keeps the two separate passes
+  const int csh = rows_csh(c >> 3, x_ps, y_ps, p_ps, w);
+  if (csh < 0 || x_rs >= (1 << 30) || y_rs >= (1 << 30)) return AMMC_EUNSUP;
+  Tensor3 xt{x_bs, x_rs, x_ps}, yt{y_bs, y_rs, y_ps}, pt{p_bs, p_rs, p_ps};
+  hipLaunchKernelGGL(scale_shift_act_s16_pool_rows_kernel, dim3(batch * (h >> 1)), dim3(256), 0, (hipStream_t)stream, x, xt,
+                     scale, shift, y32, y16, yt, pool16, pt, idx, relu, h >> 1, w >> 1, csh);
   return ammc_launch_status();
 }
 

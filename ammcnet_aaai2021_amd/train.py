@@ -56,6 +56,9 @@ STAT_SEG = 128
 # max-pool backward from the window positions recorded by the forward (a byte per pooled element) instead of finding the
 # maxima again from the pooled tensor's S16 twin
 POOL_IDX = os.environ.get("AMMC_POOL_IDX", "1") != "0"
+# ... and the pooled tensor + those positions as extra outputs of the BatchNorm apply pass that writes the tensor
+# (ammc_scale_shift_act_s16_pool_f32) instead of a max-pool pass that reads it back
+FUSE_POOL_APPLY = os.environ.get("AMMC_FUSE_POOL_APPLY", "1") != "0"
 MID_S16 = os.environ.get("AMMC_MID_S16", "1") != "0"              # double_conv middle activations exist as S16 only
 FUSE_BN_BWD = os.environ.get("AMMC_FUSE_BN_BWD", "1") != "0"      # BN backward writes the S16 twin of dc (one rank)
 
@@ -364,6 +367,7 @@ class _ConvBN:
         self.y_s16_only = False       # set by _DoubleConv: y is read by split-fp16 convolutions only -> written as S16, never as fp32
         self.y_s16_too = False        # set by _Stream / TrainEngine: y has fp32 AND S16 readers -> the apply pass writes both
         self.x_is_s16 = False         # ... and its consumer finds the twin of x ready
+        self.pool_out = None          # set by _Stream: (S16 twin of the pooled tensor, window positions) - a MaxPool2d(2) follows y
         self.cout, self.cin = conv.weight.shape[0], conv.weight.shape[1]
         self.cin_p = _cin_pad(self.cin)
         assert x.c == self.cin_p or x.c == self.cin, (name, x.c, self.cin_p)
@@ -439,6 +443,13 @@ class _ConvBN:
         else:
             o.nbt.append(bn.num_batches_tracked)              # one fused increment at the end of the forward (TrainEngine)
         r = self.res
+        if self.pool_out is not None and r is None and (self.y_s16_only or self.y_s16_too):
+            p16, idx = self.pool_out
+            _chk(lib.ammc_scale_shift_act_s16_pool_f32(c.pix0(), *c.strides, _ptr(self.scale), _ptr(self.shift),
+                                                       None if self.y_s16_only else self.y.pix0(), o.shadow(self.y).pix0(),
+                                                       *self.y.strides, p16.pix0(), *p16.strides, idx.data_ptr(), 1, c.B, c.H,
+                                                       c.W, self.cout, s), "bn_apply_s16_pool")
+            return
         if self.y_s16_only or self.y_s16_too:
             _chk(lib.ammc_scale_shift_act_s16_f32(c.pix0(), *c.strides, _ptr(self.scale), _ptr(self.shift),
                                                   r.pix0() if r is not None else None,
@@ -633,7 +644,8 @@ class _Stream:
         # S16 twins written by their producers (TWIN_S16): skips and decoder outputs by the BatchNorm apply pass, pooled
         # tensors by the S16 max-pool, the up half of the concat buffers by the ConvTranspose on conv_gemm_s16
         self.twins = bool(ops.s16 and WGRAD_S16 and TWIN_S16)
-        self.pool_idx = None          # per level: window positions of the pooled maxima (twins: encode_gen)
+        self.pool_idx = None          # per level: window positions of the pooled maxima (a byte each; twins)
+        self.pool_fused = [False] * 3  # per level: pooled twin + positions come out of the skip block's apply pass
         self.bottom_twin = False                    # the decoder input's twin is written by ITS producer (set by the owner)
         if self.twins:
             for blk in (self.inc, self.down[0], self.down[1]):
@@ -652,6 +664,13 @@ class _Stream:
             if not has_vq:
                 self.down[2].emit_twin()            # x4 is the decoder's input
                 self.bottom_twin = True
+            if POOL_IDX:
+                self.pool_idx = [torch.empty(q.B, q.H, q.W, q.c, dtype=torch.uint8, device=ops.dev) for q in self.pooled]
+                for i, blk in enumerate((self.inc, self.down[0], self.down[1])):
+                    sk, c8 = self.skip[i], CHANS[i] >> 3
+                    if FUSE_POOL_APPLY and not ((sk.H | sk.W) & 1) and not (c8 & (c8 - 1)) and c8 <= 256:
+                        blk.u1.pool_out = (ops.shadow(self.pooled[i]), self.pool_idx[i])
+                        self.pool_fused[i] = True
 
     # ---- forward pieces -------------------------------------------------------------
     def encode_gen(self, x: torch.Tensor):
@@ -661,10 +680,10 @@ class _Stream:
         yield from self.inc.forward_gen()
         for i in range(3):
             p, sk = self.pooled[i], self.skip[i]
-            if self.twins:                          # twin -> twin: the fp32 pooled tensor has no reader left
+            if self.pool_fused[i]:
+                pass                                # written by inc / down[i - 1]'s apply pass
+            elif self.twins:                        # twin -> twin: the fp32 pooled tensor has no reader left
                 p16, sk16 = o.shadow(p), o.shadow(sk)
-                if self.pool_idx is None and POOL_IDX:      # window positions of the maxima: what the backward routes by
-                    self.pool_idx = [torch.empty(q.B, q.H, q.W, q.c, dtype=torch.uint8, device=o.dev) for q in self.pooled]
                 if POOL_IDX:
                     _chk(lib.ammc_maxpool2x2_s16_idx(sk16.pix0(), *sk16.strides, p16.pix0(), *p16.strides,
                                                      self.pool_idx[i].data_ptr(), p.B, p.H, p.W, p.c, s), "pool_s16")

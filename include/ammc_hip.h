@@ -368,6 +368,14 @@ int ammc_scale_shift_act_s16_f32(const float* x, int64_t x_bs, int64_t x_rs, int
                                  const float* shift, const float* res, int64_t r_bs, int64_t r_rs, int64_t r_ps,
                                  float* y32 /* may be NULL */, float* y16, int64_t y_bs, int64_t y_rs, int64_t y_ps,
                                  int32_t relu, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream);
+/* ... of a tensor that nn.MaxPool2d(2) follows (the second unit of `inconv` / `down`, models/unet.py:23-37): y as above, plus
+ * its pooled S16 image pool16 (h/2 x w/2, own strides) and the window positions idx[batch][h/2][w/2][c] exactly as
+ * ammc_maxpool2x2_s16_idx would produce them from y16 - in the same pass.  h, w even, c/8 a power of two <= 256; else
+ * AMMC_EUNSUP (run the two passes). */
+int ammc_scale_shift_act_s16_pool_f32(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, const float* scale,
+                                      const float* shift, float* y32 /* may be NULL */, float* y16, int64_t y_bs, int64_t y_rs,
+                                      int64_t y_ps, float* pool16, int64_t p_bs, int64_t p_rs, int64_t p_ps, uint8_t* idx,
+                                      int32_t relu, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream);
 /* BN (+ReLU) backward: partial Q=2: sum g, sum g*xhat with g = dy*[c*scale+shift > 0]; then
  * dc = scale*(g - sums[0]/M - xhat*sums[1]/M); sums[0] = dbeta, sums[1] = dgamma.
  * NOTE: the `gamma`/`beta` arguments take the FOLDED scale (gamma*invstd) and shift produced by

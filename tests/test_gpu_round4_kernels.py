@@ -315,3 +315,39 @@ def test_maxpool_index_map_routes_like_the_recomputed_maxima(B, fh, fw, c):
     mism = (got - ref).abs() > 1e-6
     mism[:, 0:2, 0:2, :8] = False                               # (the planted tie: whichever position torch picks)
     assert not bool(mism.any()), int(mism.sum())
+
+
+@pytest.mark.parametrize("B,H,W,c,cbuf,relu", [(2, 16, 32, 64, 128, 1), (3, 8, 12, 128, 128, 1), (1, 64, 64, 16, 16, 0)])
+def test_bn_apply_with_pooled_output_equals_apply_then_pool(B, H, W, c, cbuf, relu):
+    """`ammc_scale_shift_act_s16_pool_f32` (the apply pass of a unit that a MaxPool2d(2) follows) = `ammc_scale_shift_act_s16_f32`
+    + `ammc_maxpool2x2_s16_idx` on its S16 output, bit for bit: y16 (written into a channel slice of a wider buffer, as the
+    skip tensors are), the fp32 y when asked for, the pooled S16 tensor and the window positions"""
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    tag = f"applypool-{B}-{H}-{W}-{c}"
+    X = Act(torch.zeros(B, H + 2, W + 2, c, device=DEV), B, H, W, c, 0, 1)
+    X.interior().copy_((S.hashed_uniform(tag + "x", (B, H, W, c)) - 0.5).to(DEV))
+    scale = (S.hashed_uniform(tag + "s", (c,)) + 0.5).to(DEV)
+    shift = (S.hashed_uniform(tag + "h", (c,)) - 0.5).to(DEV)
+    h, w = H // 2, W // 2
+    res = []
+    for fused in (False, True):
+        Y32 = Act(torch.zeros(B, H + 2, W + 2, cbuf, device=DEV), B, H, W, c, 0, 1)
+        Y16 = Act(torch.zeros_like(Y32.buf), B, H, W, c, 0, 1)
+        P16 = Act(torch.zeros(B, h + 2, w + 2, c, device=DEV), B, h, w, c, 0, 1)
+        idx = torch.full((B, h, w, c), 255, dtype=torch.uint8, device=DEV)
+        if fused:
+            _lib.check(lib.ammc_scale_shift_act_s16_pool_f32(X.pix0(), *X.strides, _ptr(scale), _ptr(shift), Y32.pix0(), Y16.pix0(),
+                                                             *Y16.strides, P16.pix0(), *P16.strides, idx.data_ptr(), relu, B, H, W, c, s),
+                       "apply+pool")
+        else:
+            _lib.check(lib.ammc_scale_shift_act_s16_f32(X.pix0(), *X.strides, _ptr(scale), _ptr(shift), None, 0, 0, 0, Y32.pix0(),
+                                                        Y16.pix0(), *Y16.strides, relu, B, H, W, c, s), "apply")
+            _lib.check(lib.ammc_maxpool2x2_s16_idx(Y16.pix0(), *Y16.strides, P16.pix0(), *P16.strides, idx.data_ptr(), B, h, w, c, s), "pool")
+        res.append((Y32.buf.clone(), Y16.buf.clone(), P16.buf.clone(), idx.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert float(res[1][0].abs().max()) > 0 and int(res[1][3].max()) <= 3
+    # an odd size is refused (MaxPool2d floors: the two passes handle it)
+    assert lib.ammc_scale_shift_act_s16_pool_f32(X.pix0(), *X.strides, _ptr(scale), _ptr(shift), None, Y16.pix0(), *Y16.strides,
+                                                 P16.pix0(), *P16.strides, idx.data_ptr(), relu, B, H - 1, W, c, s) == -2
