@@ -115,6 +115,9 @@ SIGNATURES = {
     "ammc_bn_bwd_reduce_bound_f32": (C.c_int, [_p] + _s3 + [_p] + _s3 + [_p, _p, _p, _p] + [_i32] * 5 + [_p, _p]),
     "ammc_bn_bwd_finalize_f32": (C.c_int, [_p, _i32, _i32, _i32, _p, _p, _p, _p]),
     "ammc_bn_bwd_apply_s16_f32": (C.c_int, [_p] + _s3 + [_p] + _s3 + [_p, _p, _p, _p, _p, _i32, _p, _p] + _s3 + [_i32] * 4 + [_p, _p, _i32, _p]),
+    "ammc_bn_bwd_unpool_supported": (C.c_int, [_i32, _i64, _i64, _i64, _i32]),
+    "ammc_bn_bwd_reduce_bound_unpool_f32": (C.c_int, [_p] + _s3 + [_p] + _s3 + [_p] + _s3 + [_p, _i32, _i32] + [_p, _p, _p, _p] + [_i32] * 5 + [_p, _p]),
+    "ammc_bn_bwd_apply_s16_unpool_f32": (C.c_int, [_p] + _s3 + [_p] + _s3 + [_p] + _s3 + [_p, _i32, _i32] + [_p, _p, _p, _p, _p, _i32, _p, _p] + _s3 + [_i32] * 4 + [_p, _p, _i32, _p]),
     "ammc_chan_sum_f32": (C.c_int, [_p] + _s3 + [_i32, _i32, _i32, _i32, _p, _p]),
     "ammc_chan_sum_absmax_f32": (C.c_int, [_p] + _s3 + [_i32, _i32, _i32, _i32, _p, _p, _p]),
     "ammc_split_scaled_strided_f32": (C.c_int, [_p] + _s3 + [_p] + _s3 + [_i32, _i32, _i32, _i32, _p, _p, _i32, _p]),

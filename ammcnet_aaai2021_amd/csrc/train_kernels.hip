@@ -17,6 +17,17 @@ struct Tensor3 {          // NHWC view: element offset of pixel (b, y, x), chann
   int64_t bs, rs, ps;
 };
 
+// MaxPool2d(2) backward on the fly: the gradient a BatchNorm-backward kernel reads is  add + unpool(dpo)  - `add` through the
+// kernel's dy argument, dpo[b][y >> 1][x >> 1] added where the forward recorded window position (y & 1) * 2 + (x & 1)
+// (idx: a byte per pooled element, dense [B][ph][pw][C], ammc_maxpool2x2_s16_idx / ammc_scale_shift_act_s16_pool_f32).
+// idx == nullptr: dy as it stands.  Pixels of a last odd row / column are in no window.
+struct Unpool {
+  const float* dpo;
+  Tensor3 pt;
+  const unsigned char* idx;
+  int ph, pw;
+};
+
 __device__ __forceinline__ int64_t pix_off(int m, int H, int W, const Tensor3& t) {
   const int x = m % W;
   const int q = m / W;
@@ -53,12 +64,12 @@ __host__ __device__ inline int red_pix_for(int M) {
 // left ~256 MB of it dirty in the Infinity Cache, and those lines go out to HBM under this kernel's loads - read plus
 // write-back is the 6.1 TB/s HBM streams at.  Walking the tensor back to front, or as eight runs side by side the
 // way the convolution's XCDs wrote it, to hit those lines instead of evicting them: measured, no gain.)
-template <int MODE>
+template <int MODE, bool UP = false>
 __global__ __launch_bounds__(256) void chan_reduce_kernel(
     const float* __restrict__ x, Tensor3 xt, const float* __restrict__ dy, Tensor3 dt,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, int relu, int M, int H, int W, int C, float* __restrict__ partial,
-    int* __restrict__ amax_bits = nullptr) {
+    int* __restrict__ amax_bits = nullptr, Unpool up = Unpool{nullptr, {0, 0, 0}, nullptr, 0, 0}) {
   __shared__ f32x4 red[MODE == 3 ? 4 : 2][256];
   constexpr bool BWD = MODE == 1 || MODE == 3;
   constexpr int U = BWD ? 4 : 8;                     // 16-byte loads in flight per thread: 8 either way
@@ -82,7 +93,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(
     be = *reinterpret_cast<const f32x4*>(beta + tx * 4);
   }
   if (ty < PY) {
-    int px[U], py[U];
+    int px[U], py[U], pb[U];
     int64_t ox[U], od[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -90,6 +101,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(
       px[u] = m % W;
       const int q = m / W;
       py[u] = q % H;
+      pb[u] = q / H;
       ox[u] = (int64_t)(q / H) * xt.bs + (int64_t)py[u] * xt.rs + (int64_t)px[u] * xt.ps + tx * 4;
       od[u] = BWD ? (int64_t)(q / H) * dt.bs + (int64_t)py[u] * dt.rs + (int64_t)px[u] * dt.ps + tx * 4 : 0;
     }
@@ -97,13 +109,32 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(
     // redirected to stream 0's pixel, which is in range, and their values dropped)
     auto trip = [&](const int mb, auto guard) {
       constexpr bool GUARD = decltype(guard)::value;
-      f32x4 v[U], g[U];
+      f32x4 v[U], g[U], gp[U];
+      unsigned code[U];
       bool ok[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         ok[u] = !GUARD || mb + u * PY < M;
         v[u] = *reinterpret_cast<const f32x4*>(x + (ok[u] ? ox[u] : ox[0]));
         if (BWD) g[u] = *reinterpret_cast<const f32x4*>(dy + (ok[u] ? od[u] : od[0]));
+        if (BWD && UP) {                              // the pooled gradient of this pixel's window and where its maximum was
+          const int uu = ok[u] ? u : 0;
+          const int wy = py[uu] >> 1, wx = px[uu] >> 1;
+          const bool in = wy < up.ph && wx < up.pw;
+          const int cy = in ? wy : 0, cx = in ? wx : 0;
+          gp[u] = *reinterpret_cast<const f32x4*>(up.dpo + (int64_t)pb[uu] * up.pt.bs + (int64_t)cy * up.pt.rs + (int64_t)cx * up.pt.ps + tx * 4);
+          code[u] = *reinterpret_cast<const unsigned*>(up.idx + (((int64_t)pb[uu] * up.ph + cy) * up.pw + cx) * C + tx * 4);
+          if (!in) code[u] = 0xffffffffu;             // no window: no position matches
+        }
+      }
+      if (BWD && UP) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const unsigned pos = (unsigned)((py[u] & 1) * 2 + (px[u] & 1));
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (((code[u] >> (8 * i)) & 0xffu) == pos) g[u][i] += gp[u][i];
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -142,8 +173,10 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(
           ox[u] += x_row;
           if (BWD) od[u] += d_row;
         }
+        pb[u] += sb;
         if (py[u] >= H) {
           py[u] -= H;
+          ++pb[u];
           ox[u] += x_img;
           if (BWD) od[u] += d_img;
         }
@@ -1021,17 +1054,23 @@ __global__ __launch_bounds__(256) void scale_shift_act_s16_rows_kernel(
   }
 }
 
+template <bool UP>
 __global__ __launch_bounds__(256) void bn_bwd_apply_s16_rows_kernel(
     const float* __restrict__ c, Tensor3 ct, const float* __restrict__ dy, Tensor3 dt,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ sums, float inv_count, int relu,
     float* __restrict__ dc16, float* __restrict__ dc32, Tensor3 ot, int H, int W, int csh,
-    const int* __restrict__ amax_bits, float* __restrict__ inv_scale, int n_inv) {
+    const int* __restrict__ amax_bits, float* __restrict__ inv_scale, int n_inv, Unpool up) {
   constexpr int U = 4;
   __shared__ int red[4];
   const int row = blockIdx.x, b = row / H, yy = row - b * H;
   const float* cr = c + (int64_t)b * ct.bs + (int64_t)yy * ct.rs;
   const float* gr = dy + (int64_t)b * dt.bs + (int64_t)yy * dt.rs;
+  // (up.idx: dy = add + unpool(dpo), see struct Unpool) this row's pooled row and its window-position bytes
+  const bool up_row = UP && (yy >> 1) < up.ph;
+  const float* pr = up_row ? up.dpo + (int64_t)b * up.pt.bs + (int64_t)(yy >> 1) * up.pt.rs : nullptr;
+  const unsigned char* ir = up_row ? up.idx + (((int64_t)b * up.ph + (yy >> 1)) * up.pw << (csh + 3)) : nullptr;
+  int px = threadIdx.x >> csh;
   const int64_t orow = (int64_t)b * ot.bs + (int64_t)yy * ot.rs;
   const int n = W << csh;
   const int C = 8 << csh;
@@ -1061,7 +1100,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_s16_rows_kernel(
     for (int i = threadIdx.x; i < n_inv; i += 256) inv_scale[i] = 1.f / f;
   typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
   for (int e = threadIdx.x; e < n; e += 256 * U) {
-    f32x4 v[U][2], g[U][2];
+    f32x4 v[U][2], g[U][2], gp[U][2];
+    unsigned long long code[U];
     bool ok[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -1072,7 +1112,29 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_s16_rows_kernel(
       v[u][1] = *reinterpret_cast<const f32x4*>(p + 4);
       g[u][0] = *reinterpret_cast<const f32x4*>(q);
       g[u][1] = *reinterpret_cast<const f32x4*>(q + 4);
+      if (up_row) {
+        const int wx = (px + (ok[u] ? u * dpx : 0)) >> 1;
+        const bool in = wx < up.pw;
+        const int cx = in ? wx : 0;
+        const float* w = pr + cx * (int)up.pt.ps + c8 * 8;
+        gp[u][0] = *reinterpret_cast<const f32x4*>(w);
+        gp[u][1] = *reinterpret_cast<const f32x4*>(w + 4);
+        code[u] = *reinterpret_cast<const unsigned long long*>(ir + (((int64_t)cx << csh) + c8) * 8);
+        if (!in) code[u] = ~0ull;
+      }
     }
+    if (up_row) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const unsigned pos = (unsigned)((yy & 1) * 2 + ((px + u * dpx) & 1));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if ((unsigned)((code[u] >> (8 * i)) & 0xffu) == pos) g[u][0][i] += gp[u][0][i];
+          if ((unsigned)((code[u] >> (8 * (4 + i))) & 0xffu) == pos) g[u][1][i] += gp[u][1][i];
+        }
+      }
+    }
+    px += U * dpx;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (!ok[u]) continue;
@@ -1347,12 +1409,61 @@ int ammc_bn_bwd_apply_s16_f32(const float* c_raw, int64_t c_bs, int64_t c_rs, in
   Tensor3 ct{c_bs, c_rs, c_ps}, dt{d_bs, d_rs, d_ps}, ot{o_bs, o_rs, o_ps};
   const int csh = rows_csh(c >> 3, c_ps, d_ps, o_ps, w);
   if (csh >= 0)
-    hipLaunchKernelGGL(bn_bwd_apply_s16_rows_kernel, dim3(batch * h), dim3(256), 0, (hipStream_t)stream, c_raw, ct, dy, dt, mean,
-                       invstd, gamma, beta, sums, 1.f / (float)M, relu, dc16, dc32, ot, h, w, csh, amax_bits, inv_scale, n_inv);
+    hipLaunchKernelGGL(bn_bwd_apply_s16_rows_kernel<false>, dim3(batch * h), dim3(256), 0, (hipStream_t)stream, c_raw, ct, dy, dt, mean,
+                       invstd, gamma, beta, sums, 1.f / (float)M, relu, dc16, dc32, ot, h, w, csh, amax_bits, inv_scale, n_inv,
+                       Unpool{nullptr, {0, 0, 0}, nullptr, 0, 0});
   else
     hipLaunchKernelGGL(bn_bwd_apply_s16_kernel, dim3(nblk((int64_t)M * (c >> 3))), dim3(256), 0, (hipStream_t)stream, c_raw,
                        ct, dy, dt, mean, invstd, gamma, beta, sums, 1.f / (float)M, relu, dc16, dc32, ot, M, h, w, c >> 3,
                        amax_bits, inv_scale, n_inv);
+  return ammc_launch_status();
+}
+
+// The two passes above with dy = add + MaxPool2d(2)-backward(dpo) formed on the fly (struct Unpool): the unit's output was
+// pooled in the forward, `add` is the gradient that reaches it through the skip path.
+static int unpool_args_bad(const float* dpo, int64_t p_bs, int64_t p_rs, int64_t p_ps, const uint8_t* idx, int ph, int pw, int h,
+                           int w, int c) {
+  return !dpo || !idx || ph != (h >> 1) || pw != (w >> 1) || ph <= 0 || pw <= 0 || (c & 7) || ((uintptr_t)dpo & 15) ||
+         ((uintptr_t)idx & 7) || ((p_bs | p_rs | p_ps) & 3);
+}
+
+int ammc_bn_bwd_unpool_supported(int32_t c, int64_t c_ps, int64_t d_ps, int64_t o_ps, int32_t w) {
+  return c > 0 && !(c & 7) && rows_csh(c >> 3, c_ps, d_ps, o_ps, w) >= 0;
+}
+
+int ammc_bn_bwd_reduce_bound_unpool_f32(const float* c_raw, int64_t c_bs, int64_t c_rs, int64_t c_ps, const float* add,
+                                        int64_t d_bs, int64_t d_rs, int64_t d_ps, const float* dpo, int64_t p_bs, int64_t p_rs,
+                                        int64_t p_ps, const uint8_t* idx, int32_t ph, int32_t pw, const float* mean,
+                                        const float* invstd, const float* gamma, const float* beta, int32_t relu, int32_t batch,
+                                        int32_t h, int32_t w, int32_t c, float* partial, void* stream) {
+  if (check_nhwc(c_raw, batch, h, w, c) || !add || !mean || !invstd || !gamma || !beta || !partial) return AMMC_EINVAL;
+  if (unpool_args_bad(dpo, p_bs, p_rs, p_ps, idx, ph, pw, h, w, c)) return AMMC_EINVAL;
+  const int M = batch * h * w;
+  Tensor3 ct{c_bs, c_rs, c_ps}, dt{d_bs, d_rs, d_ps};
+  hipLaunchKernelGGL((chan_reduce_kernel<3, true>), dim3(ammc_chan_reduce_blocks(M)), dim3(256), 0, (hipStream_t)stream,
+                     c_raw, ct, add, dt, mean, invstd, gamma, beta, relu, M, h, w, c, partial, nullptr,
+                     Unpool{dpo, {p_bs, p_rs, p_ps}, idx, ph, pw});
+  return ammc_launch_status();
+}
+
+int ammc_bn_bwd_apply_s16_unpool_f32(const float* c_raw, int64_t c_bs, int64_t c_rs, int64_t c_ps, const float* add,
+                                     int64_t d_bs, int64_t d_rs, int64_t d_ps, const float* dpo, int64_t p_bs, int64_t p_rs,
+                                     int64_t p_ps, const uint8_t* idx, int32_t ph, int32_t pw, const float* mean,
+                                     const float* invstd, const float* gamma, const float* beta, const float* sums,
+                                     int32_t relu, float* dc16, float* dc32, int64_t o_bs, int64_t o_rs, int64_t o_ps,
+                                     int32_t batch, int32_t h, int32_t w, int32_t c, const int32_t* amax_bits,
+                                     float* inv_scale, int32_t n_inv, void* stream) {
+  if (check_nhwc(c_raw, batch, h, w, c) || !add || !mean || !invstd || !gamma || !beta || !sums || !dc16 || !amax_bits ||
+      !inv_scale || n_inv <= 0 || (c & 7) || ((uintptr_t)dc16 & 31) || ((o_bs | o_rs | o_ps) & 7))
+    return AMMC_EINVAL;
+  if (unpool_args_bad(dpo, p_bs, p_rs, p_ps, idx, ph, pw, h, w, c)) return AMMC_EINVAL;
+  const int csh = rows_csh(c >> 3, c_ps, d_ps, o_ps, w);
+  if (csh < 0 || p_ps >= (1 << 24)) return AMMC_EUNSUP;
+  const int M = batch * h * w;
+  Tensor3 ct{c_bs, c_rs, c_ps}, dt{d_bs, d_rs, d_ps}, ot{o_bs, o_rs, o_ps};
+  hipLaunchKernelGGL(bn_bwd_apply_s16_rows_kernel<true>, dim3(batch * h), dim3(256), 0, (hipStream_t)stream, c_raw, ct, add, dt, mean,
+                     invstd, gamma, beta, sums, 1.f / (float)M, relu, dc16, dc32, ot, h, w, csh, amax_bits, inv_scale, n_inv,
+                     Unpool{dpo, {p_bs, p_rs, p_ps}, idx, ph, pw});
   return ammc_launch_status();
 }
 

@@ -59,6 +59,9 @@ POOL_IDX = os.environ.get("AMMC_POOL_IDX", "1") != "0"
 # ... and the pooled tensor + those positions as extra outputs of the BatchNorm apply pass that writes the tensor
 # (ammc_scale_shift_act_s16_pool_f32) instead of a max-pool pass that reads it back
 FUSE_POOL_APPLY = os.environ.get("AMMC_FUSE_POOL_APPLY", "1") != "0"
+# ... and in the backward the gradient of a pooled tensor (skip gradient + max-pool backward) is never materialised: the
+# BatchNorm-backward passes of the unit that produced the tensor form it on the fly from those positions
+FUSE_UNPOOL_BN = os.environ.get("AMMC_FUSE_UNPOOL_BN", "1") != "0"
 MID_S16 = os.environ.get("AMMC_MID_S16", "1") != "0"              # double_conv middle activations exist as S16 only
 FUSE_BN_BWD = os.environ.get("AMMC_FUSE_BN_BWD", "1") != "0"      # BN backward writes the S16 twin of dc (one rank)
 
@@ -466,15 +469,43 @@ class _ConvBN:
         for _ in self.backward_gen(dy, da, da_res, grads):
             raise RuntimeError("synchronised statistics need the lockstep driver (TrainEngine.backward)")
 
-    def backward_gen(self, dy: Act, da: Optional[Act], da_res: Optional[Act], grads: Dict):
+    def unpool_fusable(self, dy: Act) -> bool:
+        """can this unit's backward take its output gradient as `dy + max-pool backward` formed on the fly (`backward_gen`'s
+        `unpool`)?  The one-rank split-fp16 path with the row form of the apply kernel; the caller materialises otherwise."""
+        o = self.ops
+        s16_wgrad = o.s16 and self.cin_p >= 8 and WGRAD_S16
+        return bool(FUSE_UNPOOL_BN and FUSE_BN_BWD and o.s16 and s16_wgrad and not o.sync_on and
+                    o.lib.ammc_bn_bwd_unpool_supported(self.cout, self.craw.ps, dy.ps, self.dc.ps, self.craw.W))
+
+    def backward_gen(self, dy: Act, da: Optional[Act], da_res: Optional[Act], grads: Dict, unpool=None):
         """dy: gradient w.r.t. this unit's output.  Writes da = dgrad (+ da_res) if asked;
-        stores the parameter gradients in `grads`."""
+        stores the parameter gradients in `grads`.  `unpool` = (dpo, idx): the output was max-pooled in the forward and
+        its gradient is dy + MaxPool2d-backward(dpo) by the recorded window positions idx (only if `unpool_fusable`)."""
         o, lib, s = self.ops, self.ops.lib, self.ops.s
         c = self.craw
         world = o.sync_world
         s16_wgrad = o.s16 and self.cin_p >= 8 and WGRAD_S16
         fused_amax = o.s16 and (da is not None or s16_wgrad)
-        if fused_amax and not o.sync_on and FUSE_BN_BWD:
+        if unpool is not None:
+            assert self.unpool_fusable(dy)
+            dpo, idx = unpool
+            up = (dpo.pix0(), *dpo.strides, idx.data_ptr(), dpo.H, dpo.W)
+            _chk(lib.ammc_bn_bwd_reduce_bound_unpool_f32(c.pix0(), *c.strides, dy.pix0(), *dy.strides, *up, _ptr(self.mean),
+                                                         _ptr(self.invstd), _ptr(self.scale), _ptr(self.shift), 1, c.B, c.H,
+                                                         c.W, self.cout, _ptr(self.partial), s), "bn_bwd_reduce_bound(unpool)")
+            sums = torch.empty(2 * self.cout, device=o.dev, dtype=torch.float32)
+            _chk(lib.ammc_bn_bwd_finalize_f32(_ptr(self.partial), self.nblk, self.cout, c.B * c.H * c.W, _ptr(self.scale),
+                                              _ptr(sums), self.amax.data_ptr(), s), "bn_bwd_finalize")
+            grads[self.bn.bias] = sums[:self.cout]
+            grads[self.bn.weight] = sums[self.cout:]
+            dc16 = o.shadow(self.dc)
+            inv = torch.empty(1024, device=o.dev, dtype=torch.float32)
+            _chk(lib.ammc_bn_bwd_apply_s16_unpool_f32(c.pix0(), *c.strides, dy.pix0(), *dy.strides, *up, _ptr(self.mean),
+                                                      _ptr(self.invstd), _ptr(self.scale), _ptr(self.shift), _ptr(sums), 1,
+                                                      dc16.pix0(), None, *self.dc.strides, c.B, c.H, c.W, self.cout,
+                                                      self.amax.data_ptr(), _ptr(inv), 1024, s), "bn_bwd_apply_s16(unpool)")
+            pre = (dc16, inv)
+        elif fused_amax and not o.sync_on and FUSE_BN_BWD:
             # one rank, S16 consumers: the reduction also bounds max |dc|, so the apply pass writes the S16 twin of dc
             # directly (fp32 dc only where the fp32 weight-gradient kernel still reads it)
             _chk(lib.ammc_bn_bwd_reduce_bound_f32(c.pix0(), *c.strides, dy.pix0(), *dy.strides, _ptr(self.mean),
@@ -558,8 +589,8 @@ class _DoubleConv:
         yield from self.u0.forward_gen()
         yield from self.u1.forward_gen()
 
-    def backward_gen(self, dy: Act, da: Optional[Act], da_res: Optional[Act], grads):
-        yield from self.u1.backward_gen(dy, self.dmid, None, grads)
+    def backward_gen(self, dy: Act, da: Optional[Act], da_res: Optional[Act], grads, unpool=None):
+        yield from self.u1.backward_gen(dy, self.dmid, None, grads, unpool=unpool)
         yield from self.u0.backward_gen(self.dmid, da, da_res, grads)
 
 
@@ -865,10 +896,17 @@ class _Stream:
 
     def encode_backward_gen(self, dx4: Act, grads):
         o, lib, s = self.ops, self.ops.lib, self.ops.s
-        dy = dx4
+        dy, unpool = dx4, None
+        blocks = (self.inc, self.down[0], self.down[1])
         for i in (2, 1, 0):
-            yield from self.down[i].backward_gen(dy, self.dpooled[i], None, grads)
+            yield from self.down[i].backward_gen(dy, self.dpooled[i], None, grads, unpool=unpool)
             sk, dpo, add, out = self.skip[i], self.dpooled[i], self.dcat[i].slice(0, CHANS[i]), self.dskip_tot[i]
+            unpool = None
+            if self.twins and POOL_IDX and blocks[i].u1.unpool_fusable(add):
+                # the gradient of skip[i] (skip path + max-pool backward) is formed inside the BatchNorm-backward passes of
+                # the block that produced skip[i]: no pass writes it, none reads it back
+                dy, unpool = add, (dpo, self.pool_idx[i])
+                continue
             if self.twins and POOL_IDX:
                 _chk(lib.ammc_maxpool2x2_bwd_idx_f32(self.pool_idx[i].data_ptr(), dpo.pix0(), *dpo.strides, add.pix0(),
                                                      *add.strides, out.pix0(), *out.strides, dpo.B, dpo.H, dpo.W, sk.H, sk.W,
@@ -882,7 +920,7 @@ class _Stream:
                 _chk(lib.ammc_maxpool2x2_bwd_f32(sk.pix0(), *sk.strides, dpo.pix0(), *dpo.strides, add.pix0(), *add.strides,
                                                  out.pix0(), *out.strides, dpo.B, dpo.H, dpo.W, sk.H, sk.W, dpo.c, s), "maxpool_bwd")
             dy = out
-        yield from self.inc.backward_gen(dy, None, None, grads)
+        yield from self.inc.backward_gen(dy, None, None, grads, unpool=unpool)
 
 
 class TrainEngine:

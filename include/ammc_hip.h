@@ -440,6 +440,25 @@ int ammc_maxpool2x2_bwd_s16x_f32(const float* x16, int64_t x_bs, int64_t x_rs, i
 int ammc_maxpool2x2_bwd_idx_f32(const uint8_t* idx, const float* dp, int64_t p_bs, int64_t p_rs, int64_t p_ps, const float* add,
                                 int64_t a_bs, int64_t a_rs, int64_t a_ps, float* dx, int64_t o_bs, int64_t o_rs, int64_t o_ps,
                                 int32_t batch, int32_t h, int32_t w, int32_t in_h, int32_t in_w, int32_t c, void* stream);
+/* BatchNorm (+ReLU) backward of a unit whose output was max-pooled in the forward, WITHOUT materialising its output
+ * gradient: dy = add + MaxPool2d(2)-backward(dpo), formed on the fly from `add` (the gradient through the skip path, laid out
+ * like dy), the pooled gradient dpo[batch][ph][pw][c] (own strides) and the window positions idx[batch][ph][pw][c] recorded
+ * by the forward (ammc_maxpool2x2_s16_idx / ammc_scale_shift_act_s16_pool_f32); ph = h / 2, pw = w / 2 (floor).  Otherwise
+ * ammc_bn_bwd_reduce_bound_f32 / ammc_bn_bwd_apply_s16_f32.  The apply form needs ammc_bn_bwd_unpool_supported(c, pixel
+ * strides of c_raw / add / dc, w) != 0, else AMMC_EUNSUP (materialise dy with ammc_maxpool2x2_bwd_idx_f32). */
+int ammc_bn_bwd_unpool_supported(int32_t c, int64_t c_ps, int64_t d_ps, int64_t o_ps, int32_t w);
+int ammc_bn_bwd_reduce_bound_unpool_f32(const float* c_raw, int64_t c_bs, int64_t c_rs, int64_t c_ps, const float* add,
+                                        int64_t d_bs, int64_t d_rs, int64_t d_ps, const float* dpo, int64_t p_bs, int64_t p_rs,
+                                        int64_t p_ps, const uint8_t* idx, int32_t ph, int32_t pw, const float* mean,
+                                        const float* invstd, const float* gamma, const float* beta, int32_t relu, int32_t batch,
+                                        int32_t h, int32_t w, int32_t c, float* partial, void* stream);
+int ammc_bn_bwd_apply_s16_unpool_f32(const float* c_raw, int64_t c_bs, int64_t c_rs, int64_t c_ps, const float* add,
+                                     int64_t d_bs, int64_t d_rs, int64_t d_ps, const float* dpo, int64_t p_bs, int64_t p_rs,
+                                     int64_t p_ps, const uint8_t* idx, int32_t ph, int32_t pw, const float* mean,
+                                     const float* invstd, const float* gamma, const float* beta, const float* sums,
+                                     int32_t relu, float* dc16, float* dc32, int64_t o_bs, int64_t o_rs, int64_t o_ps,
+                                     int32_t batch, int32_t h, int32_t w, int32_t c, const int32_t* amax_bits,
+                                     float* inv_scale, int32_t n_inv, void* stream);
 /* torch.tanh backward at the module boundary: NCHW (dout, out) -> NHWC d(pre-tanh), cp channels */
 int ammc_tanh_bwd_nhwc_f32(const float* dout_nchw, const float* out_nchw, int32_t batch, int32_t c, int32_t h,
                            int32_t w, float* y, int64_t y_bs, int64_t y_rs, int64_t y_ps, int32_t cp, void* stream);

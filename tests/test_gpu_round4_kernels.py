@@ -351,3 +351,59 @@ def test_bn_apply_with_pooled_output_equals_apply_then_pool(B, H, W, c, cbuf, re
     # an odd size is refused (MaxPool2d floors: the two passes handle it)
     assert lib.ammc_scale_shift_act_s16_pool_f32(X.pix0(), *X.strides, _ptr(scale), _ptr(shift), None, Y16.pix0(), *Y16.strides,
                                                  P16.pix0(), *P16.strides, idx.data_ptr(), relu, B, H - 1, W, c, s) == -2
+
+
+@pytest.mark.parametrize("B,H,W,c,cbuf", [(2, 16, 32, 64, 128), (3, 9, 13, 16, 16), (1, 32, 32, 128, 128)])
+def test_bn_backward_with_the_max_pool_gradient_formed_on_the_fly(B, H, W, c, cbuf):
+    """`ammc_bn_bwd_reduce_bound_unpool_f32` / `ammc_bn_bwd_apply_s16_unpool_f32` (dy = add + MaxPool2d-backward(dpo) by the
+    recorded window positions, never written) = `ammc_maxpool2x2_bwd_idx_f32` into a buffer, then the plain passes on it:
+    partial rows, sums and the S16 gradient bit for bit - `add` in a channel slice of a wider buffer (the concat gradient),
+    an odd size (a last row / column outside every window) included"""
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    tag = f"unpoolbn-{B}-{H}-{W}-{c}"
+    ph, pw = H // 2, W // 2
+    craw = Act(torch.zeros(B, H + 2, W + 2, c, device=DEV), B, H, W, c, 0, 1)
+    craw.interior().copy_((S.hashed_uniform(tag + "c", (B, H, W, c)) - 0.5).to(DEV))
+    add = Act(torch.zeros(B, H + 2, W + 2, cbuf, device=DEV), B, H, W, c, 0, 1)
+    add.interior().copy_(((S.hashed_uniform(tag + "a", (B, H, W, c)) - 0.5) * 1e-3).to(DEV))
+    dpo = Act(torch.zeros(B, ph + 2, pw + 2, c, device=DEV), B, ph, pw, c, 0, 1)
+    dpo.interior().copy_(((S.hashed_uniform(tag + "p", (B, ph, pw, c)) - 0.5) * 1e-3).to(DEV))
+    idx = (S.hashed_uniform(tag + "i", (B, ph, pw, c)) * 4).clamp(0, 3).to(torch.uint8).to(DEV).contiguous()
+    mean = (S.hashed_uniform(tag + "m", (c,)) - 0.5).to(DEV)
+    invstd = (S.hashed_uniform(tag + "v", (c,)) + 1.0).to(DEV)
+    scale = ((S.hashed_uniform(tag + "g", (c,)) + 0.5) * invstd.cpu()).to(DEV)
+    shift = (S.hashed_uniform(tag + "b", (c,)) - 0.5).to(DEV)
+    assert lib.ammc_bn_bwd_unpool_supported(c, craw.ps, add.ps, c, W) == 1
+    nblk = lib.ammc_chan_reduce_blocks(B * H * W)
+    outs = []
+    for fused in (False, True):
+        partial = torch.full((nblk, 4, c), float("nan"), device=DEV)
+        sums = torch.empty(2 * c, device=DEV)
+        amax = torch.zeros(256, dtype=torch.int32, device=DEV)
+        inv = torch.empty(8, device=DEV)
+        dc16 = Act(torch.zeros(B, H + 2, W + 2, c, device=DEV), B, H, W, c, 0, 1)
+        stats = (_ptr(mean), _ptr(invstd), _ptr(scale), _ptr(shift))
+        up = (dpo.pix0(), *dpo.strides, idx.data_ptr(), ph, pw)
+        if fused:
+            _lib.check(lib.ammc_bn_bwd_reduce_bound_unpool_f32(craw.pix0(), *craw.strides, add.pix0(), *add.strides, *up, *stats, 1,
+                                                               B, H, W, c, _ptr(partial), s), "reduce(unpool)")
+        else:
+            dy = Act(torch.zeros(B, H + 2, W + 2, c, device=DEV), B, H, W, c, 0, 1)
+            _lib.check(lib.ammc_maxpool2x2_bwd_idx_f32(idx.data_ptr(), dpo.pix0(), *dpo.strides, add.pix0(), *add.strides,
+                                                       dy.pix0(), *dy.strides, B, ph, pw, H, W, c, s), "maxpool_bwd")
+            _lib.check(lib.ammc_bn_bwd_reduce_bound_f32(craw.pix0(), *craw.strides, dy.pix0(), *dy.strides, *stats, 1, B, H, W, c,
+                                                        _ptr(partial), s), "reduce")
+        _lib.check(lib.ammc_bn_bwd_finalize_f32(_ptr(partial), nblk, c, B * H * W, _ptr(scale), _ptr(sums), amax.data_ptr(), s), "finalize")
+        if fused:
+            _lib.check(lib.ammc_bn_bwd_apply_s16_unpool_f32(craw.pix0(), *craw.strides, add.pix0(), *add.strides, *up, *stats,
+                                                            _ptr(sums), 1, dc16.pix0(), None, *dc16.strides, B, H, W, c,
+                                                            amax.data_ptr(), _ptr(inv), 8, s), "apply(unpool)")
+        else:
+            _lib.check(lib.ammc_bn_bwd_apply_s16_f32(craw.pix0(), *craw.strides, dy.pix0(), *dy.strides, *stats, _ptr(sums), 1,
+                                                     dc16.pix0(), None, *dc16.strides, B, H, W, c, amax.data_ptr(), _ptr(inv), 8, s),
+                       "apply")
+        outs.append((partial.clone(), sums.clone(), dc16.buf.clone(), inv.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert float(_decode(outs[1][2], c).abs().max()) > 0
