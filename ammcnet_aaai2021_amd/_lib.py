@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # AMMC_LIB: another build of the SAME library (A/B measurements: `python -m ammcnet_aaai2021_amd.build --variant x`)
 LIB_PATH = os.environ.get("AMMC_LIB") or os.path.join(HERE, "libammc_hip.so")
-ABI_VERSION = 34
+ABI_VERSION = 35
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU = 0, 1, 2, 3
 
@@ -34,6 +34,8 @@ class AmmcConvDesc(C.Structure):
         ("y_cs", _i64), ("x_step", _i32), ("y_f32", _i32), ("s16_mf", _i32), ("outc_stream", _i32), ("overflow_flag", _p),
         ("splitk_ws", _p), ("splitk_ws_floats", _i64), ("sq_target", _p), ("sq_acc", _p),
         ("pool_y", _p), ("pool_bs", _i64), ("pool_rs", _i64), ("pool_ps", _i64), ("stats", _p),
+        ("bn_c", _p), ("bn_bs", _i64), ("bn_rs", _i64), ("bn_ps", _i64),
+        ("bn_mean", _p), ("bn_invstd", _p), ("bn_scale", _p), ("bn_shift", _p), ("bn_relu", _i32), ("reserved0", _i32),
     ]
 
 
@@ -122,7 +124,7 @@ SIGNATURES = {
     "ammc_chan_sum_absmax_f32": (C.c_int, [_p] + _s3 + [_i32, _i32, _i32, _i32, _p, _p, _p]),
     "ammc_split_scaled_strided_f32": (C.c_int, [_p] + _s3 + [_p] + _s3 + [_i32, _i32, _i32, _i32, _p, _p, _i32, _p]),
     "ammc_reduce_partials_f32": (C.c_int, [_p, _i32, _i32, _f32, _p, _p]),
-    "ammc_reduce_partials_seg_f32": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
+    "ammc_reduce_partials_seg_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
     "ammc_maxpool2x2_bwd_f32": (C.c_int, [_p] + _s3 + [_p] + _s3 + [_p] + _s3 + [_p] + _s3 + [_i32] * 6 + [_p]),
     "ammc_maxpool2x2_bwd_s16x_f32": (C.c_int, [_p] + _s3 + [_p] + _s3 + [_p] + _s3 + [_p] + _s3 + [_i32] * 6 + [_p]),
     "ammc_maxpool2x2_bwd_idx_f32": (C.c_int, [_p, _p] + _s3 + [_p] + _s3 + [_p] + _s3 + [_i32] * 6 + [_p]),

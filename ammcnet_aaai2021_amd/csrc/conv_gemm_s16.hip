@@ -739,7 +739,7 @@ extern "C" int ammc_conv_gemm_s16_stats_rows(const AmmcConvDesc* desc) {
   char label[96];
   label[0] = 0;
   if (conv_gemm_s16_dispatch(&d, nullptr, label, (int)sizeof(label)) != AMMC_OK) return 0;
-  return strstr(label, "+stats") ? conv_tap_s16_stat_rows(d) : 0;
+  return (strstr(label, "+stats") || strstr(label, "+bnbwd")) ? conv_tap_s16_stat_rows(d) : 0;
 }
 
 extern "C" int ammc_split_rows_f32(const float* src, int64_t count, float* dst, void* stream) {

@@ -96,26 +96,31 @@ constexpr int T_APIECES = T_HP * 8;                                             
 // one step of all eight registers after the other: from __builtin_amdgcn_update_dpp hipcc makes a v_mov_b32_dpp AND an
 // add per step, and a DPP read needs two wait states behind the VALU write of its source, which eight independent
 // chains hide (the s_nop covers the writes in front of the block).
-__device__ __forceinline__ void tap_half_sums32(f32x4& a, f32x4& b) {
-  float v0 = a[0], v1 = a[1], v2 = a[2], v3 = a[3], v4 = b[0], v5 = b[1], v6 = b[2], v7 = b[3];
-#define TAP_DPP_STEP(mod_)                                                                                            \
-  "v_add_f32_dpp %0, %0, %0 " mod_ "\n v_add_f32_dpp %1, %1, %1 " mod_ "\n v_add_f32_dpp %2, %2, %2 " mod_              \
-  "\n v_add_f32_dpp %3, %3, %3 " mod_ "\n v_add_f32_dpp %4, %4, %4 " mod_ "\n v_add_f32_dpp %5, %5, %5 " mod_          \
-  "\n v_add_f32_dpp %6, %6, %6 " mod_ "\n v_add_f32_dpp %7, %7, %7 " mod_ "\n"
-  asm volatile("s_nop 1\n"
-               TAP_DPP_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
-               TAP_DPP_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")
-               TAP_DPP_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
-               TAP_DPP_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
-               TAP_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
-               "s_nop 1"
-               : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));
-#undef TAP_DPP_STEP
-  a = f32x4{v0, v1, v2, v3};
+#define TAP_DPP_STEP(op_, mod_)                                                                                        \
+  op_ " %0, %0, %0 " mod_ "\n " op_ " %1, %1, %1 " mod_ "\n " op_ " %2, %2, %2 " mod_ "\n " op_ " %3, %3, %3 " mod_ "\n "  \
+  op_ " %4, %4, %4 " mod_ "\n " op_ " %5, %5, %5 " mod_ "\n " op_ " %6, %6, %6 " mod_ "\n " op_ " %7, %7, %7 " mod_ "\n"
+#define TAP_DPP_REDUCE(op_)                                                                                            \
+  float v0 = a[0], v1 = a[1], v2 = a[2], v3 = a[3], v4 = b[0], v5 = b[1], v6 = b[2], v7 = b[3];                        \
+  asm volatile("s_nop 1\n"                                                                                             \
+               TAP_DPP_STEP(op_, "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")                                  \
+               TAP_DPP_STEP(op_, "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")                                  \
+               TAP_DPP_STEP(op_, "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")                                  \
+               TAP_DPP_STEP(op_, "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")                                  \
+               TAP_DPP_STEP(op_, "row_bcast:15 row_mask:0xa bank_mask:0xf")                                            \
+               "s_nop 1"                                                                                               \
+               : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));                      \
+  a = f32x4{v0, v1, v2, v3};                                                                                           \
   b = f32x4{v4, v5, v6, v7};
-}
+__device__ __forceinline__ void tap_half_sums32(f32x4& a, f32x4& b) { TAP_DPP_REDUCE("v_add_f32_dpp") }
+// the same with max, for values >= 0 (the lanes a row_shr shifts in read as 0)
+__device__ __forceinline__ void tap_half_maxs32(f32x4& a, f32x4& b) { TAP_DPP_REDUCE("v_max_f32_dpp") }
+#undef TAP_DPP_REDUCE
+#undef TAP_DPP_STEP
 
-template <int WGM, int WGN, int TM, int TN, int AS, int MF, int KH = 0>
+// BNB: the instance with the BatchNorm-backward statistics epilogue (AmmcConvDesc::bn_c) - its own kernel, so that the
+// registers that epilogue needs (the saved tensor's values, four per-channel constants, four accumulators per channel
+// quad) do not touch the allocation of the instances every other launch runs
+template <int WGM, int WGN, int TM, int TN, int AS, int MF, int KH = 0, bool BNB = false>
 __device__ __forceinline__ void conv_tap_s16_tile(const TapArgs& a, const int vb, const int nvb, const bool hiprio) {
   static_assert((WGM * WGN == 8 || WGM * WGN == 4) && WGM * TM == T_TH, "4 or 8 waves, 8 image rows");
   static_assert(!KH || (AS == 1 && MF == 0 && WGM == 4 && WGN == 1 && TM == 2 && (TN == 2 || TN == 4)), "KH: 4 waves of 64 x (64 | 128)");
@@ -804,20 +809,62 @@ __device__ __forceinline__ void conv_tap_s16_tile(const TapArgs& a, const int vb
     // in the lane, the lanes by DPP (tap_half_sum32), lanes 31 / 63 park the wave's totals in LDS - the stages are
     // dead by now: every wave has waited for its last DMA and is past its last fragment read once the barrier falls -
     // and after a second barrier the waves' rows are added in a fixed order and leave as one row of stats[patch][2][n].
-    float* const St = smem;                                     // [WGM][2][BN]
+    // d.bn_c (the dgrad of a training backward): the statistics are those of the BatchNorm BACKWARD of the unit this
+    // gradient goes to - sum g, sum g xhat, max |g|, max |xhat| per channel with g = v [pre > 0], xhat and pre from that
+    // unit's saved convolution output bn_c at the same pixels (chan_reduce_kernel<3>'s four rows, train_kernels.hip):
+    // stats[patch][4][n].  The tensor the pass would read back (537 MB on the 256x256 level) is only written.
+    float* const St = smem;                                     // [WGM][2 | 4][BN]
+    constexpr int SQ = BNB ? 4 : 2;
+    int b_pix[TM];
     if (d.stats) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        b_pix[i] = (int)((int64_t)b * d.bn_bs + (int64_t)(y0 + wm * TM + i) * d.bn_rs + (int64_t)(x0 + l31) * d.bn_ps);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
+    // BNB: the saved tensor's values of 32 channels (one j) are requested a whole j ahead of their use (a load per
+    // quad, consumed at once, left eight to sixteen exposed round trips per tile: 455 -> 650 us on the 64 -> 64 layer
+    // at 256x256), and the four per-channel constants come through the scalar cache: their addresses are uniform but for
+    // the lane half h, so both halves' values are loaded and selected
+    constexpr bool BN_AHEAD = TN <= 2;          // (128 accumulators leave room for one j of values, not two)
+    f32x4 cvb[BN_AHEAD ? 2 : 1][4][TM];
+    const float* const bcp = d.bn_c;
+    auto bn_issue = [&](const int jj, const int buf) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          cvb[buf][q][i] = *reinterpret_cast<const f32x4*>(bcp + b_pix[i] + n0 + (wn * TN + jj) * 32 + 8 * (2 * (q >> 1) + h) + 4 * (q & 1));
+    };
+    if (BNB && BN_AHEAD) bn_issue(0, 0);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
+      if (BNB && BN_AHEAD && j + 1 < TN) bn_issue(j + 1, (j + 1) & 1);
+      if (BNB && !BN_AHEAD) bn_issue(j, 0);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {                             // register quad q: channels c0 .. c0 + 3
         const int c0 = n0 + (wn * TN + j) * 32 + 8 * (2 * (q >> 1) + h) + 4 * (q & 1);
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
         if (d.scale) sc = *reinterpret_cast<const f32x4*>(SCs + c0 - n0);
         if (d.shift) sh = *reinterpret_cast<const f32x4*>(SCs + BN + c0 - n0);
-        f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f}, st3 = {0.f, 0.f, 0.f, 0.f}, st4 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 bmu, bis, bga, bbe, cv[TM];
+        if (BNB) {
+          const int cu = n0 + (wn * TN + j) * 32 + 16 * (q >> 1) + 4 * (q & 1);        // lane half 0's channels; half 1: + 8
+#define TAP_BN_CONST(dst_, arr_)                                                                                       \
+          {                                                                                                            \
+            const f32x4 a0_ = *reinterpret_cast<const f32x4*>((arr_) + cu), a1_ = *reinterpret_cast<const f32x4*>((arr_) + cu + 8); \
+            _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) dst_[k_] = h ? a1_[k_] : a0_[k_];                        \
+          }
+          TAP_BN_CONST(bmu, d.bn_mean)
+          TAP_BN_CONST(bis, d.bn_invstd)
+          TAP_BN_CONST(bga, d.bn_scale)
+          TAP_BN_CONST(bbe, d.bn_shift)
+#undef TAP_BN_CONST
+#pragma unroll
+          for (int i = 0; i < TM; ++i) cv[i] = cvb[BN_AHEAD ? (j & 1) : 0][q][i];
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           f32x4 v;
@@ -827,8 +874,18 @@ __device__ __forceinline__ void conv_tap_s16_tile(const TapArgs& a, const int vb
             if (d.act == AMMC_ACT_RELU) t = t > 0.f ? t : 0.f;
             else if (d.act == AMMC_ACT_TANH) t = tanhf(t);
             v[k] = t;
-            st1[k] += t;
-            st2[k] += t * t;
+            if (BNB) {                                       // chan_reduce_kernel<3>'s expressions, operation for operation
+              const float xh = (cv[i][k] - bmu[k]) * bis[k];
+              const float pre = cv[i][k] * bga[k] + bbe[k];
+              const float gi = (!d.bn_relu || pre > 0.f) ? t : 0.f;
+              st1[k] += gi;
+              st2[k] += gi * xh;
+              st3[k] = fmaxf(st3[k], fabsf(gi));
+              st4[k] = fmaxf(st4[k], fabsf(xh));
+            } else {
+              st1[k] += t;
+              st2[k] += t * t;
+            }
           }
           if (d.res) {                                          // fp32 outputs take an fp32 NHWC residual
             const f32x4 rv = *reinterpret_cast<const f32x4*>(d.res + r_pix[i] + c0);
@@ -853,9 +910,14 @@ __device__ __forceinline__ void conv_tap_s16_tile(const TapArgs& a, const int vb
         }
         if (d.stats) {
           tap_half_sums32(st1, st2);
+          if (BNB) tap_half_maxs32(st3, st4);
           if (l31 == 31) {
-            *reinterpret_cast<f32x4*>(St + (wm * 2) * BN + (c0 - n0)) = st1;
-            *reinterpret_cast<f32x4*>(St + (wm * 2 + 1) * BN + (c0 - n0)) = st2;
+            *reinterpret_cast<f32x4*>(St + (wm * SQ) * BN + (c0 - n0)) = st1;
+            *reinterpret_cast<f32x4*>(St + (wm * SQ + 1) * BN + (c0 - n0)) = st2;
+            if (BNB) {
+              *reinterpret_cast<f32x4*>(St + (wm * SQ + 2) * BN + (c0 - n0)) = st3;
+              *reinterpret_cast<f32x4*>(St + (wm * SQ + 3) * BN + (c0 - n0)) = st4;
+            }
           }
         }
       }
@@ -867,12 +929,15 @@ __device__ __forceinline__ void conv_tap_s16_tile(const TapArgs& a, const int vb
     }
     if (d.stats) {
       __syncthreads();
-      float* const row = d.stats + (int64_t)(logical / a.n_tiles) * 2 * d.n + n0;
-      for (int t = tid; t < 2 * BN; t += NT) {
+      float* const row = d.stats + (int64_t)(logical / a.n_tiles) * SQ * d.n + n0;
+      for (int t = tid; t < SQ * BN; t += NT) {
         const int which = t / BN, cl = t - which * BN;
         float acc = St[which * BN + cl];
 #pragma unroll
-        for (int w = 1; w < WGM; ++w) acc += St[(w * 2 + which) * BN + cl];
+        for (int w = 1; w < WGM; ++w) {
+          const float o = St[(w * SQ + which) * BN + cl];
+          acc = which < 2 ? acc + o : fmaxf(acc, o);
+        }
         row[(int64_t)which * d.n + cl] = acc;
       }
     }
@@ -961,9 +1026,9 @@ __device__ __forceinline__ void conv_tap_s16_tile(const TapArgs& a, const int vb
 
 // (hipcc: the second __launch_bounds__ argument is the minimum number of WAVES PER SIMD, i.e. 512 / it VGPRs)
 #define TAP_BOUNDS __launch_bounds__(64 * WGM * WGN, (AS == 1 && WGM * WGN == 8 ? 4 : (WGN * TN == 1 ? 3 : 2)))
-template <int WGM, int WGN, int TM, int TN, int AS, int MF, int KH>
+template <int WGM, int WGN, int TM, int TN, int AS, int MF, int KH, bool BNB = false>
 __global__ TAP_BOUNDS void conv_tap_s16_kernel(TapArgs a) {
-  conv_tap_s16_tile<WGM, WGN, TM, TN, AS, MF, KH>(a, blockIdx.x, gridDim.x, (blockIdx.x >> 8) & 1);
+  conv_tap_s16_tile<WGM, WGN, TM, TN, AS, MF, KH, BNB>(a, blockIdx.x, gridDim.x, (blockIdx.x >> 8) & 1);
 }
 
 // (A persistent form of this kernel - 512 workgroups walking the tiles, blockIdx.x and blockIdx.x + 256 sharing a CU for
@@ -976,9 +1041,14 @@ static int launch_tap(const TapArgs& a, hipStream_t stream, char* label, int lab
   // the statistics epilogue exists in the 32x32x16 form's fp32 store of plain layers (what a training forward launches)
   if (a.d.stats && (MF != 0 || !a.d.y_f32 || a.d.act != AMMC_ACT_NONE || a.d.res || a.d.sq_target || a.d.n_store || a.d.y_cs > 1))
     return AMMC_EUNSUP;
+  if (a.d.bn_c && (KH == 0 || MF != 0)) return AMMC_EUNSUP;      // (the k-half-major kernels: what a training dgrad of >= 512 patches runs)
+  if (a.d.bn_c && (!a.d.stats || !a.d.bn_mean || !a.d.bn_invstd || !a.d.bn_scale || !a.d.bn_shift || ((uintptr_t)a.d.bn_c & 15) ||
+                   ((a.d.bn_bs | a.d.bn_rs | a.d.bn_ps) & 3) ||
+                   (int64_t)a.d.batch * a.d.bn_bs + (int64_t)a.d.height * a.d.bn_rs >= (1LL << 31)))
+    return AMMC_EINVAL;
   if (label) {                                     // the name rocprofv3 prints for this instance
-    if (KH) snprintf(label, label_len, "conv_tap_s16<%d, %d, %d, %d, %d, %d, %d>%s", WGM, WGN, TM, TN, AS, MF, KH, a.d.stats ? "+stats" : "");
-    else snprintf(label, label_len, "conv_tap_s16<%d, %d, %d, %d, %d, %d>%s", WGM, WGN, TM, TN, AS, MF, a.d.stats ? "+stats" : "");
+    if (KH) snprintf(label, label_len, "conv_tap_s16<%d, %d, %d, %d, %d, %d, %d>%s", WGM, WGN, TM, TN, AS, MF, KH, a.d.bn_c ? "+bnbwd" : (a.d.stats ? "+stats" : ""));
+    else snprintf(label, label_len, "conv_tap_s16<%d, %d, %d, %d, %d, %d>%s", WGM, WGN, TM, TN, AS, MF, a.d.bn_c ? "+bnbwd" : (a.d.stats ? "+stats" : ""));
     return AMMC_OK;
   }
   constexpr int BN = WGN * TN * 32;
@@ -992,6 +1062,9 @@ static int launch_tap(const TapArgs& a, hipStream_t stream, char* label, int lab
   const size_t lds = (size_t)STAGES * sizeof(float) + pad;
   static_assert((size_t)STAGES * sizeof(float) <= 160 * 1024, "LDS budget");
   auto kern = conv_tap_s16_kernel<WGM, WGN, TM, TN, AS, MF, KH>;
+  if constexpr (KH != 0 && MF == 0) {
+    if (a.d.bn_c) kern = conv_tap_s16_kernel<WGM, WGN, TM, TN, AS, MF, KH, true>;
+  }
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) return (int)e;

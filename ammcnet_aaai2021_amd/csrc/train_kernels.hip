@@ -269,14 +269,31 @@ __device__ __forceinline__ void column_sums(const float* __restrict__ partial, i
 
 // seg_rows > 0: blockIdx.y = a run of seg_rows rows -> out[blockIdx.y][QC] (the first of two stages when a convolution's
 // statistics epilogue leaves thousands of rows: with QC / 8 workgroups alone, 8192 rows took 58 us)
+// max_from (a multiple of 8, QC when there is none): columns from there on are combined by max instead of a sum (the
+// max |g|, max |xhat| rows of a BatchNorm-backward partial)
 __global__ __launch_bounds__(RP_THREADS) void reduce_partials_kernel(const float* __restrict__ partial, int nblk, int QC,
-                                                              float scale, float* __restrict__ out, int seg_rows) {
+                                                              float scale, float* __restrict__ out, int seg_rows, int max_from) {
   __shared__ double red[2][RP_SLICES][RP_COLS];
   if (seg_rows > 0) {
     const int r0 = blockIdx.y * seg_rows;
     partial += (int64_t)r0 * QC;
     out += (int64_t)blockIdx.y * QC;
     nblk = min(seg_rows, nblk - r0);
+  }
+  if ((int)blockIdx.x * RP_COLS >= max_from) {
+    float* redm = reinterpret_cast<float*>(&red[0][0][0]);
+    const int cl = threadIdx.x % RP_COLS, sl = threadIdx.x / RP_COLS, col = blockIdx.x * RP_COLS + cl;
+    float m = 0.f;
+    if (col < QC)
+      for (int r = sl; r < nblk; r += RP_SLICES) m = fmaxf(m, partial[(int64_t)r * QC + col]);
+    redm[sl * RP_COLS + cl] = m;
+    __syncthreads();
+    for (int o = RP_SLICES / 2; o > 0; o >>= 1) {
+      if (sl < o) redm[sl * RP_COLS + cl] = fmaxf(redm[sl * RP_COLS + cl], redm[(sl + o) * RP_COLS + cl]);
+      __syncthreads();
+    }
+    if (sl == 0 && col < QC) out[col] = redm[cl];
+    return;
   }
   const int i = blockIdx.x * RP_COLS + threadIdx.x % RP_COLS;
   double s, ss;
@@ -1502,16 +1519,17 @@ int ammc_split_scaled_strided_f32(const float* x, int64_t x_bs, int64_t x_rs, in
 int ammc_reduce_partials_f32(const float* partial, int32_t nblocks, int32_t qc, float scale, float* out, void* stream) {
   if (!partial || !out || nblocks <= 0 || qc <= 0) return AMMC_EINVAL;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((qc + RP_COLS - 1) / RP_COLS), dim3(RP_THREADS), 0, (hipStream_t)stream, partial, nblocks, qc,
-                     scale, out, 0);
+                     scale, out, 0, qc);
   return ammc_launch_status();
 }
 
-int ammc_reduce_partials_seg_f32(const float* partial, int32_t nblocks, int32_t qc, int32_t seg_rows, float* out, void* stream) {
-  if (!partial || !out || nblocks <= 0 || qc <= 0 || seg_rows <= 0) return AMMC_EINVAL;
+int ammc_reduce_partials_seg_f32(const float* partial, int32_t nblocks, int32_t qc, int32_t seg_rows, int32_t max_from,
+                                 float* out, void* stream) {
+  if (!partial || !out || nblocks <= 0 || qc <= 0 || seg_rows <= 0 || max_from < 0 || max_from > qc || (max_from & 7)) return AMMC_EINVAL;
   const int nseg = (nblocks + seg_rows - 1) / seg_rows;
   if (nseg > 65535) return AMMC_EUNSUP;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((qc + RP_COLS - 1) / RP_COLS, nseg), dim3(RP_THREADS), 0, (hipStream_t)stream, partial,
-                     nblocks, qc, 1.f, out, seg_rows);
+                     nblocks, qc, 1.f, out, seg_rows, max_from);
   return ammc_launch_status();
 }
 

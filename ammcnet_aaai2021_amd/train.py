@@ -62,6 +62,10 @@ FUSE_POOL_APPLY = os.environ.get("AMMC_FUSE_POOL_APPLY", "1") != "0"
 # ... and in the backward the gradient of a pooled tensor (skip gradient + max-pool backward) is never materialised: the
 # BatchNorm-backward passes of the unit that produced the tensor form it on the fly from those positions
 FUSE_UNPOOL_BN = os.environ.get("AMMC_FUSE_UNPOOL_BN", "1") != "0"
+# the reduction of a unit's BatchNorm backward (sum g, sum g xhat, max |g|, max |xhat|) as a second output of the
+# input-gradient convolution that PRODUCES the unit's output gradient (AmmcConvDesc.bn_c), instead of a pass that reads
+# the gradient back
+FUSE_BN_BWD_STATS = os.environ.get("AMMC_FUSE_BN_BWD_STATS", "1") != "0"
 MID_S16 = os.environ.get("AMMC_MID_S16", "1") != "0"              # double_conv middle activations exist as S16 only
 FUSE_BN_BWD = os.environ.get("AMMC_FUSE_BN_BWD", "1") != "0"      # BN backward writes the S16 twin of dc (one rank)
 
@@ -231,7 +235,7 @@ class _Ops:
 
     def conv_s16(self, x: Act, w: torch.Tensor, y: Act, *, ntaps, cin, n, res: Optional[Act] = None, what="conv",
                  rescale: bool = False, pre=None, shift=None, up=1, cgroup=None, x_step=1, y_s16: bool = False,
-                 w16: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None):
+                 w16: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None, bn=None):
         """3x3 conv on the split-fp16 MFMA kernels: x (fp32, any channel slice of its buffer) is re-encoded into its S16
         twin (or `pre` = what `to_s16` returned for it), the packed filter likewise; fp32 output (+ fp32 residual), or -
         `y_s16`: y is the S16 twin itself - an S16 output.  ammc_conv_gemm_s16 picks the kernel."""
@@ -254,15 +258,23 @@ class _Ops:
         if res is not None:
             d.r_bs, d.r_rs, d.r_ps = res.strides
         d.stats = _ptr(stats) if stats is not None else None
+        if bn is not None:                           # `stats` = the BatchNorm-backward partial rows of unit `bn`, which y goes to
+            d.bn_c = bn.craw.pix0()
+            d.bn_bs, d.bn_rs, d.bn_ps = bn.craw.strides
+            d.bn_mean, d.bn_invstd, d.bn_scale, d.bn_shift, d.bn_relu = _ptr(bn.mean), _ptr(bn.invstd), _ptr(bn.scale), _ptr(bn.shift), 1
         # (fp32 outputs: no S16 range flag here - an operand beyond the half range becomes inf in `to_s16` and the
         # loss turns non-finite, which the training loop sees)
-        self._mfma_launch(lambda: s16_variant(d).replace("+stats", ""), 2.0 * d.batch * d.height * d.width * ntaps * cin * n,
+        self._mfma_launch(lambda: s16_variant(d).replace("+stats", "").replace("+bnbwd", ""), 2.0 * d.batch * d.height * d.width * ntaps * cin * n,
                           lambda: lib.ammc_conv_gemm_s16(C.byref(d), s), what)
 
-    def conv_s16_stats_rows(self, x: Act, w: torch.Tensor, y: Act, *, cin, n) -> int:
+    def conv_s16_stats_rows(self, x: Act, w: torch.Tensor, y: Act, *, cin, n, bn=None) -> int:
         """rows of the statistics output (`AmmcConvDesc.stats`) of the kernel `conv_s16` would launch for this 3x3 layer
-        with an fp32 output, 0 when that kernel has no statistics epilogue"""
+        with an fp32 output, 0 when that kernel has no statistics epilogue (`bn`: the BatchNorm-backward form for unit bn)"""
         d = AmmcConvDesc()
+        if bn is not None:
+            d.bn_c = bn.craw.pix0()
+            d.bn_bs, d.bn_rs, d.bn_ps = bn.craw.strides
+            d.bn_mean, d.bn_invstd, d.bn_scale, d.bn_shift, d.bn_relu = _ptr(bn.mean), _ptr(bn.invstd), _ptr(bn.scale), _ptr(bn.shift), 1
         d.x, d.w, d.y = x.tap0(), _ptr(w), y.pix0()           # (addresses are only checked for alignment)
         d.batch, d.height, d.width = y.B, y.H, y.W
         d.cin, d.ntaps, d.n, d.up, d.act, d.y_f32, d.x_step, d.cgroup = cin, 9, n, 1, ACT_NONE, 1, 1, n
@@ -371,6 +383,7 @@ class _ConvBN:
         self.y_s16_too = False        # set by _Stream / TrainEngine: y has fp32 AND S16 readers -> the apply pass writes both
         self.x_is_s16 = False         # ... and its consumer finds the twin of x ready
         self.pool_out = None          # set by _Stream: (S16 twin of the pooled tensor, window positions) - a MaxPool2d(2) follows y
+        self._bwd_stats = {}          # id(producer unit) -> (rows, partial rows, segment rows): see `dgrad_stats_for`
         self.cout, self.cin = conv.weight.shape[0], conv.weight.shape[1]
         self.cin_p = _cin_pad(self.cin)
         assert x.c == self.cin_p or x.c == self.cin, (name, x.c, self.cin_p)
@@ -425,7 +438,8 @@ class _ConvBN:
         if self.stat_rows:
             part, nblk = self.stat_partial, self.stat_rows          # written by the convolution
             if self.stat_seg is not None:
-                _chk(lib.ammc_reduce_partials_seg_f32(_ptr(part), nblk, 2 * self.cout, STAT_SEG, _ptr(self.stat_seg), s), "reduce_seg")
+                _chk(lib.ammc_reduce_partials_seg_f32(_ptr(part), nblk, 2 * self.cout, STAT_SEG, 2 * self.cout, _ptr(self.stat_seg), s),
+                     "reduce_seg")
                 part, nblk = self.stat_seg, self.stat_seg.shape[0]
         else:
             _chk(lib.ammc_bn_stats_f32(c.pix0(), *c.strides, c.B, c.H, c.W, self.cout, _ptr(self.partial), s), "bn_stats")
@@ -477,10 +491,32 @@ class _ConvBN:
         return bool(FUSE_UNPOOL_BN and FUSE_BN_BWD and o.s16 and s16_wgrad and not o.sync_on and
                     o.lib.ammc_bn_bwd_unpool_supported(self.cout, self.craw.ps, dy.ps, self.dc.ps, self.craw.W))
 
-    def backward_gen(self, dy: Act, da: Optional[Act], da_res: Optional[Act], grads: Dict, unpool=None):
+    def dgrad_stats_for(self, producer: "_ConvBN", dy: Act):
+        """(rows, partial, segments) when `producer`'s input-gradient convolution - the kernel that writes this unit's output
+        gradient dy - can also leave this unit's BatchNorm-backward partial rows (`AmmcConvDesc.bn_c`), else None.  The
+        one-rank split-fp16 path, a halo-patch dgrad kernel with that epilogue, no padded filter rows."""
+        o = self.ops
+        key = id(producer)
+        if key not in self._bwd_stats:
+            ok = (FUSE_BN_BWD_STATS and FUSE_BN_BWD and o.s16 and self.cin_p >= 8 and WGRAD_S16 and producer.rows == self.cout
+                  and producer.wdp is not None)
+            rows = o.conv_s16_stats_rows(producer.dc, producer.wdp, dy, cin=producer.cout, n=producer.rows, bn=self) if ok else 0
+            if rows:
+                part = o.ws.buf(rows, 4, self.cout)
+                seg = o.ws.buf((rows + STAT_SEG - 1) // STAT_SEG, 4, self.cout) if rows > 1024 else None
+                self._bwd_stats[key] = (rows, part, seg)
+            else:
+                self._bwd_stats[key] = None
+        st = self._bwd_stats[key]
+        return st if st is not None and not o.sync_on else None
+
+    def backward_gen(self, dy: Act, da: Optional[Act], da_res: Optional[Act], grads: Dict, unpool=None, consumer=None,
+                     have_stats=None):
         """dy: gradient w.r.t. this unit's output.  Writes da = dgrad (+ da_res) if asked;
         stores the parameter gradients in `grads`.  `unpool` = (dpo, idx): the output was max-pooled in the forward and
-        its gradient is dy + MaxPool2d-backward(dpo) by the recorded window positions idx (only if `unpool_fusable`)."""
+        its gradient is dy + MaxPool2d-backward(dpo) by the recorded window positions idx (only if `unpool_fusable`).
+        `consumer`: the unit da is the output gradient of - its BatchNorm-backward partial rows come out of this unit's
+        dgrad where `consumer.dgrad_stats_for(self, da)` says so; `have_stats` = that tuple on the consumer's own call."""
         o, lib, s = self.ops, self.ops.lib, self.ops.s
         c = self.craw
         world = o.sync_world
@@ -508,11 +544,19 @@ class _ConvBN:
         elif fused_amax and not o.sync_on and FUSE_BN_BWD:
             # one rank, S16 consumers: the reduction also bounds max |dc|, so the apply pass writes the S16 twin of dc
             # directly (fp32 dc only where the fp32 weight-gradient kernel still reads it)
-            _chk(lib.ammc_bn_bwd_reduce_bound_f32(c.pix0(), *c.strides, dy.pix0(), *dy.strides, _ptr(self.mean),
-                                                  _ptr(self.invstd), _ptr(self.scale), _ptr(self.shift), 1, c.B, c.H, c.W,
-                                                  self.cout, _ptr(self.partial), s), "bn_bwd_reduce_bound")
+            part, nblk = self.partial, self.nblk
+            if have_stats is not None:                  # the rows came out of the convolution that wrote dy
+                nblk, part, seg = have_stats
+                if seg is not None:
+                    _chk(lib.ammc_reduce_partials_seg_f32(_ptr(part), nblk, 4 * self.cout, STAT_SEG, 2 * self.cout, _ptr(seg), s),
+                         "reduce_seg")
+                    part, nblk = seg, seg.shape[0]
+            else:
+                _chk(lib.ammc_bn_bwd_reduce_bound_f32(c.pix0(), *c.strides, dy.pix0(), *dy.strides, _ptr(self.mean),
+                                                      _ptr(self.invstd), _ptr(self.scale), _ptr(self.shift), 1, c.B, c.H, c.W,
+                                                      self.cout, _ptr(self.partial), s), "bn_bwd_reduce_bound")
             sums = torch.empty(2 * self.cout, device=o.dev, dtype=torch.float32)
-            _chk(lib.ammc_bn_bwd_finalize_f32(_ptr(self.partial), self.nblk, self.cout, c.B * c.H * c.W, _ptr(self.scale),
+            _chk(lib.ammc_bn_bwd_finalize_f32(_ptr(part), nblk, self.cout, c.B * c.H * c.W, _ptr(self.scale),
                                               _ptr(sums), self.amax.data_ptr(), s), "bn_bwd_finalize")
             grads[self.bn.bias] = sums[:self.cout]
             grads[self.bn.weight] = sums[self.cout:]
@@ -560,8 +604,10 @@ class _ConvBN:
                 _chk(lib.ammc_pack_conv_dgrad_weight_f32(_ptr(w), self.cout, self.cin, self.cout, self.rows,
                                                          _ptr(self.wdp), s), "pack_dgrad")
             if o.s16:
+                st = consumer.dgrad_stats_for(self, da) if (consumer is not None and da_res is None and pre is not None) else None
                 o.conv_s16(self.dc, self.wdp, da, ntaps=9, cin=self.cout, n=self.rows, res=da_res,
-                           what=self.name + ".dgrad", rescale=True, pre=pre, w16=self.wd16 if batched else None)
+                           what=self.name + ".dgrad", rescale=True, pre=pre, w16=self.wd16 if batched else None,
+                           stats=st[1] if st else None, bn=consumer if st else None)
             else:
                 o.conv(self.dc, self.wdp, da, ntaps=9, cin=self.cout, n=self.rows, res=da_res, what=self.name + ".dgrad")
 
@@ -590,8 +636,9 @@ class _DoubleConv:
         yield from self.u1.forward_gen()
 
     def backward_gen(self, dy: Act, da: Optional[Act], da_res: Optional[Act], grads, unpool=None):
-        yield from self.u1.backward_gen(dy, self.dmid, None, grads, unpool=unpool)
-        yield from self.u0.backward_gen(self.dmid, da, da_res, grads)
+        yield from self.u1.backward_gen(dy, self.dmid, None, grads, unpool=unpool, consumer=self.u0)
+        # (conv0's BatchNorm-backward reduction came out of conv1's input-gradient kernel where that kernel has the epilogue)
+        yield from self.u0.backward_gen(self.dmid, da, da_res, grads, have_stats=self.u0.dgrad_stats_for(self.u1, self.dmid))
 
 
 class _Stream:

@@ -116,6 +116,12 @@ typedef struct AmmcConvDesc {
                           /* values of every output patch, stats[patch][2][n] - the partial rows ammc_bn_finalize_f32 combines */
                           /* (training-mode BatchNorm2d statistics, models/unet.py:12,15, without re-reading the tensor);      */
                           /* rows = ammc_conv_gemm_s16_stats_rows(desc), AMMC_EUNSUP when that is 0                            */
+  const float* bn_c;      /* with `stats`, may be NULL: the output is the gradient of a BatchNorm(+ReLU) unit's output and the  */
+  int64_t bn_bs, bn_rs, bn_ps; /* statistics are those of that unit's BACKWARD (autograd through models/unet.py:12-16):         */
+  const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift; /* stats[patch][4][n] = sum g, sum g xhat, max |g|, max |xhat| with   */
+  int32_t bn_relu;        /* g = y [bn_relu == 0 or bn_c scale + shift > 0], xhat = (bn_c - mean) invstd; bn_c = the unit's     */
+  int32_t reserved0;      /* saved convolution output at the same pixels (own strides), scale / shift its folded BatchNorm:    */
+                          /* the rows ammc_bn_bwd_finalize_f32 combines, without ammc_bn_bwd_reduce_bound_f32's pass            */
 } AmmcConvDesc;
 
 int ammc_conv_gemm_f32(const AmmcConvDesc* desc, void* stream);
@@ -420,8 +426,11 @@ int ammc_split_scaled_strided_f32(const float* x, int64_t x_bs, int64_t x_rs, in
                                   const int32_t* amax_bits, float* inv_scale, int32_t n, void* stream);
 int ammc_reduce_partials_f32(const float* partial, int32_t nblocks, int32_t qc, float scale, float* out, void* stream);
 /* the same per run of seg_rows rows: out[ceil(nblocks / seg_rows)][qc] - a first stage in front of ammc_bn_finalize_f32 /
- * ammc_reduce_partials_f32 when a convolution's statistics output (AmmcConvDesc.stats) has thousands of rows */
-int ammc_reduce_partials_seg_f32(const float* partial, int32_t nblocks, int32_t qc, int32_t seg_rows, float* out, void* stream);
+ * ammc_bn_bwd_finalize_f32 when a convolution's statistics output (AmmcConvDesc.stats) has thousands of rows.  Columns
+ * max_from .. qc - 1 (max_from % 8 == 0; = qc for none) are combined by max: the max |g|, max |xhat| rows of a
+ * BatchNorm-backward partial (max_from = 2 c of its [4][c] rows). */
+int ammc_reduce_partials_seg_f32(const float* partial, int32_t nblocks, int32_t qc, int32_t seg_rows, int32_t max_from,
+                                 float* out, void* stream);
 /* nn.MaxPool2d(2) backward (+ `add`, the gradient reaching the same tensor through the skip).  h, w: the pooled size;
  * in_h, in_w: the size of x / add / dx (2h or 2h+1: the last row / column of an odd size is in no window and gets `add`
  * alone, as MaxPool2d's floor does) */

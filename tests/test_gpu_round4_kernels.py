@@ -262,9 +262,14 @@ def test_reduce_partials_in_segments():
     part = S.hashed_uniform("rpseg", (rows, qc)).to(DEV)
     nseg = (rows + seg - 1) // seg
     out = torch.full((nseg, qc), float("nan"), device=DEV)
-    _lib.check(lib.ammc_reduce_partials_seg_f32(_ptr(part), rows, qc, seg, _ptr(out), s), "reduce_seg")
+    _lib.check(lib.ammc_reduce_partials_seg_f32(_ptr(part), rows, qc, seg, qc, _ptr(out), s), "reduce_seg")
     ref = torch.stack([part[i * seg:(i + 1) * seg].double().sum(0) for i in range(nseg)])
     assert float((out.double() - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+    # columns from max_from on: the maximum of the run (exact)
+    _lib.check(lib.ammc_reduce_partials_seg_f32(_ptr(part), rows, qc, seg, 64, _ptr(out), s), "reduce_seg(max)")
+    refm = torch.stack([part[i * seg:(i + 1) * seg].max(0).values for i in range(nseg)])
+    assert float((out[:, :64].double() - ref[:, :64]).abs().max()) <= 1e-6 * float(ref.abs().max())
+    assert torch.equal(out[:, 64:], refm[:, 64:])
 
 
 @pytest.mark.parametrize("B,fh,fw,c", [(2, 16, 24, 64), (3, 9, 13, 16), (1, 64, 64, 128)])
@@ -407,3 +412,70 @@ def test_bn_backward_with_the_max_pool_gradient_formed_on_the_fly(B, H, W, c, cb
     for a, b in zip(*outs):
         assert torch.equal(a, b)
     assert float(_decode(outs[1][2], c).abs().max()) > 0
+
+
+@pytest.mark.parametrize("B,H,W,cin,n", [(3, 128, 128, 64, 64), (4, 256, 256, 32, 128)])
+def test_conv_s16_batchnorm_backward_statistics_output(B, H, W, cin, n):
+    """AmmcConvDesc.bn_c: the input-gradient convolution of a training backward also leaves the BatchNorm-backward partial
+    rows of the unit its output goes to - per patch: sum g, sum g xhat, max |g|, max |xhat| with g = y [c scale + shift > 0],
+    xhat = (c - mean) invstd, c = that unit's saved convolution output.  Combined over the patches they equal what
+    `ammc_bn_bwd_reduce_bound_f32` finds by reading y back (sums to fp32 rounding of a different partition, maxima
+    exactly), and y itself is bit-identical to the plain launch."""
+    from ammcnet_aaai2021_amd.engine import s16_variant
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    tag = f"cbnb-{B}-{H}-{W}-{cin}-{n}"
+    X = Act(torch.zeros(B, H + 2, W + 2, cin, device=DEV), B, H, W, cin, 0, 1)
+    X.interior().copy_((S.hashed_uniform(tag + "x", (B, H, W, cin)) - 0.5).to(DEV))
+    w = ((S.hashed_uniform(tag + "w", (n, 9 * cin)) - 0.5) * (2.0 / (9 * cin)) ** 0.5).to(DEV)
+    X16, w16 = Act(_s16(lib, X.buf), B, H, W, cin, 0, 1), _s16(lib, w)
+    craw = Act(torch.zeros(B, H + 2, W + 2, n, device=DEV), B, H, W, n, 0, 1)
+    craw.interior().copy_((S.hashed_uniform(tag + "c", (B, H, W, n)) - 0.5).to(DEV))
+    mean = (S.hashed_uniform(tag + "m", (n,)) - 0.5).to(DEV)
+    invstd = (S.hashed_uniform(tag + "v", (n,)) + 1.0).to(DEV)
+    scale = ((S.hashed_uniform(tag + "g", (n,)) + 0.5) * invstd.cpu()).to(DEV)
+    shift = (S.hashed_uniform(tag + "b", (n,)) - 0.5).to(DEV)
+    inv = torch.full((n,), 0.125, device=DEV)                     # the epilogue scale of a rescaled gradient operand
+    Y = Act(torch.zeros(B, H + 2, W + 2, n, device=DEV), B, H, W, n, 0, 1)
+    d = AmmcConvDesc()
+    d.x, d.w, d.y, d.scale = X16.tap0(), _ptr(w16), Y.pix0(), _ptr(inv)
+    d.batch, d.height, d.width, d.cin, d.ntaps, d.n, d.up, d.cgroup, d.act, d.y_f32, d.x_step = B, H, W, cin, 9, n, 1, n, 0, 1, 1
+    d.x_bs, d.x_rs, d.x_ps = X16.strides
+    d.y_bs, d.y_rs, d.y_ps = Y.strides
+    d.bn_c = craw.pix0()
+    d.bn_bs, d.bn_rs, d.bn_ps = craw.strides
+    d.bn_mean, d.bn_invstd, d.bn_scale, d.bn_shift, d.bn_relu = _ptr(mean), _ptr(invstd), _ptr(scale), _ptr(shift), 1
+    rows = lib.ammc_conv_gemm_s16_stats_rows(C.byref(d))
+    assert rows == B * (H // 8) * (W // 32)
+    stats = torch.full((rows, 4, n), float("nan"), device=DEV)
+    d.stats = _ptr(stats)
+    assert s16_variant(d).endswith("+bnbwd")
+    _lib.check(lib.ammc_conv_gemm_s16(C.byref(d), s), "dgrad+bnbwd")
+    nblk = lib.ammc_chan_reduce_blocks(B * H * W)
+    partial = torch.empty(nblk, 4, n, device=DEV)
+    _lib.check(lib.ammc_bn_bwd_reduce_bound_f32(craw.pix0(), *craw.strides, Y.pix0(), *Y.strides, _ptr(mean), _ptr(invstd), _ptr(scale),
+                                                _ptr(shift), 1, B, H, W, n, _ptr(partial), s), "reduce")
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(stats).all())
+    got_s, ref_s = stats[:, :2].double().sum(0), partial[:, :2].double().sum(0)
+    assert float((got_s - ref_s).abs().max()) <= 2e-6 * float(ref_s.abs().max()) + 1e-9, float((got_s - ref_s).abs().max())
+    assert torch.equal(stats[:, 2:].max(0).values, partial[:, 2:].max(0).values)
+    # per patch against fp64 of the stored y
+    y, c = Y.interior().double(), craw.interior().double()
+    g = torch.where(c * scale.double() + shift.double() > 0, y, torch.zeros_like(y))
+    xh = (c - mean.double()) * invstd.double()
+    def patches(t):
+        return t.reshape(B, H // 8, 8, W // 32, 32, n).permute(0, 1, 3, 2, 4, 5).reshape(rows, 256, n)
+    refp = torch.stack([patches(g).sum(1), patches(g * xh).sum(1), patches(g.abs()).max(1).values, patches(xh.abs()).max(1).values], 1)
+    err = (stats.double() - refp).abs().amax((0, 2)) / refp.abs().amax((0, 2))
+    assert float(err.max()) <= 3e-6, err
+    # the two-stage combination keeps sums and maxima apart
+    seg = torch.empty((rows + 127) // 128, 4, n, device=DEV)
+    _lib.check(lib.ammc_reduce_partials_seg_f32(_ptr(stats), rows, 4 * n, 128, 2 * n, _ptr(seg), s), "reduce_seg")
+    assert torch.equal(seg[:, 2:].max(0).values, stats[:, 2:].max(0).values)
+    assert float((seg[:, :2].double().sum(0) - got_s).abs().max()) <= 1e-6 * float(got_s.abs().max()) + 1e-9
+    # same y without the statistics
+    Y2 = Act(torch.zeros_like(Y.buf), B, H, W, n, 0, 1)
+    d.y, d.stats, d.bn_c = Y2.pix0(), None, None
+    _lib.check(lib.ammc_conv_gemm_s16(C.byref(d), s), "dgrad")
+    assert torch.equal(Y2.buf, Y.buf)
