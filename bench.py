@@ -781,10 +781,12 @@ def power_ceiling(kernel: str, issued_tflops: float):
 def _norm_kernel(name: str) -> str:
     """one spelling for a kernel across bench labels and rocprofv3's demangled names"""
     import re
-    name = re.sub(r"^ammc\w*::", "", name).replace("_kernel", "")
+    name = re.sub(r"\(.*\)$", "", re.sub(r"^(void\s+)?ammc\w*::", "", name)).replace("_kernel", "")
     m = re.match(r"(conv_tap_s16)<(.*)>$", name)
     if m:                                         # the template's seventh argument (KH) is 0 for the tap-by-tap forms
         a = [v.strip() for v in m.group(2).split(",")]
+        if len(a) == 8:                           # the eighth (round 4): "true" = the instance with the BatchNorm-backward
+            a = a[:7] + (["bnbwd"] if a[7] in ("true", "1") else [])        # statistics epilogue, a kernel of its own
         if len(a) == 7 and a[6] == "0":
             a = a[:6]
         name = f"{m.group(1)}<{', '.join(a)}>"
