@@ -66,6 +66,10 @@ FUSE_UNPOOL_BN = os.environ.get("AMMC_FUSE_UNPOOL_BN", "1") != "0"
 # input-gradient convolution that PRODUCES the unit's output gradient (AmmcConvDesc.bn_c), instead of a pass that reads
 # the gradient back
 FUSE_BN_BWD_STATS = os.environ.get("AMMC_FUSE_BN_BWD_STATS", "1") != "0"
+# one rank: the rgb and the flow stream of the network (independent between the bridge / memory joints) are issued on two
+# HIP streams, so that one's HBM-bound BatchNorm passes (~1170 W at 6 TB/s) run beside the other's MFMA-bound convolutions
+# instead of after them: the step is energy-bound and those passes leave ~230 W of the 1400 W cap unused
+TWO_STREAMS = os.environ.get("AMMC_TWO_STREAMS", "1") != "0"
 MID_S16 = os.environ.get("AMMC_MID_S16", "1") != "0"              # double_conv middle activations exist as S16 only
 FUSE_BN_BWD = os.environ.get("AMMC_FUSE_BN_BWD", "1") != "0"      # BN backward writes the S16 twin of dc (one rank)
 
@@ -141,6 +145,7 @@ class _Ops:
         self.s16 = (precision or TRAIN_PRECISION) == "s16"
         self._shadows: Dict[int, torch.Tensor] = {}
         self.amax = ws.buf(256, dtype=torch.int32)         # slots of ammc_absmax_bits_f32 / bn_bwd_apply
+        self.side = None                                   # two HIP streams of `_side_by_side`, made on first use
         # bench.py: a list here brackets every MFMA launch of the 3x3 layers with HIP events on the launch stream and
         # collects (kernel label, algorithmic flops, start event, end event)
         self.timing: Optional[list] = None
@@ -341,6 +346,33 @@ class _Ops:
         out = torch.empty(c, device=self.dev, dtype=torch.float32)
         _chk(self.lib.ammc_reduce_partials_f32(_ptr(scratch), nb, c, 1.0, _ptr(out), self.s), "reduce_partials")
         return out
+
+
+def _side_by_side(ops: "_Ops", grads, *gens) -> bool:
+    """One rank, nothing to all-reduce: run the generators - the rgb and the flow stream's share of a phase, or the two
+    halves of the bridge: disjoint buffers - each on a HIP stream of its own, forked from the caller's stream and joined
+    into it.  `ops.s` is the current stream, so the launches and the temporaries of a generator follow it there; the
+    gradients it leaves in `grads` outlive the join and are consumed on the caller's stream, which the caching allocator
+    is told (`record_stream`).  Returns False (nothing run) where this form does not apply: the caller falls back to
+    `_lockstep`."""
+    if not TWO_STREAMS or len(gens) != 2 or ops.sync_on or ops.timing is not None:
+        return False
+    cur = torch.cuda.current_stream(ops.dev)
+    if ops.side is None:
+        ops.side = (torch.cuda.Stream(ops.dev), torch.cuda.Stream(ops.dev))
+    before = set(id(k) for k in grads) if grads is not None else set()
+    for st, g in zip(ops.side, gens):
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            for _ in g:
+                raise RuntimeError("a generator asked for a collective on the one-rank path")
+    for st in ops.side:
+        cur.wait_stream(st)
+    if grads is not None:
+        for k, v in grads.items():
+            if id(k) not in before:
+                v.record_stream(cur)
+    return True
 
 
 def _lockstep(ops: "_Ops", *gens) -> None:
@@ -1033,18 +1065,22 @@ class TrainEngine:
         ops.packed["fwd"] = ops.packed["bwd"] = False
         if ops.s16 and PACK_BATCH:
             ops.run_pack("fwd")                    # every 3x3 forward filter of the step -> S16, one launch
-        _lockstep(ops, *[s.encode_gen(x) for s, x in zip(streams, xs)])
+        def both(*gens, grads=None):
+            if not _side_by_side(ops, grads, *gens):
+                _lockstep(ops, *gens)
+
+        both(*[s.encode_gen(x) for s, x in zip(streams, xs)])
         vq = [s for s in streams if s.has_vq]
         _lockstep(ops, *[s.memory_gen() for s in vq])
         for s in vq:
             diffs.append(s.mem_out[0])
             qs.append(s.mem_out[1])
         if self.kind == "twostream":
-            _lockstep(ops, st["o2f"].forward_gen(), st["f2o"].forward_gen())
+            both(st["o2f"].forward_gen(), st["f2o"].forward_gen())
             bottoms = [st["xb"], st["yb"]]
         else:
             bottoms = [streams[0].bottom]
-        _lockstep(ops, *[s.decode_gen(b) for s, b in zip(streams, bottoms)])
+        both(*[s.decode_gen(b) for s, b in zip(streams, bottoms)])
         if ops.nbt:
             torch._foreach_add_(ops.nbt, 1)
         ops.nbt = None
@@ -1086,7 +1122,10 @@ class TrainEngine:
             r, o = streams
             ops = st["ops"]
             douts = [dout if dout is not None else torch.zeros_like(s.out) for s, dout in ((r, d_rgb), (o, d_op))]
-            if ops.sync_on:
+            solo = reducer is None          # one rank, no all-reduce to feed: the two streams side by side (`_side_by_side`)
+            if solo and _side_by_side(ops, grads, r.decode_backward_gen(douts[0], grads), o.decode_backward_gen(douts[1], grads)):
+                pass
+            elif ops.sync_on:
                 _lockstep(ops, r.decode_backward_gen(douts[0], grads), o.decode_backward_gen(douts[1], grads))
                 stage_done()
             else:                                   # one stream after the other: its gradients leave for the all-reduce early
@@ -1094,12 +1133,16 @@ class TrainEngine:
                     _lockstep(ops, s.decode_backward_gen(dout, grads))
                     stage_done()
             # x = zx + O2F(zy); y = zy + F20(zx): dzy = dyb + dgrad_O2F(dxb), dzx = dxb + dgrad_F20(dyb)
-            _lockstep(ops, st["o2f"].backward_gen(r.dbottom, st["dzy"], o.dbottom, grads),
+            bridge = (st["o2f"].backward_gen(r.dbottom, st["dzy"], o.dbottom, grads),
                       st["f2o"].backward_gen(o.dbottom, st["dzx"], r.dbottom, grads))
+            if not (solo and _side_by_side(ops, grads, *bridge)):
+                _lockstep(ops, *bridge)
             stage_done()
             dx4r = r.memory_backward(st["dzx"], g(dd_r), g(dq_r), grads)
             dx4o = o.memory_backward(st["dzy"], g(dd_o), g(dq_o), grads)
-            if ops.sync_on:
+            if solo and _side_by_side(ops, grads, r.encode_backward_gen(dx4r, grads), o.encode_backward_gen(dx4o, grads)):
+                pass
+            elif ops.sync_on:
                 _lockstep(ops, r.encode_backward_gen(dx4r, grads), o.encode_backward_gen(dx4o, grads))
             else:
                 _lockstep(ops, r.encode_backward_gen(dx4r, grads))
