@@ -98,6 +98,12 @@ def _cin_pad(c: int) -> int:
     return p
 
 
+# eval forward of `twostream`: the rgb and the flow stream's launches on two HIP streams, crossed in front of the bridge
+# (the step is energy-bound at ~1350 of 1400 W on average: two queues let one stream's low-power kernels and kernel tails
+# run beside the other's convolutions; 6.51 -> 6.38 ms at batch 16)
+EVAL_LANES = os.environ.get("AMMC_EVAL_LANES", "1") != "0"
+
+
 class Plan:
     """A flat list of resolved C-ABI calls."""
 
@@ -105,11 +111,12 @@ class Plan:
         self.calls: List[Tuple] = []
         self.meta: List[dict] = []
         self.keep: List = []
+        self.lane = None          # set by the builder around a section: 0 / 1 = the rgb / flow stream's own work, None = joint
 
     def add(self, fn, *args, name: str = "", flops: float = 0.0, nbytes: float = 0.0, kernel: str = "", dyn=None):
         """`dyn(ctx) -> args`: arguments resolved per forward (calls that read the caller's input tensors directly)"""
         self.calls.append((fn, dyn if dyn is not None else args, name))
-        self.meta.append(dict(name=name, flops=flops, bytes=nbytes, kernel=kernel))
+        self.meta.append(dict(name=name, flops=flops, bytes=nbytes, kernel=kernel, lane=self.lane))
 
     def run(self, stream: int):
         for fn, args, name in self.calls:
@@ -279,6 +286,7 @@ class _Builder:
         self.overflow = torch.zeros(1, device=device, dtype=torch.int32) if s16 else None   # set by S16 epilogues
         # fp32 scratch for split-K on small-M layers (latency at small batch); shared by all layers of a plan
         self.splitk = torch.empty(8 << 20, device=device, dtype=torch.float32) if s16 else None
+        self.splitk_b = None      # ... a second one for the flow stream's lane (made when a plan has lanes: they run concurrently)
         self.conv_fn = self.lib.ammc_conv_gemm_s16 if s16 else self.lib.ammc_conv_gemm_f32
         self.kname = "conv_gemm_s16" if s16 else "conv_gemm_f32"
 
@@ -307,7 +315,13 @@ class _Builder:
         d.y_f32 = 1 if (y_f32 and self.s16) else 0
         d.overflow_flag = self.overflow.data_ptr() if self.s16 else None
         if self.s16 and os.environ.get("AMMC_S16_SPLITK", "1") != "0":
-            d.splitk_ws, d.splitk_ws_floats = self.splitk.data_ptr(), self.splitk.numel()
+            ws = self.splitk
+            if self.plan.lane in (1, 3):
+                if self.splitk_b is None:
+                    self.splitk_b = torch.empty_like(self.splitk)
+                    self.plan.keep.append(self.splitk_b)
+                ws = self.splitk_b
+            d.splitk_ws, d.splitk_ws_floats = ws.data_ptr(), ws.numel()
         d.x = x.tap0() if ntaps == 9 else x.pix0()
         d.w = _ptr(w)
         d.y = y.pix0()
@@ -605,21 +619,29 @@ class EvalEngine:
         if self.kind == "twostream":
             r = StreamGraph(bld, self._packs["rgb"], B, H, W, index=0)
             o = StreamGraph(bld, self._packs["op"], B, H, W, index=1)
+            # (plan.lane: which of the two network streams a call belongs to - AMMC_EVAL_LANES runs them on two HIP streams)
+            plan.lane = 0
             r.encode()
             r.memory()
+            plan.lane = 1
             o.encode()
             o.memory()
             h, w = r.hs[3], r.ws[3]
-            # AMFT bridge: x = zx + O2F(zy); y = zy + F20(zx)   (unet.py:962-965)
+            # AMFT bridge: x = zx + O2F(zy); y = zy + F20(zx)   (unet.py:962-965): each half reads BOTH bottlenecks
             mid = bld.act(B, h, w, 512)
             xb = bld.act(B, h, w, 512)
+            plan.lane = 2                                  # lane 0 behind a join of the two lanes
             bld.double_conv(o.x4q, self._packs["o2f"], mid, xb, res=r.x4q, name="bridge.O2F")
             mid2 = bld.act(B, h, w, 512)
             yb = bld.act(B, h, w, 512)
+            plan.lane = 3                                  # lane 1 behind the same join
             bld.double_conv(r.x4q, self._packs["f2o"], mid2, yb, res=o.x4q, name="bridge.F20")
             r.bottom, o.bottom = xb, yb
+            plan.lane = 0
             r.decode()
+            plan.lane = 1
             o.decode()
+            plan.lane = None
             st = dict(streams=[r, o], bridge=(xb, yb))
         else:
             s = StreamGraph(bld, self._packs["net"], B, H, W)
@@ -704,8 +726,34 @@ class EvalEngine:
                    dict(name="nchw_to_nhwc", kernel="nchw_to_nhwc", flops=0.0,
                         bytes=4.0 * B * H * W * (s.sp.cin + s.sp.inc.cin_p)))
         plan = st["plan"]
-        for (fn, args, _), meta in zip(plan.calls, plan.meta):
-            launch(fn, args(ctx) if callable(args) else args, meta)
+        lanes = getattr(self, "_lanes", None) if (EVAL_LANES and len(streams) == 2 and not self._timed and
+                                                    not torch.cuda.is_current_stream_capturing()) else None
+        if EVAL_LANES and lanes is None and len(streams) == 2 and not self._timed and not torch.cuda.is_current_stream_capturing():
+            dev = xs[0].device
+            lanes = self._lanes = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        if lanes is not None:
+            # the two network streams on two HIP streams: forked from the caller's stream, crossed once in front of the
+            # bridge (each half of it reads both bottlenecks), joined behind the decoders
+            cur = torch.cuda.current_stream(xs[0].device)
+            for l in lanes:
+                l.wait_stream(cur)
+            crossed = False
+            for (fn, args, name), meta in zip(plan.calls, plan.meta):
+                ln = meta.get("lane")
+                if ln is None:
+                    raise RuntimeError("a two-stream plan holds a call without a lane")
+                if ln >= 2 and not crossed:
+                    lanes[0].wait_stream(lanes[1])
+                    lanes[1].wait_stream(lanes[0])
+                    crossed = True
+                rc = fn(*(args(ctx) if callable(args) else args), lanes[ln & 1].cuda_stream)
+                if rc != 0:
+                    _lib.check(rc, meta["name"])
+            for l in lanes:
+                cur.wait_stream(l)
+        else:
+            for (fn, args, _), meta in zip(plan.calls, plan.meta):
+                launch(fn, args(ctx) if callable(args) else args, meta)
         st["flag_event"] = None
         if early_flag and st.get("overflow") is not None:
             if st.get("flag_host") is None:

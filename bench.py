@@ -741,16 +741,21 @@ def kernel_table(net, rgb_x, op_x, reps=3):
     eng = net._engine
     agg = {}
     eng._timed = True
+    runs = []
     for _ in range(reps):
         with torch.no_grad():
             eng.forward(rgb_x, op_x)
-        for meta, ms in eng.timings:
-            a = agg.setdefault(meta["kernel"] or meta["name"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
-            a["ms"] += ms
-            a["flops"] += meta["flops"]
-            a["bytes"] += meta["bytes"]
-            a["launches"] += 1
+        runs.append(list(eng.timings))
     eng._timed = False
+    # launch i of the forward: the MEDIAN of its durations over the forwards (one stalled bracket - a 66-ms hiccup was seen
+    # once in a full bench run - would otherwise decide which kernel is "dominant"), counted `reps` times as before
+    for i, (meta, _) in enumerate(runs[0]):
+        ms = sorted(r[i][1] for r in runs)[(len(runs) - 1) // 2]
+        a = agg.setdefault(meta["kernel"] or meta["name"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+        a["ms"] += ms * reps
+        a["flops"] += meta["flops"] * reps
+        a["bytes"] += meta["bytes"] * reps
+        a["launches"] += reps
     total_ms = sum(a["ms"] for a in agg.values()) / reps
     per_kernel = {}
     for kname, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
