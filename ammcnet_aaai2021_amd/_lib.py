@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # AMMC_LIB: another build of the SAME library (A/B measurements: `python -m ammcnet_aaai2021_amd.build --variant x`)
 LIB_PATH = os.environ.get("AMMC_LIB") or os.path.join(HERE, "libammc_hip.so")
-ABI_VERSION = 35
+ABI_VERSION = 36
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU = 0, 1, 2, 3
 
@@ -77,6 +77,7 @@ SIGNATURES = {
     "ammc_first_conv_image_floats": (C.c_int, []),
     "ammc_pack_first_conv_f32": (C.c_int, [_p, _i32, _i32, _p, _p]),
     "ammc_conv_first_s16": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _i64, _i64, _i64, _p, _p]),
+    "ammc_conv_first_s16_bs": (C.c_int, [_p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _i64, _i64, _i64, _p, _p]),
     "ammc_conv_gemm_s16_variant": (C.c_int, [C.POINTER(AmmcConvDesc), C.c_char_p, _i32]),
     "ammc_conv_gemm_s16_stats_rows": (C.c_int, [C.POINTER(AmmcConvDesc)]),
     "ammc_split_rows_f32": (C.c_int, [_p, _i64, _p, _p]),
@@ -89,6 +90,10 @@ SIGNATURES = {
     "ammc_pack_codebook_f16": (C.c_int, [_p, _i32, _i32, _p, _p, _p]),
     "ammc_memory_topk_f16_blocks": (C.c_int, [_i32]),
     "ammc_memory_topk_fwd_f16": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
+    "ammc_codebook_f16_tiles_bytes": (C.c_int64, [_i32, _i32]),
+    "ammc_pack_codebook_f16_tiles": (C.c_int, [_p, _i32, _i32, _p, _p]),
+    "ammc_memory_topk_f16r_blocks": (C.c_int, [_i32]),
+    "ammc_memory_topk_fwd_f16r": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
     "ammc_conv_wgrad_f32": (C.c_int, [C.POINTER(AmmcWgradDesc), _p]),
     "ammc_conv_wgrad_s16": (C.c_int, [C.POINTER(AmmcWgradDesc), _p, _p]),
     "ammc_unpack_conv_wgrad_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),

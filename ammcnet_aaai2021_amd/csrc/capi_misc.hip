@@ -4,7 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-extern "C" int ammc_abi_version(void) { return 35; }
+extern "C" int ammc_abi_version(void) { return 36; }
 
 // dispatch options (ammc_common.h): initialised from the environment once, changed by ammc_set_option
 int g_ammc_s16_mf = -2;              // -2 = not read yet; -1 = auto (per variant); 0 / 1 = forced

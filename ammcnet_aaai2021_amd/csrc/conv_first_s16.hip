@@ -41,6 +41,7 @@ struct FirstArgs {
   float* y;                // S16 NHWC, pixel (0, 0)
   int32_t* overflow_flag;
   int64_t y_bs, y_rs, y_ps;
+  int64_t x_bs;            // elements between consecutive batch entries of x (c * h * w when x is contiguous)
   int batch, c, h, w_, act, tiles_x, tiles_y;
 };
 
@@ -57,7 +58,7 @@ __device__ __forceinline__ int first_load_patch(const FirstArgs& a, int t, int t
   const int b = sp / a.tiles_y;
   const int plane = a.h * a.w_;
   const int nc = CT ? CT : a.c;
-  const float* xb = a.x + (int64_t)b * nc * plane;
+  const float* xb = a.x + (int64_t)b * a.x_bs;
   int inb = 0;                                     // bit rnd: that halo pixel lies inside the image
 #pragma unroll
   for (int rnd = 0; rnd < 2; ++rnd) {
@@ -289,7 +290,15 @@ extern "C" int ammc_pack_first_conv_f32(const float* w_oihw, int32_t cout, int32
 extern "C" int ammc_conv_first_s16(const float* x_nchw, int32_t batch, int32_t c, int32_t h, int32_t w,
                                    const float* w_image, const float* scale, const float* shift, int32_t act,
                                    float* y, int64_t y_bs, int64_t y_rs, int64_t y_ps, int32_t* overflow_flag, void* stream) {
-  if (!x_nchw || !w_image || !y || batch <= 0 || c <= 0 || h <= 0 || w <= 0) return AMMC_EINVAL;
+  return ammc_conv_first_s16_bs(x_nchw, (int64_t)c * h * w, batch, c, h, w, w_image, scale, shift, act, y, y_bs, y_rs, y_ps,
+                                overflow_flag, stream);
+}
+
+extern "C" int ammc_conv_first_s16_bs(const float* x_nchw, int64_t x_bs, int32_t batch, int32_t c, int32_t h, int32_t w,
+                                      const float* w_image, const float* scale, const float* shift, int32_t act,
+                                      float* y, int64_t y_bs, int64_t y_rs, int64_t y_ps, int32_t* overflow_flag,
+                                      void* stream) {
+  if (!x_nchw || !w_image || !y || batch <= 0 || c <= 0 || h <= 0 || w <= 0 || x_bs < 0) return AMMC_EINVAL;
   if (c > 16 || w % F_TW || h % F_TH) return AMMC_EUNSUP;
   if (act != AMMC_ACT_NONE && act != AMMC_ACT_RELU) return AMMC_EUNSUP;
   if (((uintptr_t)w_image & 15) || ((uintptr_t)y & 31) || ((y_bs | y_rs | y_ps) & 7)) return AMMC_EINVAL;
@@ -298,10 +307,10 @@ extern "C" int ammc_conv_first_s16(const float* x_nchw, int32_t batch, int32_t c
   static_assert(lds <= 80 * 1024, "two workgroups per CU");
   FirstArgs a;
   a.x = x_nchw, a.w = w_image, a.scale = scale, a.shift = shift, a.y = y, a.overflow_flag = overflow_flag;
-  a.y_bs = y_bs, a.y_rs = y_rs, a.y_ps = y_ps;
+  a.y_bs = y_bs, a.y_rs = y_rs, a.y_ps = y_ps, a.x_bs = x_bs;
   a.batch = batch, a.c = c, a.h = h, a.w_ = w, a.act = act;
   a.tiles_x = w / F_TW, a.tiles_y = h / F_TH;
-  if ((int64_t)batch * c * h * w >= (1LL << 31)) return AMMC_EUNSUP;
+  if ((int64_t)c * h * w >= (1LL << 31)) return AMMC_EUNSUP;     // (plane offsets inside one batch entry are 32-bit)
   const int total = batch * a.tiles_y * a.tiles_x;
   const dim3 grid(total < 512 ? total : 512);
 #define FIRST_LAUNCH(CT)                                                                                              \

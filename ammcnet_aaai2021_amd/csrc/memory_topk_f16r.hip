@@ -1,0 +1,466 @@
+// Memory addressing with fp16 MFMA operands, ROWS RESIDENT IN REGISTERS (round 5): the form of
+// `Quantize_topk.forward` (reference Code/models/unet.py:282-297, 310-313) for large memories (BASELINE.json config 5:
+// 8192 slots x 512-d) that replaces memory_topk_f16.hip where it applies.  Same outputs, same arithmetic contract: the
+// slot RANKING is computed from fp16-rounded features / slots with fp32 accumulation, the gathered rows, q_one and the
+// commit distance come from the fp32 codebook and the fp32 features.
+//
+// Why: memory_topk_f16.hip keeps 128 feature rows in LDS and every workgroup streams the whole fp16 codebook (8 MB) from
+// L2 into REGISTERS - 256 B per MFMA through the per-CU vector-memory path, 16.8 GB per 262144-row launch; that stream,
+// not the matrix pipe, set its time (0.40 of the pipe busy).  Here the roles are swapped:
+//   - a wave (one per SIMD, up to 512 VGPRs) keeps RT = 3 tiles of 32 feature rows x 512 features as fp16 B-FRAGMENTS IN
+//     ITS REGISTERS (384 VGPRs) for a whole sweep of the codebook: 384 rows per workgroup and sweep instead of 128;
+//   - the codebook, pre-packed tile by tile in fragment order (ammc_pack_codebook_f16_tiles), goes L2 -> LDS by LDS-DMA
+//     (global_load_lds_dwordx4, a ring of four 33-KB tiles, counted vmcnt + one raw s_barrier per tile) ONCE per workgroup
+//     and is read from LDS by the four waves: 85 B of L2 traffic and 341 B of LDS reads per MFMA (was 256 + 512);
+//   - the distance epilogue costs nothing: the accumulators START at -|E_s|^2 / 2 (the first MFMA of a slot tile takes
+//     them as its C operand from the 1 KB of constants that rides with the tile), so the ranking key x.E_s - |E_s|^2 / 2
+//     comes out of the contraction itself and a tile's 16 candidates of a row are only reduced with v_max3 against the
+//     row's K-th best;
+//   - a lane owns a feature row: the running top-K lives in registers, the two halves of the wave (slots 4h .. 4h+3 of
+//     every group of 8) are merged with one lane exchange at the end of the sweep - no LDS candidate lists, no
+//     workgroup-wide merge;
+//   - workgroups are persistent: each takes a contiguous run of row tiles and sweeps the codebook ceil(run / (4 RT))
+//     times, the last sweep with fewer tiles per wave (dispatched on the count: no MFMA is issued for rows that do not
+//     exist), so 262144 rows on 256 CUs are three sweeps of 3 + 3 + 2 tiles per wave with no tail round.
+// The feature rows reach their fragment registers through LDS as well (the ring is idle between sweeps): whole 128-byte
+// lines by LDS-DMA, 16-byte pieces XOR-swizzled by row on the SOURCE side so that the fragment reads are conflict free.
+// Roofline: MFMA fp16, 2 * n * d * m flop.
+#include "ammc_common.h"
+#include <hip/hip_fp16.h>
+#include <math.h>
+#include <algorithm>
+
+namespace ammc_f16r {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int RW = 4;             // waves per workgroup (one per SIMD)
+constexpr int NBUF = 4;           // codebook tiles in the LDS ring: one being read, one landed, two in flight
+constexpr int NA = 4;             // A-fragment register ring (LDS reads NA - 1 k-steps ahead of their MFMAs)
+
+struct F16rArgs {
+  const float* x;                 // [n][d] fp32
+  const unsigned char* tiles;     // ammc_pack_codebook_f16_tiles
+  const float* e_md;              // [m][d] fp32
+  int* idx_out;                   // [n][K]
+  float* q_topk;                  // [n][K][d]
+  float* q_one;                   // [n][d] or null
+  float* diff_partial;            // [ceil(n / 32)]
+  int n, d, m, ntile;             // ntile = ceil(m / 32)
+  int t32;                        // row tiles of 32 rows: ceil(n / 32)
+  int pw;                         // row tiles per wave
+};
+
+// LDS-DMA of 16 bytes per lane with the instruction hidden from the compiler (see conv_tap_s16.hip: hipcc books the
+// builtin as a FLAT access, after which every LDS wait it inserts is lgkmcnt(0)); vmcnt waits are written by hand.
+// `base` wave-uniform, `off` this lane's byte offset, `lds_byte` the wave-uniform LDS address of the wave's 1 KB.
+__device__ __forceinline__ void r_dma16(const void* base, unsigned off, unsigned lds_byte) {
+  unsigned keep;
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(off), "s"(base), "s"(lds_byte) : "memory");
+}
+// the same with a full address per lane
+__device__ __forceinline__ void r_dma16_ptr(const void* src, unsigned lds_byte) {
+  unsigned keep;
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(lds_byte) : "memory");
+}
+#define R_VMCNT(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory")
+
+// candidates arrive in increasing slot order within a lane: a tie loses to the entry already held (strict comparison =
+// the (value, index) order).  Keys are MAXIMISED (x.E - |E|^2 / 2).
+template <int K>
+__device__ __forceinline__ void r_insert_ordered(float (&v)[K], int (&ix)[K], float c, int s) {
+  if (c > v[K - 1]) {
+    v[K - 1] = c;
+    ix[K - 1] = s;
+#pragma unroll
+    for (int j = K - 1; j > 0; --j) {
+      const bool sw = v[j] > v[j - 1];
+      const float tv = sw ? v[j - 1] : v[j];
+      const int ti = sw ? ix[j - 1] : ix[j];
+      v[j - 1] = sw ? v[j] : v[j - 1];
+      ix[j - 1] = sw ? ix[j] : ix[j - 1];
+      v[j] = tv;
+      ix[j] = ti;
+    }
+  }
+}
+// general insertion ((value desc, index asc) order): the merge of the two lane halves
+template <int K>
+__device__ __forceinline__ void r_insert(float (&v)[K], int (&ix)[K], float c, int s) {
+  if (c > v[K - 1] || (c == v[K - 1] && s < ix[K - 1])) {
+    v[K - 1] = c;
+    ix[K - 1] = s;
+#pragma unroll
+    for (int j = K - 1; j > 0; --j) {
+      const bool sw = v[j] > v[j - 1] || (v[j] == v[j - 1] && ix[j] < ix[j - 1]);
+      const float tv = sw ? v[j - 1] : v[j];
+      const int ti = sw ? ix[j - 1] : ix[j];
+      v[j - 1] = sw ? v[j] : v[j - 1];
+      ix[j - 1] = sw ? ix[j] : ix[j - 1];
+      v[j] = tv;
+      ix[j] = ti;
+    }
+  }
+}
+
+// One sweep of the codebook for CNT row tiles of this wave (rows [row0 + 32 i, +32), i < CNT; rows >= n are clamped for
+// the loads and never written).  Everything of the sweep: feature staging, contraction + running top-K, the merge of
+// the lane halves, indices, gather / q_one / commit partials.
+template <int K, int NSTEP, int CNT, bool Q1>
+__device__ __forceinline__ void r_sweep(const F16rArgs& a, unsigned char* smem, unsigned lds0, int lane, int uwave, int tile0) {
+  constexpr int TB = (NSTEP + 1) * 1024;           // bytes of a codebook tile image
+  constexpr int D = NSTEP * 16;
+  constexpr int PH = D / 8;                        // 16-byte pieces of half a feature row (fp32)
+  constexpr int BPH = PH / 16;                     // 256-byte blocks of half a feature row
+  constexpr int DPT = NSTEP / 4 + 1;               // DMA instructions per tile and wave (the constants' KB by every wave)
+  const int h = lane >> 5, l31 = lane & 31;
+
+  // ---- features -> fp16 B fragments in registers, through this wave's quarter of the (idle) ring -------------------------
+  // Row tiles 0 and 1 end up in AGPRs, tile 2 in VGPRs (see the contraction).  A value only STAYS in an AGPR if it is born
+  // there - hipcc copies a VGPR-born value into a scratch AGPR in front of every asm that wants one - and the one
+  // instruction that writes a 128-bit AGPR tuple in one go is an LDS read: the converted fragments of tiles 0 / 1 go back
+  // to LDS (in place: into the 256-byte block of their own row they were just read from) and are read into AGPRs by asm.
+  constexpr int CA = CNT < 2 ? CNT : 2;
+  f16x8 xa[CA][NSTEP];                               // AGPR-resident ("a" operands only)
+  f16x8 xv[CNT == 3 ? NSTEP : 1];                    // VGPR-resident third tile
+  {
+    const unsigned stage = (unsigned)uwave * (unsigned)(32 * PH * 16);       // 32 rows x half a row
+    unsigned char* sp = smem + stage;
+#pragma unroll
+    for (int rt = 0; rt < CNT; ++rt) {
+      const int r0 = (tile0 + rt) * 32;
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        // 32 x PH pieces, piece g = (row, c): LDS slot g linear; the SOURCE piece of slot (row, c) is c ^ (row & 15) within
+        // its 256-byte block, so that the 16 lanes of a ds_read_b128 group (16 distinct rows mod 16) hit 16 distinct slots
+#pragma unroll 2
+        for (int i = 0; i < NSTEP; ++i) {
+          const int g = i * 64 + lane;
+          const int row = g / PH, c = g % PH;
+          const int srcp = (c & ~15) | ((c & 15) ^ (row & 15));
+          int gr = r0 + row;
+          gr = gr < a.n ? gr : a.n - 1;
+          r_dma16_ptr(a.x + (int64_t)gr * D + kh * (D / 2) + srcp * 4, lds0 + stage + (unsigned)i * 1024u);
+        }
+        R_VMCNT(0);
+        // lane (row l31, half h), k-step t = kh NSTEP / 2 + tt: features 16 t + 8 h .. + 7 = pieces 4 tt + 2 h, + 1 of the
+        // half row; four k-steps = one 256-byte block of the row
+#pragma unroll
+        for (int q = 0; q < NSTEP / 8; ++q) {
+          f16x8 hv[4];
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            const int c0 = 16 * q + 4 * s4 + 2 * h;                            // even: its partner is c0 ^ 1 after the swizzle too
+            const int p0 = (c0 & ~15) | ((c0 & 15) ^ (l31 & 15));
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp + ((unsigned)(l31 * PH + p0) << 4));
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(sp + ((unsigned)(l31 * PH + (p0 ^ 1)) << 4));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { hv[s4][j] = (_Float16)v0[j]; hv[s4][4 + j] = (_Float16)v1[j]; }
+          }
+          if (rt == 2) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) xv[kh * (NSTEP / 2) + 4 * q + s4] = hv[s4];
+          } else {
+            // (LDS operations of one wave execute in order: the block's fp32 pieces have been read by both of its lanes)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+              const unsigned wo = ((unsigned)(l31 * PH + 16 * q + ((2 * s4 + h) ^ (l31 & 15))) << 4);
+              *reinterpret_cast<f16x8*>(sp + wo) = hv[s4];
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+              const unsigned wo = ((unsigned)(l31 * PH + 16 * q + ((2 * s4 + h) ^ (l31 & 15))) << 4);
+              asm volatile("ds_read_b128 %0, %1" : "=a"(xa[rt < CA ? rt : 0][kh * (NSTEP / 2) + 4 * q + s4]) : "v"(lds0 + stage + wo) : "memory");
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // reads done before the region is refilled / the values used
+      }
+    }
+  }
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();                    // every wave is done with its staging region: the ring may be filled
+  asm volatile("" ::: "memory");
+
+  // ---- codebook ring ---------------------------------------------------------------------------------------------------
+  const unsigned lane_off = (unsigned)lane * 16u + (unsigned)uwave * 1024u;
+  auto issue_tile = [&](int tile) {
+    const int tl = tile < a.ntile ? tile : a.ntile - 1;                        // (past the end: a valid source, a free slot, never read)
+    const unsigned char* src = a.tiles + (int64_t)tl * TB;
+    const unsigned dst = lds0 + (unsigned)(tile & (NBUF - 1)) * (unsigned)TB;
+#pragma unroll
+    for (int j = 0; j < NSTEP / 4; ++j)
+      r_dma16(src + j * 4096, lane_off, dst + (unsigned)(j * 4096) + (unsigned)uwave * 1024u);
+    r_dma16(src + NSTEP * 1024, (unsigned)lane * 16u, dst + (unsigned)(NSTEP * 1024));
+  };
+  float bv[CNT][K];
+  int bi[CNT][K];
+#pragma unroll
+  for (int rt = 0; rt < CNT; ++rt)
+#pragma unroll
+    for (int j = 0; j < K; ++j) { bv[rt][j] = -INFINITY; bi[rt][j] = 0x7fffffff; }
+#pragma unroll
+  for (int p = 0; p < NBUF - 1; ++p) issue_tile(p);
+
+  for (int tile = 0; tile < a.ntile; ++tile) {
+    // tile's own DMAs (issued three iterations ago) have landed for this wave once all but the two younger tiles' are
+    // done; behind the barrier that holds for every wave, and everybody has finished reading tile - 1, whose slot the
+    // tile after next then goes into
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPT) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue_tile(tile + NBUF - 1);
+    const unsigned char* tb = smem + (unsigned)(tile & (NBUF - 1)) * (unsigned)TB;
+    const unsigned char* ap = tb + lane * 16;
+    // C operand of the tile's first MFMAs: -|E_s|^2 / 2 of the 16 slots this lane's accumulator registers stand for
+    f32x16 ci;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 c4 = *reinterpret_cast<const f32x4*>(tb + NSTEP * 1024 + (8 * q + 4 * h) * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ci[4 * q + i] = c4[i];
+    }
+    // The MFMAs are written in asm so that their register classes are OURS: the 3 x 128 fragment registers of the rows do
+    // not fit the 256 architectural VGPRs, and hipcc, which keeps MFMA sources in VGPRs, parked two thirds of them in
+    // AGPRs and copied four registers back per MFMA (v_accvgpr_read + the wait states behind it).  On gfx950 an MFMA takes
+    // its B operand from an AGPR directly: row tiles 0 and 1 live in AGPRs ("a"), tile 2 and the accumulators in VGPRs
+    // (the top-K screen below reads the accumulators with VALU instructions: no v_accvgpr_read either).
+    f32x16 acc[CNT];
+    f16x8 ar[NA];
+#define R_MFMA_FIRST(rt_, a_, t_)                                                                                       \
+  if (rt_ < 2) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(acc[rt_]) : "v"(a_), "a"(xa[rt_ < CA ? rt_ : 0][t_]), "v"(ci)); \
+  else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(acc[rt_]) : "v"(a_), "v"(xv[CNT == 3 ? t_ : 0]), "v"(ci));
+#define R_MFMA_NEXT(rt_, a_, t_)                                                                                        \
+  if (rt_ < 2) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[rt_]) : "v"(a_), "a"(xa[rt_ < CA ? rt_ : 0][t_])); \
+  else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[rt_]) : "v"(a_), "v"(xv[CNT == 3 ? t_ : 0]));
+#pragma unroll
+    for (int t = 0; t < NA - 1; ++t) ar[t] = *reinterpret_cast<const f16x8*>(ap + t * 1024);
+#pragma unroll
+    for (int t = 0; t < NSTEP; ++t) {
+      if (t + NA - 1 < NSTEP) ar[(t + NA - 1) % NA] = *reinterpret_cast<const f16x8*>(ap + (t + NA - 1) * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int rt = 0; rt < CNT; ++rt) {
+        if (t == 0) { R_MFMA_FIRST(rt, ar[t % NA], t) } else { R_MFMA_NEXT(rt, ar[t % NA], t) }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef R_MFMA_FIRST
+#undef R_MFMA_NEXT
+    // (nothing pads an asm statement: the VALU reads of the screen below must not issue sooner than 18 wait states after
+    // the last MFMA that writes the registers they read - cdna4 ISA, XDL write VGPR -> VALU read)
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    // running top-K: register r of a lane is slot s0 + (r & 3) + 8 (r >> 2) + 4 h (ascending in r)
+    const int s0 = tile << 5;
+#pragma unroll
+    for (int rt = 0; rt < CNT; ++rt) {
+      float mx = __builtin_fmaxf(__builtin_fmaxf(acc[rt][0], acc[rt][1]), acc[rt][2]);
+#pragma unroll
+      for (int r = 3; r + 1 < 16; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, acc[rt][r]), acc[rt][r + 1]);
+      mx = __builtin_fmaxf(mx, acc[rt][15]);
+      if (mx > bv[rt][K - 1]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) r_insert_ordered<K>(bv[rt], bi[rt], acc[rt][r], s0 + (r & 3) + 8 * (r >> 2) + 4 * h);
+      }
+    }
+  }
+  R_VMCNT(0);                                      // (the clamped DMAs past the end)
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();                    // the ring changes hands: the next sweep stages features in it
+  asm volatile("" ::: "memory");
+
+  // ---- merge the two lane halves of a row (lanes l and l ^ 32), write the indices ----------------------------------------
+#pragma unroll
+  for (int rt = 0; rt < CNT; ++rt) {
+    float ov[K];
+    int oi[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      ov[j] = __shfl_xor(bv[rt][j], 32, 64);
+      oi[j] = __shfl_xor(bi[rt][j], 32, 64);
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) r_insert<K>(bv[rt], bi[rt], ov[j], oi[j]);
+    const int row = (tile0 + rt) * 32 + l31;
+    if (h == 0 && row < a.n) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) a.idx_out[(int64_t)row * K + j] = bi[rt][j];
+    }
+  }
+
+  // ---- gather (fp32 codebook rows), q_one, commit partial sums: UN (row, 256-float chunk) units per trip ------------------
+  constexpr int NCH = (D + 255) / 256;
+  constexpr int UN = 4;
+#pragma unroll
+  for (int rt = 0; rt < CNT; ++rt) {
+    const int r0 = (tile0 + rt) * 32;
+    if (r0 >= a.n) break;
+    const int nrow = a.n - r0 < 32 ? a.n - r0 : 32;
+    float part = 0.f;
+    for (int u0 = 0; u0 < nrow * NCH; u0 += UN) {
+      f32x4 e[UN][K], xv[UN];
+      bool on[UN];
+      int64_t xo[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int uu = u0 + u < nrow * NCH ? u0 + u : nrow * NCH - 1;       // (a short last trip repeats its last unit, unwritten)
+        const int r = uu / NCH, ch = uu - r * NCH;
+        const int off = ch * 256 + lane * 4;
+        on[u] = off < D && u0 + u < nrow * NCH;
+        const int offc = off < D ? off : 0;
+        xo[u] = (int64_t)(r0 + r) * D + offc;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          const int s = __builtin_amdgcn_readlane(bi[rt][j], r);
+          e[u][j] = *reinterpret_cast<const f32x4*>(a.e_md + (int64_t)s * D + offc);
+        }
+        xv[u] = *reinterpret_cast<const f32x4*>(a.x + xo[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        if (!on[u]) continue;
+        const int uu = u0 + u;
+        const int r = uu / NCH, ch = uu - r * NCH;
+        const int64_t qo = ((int64_t)(r0 + r) * K) * D + ch * 256 + lane * 4;
+#pragma unroll
+        for (int j = 0; j < K; ++j) *reinterpret_cast<f32x4*>(a.q_topk + qo + (int64_t)j * D) = e[u][j];
+        f32x4 q1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float df = e[u][0][i] - xv[u][i];
+          part += df * df;
+          q1[i] = xv[u][i] + df;
+        }
+        if (Q1) *reinterpret_cast<f32x4*>(a.q_one + xo[u]) = q1;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if (lane == 0) a.diff_partial[tile0 + rt] = part;
+  }
+}
+
+template <int K, int NSTEP, int RT, bool Q1>
+__global__ __launch_bounds__(256, 1) void memory_topk_f16r_kernel(F16rArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int uwave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem_r;
+  // this wave's run of row tiles; every wave of the grid has `pw` of them (the last ones past the end of the rows)
+  const int first = ((int)blockIdx.x * RW + uwave) * a.pw;
+  for (int p0 = 0; p0 < a.pw; p0 += RT) {
+    const int cnt = a.pw - p0 < RT ? a.pw - p0 : RT;                         // the same for every wave of the grid
+    int t0 = first + p0;
+    // a wave whose tiles lie past the end still takes part in the ring (DMA shares, barriers); it contracts the last
+    // real tile again and writes nothing (all its rows are >= n ... unless t0 is clamped: mark by tile0 >= t32)
+    const bool live = t0 < a.t32;
+    if (!live) t0 = a.t32;                                                     // rows >= n: loads clamp to row n - 1, nothing is stored
+    if (RT >= 3 && cnt == 3) r_sweep<K, NSTEP, 3, Q1>(a, smem_r, lds0, lane, uwave, t0);
+    else if (RT >= 2 && cnt == 2) r_sweep<K, NSTEP, 2, Q1>(a, smem_r, lds0, lane, uwave, t0);
+    else r_sweep<K, NSTEP, 1, Q1>(a, smem_r, lds0, lane, uwave, t0);
+  }
+}
+
+// [d][m] fp32 -> tile images: tile T (slots 32 T .. 32 T + 31) = NSTEP KB of A fragments - KB t holds, for lane
+// (l31, h), the 8 halfs of slot 32 T + l31, features 16 t + 8 h .. + 7 - and one KB of constants: float i < 32 =
+// -|half(E_{32 T + i})|^2 / 2 (-inf for slots >= m: they never win), the rest zero
+__global__ __launch_bounds__(256) void pack_codebook_f16_tiles_kernel(const float* __restrict__ e_dm, int d, int m,
+                                                                      unsigned char* __restrict__ out) {
+  const int nstep = d >> 4;
+  const int tile = blockIdx.x, tid = threadIdx.x;
+  unsigned char* tb = out + (int64_t)tile * (nstep + 1) * 1024;
+  for (int p = tid; p < nstep * 64; p += 256) {
+    const int t = p >> 6, ln = p & 63;
+    const int s = tile * 32 + (ln & 31), f0 = 16 * t + 8 * (ln >> 5);
+    f16x8 hv;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hv[i] = (_Float16)(s < m ? e_dm[(int64_t)(f0 + i) * m + s] : 0.f);
+    *reinterpret_cast<f16x8*>(tb + (int64_t)p * 16) = hv;
+  }
+  float* cn = reinterpret_cast<float*>(tb + (int64_t)nstep * 1024);
+  if (tid < 32) {
+    const int s = tile * 32 + tid;
+    float nrm = 0.f;
+    if (s < m)
+      for (int f = 0; f < d; ++f) {
+        const float v = (float)(_Float16)e_dm[(int64_t)f * m + s];
+        nrm += v * v;
+      }
+    cn[tid] = s < m ? -0.5f * nrm : -INFINITY;
+  } else {
+    cn[tid] = 0.f;
+  }
+}
+
+template <int K, int NSTEP, bool Q1>
+int launch_f16r(const F16rArgs& a0, hipStream_t stream) {
+  constexpr int RT = 3;
+  F16rArgs a = a0;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (cus <= 0) cus = 256;
+  // one workgroup per CU at most; every wave gets the same number of row tiles
+  const int waves = std::min(cus * RW, a.t32);
+  a.pw = (a.t32 + waves - 1) / waves;
+  const int grid = (a.t32 + a.pw * RW - 1) / (a.pw * RW);
+  const size_t lds = (size_t)NBUF * (NSTEP + 1) * 1024;
+  auto kern = memory_topk_f16r_kernel<K, NSTEP, RT, Q1>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+  return ammc_launch_status();
+}
+
+template <int K, bool Q1>
+int launch_f16r_d(const F16rArgs& a, hipStream_t stream) {
+  switch (a.d) {
+    case 128: return launch_f16r<K, 8, Q1>(a, stream);
+    case 256: return launch_f16r<K, 16, Q1>(a, stream);
+    case 384: return launch_f16r<K, 24, Q1>(a, stream);
+    case 512: return launch_f16r<K, 32, Q1>(a, stream);
+  }
+  return AMMC_EUNSUP;
+}
+
+}  // namespace ammc_f16r
+using namespace ammc_f16r;
+
+extern "C" int64_t ammc_codebook_f16_tiles_bytes(int32_t d, int32_t m) {
+  if (d <= 0 || (d % 16) || m <= 0) return 0;
+  return (int64_t)((m + 31) / 32) * ((d >> 4) + 1) * 1024;
+}
+
+extern "C" int ammc_pack_codebook_f16_tiles(const float* embed_dm, int32_t d, int32_t m, void* tiles, void* stream) {
+  if (!embed_dm || !tiles || d <= 0 || (d % 16) || m <= 0) return AMMC_EINVAL;
+  if ((uintptr_t)tiles & 15) return AMMC_EINVAL;
+  hipLaunchKernelGGL(pack_codebook_f16_tiles_kernel, dim3((m + 31) / 32), dim3(256), 0, (hipStream_t)stream, embed_dm, d, m,
+                     reinterpret_cast<unsigned char*>(tiles));
+  return ammc_launch_status();
+}
+
+extern "C" int ammc_memory_topk_f16r_blocks(int32_t n) { return n <= 0 ? 0 : (n + 31) / 32; }
+
+extern "C" int ammc_memory_topk_fwd_f16r(const float* x, const void* tiles, const float* embed_md, int32_t n, int32_t d,
+                                         int32_t m, int32_t k, int32_t* idx_topk, float* q_topk, float* q_one,
+                                         float* diff_partial, void* stream) {
+  if (!x || !tiles || !embed_md || !idx_topk || !q_topk || !diff_partial) return AMMC_EINVAL;
+  if (n <= 0 || m <= 0 || k <= 0 || k > m) return AMMC_EINVAL;
+  if (d < 128 || (d % 128) || d > 512) return AMMC_EUNSUP;
+  if (k > 4) return AMMC_EUNSUP;
+  if (((uintptr_t)x | (uintptr_t)tiles | (uintptr_t)embed_md | (uintptr_t)q_topk | (uintptr_t)q_one) & 15) return AMMC_EINVAL;
+  F16rArgs a;
+  a.x = x, a.tiles = reinterpret_cast<const unsigned char*>(tiles), a.e_md = embed_md, a.idx_out = idx_topk;
+  a.q_topk = q_topk, a.q_one = q_one, a.diff_partial = diff_partial;
+  a.n = n, a.d = d, a.m = m, a.ntile = (m + 31) / 32, a.t32 = (n + 31) / 32, a.pw = 0;
+  hipStream_t s = (hipStream_t)stream;
+#define F16R_K(K_)                                                                                   \
+  case K_: return q_one ? launch_f16r_d<K_, true>(a, s) : launch_f16r_d<K_, false>(a, s);
+  switch (k) {
+    F16R_K(1) F16R_K(2) F16R_K(3) F16R_K(4)
+  }
+#undef F16R_K
+  return AMMC_EUNSUP;
+}

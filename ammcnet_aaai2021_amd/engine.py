@@ -478,10 +478,11 @@ class StreamGraph:
             p, si = sp.inc, self.index
 
             def first_args(ctx, m=mid, p=p, si=si, B=B, H=H, W=W, cin=sp.cin, img=sp.first, flag=bld.overflow):
-                return (_ptr(ctx["x"][si]), B, cin, H, W, _ptr(img), _ptr(p.s0), _ptr(p.b0), ACT_RELU, m.pix0(), *m.strides,
+                x = ctx["x"][si]              # (batch stride: clips may be overlapping windows of a resident sub-video)
+                return (_ptr(x), x.stride(0), B, cin, H, W, _ptr(img), _ptr(p.s0), _ptr(p.b0), ACT_RELU, m.pix0(), *m.strides,
                         flag.data_ptr())
             bld.plan.keep.extend([sp.first, p.s0, p.b0])
-            bld.plan.add(bld.lib.ammc_conv_first_s16, name="inc.conv0", kernel="conv_first_s16", dyn=first_args,
+            bld.plan.add(bld.lib.ammc_conv_first_s16_bs, name="inc.conv0", kernel="conv_first_s16", dyn=first_args,
                          flops=2.0 * B * H * W * 9 * sp.cin * 64, nbytes=4.0 * B * H * W * (sp.cin + 64))
             # (Measured and dropped: running this layer and the next image chunk by image chunk, so that the 268-MB
             # intermediate is read back from the Infinity Cache instead of HBM - 4 images per launch 6.73 -> 6.85 ms per step,
@@ -857,9 +858,13 @@ class EvalEngine:
                     _lib.check(rc, meta["name"])
 
             xs, keep = [], []
-            for x in inputs[:len(streams)]:
+            for s, x in zip(streams, inputs):
                 x = x.detach()
-                if x.dtype != torch.float32 or not x.is_contiguous():
+                # a batch of clips cut out of a resident sub-video as overlapping windows (harness.clip_windows: planes
+                # contiguous, any batch stride) is read in place by the first-layer kernel; everything else is gathered
+                windowed = (x.dtype == torch.float32 and getattr(s, "first_mid", None) is not None and x.dim() == 4 and
+                            x.stride()[1:] == (H * W, W, 1) and x.stride(0) >= 0)
+                if not windowed and (x.dtype != torch.float32 or not x.is_contiguous()):
                     x = x.float().contiguous()
                 xs.append(x)
             outs = [torch.empty((B, s.sp.cout, H, W), device=x0.device, dtype=torch.float32) for s in streams]

@@ -40,29 +40,47 @@ def subvideo_batches(n_frames: int, batch: int = EVAL_BATCH, rgb_len_clip: int =
     return [(s, min(s + batch, n_clip)) for s in range(0, max(n_clip, 0), batch)]
 
 
+def clip_windows(frames: torch.Tensor, s: int, e: int, n_in: int) -> torch.Tensor:
+    """clips [s, e) of a contiguous [T, c, H, W] sub-video as ONE overlapping view [e - s, n_in * c, H, W]: clip i is
+    `frames[i:i + n_in].view(n_in * c, H, W)` (test_helper.py:433-438), so consecutive clips are one frame apart"""
+    _, c, h, w = frames.shape
+    return frames.as_strided((e - s, n_in * c, h, w), (c * h * w, h * w, w, 1), frames.storage_offset() + s * c * h * w)
+
+
 def score_batch_device(model: Callable, rgb_frames: torch.Tensor, op_frames: torch.Tensor, s: int, e: int,
                        device=None, exact: bool = False) -> torch.Tensor:
     """run clips [s, e) of a sub-video as ONE batch; returns [2 b + 3] on the model's device: per-clip rgb PSNR, per-clip
     flow PSNR, the batch's two commit values and the S16 range flag of the batch (0 / 1; always 0 for models without
     one) - nothing is copied to the host, so batches can be queued back to back.  `exact`: run the HIP model's
     exact-fp32 kernels (the re-run of a flagged batch)."""
-    rgb = torch.stack([rgb_frames[i:i + RGB_LEN_CLIP] for i in range(s, e)])
-    op = torch.stack([op_frames[i:i + OP_LEN_CLIP] for i in range(s, e)])
-    if device is not None:
-        rgb, op = rgb.to(device, non_blocking=True), op.to(device, non_blocking=True)
     b = e - s
-    rgb_in = rgb[:, :-1].reshape(b, -1, *rgb.shape[-2:])
-    op_in = op[:, :-1].reshape(b, -1, *op.shape[-2:])
+    resident = device is None or (rgb_frames.device == torch.device(device) and op_frames.device == torch.device(device))
+    if resident and rgb_frames.is_contiguous() and op_frames.is_contiguous():
+        # the sub-video is where the model is: a batch of clips is an OVERLAPPING view of it (clip i = frames [i, i + 4),
+        # batch stride = one frame) and the targets are a plain slice - nothing is gathered, the HIP model's first-layer
+        # kernel reads the windows in place (ammc_conv_first_s16_bs); other callables make them contiguous themselves
+        rgb_in = clip_windows(rgb_frames, s, e, RGB_LEN_CLIP - 1)
+        op_in = clip_windows(op_frames, s, e, OP_LEN_CLIP - 1)
+        rgb_t = rgb_frames[s + RGB_LEN_CLIP - 1:e + RGB_LEN_CLIP - 1]
+        op_t = op_frames[s + OP_LEN_CLIP - 1:e + OP_LEN_CLIP - 1]
+    else:
+        rgb = torch.stack([rgb_frames[i:i + RGB_LEN_CLIP] for i in range(s, e)])
+        op = torch.stack([op_frames[i:i + OP_LEN_CLIP] for i in range(s, e)])
+        if device is not None:
+            rgb, op = rgb.to(device, non_blocking=True), op.to(device, non_blocking=True)
+        rgb_in = rgb[:, :-1].reshape(b, -1, *rgb.shape[-2:])
+        op_in = op[:, :-1].reshape(b, -1, *op.shape[-2:])
+        rgb_t, op_t = rgb[:, -1], op[:, -1]
     with torch.no_grad():
         flag = None
         if hasattr(model, "forward_scored") and rgb_in.is_cuda:
             # the HIP model accumulates the squared errors inside the `outc` kernel
             (_, _, (rgb_diff, op_diff), _), rgb_psnr, op_psnr = model.forward_scored(
-                rgb_in, op_in, rgb[:, -1], op[:, -1], defer_guard=True, exact=exact)
+                rgb_in, op_in, rgb_t, op_t, defer_guard=True, exact=exact)
             flag = getattr(model, "last_overflow", None)
         else:
             rgb_out, op_out, (rgb_diff, op_diff), _ = model(rgb_in, op_in)
-            rgb_psnr, op_psnr = psnr_per_sample(rgb_out, rgb[:, -1]), psnr_per_sample(op_out, op[:, -1])
+            rgb_psnr, op_psnr = psnr_per_sample(rgb_out, rgb_t), psnr_per_sample(op_out, op_t)
         if flag is None:
             flag = torch.zeros(1, device=rgb_psnr.device, dtype=rgb_psnr.dtype)
         return torch.cat([rgb_psnr, op_psnr, rgb_diff.reshape(1), op_diff.reshape(1), flag.reshape(1).to(rgb_psnr.dtype)])
@@ -155,6 +173,71 @@ def evaluate_dataset(model: Callable, videos: Sequence, dataset_name: str = "syn
         out["op_img_pred_records"].append(rec["op_psnr"])
         out["op_fea_comm_records"].append(rec["op_comm"])
     return out
+
+
+def evaluate_stream(model: Callable, subvideos, dataset_name: str = "synthetic", stats: Optional[dict] = None) -> dict:
+    """`evaluate_dataset` for sub-videos that ARRIVE device-resident one after the other (`pipeline.SubVideoStager`: the
+    upload and the resize / normalise kernels of sub-video v + 1 run on a side stream while v is scored) - the whole
+    loop of run_helper/test_helper.py:408-488 without a host wait inside it:
+
+      * every batch of a sub-video is queued back to back (`score_batch_device`: clips are overlapping windows of the
+        resident tensors, PSNR comes out of the output layer's epilogue);
+      * the scores and S16 range flags of a sub-video go to pinned host memory by ONE asynchronous copy;
+      * they are read one sub-video LATE - the device is then busy with the next one - and batches whose flag is set are
+        re-run on the exact-fp32 kernels while their sub-video is still resident.
+
+    `stats` (optional dict) receives `score_copies`, `rerun_batches`."""
+    out = {"dataset": dataset_name, "rgb_img_pred_records": [], "rgb_fea_comm_records": [],
+           "op_img_pred_records": [], "op_fea_comm_records": []}
+    copies = reruns = 0
+
+    def finish(item):
+        nonlocal reruns
+        rgb, op, batches, host, ev = item
+        ev.synchronize()
+        flat, off, scores = host.numpy(), 0, []
+        for s, e in batches:
+            n = 2 * (e - s) + 3
+            sc = _unpack_scores(flat[off:off + n].copy(), e - s)
+            off += n
+            if sc["overflow"]:
+                sc = _unpack_scores(score_batch_device(model, rgb, op, s, e, None, exact=True).cpu().numpy(), e - s)
+                _count_fallback(model)
+                reruns += 1
+            scores.append(sc)
+        rec = assemble_records(rgb.shape[0], batches, scores)
+        out["rgb_img_pred_records"].append(rec["rgb_psnr"])
+        out["rgb_fea_comm_records"].append(rec["rgb_comm"])
+        out["op_img_pred_records"].append(rec["op_psnr"])
+        out["op_fea_comm_records"].append(rec["op_comm"])
+
+    pending = None
+    for rgb, op in subvideos:
+        if op.shape[0] != rgb.shape[0] - 1:
+            raise ValueError("a sub-video of T frames has T-1 flows")
+        batches = subvideo_batches(rgb.shape[0])
+        flat = torch.cat([score_batch_device(model, rgb, op, s, e, None) for s, e in batches])
+        if flat.is_cuda:
+            host = torch.empty(flat.numel(), dtype=flat.dtype, pin_memory=True)
+            host.copy_(flat, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            copies += 1
+        else:
+            host, ev = flat, _Done()
+        if pending is not None:
+            finish(pending)
+        pending = (rgb, op, batches, host, ev)
+    if pending is not None:
+        finish(pending)
+    if stats is not None:
+        stats.update(score_copies=copies, rerun_batches=reruns)
+    return out
+
+
+class _Done:
+    def synchronize(self):
+        pass
 
 
 def generator_loss(out, rgb_t: torch.Tensor, op_t: torch.Tensor, lam_lp: float = 1.0, lam_lp_op: float = 1.0,

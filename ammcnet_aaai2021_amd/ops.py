@@ -9,6 +9,8 @@ parity test (tests/test_gpu_parity.py, tests/test_gpu_s16.py).  No ATen compute 
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -149,6 +151,11 @@ def embed_rows(embed: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     return embed.t()[ids]
 
 
+# which kernel `quantize_topk_f16` / `workload.MemoryStress` launch: 1 (default) = rows resident in registers
+# (csrc/memory_topk_f16r.hip, round 5), 0 = the round-2 form (csrc/memory_topk_f16.hip: rows in LDS, codebook L2 -> registers)
+F16_ROWS_IN_REGISTERS = os.environ.get("AMMC_MEMORY_F16_FORM", "1") != "0"
+
+
 def quantize_topk_f16(embed: torch.Tensor, x: torch.Tensor, k: int):
     """Stress form of the memory addressing (BASELINE.json config 5): fp16 MFMA operands, fp32
     accumulation.  embed [D,M] fp32, x [..., D] fp32 -> (q_topk [..., k*D], diff, q_one, idx [..., k]).
@@ -161,18 +168,27 @@ def quantize_topk_f16(embed: torch.Tensor, x: torch.Tensor, k: int):
     n = x2.shape[0]
     dev = x.device
     s = _stream(x)
-    mpad = (m + 31) // 32 * 32
-    e_kblk = torch.empty((d // 8, mpad, 8), device=dev, dtype=torch.float16)
-    enorm16 = torch.empty(m, device=dev, dtype=torch.float32)
-    e_md, _ = _Packer(dev).codebook(embed)
-    _lib.check(lib.ammc_pack_codebook_f16(_ptr(embed), d, m, e_kblk.data_ptr(), _ptr(enorm16), s), "pack_codebook_f16")
     idx = torch.empty((n, k), device=dev, dtype=torch.int32)
     qk = torch.empty((n, k * d), device=dev, dtype=torch.float32)
     q1 = torch.empty((n, d), device=dev, dtype=torch.float32)
-    nblk = lib.ammc_memory_topk_f16_blocks(n)
-    part = torch.empty(nblk, device=dev, dtype=torch.float32)
     diff = torch.empty(1, device=dev, dtype=torch.float32)
-    _lib.check(lib.ammc_memory_topk_fwd_f16(_ptr(x2), e_kblk.data_ptr(), _ptr(e_md), _ptr(enorm16), n, d, m, k,
-                                            idx.data_ptr(), _ptr(qk), _ptr(q1), _ptr(part), s), "memory_topk_f16")
+    e_md, _ = _Packer(dev).codebook(embed)
+    if F16_ROWS_IN_REGISTERS:
+        # round 5: feature rows resident in registers, codebook tiles through LDS (csrc/memory_topk_f16r.hip)
+        tiles = torch.empty(lib.ammc_codebook_f16_tiles_bytes(d, m), device=dev, dtype=torch.uint8)
+        _lib.check(lib.ammc_pack_codebook_f16_tiles(_ptr(embed), d, m, tiles.data_ptr(), s), "pack_codebook_f16_tiles")
+        nblk = lib.ammc_memory_topk_f16r_blocks(n)
+        part = torch.empty(nblk, device=dev, dtype=torch.float32)
+        _lib.check(lib.ammc_memory_topk_fwd_f16r(_ptr(x2), tiles.data_ptr(), _ptr(e_md), n, d, m, k, idx.data_ptr(), _ptr(qk),
+                                                 _ptr(q1), _ptr(part), s), "memory_topk_f16r")
+    else:
+        mpad = (m + 31) // 32 * 32
+        e_kblk = torch.empty((d // 8, mpad, 8), device=dev, dtype=torch.float16)
+        enorm16 = torch.empty(m, device=dev, dtype=torch.float32)
+        _lib.check(lib.ammc_pack_codebook_f16(_ptr(embed), d, m, e_kblk.data_ptr(), _ptr(enorm16), s), "pack_codebook_f16")
+        nblk = lib.ammc_memory_topk_f16_blocks(n)
+        part = torch.empty(nblk, device=dev, dtype=torch.float32)
+        _lib.check(lib.ammc_memory_topk_fwd_f16(_ptr(x2), e_kblk.data_ptr(), _ptr(e_md), _ptr(enorm16), n, d, m, k,
+                                                idx.data_ptr(), _ptr(qk), _ptr(q1), _ptr(part), s), "memory_topk_f16")
     _lib.check(lib.ammc_sum_partials_f32(_ptr(part), nblk, 1.0 / float(n * d), _ptr(diff), s), "sum_partials")
     return qk.view(*lead, k * d), diff[0], q1.view(*lead, d), idx.view(*lead, k)

@@ -108,17 +108,20 @@ class SubVideoStager:
     side stream while the caller works on sub-video i.
 
     `sources`: a sequence of callables returning (frames uint8 [T,h,w,3], flows float32 [T',h,w,2]) numpy arrays (or a
-    list of (frame_files, flow_files) from `list_subvideos`).  `shard=(rank, world)` keeps every world-th sub-video.
+    list of (frame_files, flow_files) from `list_subvideos`); pinned uint8 / float32 tensors are uploaded from where they
+    are.  `shard=(rank, world)` keeps every world-th sub-video; `ahead`: sub-videos staged beyond the current one.
     """
 
     def __init__(self, sources: Sequence, device, size: Tuple[int, int] = (256, 256), bgr: bool = False,
-                 shard: Tuple[int, int] = (0, 1)):
+                 shard: Tuple[int, int] = (0, 1), ahead: int = 1, timed: bool = False):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.AmmcHipError("SubVideoStager stages onto a GPU; there is no CPU pipeline")
         rank, world = shard
         self.sources = [s for i, s in enumerate(sources) if i % world == rank]
         self.size, self.bgr = size, bgr
+        self.ahead = max(1, int(ahead))        # sub-videos staged beyond the one being scored
+        self.timed, self.stage_events = bool(timed), []
         self.stream = torch.cuda.Stream(self.device)
         self.bytes_uploaded = 0
         self.host_seconds = 0.0        # file reads / decoding / pinning in the reader thread (overlapped with the GPU)
@@ -127,10 +130,19 @@ class SubVideoStager:
         import time
         t0 = time.perf_counter()
         frames, flows = src() if callable(src) else load_subvideo_host(*src)
-        pf = torch.from_numpy(np.ascontiguousarray(frames)).pin_memory()
-        po = torch.from_numpy(np.ascontiguousarray(flows, dtype=np.float32)).pin_memory()
+        pf, po = self._pinned(frames, torch.uint8), self._pinned(flows, torch.float32)
         self.host_seconds += time.perf_counter() - t0
         return pf, po
+
+    @staticmethod
+    def _pinned(a, dtype) -> torch.Tensor:
+        """page-locked host tensor of `a` (numpy array or tensor); a source that already hands out pinned tensors of the
+        right type - a decoder writing into its own staging buffers - is taken as it is"""
+        if isinstance(a, torch.Tensor):
+            if a.dtype == dtype and a.is_contiguous() and a.is_pinned():
+                return a
+            return a.to(dtype).contiguous().pin_memory()
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint8 if dtype == torch.uint8 else np.float32)).pin_memory()
 
     def _reader(self, q):
         """background thread: file reads, decoding and pinning, one sub-video ahead of the GPU staging"""
@@ -145,23 +157,35 @@ class SubVideoStager:
         pf, po = host
         self.bytes_uploaded += pf.numel() + 4 * po.numel()
         with torch.cuda.stream(self.stream):
+            if self.timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self.stream)
             df = pf.to(self.device, non_blocking=True)
             do = po.to(self.device, non_blocking=True)
+            if self.timed:
+                e1.record(self.stream)
             rgb = frames_to_device(df, self.size, self.bgr)
             op = flows_to_device(do, self.size)
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=self.timed)
             ev.record(self.stream)
+            if self.timed:
+                self.stage_events.append((e0, e1, ev))
         return rgb, op, ev, (pf, po, df, do)
+
+    def stage_ms(self) -> Tuple[float, float]:
+        """(copy, kernels) milliseconds summed over the staged sub-videos (`timed=True`; call after a device sync)"""
+        return (sum(a.elapsed_time(b) for a, b, _ in self.stage_events), sum(b.elapsed_time(c) for _, b, c in self.stage_events))
 
     def __len__(self) -> int:
         return len(self.sources)
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
+        import collections
         import queue
         import threading
         if not self.sources:
             return
-        q: "queue.Queue" = queue.Queue(maxsize=2)
+        q: "queue.Queue" = queue.Queue(maxsize=1 + self.ahead)
         th = threading.Thread(target=self._reader, args=(q,), daemon=True)
         th.start()
 
@@ -171,11 +195,14 @@ class SubVideoStager:
                 raise item
             return self._stage(item)
 
-        nxt = take()
+        # `ahead` sub-videos are staged (H2D + conversion kernels on the side stream) beyond the one handed out
+        staged = collections.deque()
+        taken = 0
         for i in range(len(self.sources)):
-            rgb, op, ev, keep = nxt
-            # stage sub-video i+1 (H2D + conversion kernels on the side stream) before handing out sub-video i
-            nxt = take() if i + 1 < len(self.sources) else None
+            while taken < len(self.sources) and len(staged) < 1 + self.ahead:
+                staged.append(take())
+                taken += 1
+            rgb, op, ev, keep = staged.popleft()
             cur = torch.cuda.current_stream(self.device)
             cur.wait_event(ev)                                    # the consumer's stream waits, not the host
             rgb.record_stream(cur)

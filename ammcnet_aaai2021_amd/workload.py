@@ -49,24 +49,35 @@ def shard_rows(n_frames: int, rank: int, world: int) -> Tuple[int, int]:
 
 class MemoryStress:
     """BASELINE.json configs[4]: `Quantize_topk.forward` (unet.py:282-297, 310-313) alone at D=512, M=8192, k=2 on the
-    fp16-operand kernel (`ammc_memory_topk_fwd_f16`); the codebook is packed once, every `run` is ONE launch on the
-    rows this rank owns."""
+    fp16-operand kernel (`ammc_memory_topk_fwd_f16r`, or `ammc_memory_topk_fwd_f16` - see `rows_in_registers`); the codebook is
+    packed once, every `run` is ONE launch on the rows this rank owns."""
 
-    def __init__(self, embed: torch.Tensor, k: int = 2):
+    def __init__(self, embed: torch.Tensor, k: int = 2, rows_in_registers=None):
+        """`rows_in_registers`: True = csrc/memory_topk_f16r.hip (round 5: feature rows resident in registers, codebook
+        tiles through LDS), False = csrc/memory_topk_f16.hip (rows in LDS, codebook L2 -> registers); None = the package
+        default (`ops.F16_ROWS_IN_REGISTERS`, AMMC_MEMORY_F16_FORM)"""
         if not embed.is_cuda:
             raise _lib.AmmcHipError("the HIP path needs tensors on the GPU; there is no CPU fallback")
+        from . import ops
         self.lib = _lib.load()
         self.d, self.m = embed.shape
         self.k = k
         self.dev = embed.device
         self.embed = embed.detach().float().contiguous()
+        self.rows_in_registers = ops.F16_ROWS_IN_REGISTERS if rows_in_registers is None else bool(rows_in_registers)
+        self.kernel = "memory_topk_f16r" if self.rows_in_registers else "memory_topk_f16"
         s = torch.cuda.current_stream(self.dev).cuda_stream
-        mpad = (self.m + 31) // 32 * 32
-        self.e_kblk = torch.empty((self.d // 8, mpad, 8), device=self.dev, dtype=torch.float16)
-        self.enorm = torch.empty(self.m, device=self.dev, dtype=torch.float32)
         self.e_md, _ = _Packer(self.dev).codebook(self.embed)
-        _lib.check(self.lib.ammc_pack_codebook_f16(_ptr(self.embed), self.d, self.m, self.e_kblk.data_ptr(),
-                                                   _ptr(self.enorm), s), "pack_codebook_f16")
+        if self.rows_in_registers:
+            self.tiles = torch.empty(self.lib.ammc_codebook_f16_tiles_bytes(self.d, self.m), device=self.dev, dtype=torch.uint8)
+            _lib.check(self.lib.ammc_pack_codebook_f16_tiles(_ptr(self.embed), self.d, self.m, self.tiles.data_ptr(), s),
+                       "pack_codebook_f16_tiles")
+        else:
+            mpad = (self.m + 31) // 32 * 32
+            self.e_kblk = torch.empty((self.d // 8, mpad, 8), device=self.dev, dtype=torch.float16)
+            self.enorm = torch.empty(self.m, device=self.dev, dtype=torch.float32)
+            _lib.check(self.lib.ammc_pack_codebook_f16(_ptr(self.embed), self.d, self.m, self.e_kblk.data_ptr(),
+                                                       _ptr(self.enorm), s), "pack_codebook_f16")
         self._out = {}
 
     def flops(self, n_rows: int) -> float:
@@ -86,9 +97,15 @@ class MemoryStress:
                 idx=torch.empty((n, self.k), device=self.dev, dtype=torch.int32),
                 qk=torch.empty((n, self.k * self.d), device=self.dev, dtype=torch.float32),
                 q1=torch.empty((n, self.d), device=self.dev, dtype=torch.float32),
-                part=torch.empty(self.lib.ammc_memory_topk_f16_blocks(n), device=self.dev, dtype=torch.float32))
+                part=torch.empty(self.lib.ammc_memory_topk_f16r_blocks(n) if self.rows_in_registers else
+                                 self.lib.ammc_memory_topk_f16_blocks(n), device=self.dev, dtype=torch.float32))
         s = torch.cuda.current_stream(self.dev).cuda_stream
-        _lib.check(self.lib.ammc_memory_topk_fwd_f16(_ptr(x), self.e_kblk.data_ptr(), _ptr(self.e_md), _ptr(self.enorm),
-                                                     n, self.d, self.m, self.k, o["idx"].data_ptr(), _ptr(o["qk"]),
-                                                     _ptr(o["q1"]), _ptr(o["part"]), s), "memory_topk_f16")
+        if self.rows_in_registers:
+            _lib.check(self.lib.ammc_memory_topk_fwd_f16r(_ptr(x), self.tiles.data_ptr(), _ptr(self.e_md), n, self.d, self.m,
+                                                          self.k, o["idx"].data_ptr(), _ptr(o["qk"]), _ptr(o["q1"]),
+                                                          _ptr(o["part"]), s), "memory_topk_f16r")
+        else:
+            _lib.check(self.lib.ammc_memory_topk_fwd_f16(_ptr(x), self.e_kblk.data_ptr(), _ptr(self.e_md), _ptr(self.enorm),
+                                                         n, self.d, self.m, self.k, o["idx"].data_ptr(), _ptr(o["qk"]),
+                                                         _ptr(o["q1"]), _ptr(o["part"]), s), "memory_topk_f16")
         return o["qk"], o["part"], o["q1"], o["idx"]

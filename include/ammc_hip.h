@@ -217,6 +217,13 @@ int ammc_pack_first_conv_f32(const float* w_oihw, int32_t cout, int32_t cin, flo
 int ammc_conv_first_s16(const float* x_nchw, int32_t batch, int32_t c, int32_t h, int32_t w, const float* w_image,
                         const float* scale, const float* shift, int32_t act, float* y, int64_t y_bs, int64_t y_rs,
                         int64_t y_ps, int32_t* overflow_flag, void* stream);
+/* The same with an explicit batch stride of x (elements; c * h * w = contiguous).  The evaluation loop's clips are
+ * OVERLAPPING windows of one resident sub-video - clip b = frames [s + b, s + b + 4) of a [T][3][h][w] tensor
+ * (test_helper.py:433-438: `view(B, t * c, H, W)` of consecutive frames) - so x = &frames[s], x_bs = 3 * h * w runs a batch
+ * of 16 clips without first gathering 16 x 12 planes into a contiguous tensor (harness.score_batch_device). */
+int ammc_conv_first_s16_bs(const float* x_nchw, int64_t x_bs, int32_t batch, int32_t c, int32_t h, int32_t w,
+                           const float* w_image, const float* scale, const float* shift, int32_t act, float* y,
+                           int64_t y_bs, int64_t y_rs, int64_t y_ps, int32_t* overflow_flag, void* stream);
 /* Which kernel ammc_conv_gemm_s16 launches for this descriptor, as the NUL-terminated name rocprofv3 reports for it
  * (e.g. "conv_tap_s16<4, 1, 2, 4, 1>", "conv_gemm_s16<128x128>", "...+splitk4"), without launching anything: the same
  * argument checks and the same dispatch code run with the launch replaced by the label.  Tests pin kernel coverage on
@@ -263,6 +270,21 @@ int ammc_memory_topk_f16_blocks(int32_t n);
 int ammc_memory_topk_fwd_f16(const float* x, const void* e_kblk_f16, const float* embed_md, const float* enorm16,
                              int32_t n, int32_t d, int32_t m, int32_t k, int32_t* idx_topk, float* q_topk,
                              float* q_one, float* diff_partial, void* stream);
+
+/* The same operator with the feature ROWS resident in registers and the codebook streamed through LDS (round 5; what
+ * config 5 runs): a wave keeps 3 x 32 rows x d features as fp16 MFMA operands in its VGPRs for a whole sweep of the
+ * codebook, the codebook goes L2 -> LDS once per workgroup (tile images of ammc_pack_codebook_f16_tiles:
+ * ammc_codebook_f16_tiles_bytes(d, m) bytes, 16-byte aligned) instead of L2 -> registers once per 128 rows.  Same
+ * outputs and arithmetic contract as ammc_memory_topk_fwd_f16 (ranking from fp16-rounded operands with fp32
+ * accumulation - key x.E_s - |E_s|^2 / 2, ties to the lower slot; gather / q_one / commit from the fp32 codebook and
+ * features); q_one may be NULL; diff_partial has ammc_memory_topk_f16r_blocks(n) = ceil(n / 32) entries, each written
+ * once (no atomics: deterministic).  d in {128,256,384,512}, k <= 4; pointers 16-byte aligned. */
+int64_t ammc_codebook_f16_tiles_bytes(int32_t d, int32_t m);
+int ammc_pack_codebook_f16_tiles(const float* embed_dm, int32_t d, int32_t m, void* tiles, void* stream);
+int ammc_memory_topk_f16r_blocks(int32_t n);
+int ammc_memory_topk_fwd_f16r(const float* x, const void* tiles, const float* embed_md, int32_t n, int32_t d, int32_t m,
+                              int32_t k, int32_t* idx_topk, float* q_topk, float* q_one, float* diff_partial,
+                              void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training mode (autograd of the same path; the reference derives these with torch.autograd)

@@ -115,7 +115,7 @@ def twostream_eval(ref, hw, batch, n_embed, name, full, rows=None, q_step=1, gri
     print(name, {k: getattr(v, "shape", None) for k, v in list(out.items())[:8]})
 
 
-def twostream_train(ref, hw, batch, name, out_step=1, rows=None):
+def twostream_train(ref, hw, batch, name, out_step=1, rows=None, dense_samples=0):
     """`rows`: batch rows of the strided frames that are kept (all when None) - the batch-32 fixture of the training
     benchmark's own shape stays a few hundred KB"""
     cfg = dict(in_channel=(12, 6), out_channel=(3, 2), embed_dim=64, n_embed=256, k=2)
@@ -137,6 +137,10 @@ def twostream_train(ref, hw, batch, name, out_step=1, rows=None):
         g = p.grad.detach()
         out[f"gn.{k}"] = np.float64(g.double().norm().item())
         out[f"gs.{k}"] = g.flatten()[:: max(1, g.numel() // 64)][:64].contiguous().numpy()
+        if dense_samples:
+            # round 5: 4096 strided entries per gradient (whole tensor when smaller) - the reference's own fp32 noise
+            # against the fp64 truth of make_fp64_truth.py is measured on these (e_ref of test_gpu_train.py)
+            out[f"gs4k.{k}"] = g.flatten()[:: max(1, g.numel() // dense_samples)][:dense_samples].contiguous().numpy()
     params = dict(net.named_parameters())
     for k, v in net.state_dict().items():
         if k in params:
@@ -413,7 +417,7 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "train_b32":
         # the TIMED training batch of bench.py (BASELINE.json configs[2]: batch 32 at 256x256): ~30 GB of autograd state
         # and a few minutes on 8 cores, so it is made on request only
-        twostream_train(ref, 256, 32, "twostream_256_b32_train", out_step=4, rows=(0, 31))
+        twostream_train(ref, 256, 32, "twostream_256_b32_train", out_step=4, rows=(0, 31), dense_samples=4096)
         return
     param_counts(ref)
     shipped_record_structure()

@@ -56,3 +56,48 @@ def test_stager_order_sharding_and_scoring():
     net = net.to(DEV).eval()
     rec = Hn.evaluate_subvideo(net, seen[0][0], seen[0][1])
     assert len(rec["rgb_psnr"]) == vids[0][0].shape[0] and np.isfinite(rec["rgb_psnr"]).all()
+
+
+def test_raw_frames_to_records_equal_the_oracle_loop():
+    """The evaluation loop end to end as `bench.py`'s eval_e2e leg runs it - pinned uint8 frames + flow payloads ->
+    SubVideoStager (two ahead) -> evaluate_stream (clips as overlapping windows read in place by the first-layer
+    kernel, one score copy per sub-video) - against the oracle: loaders (oracle/pipeline_oracle.py) -> model forward
+    (oracle/ammc_oracle.py) -> the restated loop of run_helper/test_helper.py:408-473.  Records to 1e-4 (PSNR is a
+    log of a mean of squares of 1e-4-accurate frames; commit values are means over the batch)."""
+    import ammcnet_aaai2021_amd as A
+    from oracle import ammc_oracle as O
+    rng = np.random.default_rng(5)
+    lens = (22, 9)                                               # 18 clips = 16 + 2, and 5 clips (one short batch)
+    vids = []
+    for t in lens:
+        fr = torch.from_numpy(rng.integers(0, 256, (t, 60, 90, 3), dtype=np.uint8)).pin_memory()
+        fl = torch.from_numpy(rng.normal(0, 2, (t - 1, 60, 90, 2)).astype(np.float32)).pin_memory()
+        vids.append((fr, fl))
+    sd = S.make_twostream_state()
+    net = A.get_twostream((12, 6), (3, 2), 64, 256, 2)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    info = {}
+    st = P.SubVideoStager([(lambda v=v: v) for v in vids], DEV, size=(64, 64), ahead=2, timed=True)
+    got = Hn.evaluate_stream(net, st, "ped2", stats=info)
+    torch.cuda.synchronize()
+    assert info == {"score_copies": 2, "rerun_batches": 0} and len(st.stage_events) == 2 and min(st.stage_ms()) > 0
+    assert all(s.first_mid is not None for s in net._engine._last["streams"])      # the windows were read in place
+    osd = O.clone_state(sd)
+    for v, (fr, fl) in enumerate(vids):
+        rgb = torch.from_numpy(np.stack([PO.load_frame(x, (64, 64)) for x in fr.numpy()]))
+        op = torch.from_numpy(np.stack([PO.load_op(x.copy(), (64, 64)) for x in fl.numpy()]))
+        want = O.eval_subvideo_records(lambda a, b: O.twostream_forward(osd, a, b, 2), rgb, op)
+        for key, name in (("rgb_img_pred_records", "rgb_psnr"), ("rgb_fea_comm_records", "rgb_comm"),
+                          ("op_img_pred_records", "op_psnr"), ("op_fea_comm_records", "op_comm")):
+            assert np.allclose(got[key][v], want[name], rtol=1e-4, atol=0), (v, key)
+    # the same records when the sub-videos are resident and scored through the batch-sharded loop
+    res = list(P.SubVideoStager([(lambda v=v: v) for v in vids], DEV, size=(64, 64)))
+    full = Hn.evaluate_dataset(net, res, "ped2")
+    # (commit values bit for bit; the PSNR sums are accumulated with one fp32 atomic per output tile, whose order is free)
+    for key in ("rgb_fea_comm_records", "op_fea_comm_records"):
+        for a, b in zip(got[key], full[key]):
+            assert np.array_equal(a, b), key
+    for key in ("rgb_img_pred_records", "op_img_pred_records"):
+        for a, b in zip(got[key], full[key]):
+            assert np.allclose(a, b, rtol=1e-5, atol=0), key

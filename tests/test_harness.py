@@ -32,6 +32,39 @@ def test_records_equal_oracle_loop(t):
         assert np.allclose(got[key], want[key], rtol=1e-6), key
 
 
+def test_clip_windows_are_the_reference_clips():
+    """clip i of a batch = `frames[i:i + 4].view(12, H, W)` (test_helper.py:433-438): the overlapping view equals the
+    gathered tensor, for both clip lengths"""
+    rgb = S.hashed_uniform("cw", (23, 3, 6, 10))
+    for s, e, n_in in ((0, 16, 4), (16, 19, 4), (3, 11, 3)):
+        want = torch.stack([rgb[i:i + n_in] for i in range(s, e)]).reshape(e - s, -1, 6, 10)
+        got = Hn.clip_windows(rgb, s, e, n_in)
+        assert got.shape == want.shape and got.stride(0) == 3 * 6 * 10 and torch.equal(got, want)
+        assert got.data_ptr() == rgb[s].data_ptr()                      # a view: nothing was copied
+
+
+@pytest.mark.parametrize("lens", [(6, 21, 37), (20,), (5, 5)])
+def test_streamed_evaluation_equals_the_oracle_loop(lens):
+    """`evaluate_stream` (sub-videos arriving one after the other, scores read one sub-video late) gives the records of
+    the oracle's restatement of run_helper/test_helper.py:408-473, sub-video by sub-video, and of `evaluate_dataset`"""
+    vids = [(S.hashed_uniform(f"sv{i}", (t, 3, 8, 8)), S.hashed_uniform(f"so{i}", (t - 1, 2, 8, 8))) for i, t in enumerate(lens)]
+
+    def model(rgb_in, op_in):
+        v = rgb_in.mean().reshape(1)
+        return rgb_in[:, :3] * 0.5, op_in[:, :2] * 0.25, (v, v * 2), (None, None)
+
+    info = {}
+    got = Hn.evaluate_stream(model, iter(vids), "ped2", stats=info)
+    full = Hn.evaluate_dataset(model, vids, "ped2")
+    assert info == {"score_copies": 0, "rerun_batches": 0}
+    for v, (rgb, op) in enumerate(vids):
+        want = O.eval_subvideo_records(model, rgb, op)
+        for key, name in (("rgb_img_pred_records", "rgb_psnr"), ("rgb_fea_comm_records", "rgb_comm"),
+                          ("op_img_pred_records", "op_psnr"), ("op_fea_comm_records", "op_comm")):
+            assert np.allclose(got[key][v], want[name], rtol=1e-6), (v, key)
+            assert np.array_equal(got[key][v], full[key][v]), (v, key)
+
+
 def test_dataset_records_match_shipped_structure_and_shard_invariance():
     with open(os.path.join(GOLDEN, "shipped_records_ped2.json")) as fp:
         shipped = json.load(fp)
