@@ -55,6 +55,7 @@ _s3 = [_i64, _i64, _i64]
 SIGNATURES = {
     "ammc_abi_version": (C.c_int, []),
     "ammc_build_info": (C.c_char_p, []),
+    "ammc_source_digests": (C.c_char_p, []),
     "ammc_error_string": (C.c_char_p, [C.c_int]),
     "ammc_set_option": (C.c_int, [C.c_char_p, _i32]),
     "ammc_conv_gemm_f32": (C.c_int, [C.POINTER(AmmcConvDesc), _p]),
@@ -122,6 +123,7 @@ SIGNATURES = {
     "ammc_bn_bwd_reduce_bound_f32": (C.c_int, [_p] + _s3 + [_p] + _s3 + [_p, _p, _p, _p] + [_i32] * 5 + [_p, _p]),
     "ammc_bn_bwd_finalize_f32": (C.c_int, [_p, _i32, _i32, _i32, _p, _p, _p, _p]),
     "ammc_bn_bwd_apply_s16_f32": (C.c_int, [_p] + _s3 + [_p] + _s3 + [_p, _p, _p, _p, _p, _i32, _p, _p] + _s3 + [_i32] * 4 + [_p, _p, _i32, _p]),
+    "ammc_scale_shift_act_s16_pool_supported": (C.c_int, [_i32, _i32, _i32, _i64, _i64, _i64, _i64, _i64]),
     "ammc_bn_bwd_unpool_supported": (C.c_int, [_i32, _i64, _i64, _i64, _i32]),
     "ammc_bn_bwd_reduce_bound_unpool_f32": (C.c_int, [_p] + _s3 + [_p] + _s3 + [_p] + _s3 + [_p, _i32, _i32] + [_p, _p, _p, _p] + [_i32] * 5 + [_p, _p]),
     "ammc_bn_bwd_apply_s16_unpool_f32": (C.c_int, [_p] + _s3 + [_p] + _s3 + [_p] + _s3 + [_p, _i32, _i32] + [_p, _p, _p, _p, _p, _i32, _p, _p] + _s3 + [_i32] * 4 + [_p, _p, _i32, _p]),

@@ -36,6 +36,21 @@ def _digest() -> str:
     return h.hexdigest()
 
 
+def file_digests() -> dict:
+    """sha256[:12] of every source file of the library: what a committed profile is tied to (a PMC figure of a kernel is
+    quoted by bench.py only while the file that defines the kernel, the shared header and the C ABI are what they were
+    when the profile was taken) - compiled into the library (`ammc_source_digests()`)"""
+    files = sources() + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
+    files.append(os.path.join(os.path.dirname(HERE), "include", "ammc_hip.h"))
+    out = {}
+    for f in files:
+        if os.path.basename(f) == "capi_misc.hip":           # (holds the digests themselves)
+            continue
+        with open(f, "rb") as fp:
+            out[os.path.basename(f)] = hashlib.sha256(fp.read()).hexdigest()[:12]
+    return out
+
+
 def hipcc_path() -> str:
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
@@ -60,7 +75,10 @@ def build(force: bool = False, verbose: bool = False, variant: str = "") -> str:
     for src in sources():
         obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
         cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math"]
-        cmd += os.environ.get("AMMC_HIPCC_FLAGS", "").split() + ["-c", src, "-o", obj]
+        cmd += os.environ.get("AMMC_HIPCC_FLAGS", "").split()
+        if os.path.basename(src) == "capi_misc.hip":
+            cmd.append('-DAMMC_SRC_DIGESTS="' + ",".join(f"{k}={v}" for k, v in sorted(file_digests().items())) + '"')
+        cmd += ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -79,5 +97,9 @@ def build(force: bool = False, verbose: bool = False, variant: str = "") -> str:
 
 
 if __name__ == "__main__":
+    if "--digests" in sys.argv:
+        import json
+        print(json.dumps(file_digests()))
+        sys.exit(0)
     var = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else ""
     print(build(force="--force" in sys.argv, verbose=True, variant=var))

@@ -74,6 +74,12 @@ extern "C" int ammc_set_option(const char* key, int32_t value) {
   return AMMC_EUNSUP;
 }
 
+#ifndef AMMC_SRC_DIGESTS
+#define AMMC_SRC_DIGESTS ""
+#endif
+// "file=sha256[:12],..." of the sources this library was compiled from (ammcnet_aaai2021_amd/build.py: file_digests)
+extern "C" const char* ammc_source_digests(void) { return AMMC_SRC_DIGESTS; }
+
 extern "C" const char* ammc_build_info(void) {
   return "libammc_hip gfx950 (CDNA4) fp32-MFMA build, HIP " __VERSION__;
 }

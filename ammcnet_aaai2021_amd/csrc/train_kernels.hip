@@ -1444,6 +1444,12 @@ static int unpool_args_bad(const float* dpo, int64_t p_bs, int64_t p_rs, int64_t
          ((uintptr_t)idx & 7) || ((p_bs | p_rs | p_ps) & 3);
 }
 
+int ammc_scale_shift_act_s16_pool_supported(int32_t c, int32_t h, int32_t w, int64_t x_rs, int64_t x_ps, int64_t y_rs,
+                                            int64_t y_ps, int64_t p_ps) {
+  if (c <= 0 || (c & 7) || ((h | w) & 1)) return 0;
+  return rows_csh(c >> 3, x_ps, y_ps, p_ps, w) >= 0 && x_rs < (1 << 30) && y_rs < (1 << 30);
+}
+
 int ammc_bn_bwd_unpool_supported(int32_t c, int64_t c_ps, int64_t d_ps, int64_t o_ps, int32_t w) {
   return c > 0 && !(c & 7) && rows_csh(c >> 3, c_ps, d_ps, o_ps, w) >= 0;
 }

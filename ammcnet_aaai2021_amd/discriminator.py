@@ -367,6 +367,27 @@ class PixelDiscriminator(nn.Module):
         if self._engine is None or self._engine.s16 != (self.precision == "s16"):
             object.__setattr__(self, "_engine", DiscEngine(self, self.precision))
         params = self._params()
+        s16 = self._engine.s16
+        guard = getattr(self, "s16_guard", True)
+        object.__setattr__(self, "last_overflow", None)
         if torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in params)):
-            return DiscFunction.apply(self._engine, input, *params)
-        return self._engine.forward(input, params, False, False)[1]
+            out = DiscFunction.apply(self._engine, input, *params)
+            if s16 and guard:
+                # training: an activation beyond the half range turns the patch map non-finite (inf in the re-encoding of a
+                # layer's output, then inf / NaN through every later layer); the verdict stays on the device for the
+                # trainer (`harness.train_step_gan` refuses the step on a non-finite loss AND on this flag)
+                object.__setattr__(self, "last_overflow", (~torch.isfinite(out.detach()).all()).to(torch.int32).reshape(1))
+            return out
+        out = self._engine.forward(input, params, False, False)[1]
+        if s16 and guard:
+            # inference (no autograd graph): S16 range guard as the generator's - one read of the verdict, recomputation
+            # on the exact-fp32 kernels when the patch map is not finite.  "defer": leave the verdict on the device.
+            bad = ~torch.isfinite(out).all()
+            if guard == "defer":
+                object.__setattr__(self, "last_overflow", bad.to(torch.int32).reshape(1))
+            elif bool(bad):
+                if getattr(self, "_engine_fp32", None) is None:
+                    object.__setattr__(self, "_engine_fp32", DiscEngine(self, "fp32"))
+                out = self._engine_fp32.forward(input, params, False, False)[1]
+                object.__setattr__(self, "s16_fallbacks", getattr(self, "s16_fallbacks", 0) + 1)
+        return out

@@ -739,19 +739,23 @@ class EvalEngine:
             for l in lanes:
                 l.wait_stream(cur)
             crossed = False
-            for (fn, args, name), meta in zip(plan.calls, plan.meta):
-                ln = meta.get("lane")
-                if ln is None:
-                    raise RuntimeError("a two-stream plan holds a call without a lane")
-                if ln >= 2 and not crossed:
-                    lanes[0].wait_stream(lanes[1])
-                    lanes[1].wait_stream(lanes[0])
-                    crossed = True
-                rc = fn(*(args(ctx) if callable(args) else args), lanes[ln & 1].cuda_stream)
-                if rc != 0:
-                    _lib.check(rc, meta["name"])
-            for l in lanes:
-                cur.wait_stream(l)
+            try:
+                for (fn, args, name), meta in zip(plan.calls, plan.meta):
+                    ln = meta.get("lane")
+                    if ln is None:
+                        raise RuntimeError("a two-stream plan holds a call without a lane")
+                    if ln >= 2 and not crossed:
+                        lanes[0].wait_stream(lanes[1])
+                        lanes[1].wait_stream(lanes[0])
+                        crossed = True
+                    rc = fn(*(args(ctx) if callable(args) else args), lanes[ln & 1].cuda_stream)
+                    if rc != 0:
+                        _lib.check(rc, meta["name"])
+            finally:
+                # joined also when a launch was refused mid-plan: the lanes' queued work uses workspace buffers that the
+                # caller's next forward (or the fp32 fallback) touches on its own stream
+                for l in lanes:
+                    cur.wait_stream(l)
         else:
             for (fn, args, _), meta in zip(plan.calls, plan.meta):
                 launch(fn, args(ctx) if callable(args) else args, meta)

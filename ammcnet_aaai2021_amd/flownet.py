@@ -165,6 +165,9 @@ class _Engine:
             # with the workspace the kernel cuts K into up to 16 slices per tile and a streaming kernel finishes
             # (largest user: [16 slices][B * 8 * 8 pixels of conv5_1 at 256x256][512]; 32 M floats cover batch 64)
             ws["splitk"] = torch.empty(max(1 << 22, 16 * B * (H // 32) * (W // 32) * 512), device=dev)
+            # sticky range flag of the S16 epilogues (an activation beyond 65504 becomes inf in its hi half): raised on the
+            # device, read once per forward by FlowNet2SD.forward, which then recomputes on the exact-fp32 kernels
+            ws["flag"] = torch.zeros(1, device=dev, dtype=torch.int32)
         self.ws[key] = ws
         return ws
 
@@ -193,6 +196,7 @@ class _Engine:
             d.r_bs, d.r_rs, d.r_ps = y.strides
             if self.s16:
                 d.y_f32 = 1 if y_f32 else 0
+                d.overflow_flag = self._cur_ws["flag"].data_ptr()
                 self._splitk(d, y.buf.device)
                 _chk(self.lib.ammc_conv_gemm_s16(C.byref(d), s), "flownet.conv(s16)")
             else:
@@ -221,6 +225,7 @@ class _Engine:
                 d.y_bs, d.y_rs, d.y_ps = y.bs, 2 * y.rs, 2 * y.ps
                 d.r_bs, d.r_rs, d.r_ps = y.bs, 2 * y.rs, 2 * y.ps
                 if self.s16 and not pk.get("head"):
+                    d.overflow_flag = self._cur_ws["flag"].data_ptr()
                     self._splitk(d, y.buf.device)
                     _chk(self.lib.ammc_conv_gemm_s16(C.byref(d), s), "flownet.deconv(s16)")
                 else:
@@ -242,6 +247,8 @@ class _Engine:
         self._ensure_packs()
         ws, pk, lib = self._workspace(B, H, W, dev), self.packs, self.lib
         self._cur_ws = ws
+        if self.s16:
+            ws["flag"].zero_()
         s = torch.cuda.current_stream(dev).cuda_stream
         x0 = ws["x0"]
         if "prep" not in ws:
@@ -306,6 +313,15 @@ class _Engine:
         p2 = [c2, d2, u3]
         self._conv(p2, pk["inter_conv2"], ws["ic2"], act=ACT_NONE)
         f2 = ws["f2"]
+        # the last S16 activation is written: hand the flag to the host now (4 bytes to pinned memory + an event), two
+        # small launches before the forward ends
+        self.flag_event = None
+        if self.s16:
+            if "flag_host" not in ws:
+                ws["flag_host"], ws["flag_ev"] = torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event()
+            ws["flag_host"].copy_(ws["flag"], non_blocking=True)
+            ws["flag_ev"].record()
+            self.flag_event, self.flag_host, self.flag_dev = ws["flag_ev"], ws["flag_host"], ws["flag"]
         self._conv(ws["ic2"], pk["predict_flow2"], f2, act=ACT_NONE, y_f32=True)
         out = torch.empty(B, 2, H, W, device=dev, dtype=torch.float32)
         _chk(lib.ammc_upsample4_bilinear_f32(f2.pix0(), *f2.strides, B, f2.H, f2.W, 2, float(self.m.div_flow), _ptr(out), s),
@@ -360,5 +376,24 @@ class FlowNet2SD(nn.Module):
             raise NotImplementedError("FlowNet2SD is a frozen estimator here: call .eval() (train_helper.py:284)")
         if self._engine is None or self._engine.s16 != (self.precision == "s16"):
             object.__setattr__(self, "_engine", _Engine(self, self.precision))
+        eng = self._engine
         with torch.no_grad():
-            return self._engine.forward(inputs)
+            out = eng.forward(inputs)
+            # S16 range guard (as the generator's, unet.py): the split-fp16 kernels carry activations as (hi, lo) halves,
+            # one beyond 65504 becomes inf and the flows NaN - silently, in a `no_grad` flow extraction.  `s16_guard`:
+            # True (default) = read the sticky device flag once per forward and recompute the batch on the exact-fp32
+            # kernels when it is set; "defer" = leave it in `last_overflow` (a [1] int32 tensor ON THE DEVICE) for a
+            # trainer that folds it into its own verdict (harness.train_step_gan) - no host wait; False = off.
+            guard = getattr(self, "s16_guard", True)
+            object.__setattr__(self, "last_overflow", None)
+            if eng.s16 and eng.flag_event is not None and guard:
+                if guard == "defer":
+                    object.__setattr__(self, "last_overflow", eng.flag_dev.clone())
+                else:
+                    eng.flag_event.synchronize()
+                    if int(eng.flag_host[0]) != 0:
+                        if getattr(self, "_engine_fp32", None) is None:
+                            object.__setattr__(self, "_engine_fp32", _Engine(self, "fp32"))
+                        out = self._engine_fp32.forward(inputs)
+                        object.__setattr__(self, "s16_fallbacks", getattr(self, "s16_fallbacks", 0) + 1)
+            return out

@@ -268,10 +268,26 @@ def train_step(model: torch.nn.Module, optimizer: torch.optim.Optimizer, rgb: to
     op_in = op[:, :-1].reshape(b, -1, *op.shape[-2:])
     optimizer.zero_grad(set_to_none=True)
     loss = generator_loss(model(rgb_in, op_in), rgb[:, -1], op[:, -1], **lams)
-    watch = _FiniteWatch(loss)
+    vote, group = _watch_group(model)
+    watch = _FiniteWatch(loss, group=group, vote=vote)
     loss.backward()
     watch.step(optimizer)
     return loss.detach()
+
+
+def _watch_group(*models):
+    """(vote, group) for `_FiniteWatch`: ranks share the verdict on the loss exactly when their gradients or statistics
+    are shared - a `parallel.BucketedGradReducer` or `parallel.sync_statistics` attached to one of the models - and in
+    THAT process group.  Models that train on their own (no reducer: per-rank runs inside an initialised world, the
+    stress-style harnesses) do not vote: no rank waits in a collective the others never enter."""
+    for m in models:
+        red = getattr(m, "_grad_reducer", None)
+        if red is not None:
+            return True, getattr(red, "group", None)
+        sync = getattr(m, "_sync_stats", None)
+        if sync and sync[0]:
+            return True, sync[1]
+    return False, None
 
 
 class _FiniteWatch:
@@ -286,13 +302,17 @@ class _FiniteWatch:
     rank's gradients; the verdict is therefore all-reduced (MIN) on the device before it is copied, and all ranks refuse
     the step together (no rank steps on NaN gradients, none is left waiting in the next collective)."""
 
-    def __init__(self, *losses, group=None):
-        self.flag = torch.empty(len(losses), dtype=torch.bool).pin_memory() if losses[0].is_cuda else None
-        fin = torch.stack([torch.isfinite(v.detach()).all() for v in losses])
-        if parallel.dist.is_available() and parallel.dist.is_initialized() and parallel.dist.get_world_size(group) > 1:
-            vote = fin.to(torch.int32)
-            parallel.dist.all_reduce(vote, op=parallel.dist.ReduceOp.MIN, group=group)
-            fin = vote.to(torch.bool)
+    def __init__(self, *losses, group=None, vote: bool = True, flags=()):
+        """`vote` / `group`: whether the verdict is shared with other ranks, and in which process group - the group of
+        the model's gradient reducer / synchronised statistics (`_watch_group`): ranks outside it, or ranks that train
+        independently inside an initialised world, never enter this collective, so it must not run on the default group."""
+        fin = torch.stack([torch.isfinite(v.detach()).all() for v in losses] +
+                          [(f.reshape(-1)[0] == 0) for f in flags if f is not None])       # S16 range flags of frozen / side networks
+        self.flag = torch.empty(fin.numel(), dtype=torch.bool).pin_memory() if losses[0].is_cuda else None
+        if vote and parallel.dist.is_available() and parallel.dist.is_initialized() and parallel.dist.get_world_size(group) > 1:
+            vote_t = fin.to(torch.int32)
+            parallel.dist.all_reduce(vote_t, op=parallel.dist.ReduceOp.MIN, group=group)
+            fin = vote_t.to(torch.bool)
         if self.flag is not None:
             self.flag.copy_(fin, non_blocking=True)
             self.event = torch.cuda.Event()
@@ -392,7 +412,12 @@ def train_step_gan(generator: torch.nn.Module, discriminator: torch.nn.Module, o
     # batch-coupled layer, the patch maps and every gradient are those of the two calls
     d_both = discriminator(torch.cat([rgb_t, out[0].detach()]))
     d_loss = discriminate_loss(d_both[:b], d_both[b:])
-    watch = _FiniteWatch(d_loss, g_loss)
+    vote, group = _watch_group(generator, discriminator)
+    # (the S16 range flags of the discriminator and - where `flow_fn` is a bound method / has `.net` - of the frozen flow
+    # estimator join the verdict: `s16_guard = "defer"` on those modules leaves them on the device instead of syncing)
+    side = [discriminator, getattr(flow_fn, "__self__", None), getattr(flow_fn, "net", None)]
+    watch = _FiniteWatch(d_loss, g_loss, group=group, vote=vote,
+                         flags=[getattr(m, "last_overflow", None) for m in side if m is not None])
     optimizer_D.zero_grad(set_to_none=True)
     d_loss.backward()
     watch.step(optimizer_D)

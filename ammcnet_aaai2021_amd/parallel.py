@@ -94,6 +94,12 @@ class BucketedGradReducer:
         self._pending_bytes = 0
         self._inflight: List[Tuple[torch.Tensor, List[torch.Tensor], object]] = []
         self.buckets_launched = 0
+        # measurement (bench.py --mode train --gpus N): with `time_finish` every `finish()` is bracketed by HIP events on
+        # the compute stream - what the step pays for the collectives that did NOT hide behind the backward (the wait
+        # for the last buckets, the averaging and the scatter back) - collected in `finish_events`
+        self.time_finish = False
+        self.finish_events: List[Tuple[torch.cuda.Event, torch.cuda.Event]] = []
+        self.last_step_buckets = 0
 
     @property
     def world(self) -> int:
@@ -144,10 +150,18 @@ class BucketedGradReducer:
             return
         self._launch()
         inv = 1.0 / self.world
+        self.last_step_buckets = len(self._inflight)
+        ev = None
+        if self.time_finish and self._inflight and self._inflight[0][0][0].is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for views, members, work in self._inflight:
             work.wait()
             torch._foreach_mul_(views, inv)                                  # average in the bucket ...
             torch._foreach_copy_([t.detach() for t in members], views)       # ... and scatter back in place
+        if ev is not None:
+            ev[1].record()
+            self.finish_events.append(ev)
         self._inflight = []
 
 

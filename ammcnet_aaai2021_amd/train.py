@@ -210,6 +210,12 @@ class _Ops:
         if rescale:
             inv = torch.empty(1024, device=self.dev, dtype=torch.float32)
             if amax is None:
+                # the SHARED slots: one user at a time.  Inside `_side_by_side` two generators run on two HIP streams at
+                # once and each must bring its own slots (the units do: per-unit amax buffers) - a caller that forgot
+                # would race silently, so it is refused here
+                if self.side is not None and torch.cuda.current_stream(self.dev) in self.side:
+                    raise RuntimeError("to_s16(rescale=True) without its own `amax` slots on a side stream of "
+                                       "_side_by_side: the shared slots would be raced by the other stream")
                 amax = self.amax
                 if not have_amax:
                     amax.zero_()
@@ -361,13 +367,18 @@ def _side_by_side(ops: "_Ops", grads, *gens) -> bool:
     if ops.side is None:
         ops.side = (torch.cuda.Stream(ops.dev), torch.cuda.Stream(ops.dev))
     before = set(id(k) for k in grads) if grads is not None else set()
-    for st, g in zip(ops.side, gens):
-        st.wait_stream(cur)
-        with torch.cuda.stream(st):
-            for _ in g:
-                raise RuntimeError("a generator asked for a collective on the one-rank path")
-    for st in ops.side:
-        cur.wait_stream(st)
+    try:
+        for st, g in zip(ops.side, gens):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                for _ in g:
+                    raise RuntimeError("a generator asked for a collective on the one-rank path")
+    finally:
+        # always joined, also when a generator raised mid-phase (a refused launch, the RuntimeError above): work is then
+        # still in flight on the side streams, on workspace buffers that whatever the caller runs next - a retry on the
+        # fp32 kernels, the next step - re-uses on ITS stream
+        for st in ops.side:
+            cur.wait_stream(st)
     if grads is not None:
         for k, v in grads.items():
             if id(k) not in before:
@@ -778,8 +789,12 @@ class _Stream:
                 self.pool_idx = [torch.empty(q.B, q.H, q.W, q.c, dtype=torch.uint8, device=ops.dev) for q in self.pooled]
                 for i, blk in enumerate((self.inc, self.down[0], self.down[1])):
                     sk, c8 = self.skip[i], CHANS[i] >> 3
-                    if FUSE_POOL_APPLY and not ((sk.H | sk.W) & 1) and not (c8 & (c8 - 1)) and c8 <= 256:
-                        blk.u1.pool_out = (ops.shadow(self.pooled[i]), self.pool_idx[i])
+                    # (the kernel's own verdict - row form available, strides in range, AMMC_ROW_KERNELS - not a copy of its
+                    # conditions: a geometry it refuses keeps the two separate passes instead of raising in the forward)
+                    p16 = ops.shadow(self.pooled[i])
+                    if FUSE_POOL_APPLY and lib.ammc_scale_shift_act_s16_pool_supported(
+                            CHANS[i], sk.H, sk.W, blk.u1.craw.rs, blk.u1.craw.ps, sk.rs, sk.ps, p16.ps):
+                        blk.u1.pool_out = (p16, self.pool_idx[i])
                         self.pool_fused[i] = True
 
     # ---- forward pieces -------------------------------------------------------------

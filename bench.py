@@ -145,6 +145,18 @@ def pin_to_gpu_numa_node(device_index: int):
         return None
 
 
+def default_rccl_channels(mode: str, share: bool, env=None):
+    """the training step's convolutions run one or two workgroups per CU at the power cap, so every
+    RCCL channel takes a CU's share away from them; 4 channels x ~20 GB/s move a 25-MB gradient bucket in ~0.6 ms, well
+    inside the ~15 ms of backward behind it.  Training ranks therefore default NCCL_MAX_NCHANNELS to 4 - BEFORE the
+    communicator exists; an explicit environment setting wins; inference / stress ranks (no data-path collective) and the
+    gloo test mode are left alone.  Returns the value in force (or None)."""
+    env = os.environ if env is None else env
+    if mode in ("train", "train_gan") and not share:
+        env.setdefault("NCCL_MAX_NCHANNELS", "4")
+    return env.get("NCCL_MAX_NCHANNELS")
+
+
 def init_ranks(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -167,6 +179,7 @@ def init_ranks(args):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        default_rccl_channels(args.mode, share)
         if share:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -206,45 +219,111 @@ NUMA_PIN = None
 def backend_info(dist, world):
     if dist is None:
         return {"rccl_ranks": 1}
-    return {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "rank0_cpu_affinity": NUMA_PIN}
+    return {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "rank0_cpu_affinity": NUMA_PIN,
+            "nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS")}
 
 
 # ---- CPU baselines ("port": the oracle restatement, on this host) ---------------------------------------------------------
 
-def cpu_baseline(args):
-    """the CPU restatement of the same forward on a bounded sample (kind "port")"""
+def host_topology():
+    """physical cores of this host by NUMA node: {node: [one logical CPU per physical core]} (first SMT sibling each),
+    restricted to the CPUs this process may run on"""
+    allowed = os.sched_getaffinity(0)
+    nodes = {}
+    base = "/sys/devices/system/node"
+    try:
+        names = sorted(n for n in os.listdir(base) if n.startswith("node") and n[4:].isdigit())
+    except OSError:
+        names = []
+    for n in names:
+        cpus = set()
+        for part in open(f"{base}/{n}/cpulist").read().strip().split(","):
+            if part:
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        phys = []
+        for c in sorted(cpus & allowed):
+            try:
+                sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+                first = int(sib.replace("-", ",").split(",")[0])
+            except OSError:
+                first = c
+            if first == c:
+                phys.append(c)
+        if phys:
+            nodes[int(n[4:])] = phys
+    if not nodes:
+        nodes[0] = sorted(allowed)
+    return nodes
+
+
+def _cpu_child(spec: str) -> int:
+    """`bench.py --cpu-child <json>`: one measurement of the CPU baseline in a process of its own, pinned to `cpus` BEFORE
+    the first CPU operator creates the intra-op thread pool (the threads inherit the mask); prints seconds per forward"""
+    spec = json.loads(spec)
+    if spec.get("cpus"):
+        os.sched_setaffinity(0, set(spec["cpus"]))
+    torch.set_num_threads(int(spec["threads"]))
     from ammcnet_aaai2021_amd import synthetic as S
     from oracle import ammc_oracle as O
-    sd = S.make_twostream_state(n_embed=args.n_embed)
-    b = args.cpu_sample_batch
-    rgb_x, op_x, _, _ = S.make_clips(b, args.size, args.size, tag="bench")
-    ncpu = os.cpu_count() or 1
-    # ATen's CPU convolutions stop scaling (and then collapse) well before 256 threads on the
-    # GPU box's 2x64-core host: take the best of a few thread counts, one forward each
-    best = None
-    pb = min(b, 4)                                   # the thread count is chosen on 4 clips, the baseline timed on all b
+    sd = S.make_twostream_state(n_embed=spec["n_embed"])
+    rgb_x, op_x, _, _ = S.make_clips(spec["batch"], spec["size"], spec["size"], tag="bench")
+    times = []
     with torch.no_grad():
-        for th in sorted({min(t, ncpu) for t in (8, 16, 32, 64, 128, ncpu)}):
-            torch.set_num_threads(th)
-            O.twostream_forward(sd, rgb_x[:pb], op_x[:pb], 2)       # warm-up at this thread count
-            t0 = time.perf_counter()
-            O.twostream_forward(sd, rgb_x[:pb], op_x[:pb], 2)
-            dt = time.perf_counter() - t0
-            if best is None or dt < best[1]:
-                best = (th, dt)
-        threads = best[0]
-        torch.set_num_threads(threads)
-        times = []
-        for _ in range(args.cpu_iters):
+        O.twostream_forward(sd, rgb_x, op_x, 2)                        # warm-up
+        for _ in range(spec["iters"]):
             t0 = time.perf_counter()
             O.twostream_forward(sd, rgb_x, op_x, 2)
             times.append(time.perf_counter() - t0)
     times.sort()
-    med = times[len(times) // 2]
-    return {"value": round(b / med, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+    print(json.dumps({"seconds": times[len(times) // 2]}))
+    return 0
+
+
+def cpu_baseline(args):
+    """the CPU restatement of the same forward on a bounded sample (kind "port").  Thread count AND placement are searched
+    (round-4 review, weak #9: an unpinned 8-thread optimum on a 2 x 64-core host says more about thread placement than
+    about the host): each candidate runs in a child process pinned to PHYSICAL cores - one NUMA node's, or all - with as
+    many intra-op threads as cores in its mask; the unpinned counts of the earlier rounds stay in the sweep."""
+    topo = host_topology()
+    node0 = topo[sorted(topo)[0]]
+    phys_all = [c for n in sorted(topo) for c in topo[n]]
+    ncpu = os.cpu_count() or 1
+    cands = [{"label": f"{t} threads, unpinned", "cpus": None, "threads": t} for t in sorted({min(t, ncpu) for t in (8, 16, 32)})]
+    for t in (8, 16, 32, 64):
+        if t <= len(node0):
+            cands.append({"label": f"{t} threads on {t} physical cores of NUMA node {sorted(topo)[0]}", "cpus": node0[:t], "threads": t})
+    if len(phys_all) > len(node0):
+        cands.append({"label": f"{len(phys_all)} threads on all {len(phys_all)} physical cores", "cpus": phys_all, "threads": len(phys_all)})
+    b = args.cpu_sample_batch
+    pb = min(b, 4)                                   # placement is chosen on 4 clips, the baseline timed on all b
+
+    def run(c, batch, iters):
+        spec = dict(c, batch=batch, size=args.size, n_embed=args.n_embed, iters=iters)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", json.dumps(spec)], capture_output=True,
+                           text=True, env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+        try:
+            return json.loads(r.stdout.strip().splitlines()[-1])["seconds"]
+        except Exception:
+            return None
+    sweep = []
+    for c in cands:
+        dt = run(c, pb, 1)
+        if dt is not None:
+            sweep.append((dt, c))
+    if not sweep:
+        raise SystemExit("cpu baseline: no candidate ran")
+    sweep.sort(key=lambda t: t[0])
+    best = sweep[0][1]
+    med = run(best, b, args.cpu_iters)
+    return {"value": round(b / med, 4), "unit": "frames/s", "cores": best["threads"], "kind": "port",
+            "affinity": "unpinned" if best["cpus"] is None else f"{len(best['cpus'])} logical CPUs: {best['cpus'][0]}..{best['cpus'][-1]}",
+            "placement": best["label"],
+            "host": {"logical_cpus": ncpu, "physical_cores": len(phys_all), "numa_nodes": len(topo)},
+            "sweep_frames_per_s_on_%d_clips" % pb: {c["label"]: round(pb / dt, 3) for dt, c in sweep},
             "sample": f"{args.cpu_iters} timed forwards (median) of batch {b} at {args.size}x{args.size}, "
-                      f"n_embed {args.n_embed} (the headline workload's own batch), torch CPU fp32, best of 8/16/32/64/128/{ncpu} threads = "
-                      f"{threads} chosen on {pb} clips (host has {ncpu} logical CPUs)"}
+                      f"n_embed {args.n_embed} (the headline workload's own batch), torch CPU fp32, in a child process "
+                      f"pinned as `placement` says (chosen among {len(sweep)} thread counts / placements on {pb} clips)"}
 
 
 def cpu_baseline_train(size: int):
@@ -297,8 +376,9 @@ def cpu_baseline_stress(d: int, m: int, k: int):
 
 # ---- configs[2] / configs[3]: training ---------------------------------------------------------------------------------------
 
-GRAD_NORM_TOL = 4e-3              # per-tensor gradient norms at batch 32 (tests/test_gpu_train.py, last test: measured 2.0e-3 for
-                                  # the split-fp16 kernels, 1.1e-3 for the exact-fp32 ones, 2.5e-3 between the two)
+GRAD_NORM_TOL = 1e-3              # per-tensor gradient norms within 1e-3 - of the fp64 TRUTH on the branch this evaluation
+                                  # took (`train_vs_fp64`; measured 5.3e-4 max, the reference's own fp32 gradients 4.0e-4)
+GRAD_L2_FACTOR = 2.0              # entry by entry: |g - g64| / |g64| <= max(1e-3, 2 e_ref) per tensor, median ratio <= 1.5
 CODEBOOK_TOL = 1e-3               # EMA codebook buffers: one memory lookup of 32768 re-routed inside fp32 noise moves them 2e-4
 MAX_REROUTED_ROWS = 3
 
@@ -344,18 +424,74 @@ def train_parity(net, out, loss, fixture, with_grads: bool):
         float((sd[k[4:]].detach().double().cpu() - torch.as_tensor(np.asarray(d[k])).double()).abs().sum()) / 0.01 / 2
         for k in d.files if k.startswith("buf.") and k.endswith("cluster_size")), 2)
     if with_grads:
-        gn = []
-        for name, p in net.named_parameters():
-            want = float(d[f"gn.{name}"])
-            gn.append((abs(float(p.grad.double().norm()) - want) / max(want, 1e-30), name))
-        gn.sort()
-        res["grad_norm_rel_median"], res["grad_norm_rel_max"] = gn[len(gn) // 2][0], gn[-1][0]
-        res["grad_norm_worst"] = [f"{n} {e:.2e}" for e, n in gn[-3:][::-1]]
+        res["vs_fp64"] = train_vs_fp64(net, d, cfg)
     res["ok"] = bool(res["loss_rel"] <= PARITY_TOL and res["frames_max_rel"] <= PARITY_TOL and
                      res["commit_max_rel"] <= PARITY_TOL and (res["buffers_max_rel"] or 0.0) <= PARITY_TOL and
                      (res["codebook_max_rel"] or 0.0) <= CODEBOOK_TOL and res["codebook_rerouted_rows"] <= MAX_REROUTED_ROWS + 0.01 and
-                     res.get("grad_norm_rel_max", 0.0) <= GRAD_NORM_TOL)
+                     (res.get("vs_fp64") or {"ok": True})["ok"])
     return res
+
+
+def train_vs_fp64(net, d, cfg):
+    """The timed model's first-step gradients against the fp64 TRUTH (tests/test_gpu_train.py::
+    test_batch32_gradients_against_the_fp64_truth has the reasoning): the oracle in float64, evaluated here on the device
+    (~6 s; it agrees with the host evaluation committed as tests/golden/twostream_<size>_b<batch>_train_fp64.npz to 6e-12)
+    with the memory lookups THIS evaluation made - two fp32-accurate evaluations differ from the unconstrained fp64 one
+    mostly by which way one or two near-tie lookups of 65536 fall, for the reference's own gradients as well
+    (`e_ref_unconstrained`).  e_ref: the reference's recorded 4096 entries per tensor against the truth on ITS branch."""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", f"twostream_{cfg['hw']}_b{cfg['batch']}_train_fp64.npz")
+    if not os.path.exists(path) or "gs4k." + next(n for n, _ in net.named_parameters()) not in d.files:
+        return None
+    t64 = np.load(path)
+    if "loss64r" not in t64.files:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_fp64_truth import dense_samples, oracle_step
+    from ammcnet_aaai2021_amd import synthetic as S
+    dev = next(net.parameters()).device
+    st = net._train_engine._last
+    idx = {p: st["streams"][si].idx.reshape(-1, 2).long().clone() for si, p in enumerate(("rgb", "op"))}
+    differ = {p: int((idx[p].cpu() != torch.as_tensor(t64[f"idx64.{p}"].astype(np.int64))).any(dim=1).sum()) for p in idx}
+    differ_ref = {p: int((d[f"idx.{p}"].astype(np.int64) != t64[f"idx64.{p}"].astype(np.int64)).any(axis=1).sum()) for p in idx}
+    t0 = time.perf_counter()
+    _, g64 = oracle_step(S.make_twostream_state(), S.make_clips(cfg["batch"], cfg["hw"], cfg["hw"], tag=cfg["tag"]),
+                         torch.float64, dev, force_idx=idx)
+    torch.cuda.synchronize()
+    secs = time.perf_counter() - t0
+
+    def l2(a, b):
+        a, b = a.double().flatten(), b.double().flatten()
+        return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+    rows = []
+    for name, p in net.named_parameters():
+        t = g64[name]
+        n64 = float(t.norm())
+        gs_ref = torch.as_tensor(np.asarray(d[f"gs4k.{name}"]))
+        rows.append(dict(name=name, e_hip=l2(p.grad, t), norm_hip=abs(float(p.grad.double().norm()) - n64) / n64,
+                         e_ref=l2(gs_ref, torch.as_tensor(t64[f"gs64r.{name}"])),
+                         norm_ref=abs(float(d[f"gn.{name}"]) - float(t64[f"gn64r.{name}"])) / float(t64[f"gn64r.{name}"]),
+                         e_ref_unconstrained=l2(gs_ref, torch.as_tensor(t64[f"gs64.{name}"]))))
+    del g64
+    torch.cuda.empty_cache()
+
+    def stat(key):
+        v = sorted(r[key] for r in rows)
+        return {"max": v[-1], "median": v[len(v) // 2]}
+    ratios = sorted(r["e_hip"] / r["e_ref"] for r in rows if r["e_ref"] > 5e-4)
+    bad = [r["name"] for r in rows if r["norm_hip"] > GRAD_NORM_TOL or r["e_hip"] > max(1e-3, GRAD_L2_FACTOR * r["e_ref"])]
+    worst = sorted(rows, key=lambda r: -r["e_hip"] / max(1e-3, GRAD_L2_FACTOR * r["e_ref"]))[:3]
+    return {"truth": "oracle/ammc_oracle.py in float64 on the device, memory lookups forced to this evaluation's (the same branch)",
+            "fixture": os.path.relpath(path, ROOT), "seconds": round(secs, 1),
+            "lookups_differing_from_unconstrained_fp64": differ, "reference_lookups_differing": differ_ref,
+            "grad_norm_rel": stat("norm_hip"), "reference_grad_norm_rel": stat("norm_ref"),
+            "grad_l2_rel": stat("e_hip"), "reference_grad_l2_rel": stat("e_ref"),
+            "reference_grad_l2_rel_unconstrained": stat("e_ref_unconstrained"),
+            "ratio_hip_over_reference": {"median": ratios[len(ratios) // 2], "max": ratios[-1]} if ratios else None,
+            "gates": {"grad_norm_rel": GRAD_NORM_TOL, "grad_l2_rel": f"max(1e-3, {GRAD_L2_FACTOR} x reference)", "ratio_median": 1.5},
+            "worst": [f"{r['name']} e {r['e_hip']:.2e} (ref {r['e_ref']:.2e}) norm {r['norm_hip']:.2e}" for r in worst],
+            "failing": bad, "ok": bool(not bad and (not ratios or ratios[len(ratios) // 2] <= 1.5))}
 
 
 def train_traffic(kernel: str, batch: int, size: int):
@@ -378,9 +514,14 @@ def train_traffic(kernel: str, batch: int, size: int):
         if not sel:
             continue
         n = sum(v["dispatches"] for v in sel)
-        return (sum(v["dispatches"] * v["traffic_bytes_per_launch"] for v in sel) / n,
-                {"file": os.path.relpath(path, ROOT), "command": prof.get("source"), "workload": wl, "commit": prof.get("commit"),
-                 "averaged_over_launches": n})
+        src = {"file": os.path.relpath(path, ROOT), "command": prof.get("source"), "workload": wl, "commit": prof.get("commit"),
+               "averaged_over_launches": n}
+        names = [k for k, v in rows.items() if v in sel]
+        for k in names:
+            ok, why = profile_is_current(prof, k)
+            if not ok:
+                return None, dict(src, stale=why)
+        return sum(v["dispatches"] * v["traffic_bytes_per_launch"] for v in sel) / n, src
     return None, None
 
 
@@ -394,9 +535,12 @@ def run_train(args, rank, world, dev, dist, steps, warmup, with_cpu):
     net = A.get_twostream((12, 6), (3, 2), 64, 256, 2)
     net.load_state_dict(S.make_twostream_state())
     net = net.to(dev).train()
+    reducer = None
     if world > 1:
         parallel.broadcast_state(net)
-        parallel.attach_reducer(net, parallel.BucketedGradReducer())
+        reducer = parallel.BucketedGradReducer()
+        reducer.time_finish = True             # HIP events around every finish(): what the collectives cost the step's stream
+        parallel.attach_reducer(net, reducer)
         if getattr(args, "sync_stats", False):
             parallel.sync_statistics(net, True)
     opt = harness.adam(net.parameters(), lr=1e-4)
@@ -418,7 +562,8 @@ def run_train(args, rank, world, dev, dist, steps, warmup, with_cpu):
     opt.zero_grad(set_to_none=True)
     out = net(rgb_x, op_x)
     loss = harness.generator_loss(out, rgb_t, op_t)
-    watch = harness._FiniteWatch(loss)
+    vote, group = harness._watch_group(net)
+    watch = harness._FiniteWatch(loss, group=group, vote=vote)
     loss.backward()
     parity = train_parity(net, out, loss, fixture, with_grads=world == 1) if fixture else None
     watch.step(opt)
@@ -426,9 +571,19 @@ def run_train(args, rank, world, dev, dist, steps, warmup, with_cpu):
     del out, loss
     for _ in range(max(warmup, 1) - 1):
         step()
+    if reducer is not None:
+        reducer.finish_events.clear()
     elapsed = clock.time(step, steps)
     if not bool(torch.isfinite(state["loss"])):
         raise SystemExit("training step produced a non-finite loss")
+    collectives = None
+    if reducer is not None:
+        ev = sorted(a.elapsed_time(b) for a, b in reducer.finish_events)
+        collectives = {"gradient_buckets_per_step": reducer.last_step_buckets, "bucket_mb": reducer.bucket_bytes / 2 ** 20,
+                       "exposed_ms_per_step": {"median": round(ev[len(ev) // 2], 3), "max": round(ev[-1], 3)} if ev else None,
+                       "what": "HIP events on the compute stream around BucketedGradReducer.finish(): the wait for the buckets "
+                               "still in flight when the backward ends + averaging + scatter back (rank 0)",
+                       "nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS")}
     # per-kernel durations of the 3x3 layers' MFMA launches: one more step with every such launch bracketed by HIP
     # events on the launch stream (outside the timed region)
     roof, fams = None, {}
@@ -477,7 +632,7 @@ def run_train(args, rank, world, dev, dist, steps, warmup, with_cpu):
         "whole_path_tflops": round(value * flops / 1e12 / world, 2), "loss": float(state["loss"]),
         "parity_loss_rel": parity["loss_rel"] if parity else None, "parity_tol": PARITY_TOL,
         "grad_norm_tol": GRAD_NORM_TOL, "codebook_tol": CODEBOOK_TOL, "max_rerouted_rows": MAX_REROUTED_ROWS, "parity": parity,
-        "roofline": roof,
+        "roofline": roof, "collectives": collectives,
         "kernels": {k: dict(launches_per_step=v["launches"], avg_us=round(1e3 * v["ms"] / v["launches"], 2),
                             tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)) for k, v in
                     sorted(fams.items(), key=lambda kv: -kv[1]["ms"])},
@@ -577,16 +732,18 @@ def run_train_gan(args, dev, steps, warmup):
 
 # ---- configs[4]: the memory-addressing kernel alone ------------------------------------------------------------------------
 
-def stress_traffic(n_rows):
-    """HBM-side bytes per launch of the stress kernel from the committed PMC passes (null when the profile was taken at
-    another row count)"""
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_stress_pmc_traffic.json")))[::-1]:
+def stress_traffic(n_rows, kernel="memory_topk_f16r"):
+    """HBM-side bytes per launch of the stress kernel from the committed PMC passes: (bytes, provenance); bytes are null
+    when no profile of this kernel at this row count exists or its source changed since (`profile_is_current`)"""
+    for path in _profiles(["stress_pmc_traffic.json"]):
         with open(path) as fp:
             prof = json.load(fp)
-        if prof.get("workload", {}).get("rows") == n_rows and "memory_topk_f16" in prof.get("kernels", {}):
-            return prof["kernels"]["memory_topk_f16"]["traffic_bytes_per_launch"]
-    return None
+        rows = {_norm_kernel(k): v for k, v in prof.get("kernels", {}).items()}
+        if prof.get("workload", {}).get("rows") == n_rows and kernel in rows:
+            ok, why = profile_is_current(prof, kernel)
+            src = {"file": os.path.relpath(path, ROOT), "commit": prof.get("commit")}
+            return (rows[kernel]["traffic_bytes_per_launch"], src) if ok else (None, dict(src, stale=why))
+    return None, None
 
 
 def stress_parity(ms, x, qk, idx, d, m, k, rows=32768, chunk=4096):
@@ -674,6 +831,27 @@ def run_stress(args, rank, world, dev, dist, steps, warmup, with_cpu):
     parity = stress_parity(ms, x, qk, idx, d, m, k) if rank == 0 else None
     if parity is not None and not parity["ok"]:
         ok = False
+    # The same check on CLUSTERED features (round-4 review, weak #7): random features leave most rows' top-2 margins below
+    # what fp16 operands can resolve (39 % resolvable above), so most of the index path is only held to "a true near
+    # neighbour".  What a trained memory sees lies between slots: x = 0.6 E_s + 0.4 E_t + noise puts both margins far
+    # above fp16 noise, and every such row must return exactly (s, t).
+    parity_c = None
+    if rank == 0:
+        gc = torch.Generator(device=dev)
+        gc.manual_seed(99)
+        nc = 32768
+        st_ = torch.randint(0, m, (nc, 2), device=dev, generator=gc)
+        st_[:, 1] = torch.where(st_[:, 1] == st_[:, 0], (st_[:, 1] + 1) % m, st_[:, 1])
+        e_md = ms.embed.t().contiguous()
+        xc = 0.6 * e_md[st_[:, 0]] + 0.4 * e_md[st_[:, 1]] + 0.05 * torch.randn(nc, d, device=dev, generator=gc)
+        qkc, _, _, idxc = ms.run(xc)
+        parity_c = stress_parity(ms, xc, qkc.clone(), idxc.clone(), d, m, k, rows=8192)
+        parity_c["planted_pairs_returned"] = float((idxc.long() == st_).all(dim=1).double().mean())
+        parity_c["ok"] = bool(parity_c["ok"] and parity_c["planted_pairs_returned"] == 1.0 and
+                              parity_c["rows_with_resolvable_margin"] >= 0.9 * parity_c["rows_checked"])
+        if not parity_c["ok"]:
+            ok = False
+        ms.run(x)                                                  # (the output buffers of this row count again)
     if dist is not None:                                           # the only collective: after the timed region
         tot = part.double().sum().reshape(1).to(torch.float32)
         dist.all_reduce(tot)
@@ -688,17 +866,20 @@ def run_stress(args, rank, world, dev, dist, steps, warmup, with_cpu):
         "value": round(rows * steps / elapsed, 1), "unit": "rows/s", "n_gpus": world, "steps": steps, "warmup": max(warmup, 1),
         "ms_per_step": round(1e3 * elapsed / steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16 operands, f32 accumulate (v_mfma_f32_32x32x16_f16); gather / commit from the f32 codebook",
+        "kernel": ms.kernel + (": feature rows resident in registers, codebook tiles L2 -> LDS once per 384 rows" if ms.rows_in_registers
+                               else ": feature rows in LDS, codebook L2 -> registers once per 128 rows"),
         "data": "synthetic",
         "config": {"workload": "Stress: 8192 memory slots x 512-d features, fp16 MFMA memory-addressing kernel "
                                "(BASELINE.json configs[4])", "rows_per_gpu": n, "frames_per_gpu": frames_per_gpu,
                    "parallelism": f"rows sharded x{world}, codebook replicated, no data-path collective"},
         "whole_path_tflops": round(rows * steps / elapsed * 2.0 * d * m / 1e12 / world, 2),
-        "parity": parity,
-        "roofline": {"kernel": "memory_topk_f16", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": stress_traffic(n),
-                     "power_ceiling": power_ceiling("memory_topk_f16", ach),
-                     "mfma_busy_frac": pmc_busy("memory_topk_f16", "stress")[0] if frames_per_gpu == 256 else None,
-                     "mfma_busy_source": pmc_busy("memory_topk_f16", "stress")[1] if frames_per_gpu == 256 else None,
+        "parity": parity, "parity_clustered_features": parity_c,
+        "roofline": {"kernel": ms.kernel, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": stress_traffic(n, ms.kernel)[0],
+                     "traffic_source": stress_traffic(n, ms.kernel)[1],
+                     "power_ceiling": power_ceiling(ms.kernel, ach),
+                     "mfma_busy_frac": pmc_busy(ms.kernel, "stress")[0] if frames_per_gpu == 256 else None,
+                     "mfma_busy_source": pmc_busy(ms.kernel, "stress")[1] if frames_per_gpu == 256 else None,
                      "flops_per_launch": ms.flops(n), "avg_launch_us": round(us, 2), "launches_per_step": 1,
                      "algorithmic_bytes_per_launch": ms.algorithmic_bytes(n)},
         "cpu_baseline": cpu_baseline_stress(d, m, k) if with_cpu else None,
@@ -904,6 +1085,46 @@ def _profiles(suffixes):
     return sorted(set(paths), key=lambda q: os.path.basename(q).split("_")[0], reverse=True)
 
 
+_KERNEL_FILE = {}
+
+
+def kernel_source_file(kernel: str):
+    """csrc/*.hip that defines the __global__ function behind a bench / rocprofv3 kernel label"""
+    import re
+    base = re.sub(r"<.*$", "", _norm_kernel(kernel)).split("+")[0].strip()
+    if base not in _KERNEL_FILE:
+        hit = None
+        csrc = os.path.join(ROOT, "ammcnet_aaai2021_amd", "csrc")
+        for f in sorted(os.listdir(csrc)):
+            if f.endswith(".hip"):
+                with open(os.path.join(csrc, f)) as fp:
+                    if re.search(r"__global__[^;{]*?\b" + re.escape(base) + r"(_kernel)?\s*\(", fp.read(), re.S):
+                        hit = f
+                        break
+        _KERNEL_FILE[base] = hit
+    return _KERNEL_FILE[base]
+
+
+def profile_is_current(prof: dict, kernel: str):
+    """(True, None) when the committed profile `prof` was taken on the code that is running: the file that defines
+    `kernel` and csrc/ammc_common.h have the digests the LOADED library was compiled from
+    (`ammc_source_digests()`); else (False, reason) and the caller reports null instead of a figure measured on other code"""
+    from ammcnet_aaai2021_amd import _lib
+    have = dict(kv.split("=") for kv in _lib.load().ammc_source_digests().decode().split(",") if "=" in kv)
+    want = prof.get("csrc_digests")
+    if not want:
+        return False, "profile carries no source digests (taken before round 5)"
+    if not have:
+        return False, "the loaded library carries no source digests (not built by ammcnet_aaai2021_amd/build.py)"
+    src = kernel_source_file(kernel)
+    if src is None:
+        return False, f"no source file found for kernel {kernel}"
+    for f in (src, "ammc_common.h"):
+        if want.get(f) != have.get(f):
+            return False, f"{f} changed since the profile was taken ({want.get(f)} -> {have.get(f)})"
+    return True, None
+
+
 def pmc_traffic(kernel: str, precision: str, args):
     """HBM-side bytes per launch cannot be read live: they come from the committed PMC passes of THIS command
     (tools/profile_round.sh -> profiles/rNN_infer_pmc_traffic.json; rounds 1-2: rNN_<precision>_pmc_traffic.json).  Null
@@ -919,8 +1140,10 @@ def pmc_traffic(kernel: str, precision: str, args):
         for k, row in prof["kernels"].items():
             v = row.get("traffic_bytes_per_launch")
             if v is not None and _norm_kernel(k) == _norm_kernel(kernel):
-                return v, {"file": os.path.relpath(path, ROOT), "command": prof.get("source"), "workload": wl,
-                           "commit": prof.get("commit")}
+                ok, why = profile_is_current(prof, kernel)
+                src = {"file": os.path.relpath(path, ROOT), "command": prof.get("source"), "workload": wl,
+                       "commit": prof.get("commit")}
+                return (v, src) if ok else (None, dict(src, stale=why))
     return None, None
 
 
@@ -933,8 +1156,9 @@ def pmc_busy(kernel: str, mode: str):
             prof = json.load(fp)
         for k, v in prof.get("kernels", {}).items():
             if _norm_kernel(k) == _norm_kernel(kernel) and "mfma_busy_frac" in v:
-                return v["mfma_busy_frac"], {"file": os.path.relpath(path, ROOT), "command": prof.get("workload"),
-                                             "commit": prof.get("commit")}
+                ok, why = profile_is_current(prof, kernel)
+                src = {"file": os.path.relpath(path, ROOT), "command": prof.get("workload"), "commit": prof.get("commit")}
+                return (v["mfma_busy_frac"], src) if ok else (None, dict(src, stale=why))
     return None, None
 
 
@@ -1055,14 +1279,16 @@ def run_infer(args, rank, world, dev, dist):
         del gan
         torch.cuda.empty_cache()
         s = run_stress(args, 0, 1, dev, None, steps=10, warmup=2, with_cpu=False)
-        line["stress_memory"] = {k: s[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype",
-                                                   "config", "whole_path_tflops", "parity", "roofline")}
+        line["stress_memory"] = {k: s[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "kernel",
+                                                   "config", "whole_path_tflops", "parity", "parity_clustered_features", "roofline")}
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args)
     return line, rc
 
 
 def main():
+    if len(sys.argv) >= 3 and sys.argv[1] == "--cpu-child":
+        sys.exit(_cpu_child(sys.argv[2]))
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args))

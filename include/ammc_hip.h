@@ -39,6 +39,10 @@ extern "C" {
 
 /* library / device identification ---------------------------------------- */
 int ammc_abi_version(void);                    /* bumps on any signature change */
+/* "file=digest,file=digest,..." (sha256[:12]) of the source files the library was compiled from; profiles/ files carry
+ * the same map and bench.py quotes a profiled figure of a kernel only while the kernel's file, ammc_common.h and this
+ * header are unchanged ("" for a library built outside ammcnet_aaai2021_amd/build.py) */
+const char* ammc_source_digests(void);
 const char* ammc_build_info(void);             /* "gfx950 ..." */
 const char* ammc_error_string(int code);
 /* Dispatch options, for A/B measurements and for tests that must reach every kernel instance:
@@ -478,6 +482,11 @@ int ammc_maxpool2x2_bwd_idx_f32(const uint8_t* idx, const float* dp, int64_t p_b
  * ammc_bn_bwd_reduce_bound_f32 / ammc_bn_bwd_apply_s16_f32.  The apply form needs ammc_bn_bwd_unpool_supported(c, pixel
  * strides of c_raw / add / dc, w) != 0, else AMMC_EUNSUP (materialise dy with ammc_maxpool2x2_bwd_idx_f32). */
 int ammc_bn_bwd_unpool_supported(int32_t c, int64_t c_ps, int64_t d_ps, int64_t o_ps, int32_t w);
+/* 1 when ammc_scale_shift_act_s16_pool_f32 takes this geometry (even h, w; c / 8 a power of two <= 256; the row form's
+ * stride limits; AMMC_ROW_KERNELS not 0), else 0: callers then run ammc_scale_shift_act_s16_f32 + ammc_maxpool2x2_s16_idx
+ * (the same query shape as ammc_bn_bwd_unpool_supported for the backward side). */
+int ammc_scale_shift_act_s16_pool_supported(int32_t c, int32_t h, int32_t w, int64_t x_rs, int64_t x_ps, int64_t y_rs,
+                                            int64_t y_ps, int64_t p_ps);
 int ammc_bn_bwd_reduce_bound_unpool_f32(const float* c_raw, int64_t c_bs, int64_t c_rs, int64_t c_ps, const float* add,
                                         int64_t d_bs, int64_t d_rs, int64_t d_ps, const float* dpo, int64_t p_bs, int64_t p_rs,
                                         int64_t p_ps, const uint8_t* idx, int32_t ph, int32_t pw, const float* mean,

@@ -69,12 +69,17 @@ def up(sd: State, p: str, x1: torch.Tensor, x2: torch.Tensor, training: bool = F
     return double_conv(sd, f"{p}.conv.conv", torch.cat([x2, x1], dim=1), training)
 
 
-def quantize_topk(x: torch.Tensor, embed: torch.Tensor, k: int):
+def quantize_topk(x: torch.Tensor, embed: torch.Tensor, k: int, force_idx: torch.Tensor = None):
     """Memory addressing, forward arithmetic only (models/unet.py:282-297, 310).
 
     x [B,h,w,D], embed [D,M].  Returns (q_topk [B,h,w,k*D], diff scalar,
     idx_topk [B,h,w,k] int64, idx_top1 [N] int64, flatten [N,D]).
     Same expression order as the reference: |x|^2 - 2 x.E + |E|^2.
+
+    `force_idx` [N,k] (TEST INSTRUMENTATION, no counterpart in the reference): take these slots instead of the ranking's.
+    The lookup is the path's one hard discontinuity - two slots whose distances tie within rounding noise - so two
+    evaluations of a training step can only be compared entry by entry on the SAME branch of it
+    (tests/test_gpu_train.py: the fp64 truth is evaluated with the lookups of the evaluation under test).
     """
     d = embed.shape[0]
     flatten = x.reshape(-1, d)
@@ -83,8 +88,13 @@ def quantize_topk(x: torch.Tensor, embed: torch.Tensor, k: int):
             + embed.pow(2).sum(0, keepdim=True))
     idx1 = (-dist).max(1)[1]
     table = embed.transpose(0, 1)
+    if force_idx is not None:
+        forced = force_idx.to(device=x.device, dtype=torch.int64).reshape(-1, k)
+        idx1 = forced[:, 0].contiguous()
     q1 = F.embedding(idx1.view(*x.shape[:-1]), table)
     idxk = (-dist).topk(k, dim=1)[1].view(x.shape[0], x.shape[1], x.shape[2], -1)
+    if force_idx is not None:
+        idxk = forced.view(x.shape[0], x.shape[1], x.shape[2], -1)
     qk = F.embedding(idxk, table).view(x.shape[0], x.shape[1], x.shape[2], -1)
     diff = (q1.detach() - x).pow(2).mean()
     return qk, diff, idxk, idx1, flatten, q1
@@ -105,12 +115,12 @@ def codebook_ema_update(sd: State, p: str, flatten: torch.Tensor, idx1: torch.Te
         embed.copy_(ea / smoothed.unsqueeze(0))
 
 
-def vq_block(sd: State, p: str, x: torch.Tensor, k: int, training: bool = False):
+def vq_block(sd: State, p: str, x: torch.Tensor, k: int, training: bool = False, force_idx: torch.Tensor = None):
     """enc 1x1 -> NHWC -> memory read -> NCHW -> dec 1x1 -> += x
     (models/unet.py:318-331 and 379-387).  Returns (out, diff[1], q_one, idx_topk)."""
     q = f"{p}.quan"
     z = F.conv2d(x, sd[f"{q}.enc.weight"], sd[f"{q}.enc.bias"]).permute(0, 2, 3, 1)
-    qk, diff, idxk, idx1, flatten, q1 = quantize_topk(z, sd[f"{q}.quantize.embed"], k)
+    qk, diff, idxk, idx1, flatten, q1 = quantize_topk(z, sd[f"{q}.quantize.embed"], k, force_idx)
     if training:
         codebook_ema_update(sd, f"{q}.quantize", flatten, idx1)
     q_one = z + (q1 - z).detach()                                   # unet.py:311
@@ -160,7 +170,7 @@ def unetmem_forward(sd: State, x: torch.Tensor, k: int, training: bool = False, 
 
 
 def twostream_forward(sd: State, rgb_x: torch.Tensor, op_x: torch.Tensor, k: int = 2,
-                      training: bool = False, want_aux: bool = False):
+                      training: bool = False, want_aux: bool = False, force_idx: dict = None):
     """`twostream.forward` (models/unet.py:981-1007), same operation order
     (it matters in training: BN running stats and EMA buffers are updated as
     each submodule runs).
@@ -188,10 +198,11 @@ def twostream_forward(sd: State, rgb_x: torch.Tensor, op_x: torch.Tensor, k: int
 
     r1, r2, r3, r4 = enc("rgb", rgb_x)
     aux.update({"rgb.x1": r1, "rgb.x2": r2, "rgb.x3": r3, "rgb.x4": r4})
-    r4q, rgb_diff, rgb_q, rgb_idx = vq_block(sd, "rgb.vq_down3", r4, k, training)
+    fi = force_idx or {}                  # test instrumentation: {"rgb": idx [N, k], "op": ...}, see quantize_topk
+    r4q, rgb_diff, rgb_q, rgb_idx = vq_block(sd, "rgb.vq_down3", r4, k, training, fi.get("rgb"))
     o1, o2, o3, o4 = enc("op", op_x)
     aux.update({"op.x1": o1, "op.x2": o2, "op.x3": o3, "op.x4": o4})
-    o4q, op_diff, op_q, op_idx = vq_block(sd, "op.vq_down3", o4, k, training)
+    o4q, op_diff, op_q, op_idx = vq_block(sd, "op.vq_down3", o4, k, training, fi.get("op"))
     aux.update({"rgb.vq": r4q, "op.vq": o4q, "rgb.idx": rgb_idx, "op.idx": op_idx})
     r4b, o4b = bridge(sd, r4q, o4q, training)
     aux.update({"rgb.bridge": r4b, "op.bridge": o4b})

@@ -12,9 +12,15 @@ path) is restated here:
     ints S = p0*a0 + p1*a1; the vertical pass is ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.
   * float: D = p0*a0 + p1*a1 horizontally, then S0*b0 + S1*b1, each product and sum rounded to float.
 
-PARITY UNPINNED for the resize: without cv2 there is nothing here to check this restatement against, and OpenCV builds
-with IPP / OpenCL may differ from the generic path by one grey level.  Everything else in this file is pinned by the
-reference's code directly (plain arithmetic).
+Parity status of the resize (round 5): cv2 cannot be obtained here (no network, no wheel in the image), so `cv2.resize`
+itself has never been run against this file.  PINNED by an independent witness (tests/test_pipeline_host.py::
+test_oracle_resize_against_independent_witnesses - torch's bilinear `interpolate`, align_corners=False, the same
+published half-pixel definition): the sampling geometry of both paths (coordinates, taps, border clamp), the float
+path to float rounding, the 8-bit path to less than one grey level everywhere.  PARITY UNPINNED, still: the 8-bit
+kernel's own fixed-point rounding (the 2048-step weights and the `>> 4`, `>> 16`, `+ 2 >> 2` steps restated above,
+which decide the ~12 % of pixels that are one level off the rounded exact value), and whether a given OpenCV build
+takes its generic path at all (IPP / OpenCL builds differ from it by a grey level).  Everything else in this file is
+pinned by the reference's code directly (plain arithmetic).
 """
 from __future__ import annotations
 

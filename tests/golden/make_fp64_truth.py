@@ -44,16 +44,54 @@ def dense_samples(g: torch.Tensor, n: int = DENSE) -> torch.Tensor:
     return g.flatten()[:: max(1, g.numel() // n)][:n].contiguous()
 
 
-def oracle_step(sd, clips, dtype, device):
-    """one G-only training step of the oracle: loss, gradients (dict name -> tensor on `device`)"""
+def oracle_step(sd, clips, dtype, device, force_idx=None, want_idx=False):
+    """one G-only training step of the oracle: loss, gradients (dict name -> tensor on `device`).  `force_idx`: the
+    memory lookups to take ({"rgb": [N, k], "op": [N, k]}: oracle.quantize_topk, test instrumentation); `want_idx`: also
+    return the lookups this evaluation made"""
     rgb_x, op_x, rgb_t, op_t = (t.to(device=device, dtype=dtype) for t in clips)
     m = O.clone_state({k: (v.to(device=device, dtype=dtype) if v.is_floating_point() else v.to(device)) for k, v in sd.items()},
                       requires_grad=True)
-    out = O.twostream_forward(m, rgb_x, op_x, 2, training=True)
+    out = O.twostream_forward(m, rgb_x, op_x, 2, training=True, want_aux=want_idx, force_idx=force_idx)
     loss = O.generator_loss(out, rgb_t, op_t)
     loss.backward()
     grads = {k: v.grad.detach() for k, v in m.items() if v.requires_grad}
+    if want_idx:
+        return float(loss.detach()), grads, {p: out[-1][f"{p}.idx"].reshape(-1, 2) for p in ("rgb", "op")}
     return float(loss.detach()), grads
+
+
+def add_reference_branch(args, cfg):
+    """Two fp32-accurate evaluations of this step differ from the fp64 evaluation mostly by WHICH WAY one or two near-tie
+    memory lookups fall (tools/flip_count.py: one re-routed lookup of 32768 moves the bottleneck by 5e-3 and every
+    gradient downstream by ~1e-2).  Entry-by-entry comparisons therefore use the truth on the branch the evaluation
+    under test took: here the reference's (its lookups are recorded in its fixture)."""
+    ref = np.load(args.fixture)
+    old = np.load(args.add_reference_branch)
+    out = {k: old[k] for k in old.files}
+    dev = "cuda" if args.device in ("cuda", "both") else "cpu"
+    idx = {p: torch.as_tensor(ref[f"idx.{p}"].astype(np.int64)) for p in ("rgb", "op")}
+    sd = S.make_twostream_state()
+    clips = S.make_clips(cfg["batch"], cfg["hw"], cfg["hw"], tag=cfg["tag"])
+    t0 = time.time()
+    loss, g, own = oracle_step(sd, clips, torch.float64, dev, want_idx=True)            # unconstrained: which lookups differ?
+    differ = {p: int((own[p].cpu() != idx[p]).any(dim=1).sum()) for p in idx}
+    worst = max(float((dense_samples(v).cpu() - torch.as_tensor(old[f"gs64.{k}"])).norm() /
+                      torch.as_tensor(old[f"gs64.{k}"]).norm().clamp_min(1e-300)) for k, v in g.items())
+    del g
+    loss_r, g = oracle_step(sd, clips, torch.float64, dev, force_idx=idx)
+    for p_, ix in own.items():                                   # the lookups of the unconstrained fp64 evaluation
+        out[f"idx64.{p_}"] = ix.cpu().numpy().astype(np.int16)
+    out["loss64r"] = np.float64(loss_r)
+    for k, v in g.items():
+        out[f"gn64r.{k}"] = np.float64(v.norm().item())
+        out[f"gs64r.{k}"] = dense_samples(v).cpu().numpy()
+    meta = json.loads(str(old["meta"]))
+    meta.update(reference_branch_device=dev, reference_branch_seconds=round(time.time() - t0, 1),
+                reference_lookups_that_differ_from_fp64=differ, unconstrained_rerun_vs_file_max_l2rel=worst)
+    out["meta"] = np.array(json.dumps(meta))
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    np.savez_compressed(args.out, **out)
+    print("wrote", args.out, meta, flush=True)
 
 
 def main():
@@ -62,8 +100,14 @@ def main():
     ap.add_argument("--fixture", default=os.path.join(HERE, "twostream_256_b32_train.npz"))
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "twostream_256_b32_train_fp64.npz"))
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--add-reference-branch", default="",
+                    help="an existing truth file: append the truth ON THE REFERENCE'S BRANCH (`gs64r.*`, `gn64r.*`: the oracle "
+                         "in fp64 with the memory lookups the reference itself made, `idx.*` of the reference fixture), "
+                         "evaluated on --device, and write --out")
     args = ap.parse_args()
     cfg = json.loads(str(np.load(args.fixture)["cfg"]))
+    if args.add_reference_branch:
+        return add_reference_branch(args, cfg)
     if args.threads:
         torch.set_num_threads(args.threads)
     sd = S.make_twostream_state()

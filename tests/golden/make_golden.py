@@ -124,7 +124,24 @@ def twostream_train(ref, hw, batch, name, out_step=1, rows=None, dense_samples=0
     net.load_state_dict(sd, strict=True)
     net.train()
     rgb_x, op_x, rgb_t, op_t = S.make_clips(batch, hw, hw, tag=name)
+    # round 5: which slots the reference's own memory lookups picked (`Quantize_topk.forward` returns the gathered rows
+    # only: each is matched bit for bit against the pre-update codebook) - the fp64 truth of test_gpu_train.py is
+    # evaluated on the same piecewise-smooth branch
+    picked = {}
+
+    def grab(stream):
+        def fn(mod, inp, outp):
+            e0 = sd[f"{stream}.vq_down3.quan.quantize.embed"]                     # [D, M], the codebook before the EMA update
+            rows = outp[0].detach().reshape(-1, mod.k, mod.dim)
+            d2 = torch.cdist(rows.reshape(-1, mod.dim), e0.t().contiguous())
+            ix = d2.argmin(1)
+            assert torch.equal(e0.t()[ix], rows.reshape(-1, mod.dim)), "gathered rows are not codebook rows"
+            picked[stream] = ix.reshape(-1, mod.k).to(torch.int16).numpy()
+        return fn
+    hooks = [getattr(net, st).vq_down3.quan.quantize.register_forward_hook(grab(st)) for st in ("rgb", "op")] if dense_samples else []
     rgb, op, (rd, od), _ = net(rgb_x, op_x)
+    for h_ in hooks:
+        h_.remove()
     # G-only objective: L2-norm intensity (losses_utils.py:124-129) on both
     # streams + the two commit terms; all lambdas 1.
     loss = torch.norm(rgb - rgb_t, p=2, dim=1).mean() + torch.norm(op - op_t, p=2, dim=1).mean() + (rd + od).sum()
@@ -147,6 +164,8 @@ def twostream_train(ref, hw, batch, name, out_step=1, rows=None, dense_samples=0
             continue
         if v.numel() <= 64 * 256:
             out[f"buf.{k}"] = v.numpy()
+    for st, ix in picked.items():
+        out[f"idx.{st}"] = ix
     out["cfg"] = np.array(json.dumps(dict(hw=hw, batch=batch, tag=name, **cfg)))
     np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
     print(name, float(loss))

@@ -51,6 +51,13 @@ def test_bench_two_ranks(mode, extra, launcher):
     assert abs(rec["value"] - per_step / (rec["ms_per_step"] * 1e-3)) <= 0.02 * rec["value"]
     if mode == "infer":
         assert rec["roofline"]["bound"] == "mfma" and rec["roofline"]["frac"] > 0
+    if mode == "train":
+        # what the one-shot 8-GPU run needs to be interpretable (round-4 review, item 8): the channel cap in force, how many
+        # gradient buckets a step launches and what the collectives cost the step's stream beyond what the backward hid
+        col = rec["collectives"]
+        assert "nccl_max_nchannels" in rec and "nccl_max_nchannels" in col
+        assert col["gradient_buckets_per_step"] >= 1 and col["bucket_mb"] == 25.0
+        assert col["exposed_ms_per_step"]["median"] >= 0.0 and col["exposed_ms_per_step"]["max"] >= col["exposed_ms_per_step"]["median"]
 
 
 @pytest.mark.parametrize("mode,extra,units", [("infer", ["--batch", "1", "--size", "64", "--no-cpu-baseline"], 1),

@@ -13,6 +13,7 @@ Two kinds of gradient gates (L2-relative per tensor):
 Outputs 1e-4 of max|ref|; buffers 1e-4."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -620,12 +621,7 @@ def test_twostream_train_step_256_batch32_vs_reference_vectors():
                                                    the flow stream (a near-tie inside fp32 noise; the exact-fp32 kernels none),
                                                    which moves that stream's cluster_size / embed_avg / embed by 1-2e-4:
                                                    the codebook buffers are held to 1e-3 and the count is asserted
-      gradient norms per tensor                    4e-3        measured 2.0e-3 (S16) and 1.1e-3 (exact fp32) against the
-                                                   reference, 2.5e-3 between the two GPU precisions
-      64 samples per gradient tensor, L2           6e-2 max / 8e-3 median = 1.5x the measured 3.6e-2 / 5.0e-3 (exact fp32:
-                                                   3.0e-2 / 3.8e-3; S16 vs exact fp32: 3.8e-2 / 5.7e-3): single entries of a
-                                                   batch-32 gradient are sums of 16x more terms than at batch 2 and the
-                                                   ReLU / pool re-routings inside fp32 noise weigh more in them."""
+      gradients                                    against the fp64 truth, next test."""
     d = np.load(os.path.join(GOLDEN, "twostream_256_b32_train.npz"))
     cfg = json.loads(str(d["cfg"]))
     assert (cfg["hw"], cfg["batch"], cfg["n_embed"]) == (256, 32, 256)
@@ -641,15 +637,10 @@ def test_twostream_train_step_256_batch32_vs_reference_vectors():
     assert rel_err(out[0].detach().cpu()[rows][..., ::st, ::st], d["rgb"]) <= 1e-4
     assert rel_err(out[1].detach().cpu()[rows][..., ::st, ::st], d["op"]) <= 1e-4
     assert rel_err(out[2][0].detach().cpu(), d["rgb_diff"]) <= 1e-4 and rel_err(out[2][1].detach().cpu(), d["op_diff"]) <= 1e-4
-    errs = []
+    # (gradients: `test_batch32_gradients_against_the_fp64_truth` below - two fp32-accurate evaluations cannot gate each
+    # other entry by entry, their distance is set by which way one or two near-tie memory lookups fall)
     for name, p in net.named_parameters():
-        assert p.grad is not None, name
-        g = p.grad.detach().cpu()
-        gn = float(d[f"gn.{name}"])
-        assert abs(float(g.double().norm()) - gn) <= 4e-3 * gn + 1e-10, name
-        smp = g.flatten()[:: max(1, g.numel() // 64)][:64].double()
-        errs.append(_l2rel(smp, torch.as_tensor(d[f"gs.{name}"]).double()))
-    assert max(errs) <= 6e-2 and float(np.median(errs)) <= 8e-3, (max(errs), float(np.median(errs)))
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name
     nsd = net.state_dict()
     for key in d.files:
         if not key.startswith("buf."):
@@ -662,3 +653,84 @@ def test_twostream_train_step_256_batch32_vs_reference_vectors():
                 assert moved <= 3.01, (key, moved)
         else:
             assert rel_err(got, want) <= 1e-4, key
+
+
+def _dense(g: torch.Tensor, n: int = 4096) -> torch.Tensor:
+    """the sample positions of `gs4k.*` / `gs64*.*` (tests/golden/make_golden.py, make_fp64_truth.py)"""
+    return g.flatten()[:: max(1, g.numel() // n)][:n].contiguous()
+
+
+def test_batch32_gradients_against_the_fp64_truth():
+    """Round-4 review, weak #1: the gradient gates of the TIMED training batch (32 clips at 256x256) were set from the
+    distances between fp32-accurate evaluations; nobody had shown that the HIP gradients are no farther from the TRUTH
+    than the reference's own fp32 gradients are.  The truth: the oracle in FLOAT64 (tests/golden/make_fp64_truth.py -
+    on the GPU box's host cores, 149 s, committed as twostream_256_b32_train_fp64.npz; here re-evaluated on the device,
+    6 s, which agrees with the host file to 6e-12).
+
+    What the comparison has to respect (tools/flip_count.py, tools/grad_truth.py): the step is piecewise
+    smooth, and its one violent discontinuity is the memory lookup.  ONE of the 2 x 32768 top-2 lookups falling the
+    other way - two slots whose fp64 distances differ by less than fp32 resolution - moves the bottleneck by 5e-3 and
+    every gradient downstream of it by ~1e-2, for ANY fp32 evaluation: the reference's own gradients are 3.6e-3 (median)
+    / 3e-2 (max) from the unconstrained fp64 evaluation, the HIP ones 5e-3 / 3.5e-2, the exact-fp32 HIP ones 3.5e-3 /
+    2.6e-2, depending only on whose near-ties happened to fall like fp64's.  So every evaluation is compared with the
+    truth ON ITS OWN BRANCH: the oracle in fp64 taking the lookups that evaluation made (`force_idx`, test
+    instrumentation of oracle.quantize_topk; the reference's lookups are in its fixture).  What is left is arithmetic
+    plus the ReLU masks / pool routes that flip inside fp32 noise (10-30 per 1e8 activations and layer for all three).
+
+    Asserted:
+      * the lookups: at most 3 of a stream's 32768 differ from the unconstrained fp64 evaluation's (measured: 1 and 1; the
+        reference: 0 and 1; the exact-fp32 kernels: 1 and 0);
+      * SURVEY 8(d)'s gate itself - gradient norm of every tensor within 1e-3 of the truth (measured 5.3e-4 max, the
+        reference 4.0e-4);
+      * entry by entry (L2 over the whole tensor): e_hip <= max(1e-3, 2 e_ref) for every tensor and the median over the
+        tensors of e_hip / e_ref <= 1.5, e_ref = the reference's recorded 4096 entries per tensor against the truth on
+        the reference's branch.  Measured: median ratio 1.29, max 1.82 (a 64-entry BatchNorm weight; the ratio of two
+        errors that are each a handful of flipped masks has that spread).  The split-fp16 operands carry 22 bits where
+        fp32 storage carries 24: its forward noise per layer is 1.1-1.25x oneDNN's (tools/flip_count.py), its flips
+        accordingly."""
+    d = np.load(os.path.join(GOLDEN, "twostream_256_b32_train.npz"))
+    t64 = np.load(os.path.join(GOLDEN, "twostream_256_b32_train_fp64.npz"))
+    cfg = json.loads(str(d["cfg"]))
+    sys.path.insert(0, GOLDEN)
+    from make_fp64_truth import oracle_step
+    sd = S.make_twostream_state()
+    clips = S.make_clips(cfg["batch"], cfg["hw"], cfg["hw"], tag=cfg["tag"])
+    net = A.get_twostream((12, 6), (3, 2), 64, cfg["n_embed"], cfg["k"])
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    rgb_x, op_x, rgb_t, op_t = (t.to(DEV) for t in clips)
+    out = net(rgb_x, op_x)
+    loss = O.generator_loss(out, rgb_t, op_t)
+    loss.backward()
+    torch.cuda.synchronize()
+    st = net._train_engine._last
+    idx_hip = {p: st["streams"][si].idx.reshape(-1, 2).long().clone() for si, p in enumerate(("rgb", "op"))}
+    g_hip = {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+    loss_hip = float(loss.detach())
+    del net, out, loss
+    torch.cuda.empty_cache()
+    # the unconstrained truth (host file) and the device re-evaluation of it: the same numbers
+    loss64, g64, idx64 = oracle_step(sd, clips, torch.float64, DEV, want_idx=True)
+    assert abs(loss64 - float(t64["loss64"])) <= 1e-12 * loss64
+    assert max(_l2rel(_dense(g64[n]).cpu(), torch.as_tensor(t64[f"gs64.{n}"])) for n in g64) <= 1e-9
+    assert abs(loss_hip - loss64) <= 1e-6 * loss64
+    # which way the near-ties fell
+    for p in ("rgb", "op"):
+        rows = (idx_hip[p] != idx64[p]).any(dim=1).nonzero().flatten()
+        assert rows.numel() <= 3, (p, rows.numel())
+    del g64
+    torch.cuda.empty_cache()
+    # the truth on the branch the HIP evaluation took
+    _, g64c = oracle_step(sd, clips, torch.float64, DEV, force_idx=idx_hip)
+    rows, bad = [], []
+    for n, g in g_hip.items():
+        e_hip = _l2rel(g, g64c[n])
+        n64 = float(g64c[n].norm())
+        norm_hip = abs(float(g.double().norm()) - n64) / n64
+        e_ref = _l2rel(torch.as_tensor(d[f"gs4k.{n}"]), torch.as_tensor(t64[f"gs64r.{n}"]))
+        rows.append((e_hip / max(e_ref, 1e-30), e_hip, e_ref, norm_hip, n))
+        if norm_hip > 1e-3 or e_hip > max(1e-3, 2.0 * e_ref):
+            bad.append(rows[-1])
+    assert not bad, bad
+    big = sorted(r[0] for r in rows if r[2] > 5e-4)               # (ratios of errors that are both above the 1e-3 / 2 floor)
+    assert big[len(big) // 2] <= 1.5, big[len(big) // 2]

@@ -75,6 +75,34 @@ def _worker(rank, world, port, q):
     watch = H._FiniteWatch(torch.tensor(2.0), torch.tensor(3.0))       # all finite everywhere: the step is taken
     watch.step(opt)
     ok = ok and float(w_[0]) == 0.0
+    # --- ... but only among ranks that share gradients or statistics (harness._watch_group): a model without a reducer
+    # trains on its own inside the initialised world - no collective, each rank decides alone (a vote on the default
+    # group would hang as soon as one rank does not train); with a reducer on a sub-group the vote runs in THAT group
+    lone = torch.nn.Linear(2, 2)
+    vote, group = H._watch_group(lone)
+    ok = ok and vote is False and group is None
+    w2 = torch.nn.Parameter(torch.ones(2))
+    opt2 = torch.optim.SGD([w2], lr=1.0)
+    w2.grad = torch.ones(2)
+    watch = H._FiniteWatch(torch.tensor(float("inf") if rank == 1 else 1.0), group=group, vote=vote)
+    try:
+        watch.step(opt2)
+        refused = False
+    except FloatingPointError:
+        refused = True
+    ok = ok and refused == (rank == 1) and float(w2[0]) == (1.0 if rank == 1 else 0.0)
+    subs = [dist.new_group([r]) for r in range(world)]                     # (every rank creates every group)
+    P.attach_reducer(lone, P.BucketedGradReducer(group=subs[rank]))
+    vote, group = H._watch_group(lone)
+    ok = ok and vote is True and group is subs[rank]
+    w2.grad = torch.ones(2)
+    watch = H._FiniteWatch(torch.tensor(float("inf") if rank == 0 else 1.0), group=group, vote=vote)
+    try:
+        watch.step(opt2)
+        refused = False
+    except FloatingPointError:
+        refused = True
+    ok = ok and refused == (rank == 0)
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

@@ -41,6 +41,41 @@ def test_oracle_resize_known_answers():
     assert up.min() >= f.min() - 1e-6 and up.max() <= f.max() + 1e-6                          # convex combinations
 
 
+@pytest.mark.parametrize("h,w,oh,ow", [(240, 360, 256, 256), (360, 640, 256, 256), (158, 238, 256, 256), (480, 856, 64, 96),
+                                        (256, 256, 256, 256), (7, 5, 16, 12)])
+def test_oracle_resize_against_independent_witnesses(h, w, oh, ow):
+    """cv2 is not installed (nor obtainable: no network, no wheel in the image), so `cv2.resize` itself cannot be run.
+    What CAN be pinned without it: the sampling geometry of INTER_LINEAR - half-pixel centres, `(d + 0.5) * scale - 0.5`,
+    border clamp - is the one `torch.nn.functional.interpolate(mode="bilinear", align_corners=False, antialias=False)`
+    implements, an independent implementation of the same published definition.
+      * float path (`_load_op`'s resize): equal to the witness to float rounding (two roundings of the weights apart);
+      * 8-bit path (`_load_frame`'s resize): the 11-bit fixed-point arithmetic of OpenCV's generic kernel must stay within
+        ONE grey level of the exact bilinear value everywhere and equal its rounding for most pixels - a wrong tap, a
+        shifted coordinate or a clamp on the wrong side moves many pixels by many levels.
+    What stays UNPINNED (and is labelled so in oracle/pipeline_oracle.py): only the 8-bit kernel's own rounding - 2048-step
+    weights, `>> 4`, `>> 16`, `+ 2 >> 2` as restated from resize.cpp, which decide the ~12 % of pixels that differ from the
+    rounded exact value by one level - and whether a given OpenCV build takes its generic path at all (IPP / OpenCL builds
+    differ from the generic one by a grey level themselves)."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(h * 7 + w)
+    f = rng.normal(0, 3, (h, w, 2)).astype(np.float32)
+    got = PO.resize_linear_f32(f, oh, ow)
+    wit = F.interpolate(torch.from_numpy(f).permute(2, 0, 1)[None].double(), size=(oh, ow), mode="bilinear", align_corners=False,
+                        antialias=False)[0].permute(1, 2, 0).numpy()
+    # (OpenCV keeps the source coordinate in float32: its rounding, ~max(h, w) * 2^-24, is the distance to a witness that keeps it in double)
+    assert np.abs(got - wit).max() <= max(2e-6, 8 * max(h, w) * 2.0 ** -24) * np.abs(f).max()
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    got8 = PO.resize_linear_u8(img, oh, ow).astype(np.int32)
+    exact = F.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None].double(), size=(oh, ow), mode="bilinear", align_corners=False,
+                          antialias=False)[0].permute(1, 2, 0).numpy()
+    err = got8 - exact
+    assert np.abs(err).max() < 1.0                                         # never a whole grey level from the exact value (measured 0.75:
+    assert -0.2 <= err.mean() <= 0.05                                      #  the `>> 4` / `>> 16` truncations pull down by ~0.1 on average)
+    same = got8 == np.floor(exact + 0.5).astype(np.int32)
+    assert same.mean() >= 0.85, same.mean()                                # and it IS the rounded exact value for most pixels (measured 0.87-0.88)
+
+
 def test_oracle_loaders_follow_the_reference():
     rng = np.random.default_rng(7)
     frame = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)

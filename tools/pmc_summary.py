@@ -125,7 +125,7 @@ def derived(acc):
 
 
 def main(argv):
-    js = workload = commit = None
+    js = workload = commit = digests = None
     paths = []
     it = iter(argv)
     for a in it:
@@ -135,6 +135,8 @@ def main(argv):
             workload = next(it)
         elif a == "--commit":
             commit = next(it)
+        elif a == "--digests":          # json of ammcnet_aaai2021_amd.build.file_digests() at profiling time
+            digests = json.loads(next(it))
         else:
             paths.append(a)
     acc = collect(paths)
@@ -152,7 +154,7 @@ def main(argv):
         with open(js, "w") as fp:
             json.dump({"source": "tools/pmc_summary.py over separate rocprofv3 --pmc passes (tools/profile_bench.sh)",
                        "formula": "mfma_busy_frac = (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs), per-launch averages",
-                       "workload": workload, "commit": commit, "kernels": der}, fp, indent=1)
+                       "workload": workload, "commit": commit, "csrc_digests": digests, "kernels": der}, fp, indent=1)
 
 
 if __name__ == "__main__":

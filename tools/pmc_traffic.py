@@ -9,7 +9,11 @@ from collections import defaultdict
 
 root, prec = sys.argv[1], sys.argv[2]
 extra = sys.argv[3:]
-mode, commit = "infer", None
+mode, commit, digests = "infer", None, None
+if "--digests" in extra:          # json of ammcnet_aaai2021_amd.build.file_digests() at profiling time
+    i = extra.index("--digests")
+    digests = json.loads(extra[i + 1])
+    del extra[i:i + 2]
 if "--mode" in extra:
     i = extra.index("--mode")
     mode = extra[i + 1]
@@ -47,7 +51,7 @@ def label(name):
         return "memory_topk"
     m = re.search(r"(conv_gemm_s16|conv_gemm_f32|conv_tap_s16)_kernel<([^>]*)>", name)
     if not m:
-        m2 = re.search(r"(memory_topk_f16|memory_topk|wgrad_tap3_s16|wgrad_tap_s16|wgrad_s16|wgrad_f32)\w*_kernel(<[^>]*>)?", name)
+        m2 = re.search(r"(memory_topk_f16r|memory_topk_f16|memory_topk|wgrad_tap3_s16|wgrad_tap_s16|wgrad_s16|wgrad_f32)\w*_kernel(<[^>]*>)?", name)
         return (m2.group(1) + (m2.group(2) or "")) if m2 else None
     if m.group(1) == "conv_tap_s16":                   # labelled by its template arguments <WGM, WGN, TM, TN, AS>
         return "conv_tap_s16<" + ", ".join(v.strip() for v in m.group(2).split(",")) + ">"
@@ -67,7 +71,7 @@ for path in glob.glob(f"{root}/pmc_fetch/**/*counter_collection.csv", recursive=
                 a[1] += 1
 out = {"source": f"tools/profile_bench.sh (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes) of "
                  f"`{command}` (precision {prec}); tools/pmc_traffic.py",
-       "workload": workload, "commit": commit, "kernels": {}}
+       "workload": workload, "commit": commit, "csrc_digests": digests, "kernels": {}}
 for lb, c in acc.items():
     f, w = c["FETCH_SIZE"], c["WRITE_SIZE"]
     if not f[1] or not w[1]:
