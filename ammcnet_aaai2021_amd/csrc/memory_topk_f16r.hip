@@ -30,6 +30,7 @@
 #include <math.h>
 #include <algorithm>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace ammc_f16r {
 
@@ -67,6 +68,17 @@ __device__ __forceinline__ void r_dma16_ptr(const void* src, unsigned lds_byte) 
                : "=&s"(keep) : "v"(src), "s"(lds_byte) : "memory");
 }
 #define R_VMCNT(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory")
+
+// f(integral_constant<int, I>) for I = I0 .. N - 1, every call inlined: a k-loop whose step number is a constant
+// expression (register arrays indexed by it stay in registers whatever the body holds; `#pragma unroll` gives up - and
+// parks the fragment registers in scratch - once the body, with the top-K update inlined at two of its steps, is large)
+template <int I, int N, class F>
+__device__ __forceinline__ void r_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    r_static_for<I + 1, N>(f);
+  }
+}
 
 // candidates arrive in increasing slot order within a lane: a tie loses to the entry already held (strict comparison =
 // the (value, index) order).  Keys are MAXIMISED (x.E - |E|^2 / 2).
@@ -118,12 +130,74 @@ __device__ __forceinline__ void r_insert(float (&v)[K], int (&ix)[K], float c, i
   }
 }
 
+// running top-K of one row tile from one accumulator tile: register r of a lane is slot s0 + (r & 3) + 8 (r >> 2) + 4 h
+// (ascending in r).  Two-level screen: the maximum of each group of four registers, then of the tile - 10 VALU operations
+// and ONE branch that the whole wave takes when no candidate of the tile beats the K-th best of its row; else one branch
+// per group and, only inside a group that holds a candidate, one per register (a sweep inserts ~2 candidates per tile
+// and row tile: the flat form - sixteen compare / exec-mask / branch sequences whenever the tile held one - cost 19 %)
+template <int K, int DBG>
+__device__ __forceinline__ void r_update(const f32x16& acc, float (&bv)[K], int (&bi)[K], int s0, int h, int m) {
+  float gm[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    gm[q] = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(acc[4 * q], acc[4 * q + 1]), acc[4 * q + 2]), acc[4 * q + 3]);
+  const float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(gm[0], gm[1]), gm[2]), gm[3]);
+  if (DBG & 1) {
+    bv[0] = __builtin_fmaxf(bv[0], mx);
+    bi[0] = s0 & (m - 1);
+    if (K > 1) bi[K > 1 ? 1 : 0] = (s0 + 1) & (m - 1);
+  } else if (mx > bv[K - 1]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (gm[q] > bv[K - 1]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * q + i;
+          if constexpr (K == 2) r_insert_ordered2(bv, bi, acc[r], s0 + i + 8 * q + 4 * h);
+          else r_insert_ordered<K>(bv, bi, acc[r], s0 + i + 8 * q + 4 * h);
+        }
+      }
+    }
+  }
+}
+
+// ---- branch-free running top-2 on PACKED keys (the pipelined form, K = 2) ----------------------------------------------
+// A candidate's key x.E - |E|^2 / 2 carries its own accumulator register in its four lowest mantissa bits (15 - r, so
+// that of two keys equal in the upper 28 bits the lower slot is the larger float for positive keys), and the running
+// (best, second) of a row is updated by TWO operations per candidate, no compare, no branch:
+//     second = med3(key, best, second);  best = max(key, best)
+// - 3 VALU operations per candidate with the packing, 16 candidates per tile and row tile, spread one candidate per
+// k-step behind the NEXT tile's MFMAs (the compare-and-branch form, even hidden behind a second accumulator set, cost 15 %
+// of the sweep: ~100 scalar / vector instructions per tile that the in-order wave issues instead of MFMAs).  The slot
+// tile of the two survivors is tracked once per tile (6 operations).  What changes against the exact compare: candidates closer than 2^-19 of their
+// magnitude - far inside the noise of the fp32 accumulation order, let alone of the fp16 operands - rank by register.
+__device__ __forceinline__ float r_pack_key(float v, int r) {
+  return __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, v) & 0xFFFFFFF0u) | (unsigned)(15 - r));
+}
+__device__ __forceinline__ void r_top2_step(float key, float& b0, float& b1) {
+  // (asm: from __builtin_fmaxf / fmed3f hipcc first canonicalises the bit-built key - v_max_f32 k, k, k - a quarter more
+  // VALU work.  No key is a NaN: slots beyond m carry the finite -3e38, see pack_codebook_f16_tiles_kernel)
+  float n1, n0;
+  asm("v_med3_f32 %0, %1, %2, %3" : "=v"(n1) : "v"(key), "v"(b0), "v"(b1));
+  asm("v_max_f32 %0, %1, %2" : "=v"(n0) : "v"(key), "v"(b0));
+  b1 = n1;
+  b0 = n0;
+}
+// after the 16 candidates of slot tile `tile`: which tile do the two survivors come from?  (o0, o1: the pair before)
+__device__ __forceinline__ void r_top2_track(float b0, float b1, float o0, float o1, int& t0, int& t1, int tile) {
+  const bool ch0 = b0 != o0;                        // a strictly better candidate arrived
+  const float from = ch0 ? o0 : o1;                 // where an unchanged-looking second would have come from
+  const int tfrom = ch0 ? t0 : t1;
+  t1 = (b1 == from) ? tfrom : tile;
+  t0 = ch0 ? tile : t0;
+}
+
 // One sweep of the codebook for CNT row tiles of this wave (rows [row0 + 32 i, +32), i < CNT; rows >= n are clamped for
 // the loads and never written).  Everything of the sweep: feature staging, contraction + running top-K, the merge of
 // the lane halves, indices, gather / q_one / commit partials.
 // DBG (measurement builds of the K = 2, d = 512 instance only, AMMC_F16R_DBG): 1 = no top-K update, 2 = no codebook DMA
 // inside the sweep (the MFMAs read stale LDS), 4 = no gather / commit tail, 8 = no feature staging; results are then wrong
-template <int K, int NSTEP, int CNT, bool Q1, int DBG = 0>
+template <int K, int NSTEP, int CNT, bool Q1, int DBG = 0, bool PIPE = false>
 __device__ __forceinline__ void r_sweep(const F16rArgs& a, unsigned char* smem, unsigned lds0, int lane, int uwave, int tile0) {
   constexpr int TB = (NSTEP + 1) * 1024;           // bytes of a codebook tile image
   constexpr int D = NSTEP * 16;
@@ -245,6 +319,116 @@ __device__ __forceinline__ void r_sweep(const F16rArgs& a, unsigned char* smem, 
 #pragma unroll
   for (int p = 0; p < NBUF - 1; ++p) issue_tile(p);
 
+  if constexpr (PIPE) {
+    // ---- the pipelined form (CNT <= 2: all row fragments in AGPRs, ~130 VGPRs free) ---------------------------------------
+    // TWO accumulator sets: the MFMAs of tile i write one while the top-K update of tile i - 1 reads the other, its VALU
+    // instructions issued in the shadow of the MFMAs (a quarter of it per k-step) - with one set the matrix pipe drained
+    // at every tile end (last MFMA's latency, the update, the barrier, the constants' LDS round trip: ~15 % of the sweep).
+    // The tile loop is unrolled by two so that the set of a tile is a literal.
+    static_assert(CNT <= 2, "the pipelined form keeps every row fragment in AGPRs");
+    f32x16 acc[2][CNT];
+#pragma unroll
+    for (int rt = 0; rt < CNT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[1][rt][r] = -3.0e38f;                   // ("tile -1": nothing beats anything)
+    constexpr bool PACKED = K == 2 && NSTEP >= 18;                               // (see r_top2_step; else r_update)
+    float pb0[CNT], pb1[CNT], ob0[CNT], ob1[CNT];                                // packed keys: best, second; the pair a tile ago
+    int pt0[CNT], pt1[CNT];                                                      // the slot tiles they come from
+#pragma unroll
+    for (int rt = 0; rt < CNT; ++rt) { pb0[rt] = pb1[rt] = ob0[rt] = ob1[rt] = -INFINITY; pt0[rt] = pt1[rt] = -1; }
+#define R_BODY(tile_, B_)                                                                                              \
+  {                                                                                                                     \
+    if (!(DBG & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPT) : "memory");                                      \
+    __builtin_amdgcn_s_barrier();                                                                                       \
+    asm volatile("" ::: "memory");                                                                                      \
+    const int nt_ = (tile_) + NBUF - 1;                                                                                 \
+    const int ntl_ = nt_ < a.ntile ? nt_ : a.ntile - 1;                                                                 \
+    const unsigned char* nsrc = a.tiles + (int64_t)ntl_ * TB;                                                           \
+    const unsigned ndst = lds0 + (unsigned)(nt_ & (NBUF - 1)) * (unsigned)TB;                                           \
+    const unsigned char* tb = smem + (unsigned)((tile_) & (NBUF - 1)) * (unsigned)TB;                                   \
+    const unsigned char* ap = tb + lane * 16;                                                                           \
+    /* the accumulators START at -|E_s|^2 / 2: read straight into them (set B_ was last read a tile ago) */             \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                     \
+      const f32x4 c4 = *reinterpret_cast<const f32x4*>(tb + NSTEP * 1024 + (8 * q + 4 * h) * 4);                       \
+      _Pragma("unroll") for (int rt = 0; rt < CNT; ++rt)                                                                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[B_][rt][4 * q + i] = c4[i];                                   \
+    }                                                                                                                   \
+    f16x8 ar[NA];                                                                                                       \
+    _Pragma("unroll") for (int t = 0; t < NA - 1; ++t) ar[t] = *reinterpret_cast<const f16x8*>(ap + t * 1024);          \
+    const int sp_ = ((tile_) - 1) << 5;                                                                                 \
+    r_static_for<0, NSTEP>([&](auto T_) __attribute__((always_inline)) {                                                \
+      constexpr int t = decltype(T_)::value;                                                                            \
+      if constexpr (t + NA - 1 < NSTEP) ar[(t + NA - 1) % NA] = *reinterpret_cast<const f16x8*>(ap + (t + NA - 1) * 1024); \
+      __builtin_amdgcn_sched_barrier(0);                                                                                \
+      _Pragma("unroll") for (int rt = 0; rt < CNT; ++rt) {                                                              \
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[B_][rt]) : "v"(ar[t % NA]), "a"(xa[rt][t]));   \
+        if (!(DBG & 2) && rt == 0 && t % 3 == 1 && t / 3 < DPT) {                                                       \
+          constexpr int j = t / 3;                                                                                      \
+          if (j < NSTEP / 4) r_dma16(nsrc + j * 4096, lane_off, ndst + (unsigned)(j * 4096) + (unsigned)uwave * 1024u); \
+          else r_dma16(nsrc + NSTEP * 1024, (unsigned)lane * 16u, ndst + (unsigned)(NSTEP * 1024));                     \
+        }                                                                                                               \
+      }                                                                                                                 \
+      /* the previous tile's update behind this step's MFMAs: K = 2 - one candidate per k-step (packed keys, no      \
+         branch); other K - the compare-and-branch form, one row tile per chosen k-step */                             \
+      if constexpr (K == 2 && NSTEP >= 18) {                                                                            \
+        if constexpr (t < 16 && !(DBG & 1)) {                                                                           \
+          _Pragma("unroll") for (int rt = 0; rt < CNT; ++rt) {                                                          \
+            if (t == 0) { ob0[rt] = pb0[rt]; ob1[rt] = pb1[rt]; }                                                       \
+            r_top2_step(r_pack_key(acc[(B_) ^ 1][rt][t < 16 ? t : 0], t), pb0[rt], pb1[rt]);                            \
+          }                                                                                                             \
+        }                                                                                                               \
+        if constexpr (t == 16 && !(DBG & 1)) {                                                                          \
+          _Pragma("unroll") for (int rt = 0; rt < CNT; ++rt)                                                            \
+            r_top2_track(pb0[rt], pb1[rt], ob0[rt], ob1[rt], pt0[rt], pt1[rt], (tile_) - 1);                            \
+        }                                                                                                               \
+      } else {                                                                                                          \
+        if constexpr (t == NSTEP / 4) r_update<K, DBG>(acc[(B_) ^ 1][0], bv[0], bi[0], sp_, h, a.m);                    \
+        if constexpr (CNT == 2 && t == (3 * NSTEP) / 4)                                                                 \
+          r_update<K, DBG>(acc[(B_) ^ 1][CNT - 1], bv[CNT - 1], bi[CNT - 1], sp_, h, a.m);                              \
+      }                                                                                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                                                \
+    });                                                                                                                 \
+  }
+    for (int tile = 0; tile < a.ntile; tile += 2) {
+      R_BODY(tile, 0)
+      if (tile + 1 < a.ntile) R_BODY(tile + 1, 1)
+      else {                                                                   // (odd tile count: the set 1 of "tile + 1" stays unwritten)
+#pragma unroll
+        for (int rt = 0; rt < CNT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[1][rt][r] = -3.0e38f;
+      }
+    }
+#undef R_BODY
+    // the last tile's update (nothing left to hide it behind): wait out its MFMAs first
+    {
+      const bool odd = a.ntile & 1;
+      if constexpr (CNT == 2) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+      else asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[1][0]));
+      const int sl = (a.ntile - 1) << 5;
+#pragma unroll
+      for (int rt = 0; rt < CNT; ++rt) {
+        if constexpr (PACKED) {
+          if (!(DBG & 1)) {
+            const float o0 = pb0[rt], o1 = pb1[rt];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) r_top2_step(r_pack_key(odd ? acc[0][rt][r] : acc[1][rt][r], r), pb0[rt], pb1[rt]);
+            r_top2_track(pb0[rt], pb1[rt], o0, o1, pt0[rt], pt1[rt], a.ntile - 1);
+          }
+          // the survivors as (key, slot): register 15 - (key & 15) of tile pt, slot = 32 pt + (r & 3) + 8 (r >> 2) + 4 h
+          const int r0_ = 15 - (int)(__builtin_bit_cast(unsigned, pb0[rt]) & 15u), r1_ = 15 - (int)(__builtin_bit_cast(unsigned, pb1[rt]) & 15u);
+          bv[rt][0] = pb0[rt];
+          bv[rt][K > 1 ? 1 : 0] = pb1[rt];
+          bi[rt][0] = pt0[rt] < 0 ? 0x7fffffff : (pt0[rt] << 5) + (r0_ & 3) + 8 * (r0_ >> 2) + 4 * h;
+          bi[rt][K > 1 ? 1 : 0] = pt1[rt] < 0 ? 0x7fffffff : (pt1[rt] << 5) + (r1_ & 3) + 8 * (r1_ >> 2) + 4 * h;
+          if (DBG & 1) { bi[rt][0] = 0; bi[rt][K > 1 ? 1 : 0] = 1; }
+        } else {
+          if (odd) r_update<K, DBG>(acc[0][rt], bv[rt], bi[rt], sl, h, a.m);
+          else r_update<K, DBG>(acc[1][rt], bv[rt], bi[rt], sl, h, a.m);
+        }
+      }
+    }
+  } else {
   for (int tile = 0; tile < a.ntile; ++tile) {
     // tile's own DMAs (issued three iterations ago) have landed for this wave once all but the two younger tiles' are
     // done; behind the barrier that holds for every wave, and everybody has finished reading tile - 1, whose slot the
@@ -306,36 +490,10 @@ __device__ __forceinline__ void r_sweep(const F16rArgs& a, unsigned char* smem, 
     if constexpr (CNT == 3) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[CNT - 1]));
     else if constexpr (CNT == 2) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[CNT - 1]));
     else asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]));
-    // running top-K: register r of a lane is slot s0 + (r & 3) + 8 (r >> 2) + 4 h (ascending in r).  Two-level screen:
-    // the maximum of each group of four registers, then of the tile - per row tile 10 VALU operations and ONE branch that
-    // the whole wave takes when no candidate of the tile beats the K-th best of its row; else one branch per group and,
-    // only inside a group that holds a candidate, one per register (a sweep inserts ~2 candidates per tile and row tile:
-    // the flat form - sixteen compare / exec-mask / branch sequences whenever the tile held one - cost 19 % of the kernel)
     const int s0 = tile << 5;
 #pragma unroll
-    for (int rt = 0; rt < CNT; ++rt) {
-      float gm[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        gm[q] = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(acc[rt][4 * q], acc[rt][4 * q + 1]), acc[rt][4 * q + 2]), acc[rt][4 * q + 3]);
-      const float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(gm[0], gm[1]), gm[2]), gm[3]);
-      if (DBG & 1) {
-        bv[rt][0] = __builtin_fmaxf(bv[rt][0], mx);
-        bi[rt][0] = s0 & (a.m - 1), bi[rt][1] = (s0 + 1) & (a.m - 1);
-      } else if (mx > bv[rt][K - 1]) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (gm[q] > bv[rt][K - 1]) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int r = 4 * q + i;
-              if constexpr (K == 2) r_insert_ordered2(bv[rt], bi[rt], acc[rt][r], s0 + i + 8 * q + 4 * h);
-              else r_insert_ordered<K>(bv[rt], bi[rt], acc[rt][r], s0 + i + 8 * q + 4 * h);
-            }
-          }
-        }
-      }
-    }
+    for (int rt = 0; rt < CNT; ++rt) r_update<K, DBG>(acc[rt], bv[rt], bi[rt], s0, h, a.m);
+  }
   }
   R_VMCNT(0);                                      // (the clamped DMAs past the end)
   asm volatile("" ::: "memory");
@@ -413,7 +571,7 @@ __device__ __forceinline__ void r_sweep(const F16rArgs& a, unsigned char* smem, 
   }
 }
 
-template <int K, int NSTEP, int RT, bool Q1, int DBG = 0>
+template <int K, int NSTEP, int RT, bool Q1, int DBG = 0, bool PIPE = false>
 __global__ __launch_bounds__(256, 1) void memory_topk_f16r_kernel(F16rArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -435,9 +593,14 @@ __global__ __launch_bounds__(256, 1) void memory_topk_f16r_kernel(F16rArgs a) {
     // a wave whose tiles lie past the end still takes part in the ring (DMA shares, barriers): its loads clamp to the last
     // row and it writes nothing
     if (t0 >= a.t32) t0 = a.t32;
-    if (RT >= 3 && cnt == 3) r_sweep<K, NSTEP, 3, Q1, DBG>(a, smem_r, lds0, lane, uwave, t0);
-    else if (RT >= 2 && cnt == 2) r_sweep<K, NSTEP, 2, Q1, DBG>(a, smem_r, lds0, lane, uwave, t0);
-    else r_sweep<K, NSTEP, 1, Q1, DBG>(a, smem_r, lds0, lane, uwave, t0);
+    if constexpr (RT >= 3) {
+      if (cnt == 3) r_sweep<K, NSTEP, 3, Q1, DBG, false>(a, smem_r, lds0, lane, uwave, t0);
+      else if (cnt == 2) r_sweep<K, NSTEP, 2, Q1, DBG, false>(a, smem_r, lds0, lane, uwave, t0);
+      else r_sweep<K, NSTEP, 1, Q1, DBG, false>(a, smem_r, lds0, lane, uwave, t0);
+    } else {
+      if (cnt == 2) r_sweep<K, NSTEP, 2, Q1, DBG, PIPE>(a, smem_r, lds0, lane, uwave, t0);
+      else r_sweep<K, NSTEP, 1, Q1, DBG, PIPE>(a, smem_r, lds0, lane, uwave, t0);
+    }
     p0 += cnt;
     cnt = a.pw - p0 < RT ? a.pw - p0 : RT;
   }
@@ -445,7 +608,7 @@ __global__ __launch_bounds__(256, 1) void memory_topk_f16r_kernel(F16rArgs a) {
 
 // [d][m] fp32 -> tile images: tile T (slots 32 T .. 32 T + 31) = NSTEP KB of A fragments - KB t holds, for lane
 // (l31, h), the 8 halfs of slot 32 T + l31, features 16 t + 8 h .. + 7 - and one KB of constants: float i < 32 =
-// -|half(E_{32 T + i})|^2 / 2 (-inf for slots >= m: they never win), the rest zero
+// -|half(E_{32 T + i})|^2 / 2 (-3e38 for slots >= m: they never beat a real slot), the rest zero
 __global__ __launch_bounds__(256) void pack_codebook_f16_tiles_kernel(const float* __restrict__ e_dm, int d, int m,
                                                                       unsigned char* __restrict__ out) {
   const int nstep = d >> 4;
@@ -468,7 +631,7 @@ __global__ __launch_bounds__(256) void pack_codebook_f16_tiles_kernel(const floa
         const float v = (float)(_Float16)e_dm[(int64_t)f * m + s];
         nrm += v * v;
       }
-    cn[tid] = s < m ? -0.5f * nrm : -INFINITY;
+    cn[tid] = s < m ? -0.5f * nrm : -3.0e38f;       // (finite: a packed key must never be a NaN; it never beats a real slot)
   } else {
     cn[tid] = 0.f;
   }
@@ -496,6 +659,23 @@ int launch_f16r(const F16rArgs& a0, hipStream_t stream) {
     else if (dbg == 5) kern = memory_topk_f16r_kernel<K, NSTEP, RT, Q1, 5>;
     else if (dbg == 7) kern = memory_topk_f16r_kernel<K, NSTEP, RT, Q1, 7>;
     else if (dbg == 15) kern = memory_topk_f16r_kernel<K, NSTEP, RT, Q1, 15>;
+  }
+  if constexpr (K == 2 && NSTEP == 32) {
+    // AMMC_F16R_FORM: 2 (default for the model's K = 2 at d = 512) = two row tiles per wave, all fragments in AGPRs, two
+    // accumulator sets, the top-2 update of a tile branch-free on packed keys behind the next tile's MFMAs (2.15-2.2 ms
+    // per 262144 rows); 3 = three row tiles per wave, one accumulator set, compare-and-branch update (2.35-2.4 ms; what
+    // every other K / d runs)
+    static const int form = getenv("AMMC_F16R_FORM") ? atoi(getenv("AMMC_F16R_FORM")) : 2;
+    if (form == 2) {
+      kern = memory_topk_f16r_kernel<K, NSTEP, 2, Q1, 0, true>;
+      if constexpr (Q1) {
+        static const int dbg2 = getenv("AMMC_F16R_DBG") ? atoi(getenv("AMMC_F16R_DBG")) : 0;
+        if (dbg2 == 1) kern = memory_topk_f16r_kernel<K, NSTEP, 2, Q1, 1, true>;
+        else if (dbg2 == 4) kern = memory_topk_f16r_kernel<K, NSTEP, 2, Q1, 4, true>;
+        else if (dbg2 == 5) kern = memory_topk_f16r_kernel<K, NSTEP, 2, Q1, 5, true>;
+        else if (dbg2 == 15) kern = memory_topk_f16r_kernel<K, NSTEP, 2, Q1, 15, true>;
+      }
+    }
   }
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;

@@ -866,7 +866,8 @@ def run_stress(args, rank, world, dev, dist, steps, warmup, with_cpu):
         "value": round(rows * steps / elapsed, 1), "unit": "rows/s", "n_gpus": world, "steps": steps, "warmup": max(warmup, 1),
         "ms_per_step": round(1e3 * elapsed / steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16 operands, f32 accumulate (v_mfma_f32_32x32x16_f16); gather / commit from the f32 codebook",
-        "kernel": ms.kernel + (": feature rows resident in registers, codebook tiles L2 -> LDS once per 384 rows" if ms.rows_in_registers
+        "kernel": ms.kernel + (": feature rows resident in registers (2 x 32 rows x 512-d per wave, in AGPRs), codebook tiles L2 -> LDS "
+                               "once per 256 rows, branch-free packed-key top-2 behind the next tile's MFMAs" if ms.rows_in_registers
                                else ": feature rows in LDS, codebook L2 -> registers once per 128 rows"),
         "data": "synthetic",
         "config": {"workload": "Stress: 8192 memory slots x 512-d features, fp16 MFMA memory-addressing kernel "

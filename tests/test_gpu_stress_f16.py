@@ -54,7 +54,7 @@ def test_memory_topk_f16_clustered_features_return_the_planted_slots(n):
     wqk, wdiff, widx, _, flat, wq1 = O.quantize_topk(x.view(1, 1, n, d), embed, k)
     assert torch.equal(idx, widx.reshape(n, k))
     assert torch.equal(qk.cpu().reshape(n, k * d), wqk.reshape(n, k * d))
-    assert torch.equal(q1.cpu().reshape(n, d), wq1.reshape(n, d))
+    assert torch.equal(q1.cpu().reshape(n, d), flat + (wq1.reshape(n, d) - flat))           # unet.py:311: input + (quantize - input)
     assert rel_err(diff.cpu(), wdiff) <= 1e-5                      # (the commit term is fp32 arithmetic on the same rows)
     dist = flat.double().pow(2).sum(1, keepdim=True) - 2 * flat.double() @ embed.double() + embed.double().pow(2).sum(0, keepdim=True)
     srt = dist.sort(dim=1).values

@@ -32,7 +32,7 @@ ts.sort()
 print(json.dumps({"us": round(ts[len(ts) // 2], 1), "min": round(ts[0], 1), "tflops": round(ms.flops(n) / ts[len(ts) // 2] / 1e6, 1)}))
 '''
 frames = sys.argv[1] if len(sys.argv) > 1 else "256"
-for dbg in (0, 1, 2, 4, 8, 5, 7, 15, 0):
+for dbg in [int(v) for v in os.environ.get("STRESS_DBG_LIST", "0,1,2,4,5,7,15,0").split(",")]:
     env = dict(os.environ, AMMC_F16R_DBG=str(dbg))
     r = subprocess.run([sys.executable, "-c", CHILD, frames], env=env, capture_output=True, text=True)
     print(f"dbg {dbg:2d}:", (r.stdout.strip().splitlines() or [r.stderr[-300:]])[-1], flush=True)
