@@ -51,6 +51,7 @@ struct F16rArgs {
   int n, d, m, ntile;             // ntile = ceil(m / 32)
   int t32;                        // row tiles of 32 rows: ceil(n / 32)
   int pw;                         // row tiles per wave
+  int no_inline_tail;             // A/B (AMMC_F16R_TAIL_INLINE=0): the pipelined form writes every sweep's rows out serially
 };
 
 // LDS-DMA of 16 bytes per lane with the instruction hidden from the compiler (see conv_tap_s16.hip: hipcc books the
@@ -66,6 +67,11 @@ __device__ __forceinline__ void r_dma16_ptr(const void* src, unsigned lds_byte) 
   unsigned keep;
   asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(src), "s"(lds_byte) : "memory");
+}
+// 16 bytes per lane to global memory, hidden from the compiler like the DMAs (its vmcnt bookkeeping must not see one kind
+// of vector-memory operation and miss the other); `base` wave-uniform
+__device__ __forceinline__ void r_store16(void* base, unsigned off, f32x4 v) {
+  asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base) : "memory");
 }
 #define R_VMCNT(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory")
 
@@ -192,13 +198,72 @@ __device__ __forceinline__ void r_top2_track(float b0, float b1, float o0, float
   t0 = ch0 ? tile : t0;
 }
 
+// what a sweep leaves for later: the lookups of its row tiles (lane r < 32 holds row r's slots), still to be written out
+template <int K>
+struct RCarry {
+  int bi[2][K];
+  int tile0, cnt, pending;
+};
+
+// gather (fp32 codebook rows), q_one, commit partial sum of ONE row tile, serially: UN (row, 256-float chunk) units per trip
+template <int K, int D, bool Q1>
+__device__ __forceinline__ void r_tail_tile(const F16rArgs& a, const int (&bi)[K], int rtile, int lane) {
+  constexpr int NCH = (D + 255) / 256;
+  constexpr int UN = 8;                              // 24 loads of 1 KB in flight per wave: the tail runs at HBM speed
+  const int r0 = rtile * 32;
+  if (r0 >= a.n) return;
+  const int nrow = a.n - r0 < 32 ? a.n - r0 : 32;
+  float part = 0.f;
+  for (int u0 = 0; u0 < nrow * NCH; u0 += UN) {
+    f32x4 e[UN][K], xv[UN];
+    bool on[UN];
+    int64_t xo[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int uu = u0 + u < nrow * NCH ? u0 + u : nrow * NCH - 1;       // (a short last trip repeats its last unit, unwritten)
+      const int r = uu / NCH, ch = uu - r * NCH;
+      const int off = ch * 256 + lane * 4;
+      on[u] = off < D && u0 + u < nrow * NCH;
+      const int offc = off < D ? off : 0;
+      xo[u] = (int64_t)(r0 + r) * D + offc;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const int s = __builtin_amdgcn_readlane(bi[j], r);
+        e[u][j] = *reinterpret_cast<const f32x4*>(a.e_md + (int64_t)s * D + offc);
+      }
+      xv[u] = *reinterpret_cast<const f32x4*>(a.x + xo[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (!on[u]) continue;
+      const int uu = u0 + u;
+      const int r = uu / NCH, ch = uu - r * NCH;
+      const int64_t qo = ((int64_t)(r0 + r) * K) * D + ch * 256 + lane * 4;
+#pragma unroll
+      for (int j = 0; j < K; ++j) *reinterpret_cast<f32x4*>(a.q_topk + qo + (int64_t)j * D) = e[u][j];
+      f32x4 q1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float df = e[u][0][i] - xv[u][i];
+        part += df * df;
+        q1[i] = xv[u][i] + df;
+      }
+      if (Q1) *reinterpret_cast<f32x4*>(a.q_one + xo[u]) = q1;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+  if (lane == 0) a.diff_partial[rtile] = part;
+}
+
 // One sweep of the codebook for CNT row tiles of this wave (rows [row0 + 32 i, +32), i < CNT; rows >= n are clamped for
 // the loads and never written).  Everything of the sweep: feature staging, contraction + running top-K, the merge of
 // the lane halves, indices, gather / q_one / commit partials.
 // DBG (measurement builds of the K = 2, d = 512 instance only, AMMC_F16R_DBG): 1 = no top-K update, 2 = no codebook DMA
 // inside the sweep (the MFMAs read stale LDS), 4 = no gather / commit tail, 8 = no feature staging; results are then wrong
 template <int K, int NSTEP, int CNT, bool Q1, int DBG = 0, bool PIPE = false>
-__device__ __forceinline__ void r_sweep(const F16rArgs& a, unsigned char* smem, unsigned lds0, int lane, int uwave, int tile0) {
+__device__ __forceinline__ void r_sweep(const F16rArgs& a, unsigned char* smem, unsigned lds0, int lane, int uwave, int tile0,
+                                        RCarry<K>& prev, RCarry<K>& cur) {
   constexpr int TB = (NSTEP + 1) * 1024;           // bytes of a codebook tile image
   constexpr int D = NSTEP * 16;
   constexpr int PH = D / 8;                        // 16-byte pieces of half a feature row (fp32)
@@ -332,16 +397,80 @@ __device__ __forceinline__ void r_sweep(const F16rArgs& a, unsigned char* smem, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[1][rt][r] = -3.0e38f;                   // ("tile -1": nothing beats anything)
     constexpr bool PACKED = K == 2 && NSTEP >= 18;                               // (see r_top2_step; else r_update)
+    // ---- the rows of the PREVIOUS sweep: their gather / q_one / commit write-out rides along with this sweep's first
+    // tiles (K = 2, d = 512: a unit = one 256-float half of one row - two codebook rows and the feature row in, three rows
+    // out - one unit per slot tile: its three LDS-DMAs a tile ahead into a 3-KB slot of this wave, read, summed and stored
+    // behind the MFMAs of k-step 21).  Serially - every CU of the chip in its write-out at the same moments - those 2.7 GB
+    // cost 0.28 ms of 2.15.  Carried tiles with rows past n, or more units than slot tiles, are written serially instead.
+    constexpr bool TAIL_INLINE = PACKED && D == 512;
+    constexpr int TSLOT = 3072, TWAVE = 2 * TSLOT;                               // LDS behind the ring: [wave][2 slots][e0 | e1 | x]
+    const unsigned tl0 = (unsigned)(NBUF * TB) + (unsigned)uwave * (unsigned)TWAVE;
+    int nunit = 0;
+    float tpart0 = 0.f, tpart1 = 0.f;
+    // (the carry's scalars are wave-uniform; readfirstlane tells the compiler, which would otherwise treat the loop over
+    // the units - and every LDS address inside it - as divergent)
+    const int pcnt = __builtin_amdgcn_readfirstlane(prev.cnt), ptile0 = __builtin_amdgcn_readfirstlane(prev.tile0);
+    if (__builtin_amdgcn_readfirstlane(prev.pending)) {
+      const bool full = (ptile0 + pcnt) * 32 <= a.n;
+      if (TAIL_INLINE && !(DBG & 2) && !a.no_inline_tail && full && pcnt * 64 <= a.ntile) {
+        nunit = pcnt * 64;
+      } else {
+        for (int rt = 0; rt < pcnt; ++rt) {
+          if (rt == 0) r_tail_tile<K, D, Q1>(a, prev.bi[0], ptile0, lane);
+          else r_tail_tile<K, D, Q1>(a, prev.bi[1], ptile0 + 1, lane);
+        }
+      }
+      prev.pending = 0;
+    }
+    // the three LDS-DMAs of unit u (row tile u >> 6, row (u >> 1) & 31, half u & 1) into slot u & 1
+    auto issue_unit = [&](int u) {
+      // (everything here is wave-uniform - readfirstlane says so where the compiler cannot see it: "s" operands)
+      const int uc = __builtin_amdgcn_readfirstlane(u < nunit ? u : nunit - 1);  // (the unit after the last: a valid re-load, never read)
+      const int urt = uc >> 6, ur = (uc >> 1) & 31, uch = uc & 1;
+      const int row = (ptile0 + urt) * 32 + ur;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + tl0 + (unsigned)(u & 1) * (unsigned)TSLOT);
+      const int s0_ = __builtin_amdgcn_readlane(urt ? prev.bi[1][0] : prev.bi[0][0], ur);
+      const int s1_ = __builtin_amdgcn_readlane(urt ? prev.bi[1][K > 1 ? 1 : 0] : prev.bi[0][K > 1 ? 1 : 0], ur);
+      r_dma16(a.e_md + (int64_t)s0_ * D + uch * 256, (unsigned)lane * 16u, (unsigned)__builtin_amdgcn_readfirstlane((int)dst));
+      r_dma16(a.e_md + (int64_t)s1_ * D + uch * 256, (unsigned)lane * 16u, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + 1024u)));
+      r_dma16(a.x + (int64_t)row * D + uch * 256, (unsigned)lane * 16u, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + 2048u)));
+    };
+    // unit u out of its slot: q_topk rows, q_one, the commit sum of its row tile
+    auto drain_unit = [&](int u_) {
+      const int u = __builtin_amdgcn_readfirstlane(u_);
+      const int urt = u >> 6, ur = (u >> 1) & 31, uch = u & 1;
+      const int row = (ptile0 + urt) * 32 + ur;
+      const unsigned char* tp = smem + tl0 + (unsigned)(u & 1) * (unsigned)TSLOT + lane * 16;
+      const f32x4 e0 = *reinterpret_cast<const f32x4*>(tp);
+      const f32x4 e1 = *reinterpret_cast<const f32x4*>(tp + 1024);
+      const f32x4 xr = *reinterpret_cast<const f32x4*>(tp + 2048);
+      f32x4 q1;
+      float sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float df = e0[i] - xr[i];
+        sq += df * df;
+        q1[i] = xr[i] + df;
+      }
+      tpart0 += urt ? 0.f : sq;
+      tpart1 += urt ? sq : 0.f;
+      float* q0p = a.q_topk + ((int64_t)row * K) * D + uch * 256;
+      r_store16(q0p, (unsigned)lane * 16u, e0);
+      r_store16(q0p + D, (unsigned)lane * 16u, e1);
+      if (Q1) r_store16(a.q_one + (int64_t)row * D + uch * 256, (unsigned)lane * 16u, q1);
+    };
     float pb0[CNT], pb1[CNT], ob0[CNT], ob1[CNT];                                // packed keys: best, second; the pair a tile ago
     int pt0[CNT], pt1[CNT];                                                      // the slot tiles they come from
 #pragma unroll
     for (int rt = 0; rt < CNT; ++rt) { pb0[rt] = pb1[rt] = ob0[rt] = ob1[rt] = -INFINITY; pt0[rt] = pt1[rt] = -1; }
-#define R_BODY(tile_, B_)                                                                                              \
+#define R_BODY(tile_, B_, TI_)                                                                                         \
   {                                                                                                                     \
-    if (!(DBG & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPT) : "memory");                                      \
+    /* with the write-out riding along (TI_): every tile issues 3 more LDS-DMAs and 2 - 3 stores; 2 DPT + 3 is what is  \
+       younger than the tile's own codebook DMAs in the FIRST such tile (later ones: more), so the wait is never short */ \
+    if (!(DBG & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPT + ((TI_) ? 3 : 0)) : "memory");                    \
     __builtin_amdgcn_s_barrier();                                                                                       \
     asm volatile("" ::: "memory");                                                                                      \
-    const int nt_ = (tile_) + NBUF - 1;                                                                                 \
+    const int nt_ = __builtin_amdgcn_readfirstlane((tile_) + NBUF - 1);                                                 \
     const int ntl_ = nt_ < a.ntile ? nt_ : a.ntile - 1;                                                                 \
     const unsigned char* nsrc = a.tiles + (int64_t)ntl_ * TB;                                                           \
     const unsigned ndst = lds0 + (unsigned)(nt_ & (NBUF - 1)) * (unsigned)TB;                                           \
@@ -368,6 +497,12 @@ __device__ __forceinline__ void r_sweep(const F16rArgs& a, unsigned char* smem, 
           else r_dma16(nsrc + NSTEP * 1024, (unsigned)lane * 16u, ndst + (unsigned)(NSTEP * 1024));                     \
         }                                                                                                               \
       }                                                                                                                 \
+      if constexpr ((TI_) && t == 2) issue_unit((tile_) + 1);                                                           \
+      if constexpr ((TI_) && t == 21) {                                                                                 \
+        /* unit tile_'s DMAs are older than DMA 0, the next unit's three and DMAs 1-6 of this tile: all but those 10 */ \
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                                               \
+        drain_unit(tile_);                                                                                              \
+      }                                                                                                                 \
       /* the previous tile's update behind this step's MFMAs: K = 2 - one candidate per k-step (packed keys, no      \
          branch); other K - the compare-and-branch form, one row tile per chosen k-step */                             \
       if constexpr (K == 2 && NSTEP >= 18) {                                                                            \
@@ -389,9 +524,27 @@ __device__ __forceinline__ void r_sweep(const F16rArgs& a, unsigned char* smem, 
       __builtin_amdgcn_sched_barrier(0);                                                                                \
     });                                                                                                                 \
   }
-    for (int tile = 0; tile < a.ntile; tile += 2) {
-      R_BODY(tile, 0)
-      if (tile + 1 < a.ntile) R_BODY(tile + 1, 1)
+    int tile_b = 0;
+    if constexpr (TAIL_INLINE) {
+      if (nunit > 0) {
+        issue_unit(0);
+        for (int tile = 0; tile < nunit; tile += 2) {                            // (nunit is even and <= ntile)
+          R_BODY(tile, 0, true)
+          R_BODY(tile + 1, 1, true)
+        }
+        tile_b = nunit;
+        // the commit sums of the carried row tiles
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { tpart0 += __shfl_xor(tpart0, o, 64); tpart1 += __shfl_xor(tpart1, o, 64); }
+        if (lane == 0) {
+          a.diff_partial[ptile0] = tpart0;
+          if (pcnt > 1) a.diff_partial[ptile0 + 1] = tpart1;
+        }
+      }
+    }
+    for (int tile = tile_b; tile < a.ntile; tile += 2) {
+      R_BODY(tile, 0, false)
+      if (tile + 1 < a.ntile) R_BODY(tile + 1, 1, false)
       else {                                                                   // (odd tile count: the set 1 of "tile + 1" stays unwritten)
 #pragma unroll
         for (int rt = 0; rt < CNT; ++rt)
@@ -519,55 +672,18 @@ __device__ __forceinline__ void r_sweep(const F16rArgs& a, unsigned char* smem, 
     }
   }
 
-  // ---- gather (fp32 codebook rows), q_one, commit partial sums: UN (row, 256-float chunk) units per trip ------------------
-  constexpr int NCH = (D + 255) / 256;
-  constexpr int UN = 8;                              // 24 loads of 1 KB in flight per wave: the tail runs at HBM speed
+  // ---- gather / q_one / commit: right away (one accumulator set), or left to the NEXT sweep, which writes these rows out
+  // behind its own MFMAs (pipelined form; the kernel flushes the last sweep's) ------------------------------------------------
+  if constexpr (PIPE) {
 #pragma unroll
-  for (int rt = 0; rt < CNT; ++rt) {
-    const int r0 = (tile0 + rt) * 32;
-    if (r0 >= a.n || (DBG & 4)) break;
-    const int nrow = a.n - r0 < 32 ? a.n - r0 : 32;
-    float part = 0.f;
-    for (int u0 = 0; u0 < nrow * NCH; u0 += UN) {
-      f32x4 e[UN][K], xv[UN];
-      bool on[UN];
-      int64_t xo[UN];
+    for (int rt = 0; rt < CNT; ++rt)
 #pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int uu = u0 + u < nrow * NCH ? u0 + u : nrow * NCH - 1;       // (a short last trip repeats its last unit, unwritten)
-        const int r = uu / NCH, ch = uu - r * NCH;
-        const int off = ch * 256 + lane * 4;
-        on[u] = off < D && u0 + u < nrow * NCH;
-        const int offc = off < D ? off : 0;
-        xo[u] = (int64_t)(r0 + r) * D + offc;
+      for (int j = 0; j < K; ++j) cur.bi[rt][j] = bi[rt][j];
+    cur.tile0 = tile0, cur.cnt = CNT, cur.pending = (DBG & 4) ? 0 : 1;
+  } else {
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-          const int s = __builtin_amdgcn_readlane(bi[rt][j], r);
-          e[u][j] = *reinterpret_cast<const f32x4*>(a.e_md + (int64_t)s * D + offc);
-        }
-        xv[u] = *reinterpret_cast<const f32x4*>(a.x + xo[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        if (!on[u]) continue;
-        const int uu = u0 + u;
-        const int r = uu / NCH, ch = uu - r * NCH;
-        const int64_t qo = ((int64_t)(r0 + r) * K) * D + ch * 256 + lane * 4;
-#pragma unroll
-        for (int j = 0; j < K; ++j) *reinterpret_cast<f32x4*>(a.q_topk + qo + (int64_t)j * D) = e[u][j];
-        f32x4 q1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float df = e[u][0][i] - xv[u][i];
-          part += df * df;
-          q1[i] = xv[u][i] + df;
-        }
-        if (Q1) *reinterpret_cast<f32x4*>(a.q_one + xo[u]) = q1;
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-    if (lane == 0) a.diff_partial[tile0 + rt] = part;
+    for (int rt = 0; rt < CNT; ++rt)
+      if (!(DBG & 4)) r_tail_tile<K, D, Q1>(a, bi[rt], tile0 + rt, lane);
   }
 }
 
@@ -588,21 +704,33 @@ __global__ __launch_bounds__(256, 1) void memory_topk_f16r_kernel(F16rArgs a) {
   int cnt = RT - (int)(blockIdx.x % 3);
   if (cnt < 1 || a.pw <= RT) cnt = RT;
   if (cnt > a.pw) cnt = a.pw;
+  RCarry<K> prev, cur;
+  prev.pending = 0, prev.tile0 = 0, prev.cnt = 0;
   for (int p0 = 0; p0 < a.pw;) {
     int t0 = first + p0;
     // a wave whose tiles lie past the end still takes part in the ring (DMA shares, barriers): its loads clamp to the last
     // row and it writes nothing
     if (t0 >= a.t32) t0 = a.t32;
+    cur.pending = 0;
     if constexpr (RT >= 3) {
-      if (cnt == 3) r_sweep<K, NSTEP, 3, Q1, DBG, false>(a, smem_r, lds0, lane, uwave, t0);
-      else if (cnt == 2) r_sweep<K, NSTEP, 2, Q1, DBG, false>(a, smem_r, lds0, lane, uwave, t0);
-      else r_sweep<K, NSTEP, 1, Q1, DBG, false>(a, smem_r, lds0, lane, uwave, t0);
+      if (cnt == 3) r_sweep<K, NSTEP, 3, Q1, DBG, false>(a, smem_r, lds0, lane, uwave, t0, prev, cur);
+      else if (cnt == 2) r_sweep<K, NSTEP, 2, Q1, DBG, false>(a, smem_r, lds0, lane, uwave, t0, prev, cur);
+      else r_sweep<K, NSTEP, 1, Q1, DBG, false>(a, smem_r, lds0, lane, uwave, t0, prev, cur);
     } else {
-      if (cnt == 2) r_sweep<K, NSTEP, 2, Q1, DBG, PIPE>(a, smem_r, lds0, lane, uwave, t0);
-      else r_sweep<K, NSTEP, 1, Q1, DBG, PIPE>(a, smem_r, lds0, lane, uwave, t0);
+      if (cnt == 2) r_sweep<K, NSTEP, 2, Q1, DBG, PIPE>(a, smem_r, lds0, lane, uwave, t0, prev, cur);
+      else r_sweep<K, NSTEP, 1, Q1, DBG, PIPE>(a, smem_r, lds0, lane, uwave, t0, prev, cur);
     }
+    prev = cur;
     p0 += cnt;
     cnt = a.pw - p0 < RT ? a.pw - p0 : RT;
+  }
+  if constexpr (PIPE) {                              // the last sweep's rows: nothing left to hide their write-out behind
+    if (prev.pending) {
+      for (int rt = 0; rt < prev.cnt; ++rt) {
+        if (rt == 0) r_tail_tile<K, NSTEP * 16, Q1>(a, prev.bi[0], prev.tile0, lane);
+        else r_tail_tile<K, NSTEP * 16, Q1>(a, prev.bi[1], prev.tile0 + 1, lane);
+      }
+    }
   }
 }
 
@@ -648,7 +776,7 @@ int launch_f16r(const F16rArgs& a0, hipStream_t stream) {
   const int waves = std::min(cus * RW, a.t32);
   a.pw = (a.t32 + waves - 1) / waves;
   const int grid = (a.t32 + a.pw * RW - 1) / (a.pw * RW);
-  const size_t lds = (size_t)NBUF * (NSTEP + 1) * 1024;
+  size_t lds = (size_t)NBUF * (NSTEP + 1) * 1024;
   auto kern = memory_topk_f16r_kernel<K, NSTEP, RT, Q1>;
   if constexpr (K == 2 && NSTEP == 32 && Q1) {          // measurement builds (wrong results): AMMC_F16R_DBG = 1 | 2 | 4 | 8 | 15
     static const int dbg = getenv("AMMC_F16R_DBG") ? atoi(getenv("AMMC_F16R_DBG")) : 0;
@@ -667,6 +795,7 @@ int launch_f16r(const F16rArgs& a0, hipStream_t stream) {
     // every other K / d runs)
     static const int form = getenv("AMMC_F16R_FORM") ? atoi(getenv("AMMC_F16R_FORM")) : 2;
     if (form == 2) {
+      lds += (size_t)RW * 2 * 3072;                      // two 3-KB write-out slots per wave behind the ring
       kern = memory_topk_f16r_kernel<K, NSTEP, 2, Q1, 0, true>;
       if constexpr (Q1) {
         static const int dbg2 = getenv("AMMC_F16R_DBG") ? atoi(getenv("AMMC_F16R_DBG")) : 0;
@@ -724,6 +853,8 @@ extern "C" int ammc_memory_topk_fwd_f16r(const float* x, const void* tiles, cons
   a.x = x, a.tiles = reinterpret_cast<const unsigned char*>(tiles), a.e_md = embed_md, a.idx_out = idx_topk;
   a.q_topk = q_topk, a.q_one = q_one, a.diff_partial = diff_partial;
   a.n = n, a.d = d, a.m = m, a.ntile = (m + 31) / 32, a.t32 = (n + 31) / 32, a.pw = 0;
+  static const int inline_tail = getenv("AMMC_F16R_TAIL_INLINE") ? atoi(getenv("AMMC_F16R_TAIL_INLINE")) : 1;
+  a.no_inline_tail = inline_tail == 0;
   hipStream_t s = (hipStream_t)stream;
 #define F16R_K(K_)                                                                                   \
   case K_: return q_one ? launch_f16r_d<K_, true>(a, s) : launch_f16r_d<K_, false>(a, s);
