@@ -97,6 +97,8 @@ SIGNATURES = {
     "ammc_memory_topk_fwd_f16r": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
     "ammc_conv_wgrad_f32": (C.c_int, [C.POINTER(AmmcWgradDesc), _p]),
     "ammc_conv_wgrad_s16": (C.c_int, [C.POINTER(AmmcWgradDesc), _p, _p]),
+    "ammc_conv_wgrad_s16_slab_floats": (C.c_int64, [C.POINTER(AmmcWgradDesc)]),
+    "ammc_conv_wgrad_s16_slabs": (C.c_int, [C.POINTER(AmmcWgradDesc), _p, _p, _i64, _p, _i32, _i32, _p]),
     "ammc_unpack_conv_wgrad_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
     "ammc_unpack_convt_wgrad_f32": (C.c_int, [_p, _i32, _i32, _p, _p]),
     "ammc_pack_conv_dgrad_weight_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),

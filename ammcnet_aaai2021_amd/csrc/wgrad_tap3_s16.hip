@@ -44,6 +44,12 @@ struct WgradTap3Args {
   AmmcWgradDesc d;
   const float* g_inv_scale;
   int kpad, tiles_x, tiles_y, npatch, patches_per_block, msplit, col_tiles;
+  // round 5: with `slabs` every workgroup STORES its tile of the packed gradient into the slab of its patch split
+  // ([msplit x row groups][n][kpad], plain stores) and reduce_unpack_wgrad_kernel sums the slabs straight into the OIHW parameter
+  // gradient - instead of fp32 atomics of all `msplit` tiles into one packed buffer (up to 75 MB of atomic traffic per
+  // launch at the memory side's ~1.3 TB/s for a <= 9.4-MB result, a memset of that buffer and an unpack launch)
+  float* slabs;
+  int query;                       // 1: launch nothing, return msplit * n * kpad (floats of slabs the launch would need)
 };
 
 constexpr int W3_PW = 32, W3_HW = W3_PW + 2;                           // patch width, halo width
@@ -298,7 +304,11 @@ __global__ __launch_bounds__(64 * NG * NA * NP, (GW == 2 ? 1 : 2)) void wgrad_ta
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = row0 + 32 * (wg * GW + b) + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < d.n && c < d.cin) unsafeAtomicAdd(d.dw + (int64_t)row * a.kpad + col, acc[b][t][r] * inv);
+        if (row < d.n && c < d.cin) {
+          // (waves of different row groups hold parts of the SAME outputs - the atomics used to add them: each group its own slab)
+          if (a.slabs) a.slabs[((int64_t)(ms * NP + wp) * d.n + row) * a.kpad + col] = acc[b][t][r] * inv;
+          else unsafeAtomicAdd(d.dw + (int64_t)row * a.kpad + col, acc[b][t][r] * inv);
+        }
       }
     }
 }
@@ -311,9 +321,11 @@ static int launch_wgrad_tap3(WgradTap3Args a, hipStream_t stream) {
   constexpr size_t lds = (size_t)(2 * PH * W3_PW * TN + 2 * AJ * W3_NT * 4) * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto kern = wgrad_tap3_s16_kernel<NG, NA, NP, PH, GW>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds);
-  if (e != hipSuccess) return (int)e;
+  if (!a.query) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
   a.col_tiles = (a.d.cin + TC - 1) / TC;
   a.tiles_y = a.d.height / PH;
   a.npatch = a.d.batch * a.tiles_x * a.tiles_y;
@@ -323,13 +335,15 @@ static int launch_wgrad_tap3(WgradTap3Args a, hipStream_t stream) {
   if (msplit > max_split) msplit = max_split;
   if (msplit < 1) msplit = 1;
   a.patches_per_block = (a.npatch + msplit - 1) / msplit;
-  a.msplit = (a.npatch + a.patches_per_block - 1) / a.patches_per_block;
+  a.msplit = (a.npatch + a.patches_per_block - 1) / a.patches_per_block;       // (every split owns at least one patch)
+  if (a.query) return a.msplit * NP;                               // slabs: one per patch split and row group of the workgroup
   hipLaunchKernelGGL(kern, dim3(tiles * a.msplit), dim3(W3_NT), lds, stream, a);
   return ammc_launch_status();
 }
 
 // Called by wgrad_tap_s16_try; -12345 = not this kernel's case.
-int wgrad_tap3_s16_try(const AmmcWgradDesc& d, const float* g_inv_scale, int kpad, hipStream_t stream) {
+// `slabs` / `query`: see WgradTap3Args (query: the return value is the number of patch splits, or -12345)
+int wgrad_tap3_s16_try(const AmmcWgradDesc& d, const float* g_inv_scale, int kpad, hipStream_t stream, float* slabs, int query) {
   if (d.height % 2 || d.width % W3_PW) return -12345;
   const int64_t gmax = (int64_t)3 * d.g_rs + (int64_t)(W3_PW - 1) * d.g_ps + d.n;
   const int64_t amax = (int64_t)5 * d.a_rs + (int64_t)(W3_PW + 1) * d.a_ps + d.cin;
@@ -338,6 +352,7 @@ int wgrad_tap3_s16_try(const AmmcWgradDesc& d, const float* g_inv_scale, int kpa
   a.d = d;
   a.g_inv_scale = g_inv_scale;
   a.kpad = kpad;
+  a.slabs = slabs, a.query = query;
   a.tiles_x = d.width / W3_PW;
   a.tiles_y = a.npatch = 0;                                       // set by the launcher (patch height)
   if (d.cin % 64 == 0) {
@@ -354,4 +369,59 @@ int wgrad_tap3_s16_try(const AmmcWgradDesc& d, const float* g_inv_scale, int kpa
   return -12345;
 }
 
+// slabs [msplit][n][kpad] (k = tap * cin_p + c) -> OIHW [cout][cin][3][3]: one thread per output element sums its
+// `msplit` partial values in a fixed order (deterministic, unlike the atomics it replaces)
+__global__ __launch_bounds__(256) void reduce_unpack_wgrad_kernel(const float* __restrict__ slabs, int msplit, int n, int kpad,
+                                                                  int cout, int cin, int cin_p, float* __restrict__ out) {
+  const int64_t total = (int64_t)cout * cin * 9;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  // threads of a warp walk the PACKED row (coalesced reads of every slab); the OIHW element is computed from it
+  const int o = (int)(gid / ((int64_t)cin * 9));
+  const int k = (int)(gid - (int64_t)o * cin * 9);              // k = tap * cin + c over the TRUE channels
+  const int tap = k / cin, c = k - tap * cin;
+  const float* p = slabs + (int64_t)o * kpad + tap * cin_p + c;
+  const int64_t stride = (int64_t)n * kpad;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int m = 0;
+  for (; m + 4 <= msplit; m += 4) {
+    s0 += p[(int64_t)m * stride];
+    s1 += p[(int64_t)(m + 1) * stride];
+    s2 += p[(int64_t)(m + 2) * stride];
+    s3 += p[(int64_t)(m + 3) * stride];
+  }
+  for (; m < msplit; ++m) s0 += p[(int64_t)m * stride];
+  out[((int64_t)o * cin + c) * 9 + tap] = (s0 + s1) + (s2 + s3);
+}
+
 }  // namespace ammc_s16
+using namespace ammc_s16;
+
+extern "C" int64_t ammc_conv_wgrad_s16_slab_floats(const AmmcWgradDesc* desc) {
+  if (!desc || desc->ntaps != 9 || desc->a_step > 1 || desc->n <= 0 || (desc->n % 32) || desc->cin < 8 ||
+      (desc->cin & (desc->cin - 1)) || desc->batch <= 0 || desc->height <= 0 || desc->width <= 0)
+    return 0;
+  const int kpad = ((9 * desc->cin + 31) / 32) * 32;
+  const int ms = wgrad_tap3_s16_try(*desc, nullptr, kpad, nullptr, nullptr, 1);
+  return ms <= 0 ? 0 : (int64_t)ms * desc->n * kpad;
+}
+
+extern "C" int ammc_conv_wgrad_s16_slabs(const AmmcWgradDesc* desc, const float* g_inv_scale, float* slabs,
+                                         int64_t slab_floats, float* dw_oihw, int32_t cout, int32_t cin, void* stream) {
+  if (!desc || !desc->g || !desc->a || !desc->zeros || !slabs || !dw_oihw) return AMMC_EINVAL;
+  const AmmcWgradDesc& d = *desc;
+  if (cout <= 0 || cout > d.n || cin <= 0 || cin > d.cin) return AMMC_EINVAL;
+  if (((uintptr_t)d.g | (uintptr_t)d.a | (uintptr_t)d.zeros) & 31) return AMMC_EINVAL;
+  if ((d.g_bs | d.g_rs | d.g_ps | d.a_bs | d.a_rs | d.a_ps) & 7) return AMMC_EINVAL;
+  const int64_t need = ammc_conv_wgrad_s16_slab_floats(desc);
+  if (need <= 0) return AMMC_EUNSUP;
+  if (slab_floats < need) return AMMC_EINVAL;
+  const int kpad = ((9 * d.cin + 31) / 32) * 32;
+  const int msplit = (int)(need / ((int64_t)d.n * kpad));
+  const int rc = wgrad_tap3_s16_try(d, g_inv_scale, kpad, (hipStream_t)stream, slabs, 0);
+  if (rc != AMMC_OK) return rc == -12345 ? AMMC_EUNSUP : rc;
+  const int64_t total = (int64_t)cout * cin * 9;
+  hipLaunchKernelGGL(reduce_unpack_wgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     slabs, msplit, d.n, kpad, cout, cin, d.cin, dw_oihw);
+  return ammc_launch_status();
+}

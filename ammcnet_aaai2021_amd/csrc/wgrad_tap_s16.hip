@@ -215,14 +215,14 @@ static int launch_wgrad_tap(WgradTapArgs a, hipStream_t stream) {
 }
 
 // wgrad_tap3_s16.hip: three MFMAs per product block, 128 x 64 channel tiles (N % 128 == 0, Cin % 64 == 0)
-int wgrad_tap3_s16_try(const AmmcWgradDesc& d, const float* g_inv_scale, int kpad, hipStream_t stream);
+int wgrad_tap3_s16_try(const AmmcWgradDesc& d, const float* g_inv_scale, int kpad, hipStream_t stream, float* slabs, int query);
 
 // Called by ammc_conv_wgrad_s16 after its argument checks; -12345 = not this kernel's case.
 int wgrad_tap_s16_try(const AmmcWgradDesc& d, const float* g_inv_scale, int kpad, hipStream_t stream) {
   static const int mode = getenv("AMMC_WGRAD_TAP") ? atoi(getenv("AMMC_WGRAD_TAP")) : 1;
   if (!mode) return -12345;
   if (mode != 2) {                                         // AMMC_WGRAD_TAP=2: this file's kernels only (A/Bs)
-    const int rc = wgrad_tap3_s16_try(d, g_inv_scale, kpad, stream);
+    const int rc = wgrad_tap3_s16_try(d, g_inv_scale, kpad, stream, nullptr, 0);
     if (rc != -12345) return rc;
   }
   if (d.height % WT_PH || d.width % WT_PW) return -12345;

@@ -70,6 +70,9 @@ FUSE_BN_BWD_STATS = os.environ.get("AMMC_FUSE_BN_BWD_STATS", "1") != "0"
 # HIP streams, so that one's HBM-bound BatchNorm passes (~1170 W at 6 TB/s) run beside the other's MFMA-bound convolutions
 # instead of after them: the step is energy-bound and those passes leave ~230 W of the 1400 W cap unused
 TWO_STREAMS = os.environ.get("AMMC_TWO_STREAMS", "1") != "0"
+# the 3x3 weight gradients' split partials as slabs summed straight into the parameter gradient (round 5) instead of fp32
+# atomics into a zeroed packed buffer + an unpack launch
+WGRAD_SLABS = os.environ.get("AMMC_WGRAD_SLABS", "1") != "0"
 MID_S16 = os.environ.get("AMMC_MID_S16", "1") != "0"              # double_conv middle activations exist as S16 only
 FUSE_BN_BWD = os.environ.get("AMMC_FUSE_BN_BWD", "1") != "0"      # BN backward writes the S16 twin of dc (one rank)
 
@@ -146,6 +149,7 @@ class _Ops:
         self._shadows: Dict[int, torch.Tensor] = {}
         self.amax = ws.buf(256, dtype=torch.int32)         # slots of ammc_absmax_bits_f32 / bn_bwd_apply
         self.side = None                                   # two HIP streams of `_side_by_side`, made on first use
+        self._wgrad_slabs: Dict[int, torch.Tensor] = {}    # slab workspace of the 3x3 weight gradients, per HIP stream
         # bench.py: a list here brackets every MFMA launch of the 3x3 layers with HIP events on the launch stream and
         # collects (kernel label, algorithmic flops, start event, end event)
         self.timing: Optional[list] = None
@@ -227,22 +231,39 @@ class _Ops:
             _chk(lib.ammc_split_rows_f32(_ptr(x.buf), x.buf.numel(), _ptr(xs.buf), s), "split_rows(x)")
         return xs, inv
 
-    def wgrad_s16(self, g16: Act, a16: Act, dw: torch.Tensor, inv, *, n, cin, what="wgrad", true_nc=None, ntaps=9, a_step=1):
+    def wgrad_s16(self, g16: Act, a16: Act, dw: torch.Tensor, inv, *, n, cin, what="wgrad", true_nc=None, ntaps=9, a_step=1,
+                  out_oihw: Optional[torch.Tensor] = None):
         """weight gradient from the S16 twins of the output gradient and of the layer input (3x3; ntaps 4 / a_step 2: the
-        ConvTranspose form of ammc_conv_wgrad_f32 - g = the layer input, a = the output gradient at twice the resolution)"""
-        if not getattr(dw, "_ammc_zslab", False):          # slab buffers were cleared by `_WS.zero_step` (backward start)
-            dw.zero_()
+        ConvTranspose form of ammc_conv_wgrad_f32 - g = the layer input, a = the output gradient at twice the resolution).
+        `out_oihw` (3x3 layers): the parameter's gradient tensor; where the layer's kernel has a slab form (round 5,
+        AMMC_WGRAD_SLABS) the split partials are stored as slabs and summed straight into it - no atomics into the zeroed
+        packed buffer `dw`, no unpack launch - and the call returns True (the caller then skips its unpack)."""
         d = AmmcWgradDesc()
         d.g, d.a, d.dw, d.zeros = g16.pix0(), (a16.tap0() if ntaps == 9 else a16.pix0()), _ptr(dw), _ptr(self.zeros)
         d.batch, d.height, d.width = g16.B, g16.H, g16.W
         d.n, d.cin, d.ntaps, d.a_step = n, cin, ntaps, a_step
         d.g_bs, d.g_rs, d.g_ps = g16.strides
         d.a_bs, d.a_rs, d.a_ps = a16.strides
-        self._mfma_launch("conv_wgrad_s16 (3x3 weight gradients: wgrad_tap3_s16 / wgrad_tap_s16 instances)" if ntaps == 9 else
-                          "conv_wgrad_s16 (ConvTranspose weight gradients: wgrad_s16)",
-                          2.0 * g16.B * g16.H * g16.W * ntaps * (true_nc if true_nc is not None else n * cin),   # unpadded channels
-                          lambda: self.lib.ammc_conv_wgrad_s16(C.byref(d), _ptr(inv) if inv is not None else None, self.s),
-                          what)
+        label = ("conv_wgrad_s16 (3x3 weight gradients: wgrad_tap3_s16 / wgrad_tap_s16 instances)" if ntaps == 9 else
+                 "conv_wgrad_s16 (ConvTranspose weight gradients: wgrad_s16)")
+        flops = 2.0 * g16.B * g16.H * g16.W * ntaps * (true_nc if true_nc is not None else n * cin)      # unpadded channels
+        if out_oihw is not None and ntaps == 9 and a_step == 1 and WGRAD_SLABS:
+            need = int(self.lib.ammc_conv_wgrad_s16_slab_floats(C.byref(d)))
+            if need > 0:
+                # one slab workspace per HIP stream (the rgb / flow halves of a step run on two): sized for the largest user
+                key = torch.cuda.current_stream(self.dev).cuda_stream
+                ws = self._wgrad_slabs.get(key)
+                if ws is None or ws.numel() < need:
+                    ws = self._wgrad_slabs[key] = torch.empty(max(need, 20 << 20), device=self.dev, dtype=torch.float32)
+                cout, cin_t = out_oihw.shape[0], out_oihw.shape[1]
+                self._mfma_launch(label, flops, lambda: self.lib.ammc_conv_wgrad_s16_slabs(
+                    C.byref(d), _ptr(inv) if inv is not None else None, _ptr(ws), ws.numel(), _ptr(out_oihw), cout, cin_t, self.s), what)
+                return True
+        if not getattr(dw, "_ammc_zslab", False):          # slab buffers were cleared by `_WS.zero_step` (backward start)
+            dw.zero_()
+        self._mfma_launch(label, flops,
+                          lambda: self.lib.ammc_conv_wgrad_s16(C.byref(d), _ptr(inv) if inv is not None else None, self.s), what)
+        return False
 
     def conv_s16(self, x: Act, w: torch.Tensor, y: Act, *, ntaps, cin, n, res: Optional[Act] = None, what="conv",
                  rescale: bool = False, pre=None, shift=None, up=1, cgroup=None, x_step=1, y_s16: bool = False,
@@ -632,13 +653,15 @@ class _ConvBN:
                                            *self.dc.strides, c.B, c.H, c.W, self.cout,
                                            self.amax.data_ptr() if fused_amax else None, s), "bn_bwd_apply")
             pre = o.to_s16(self.dc, rescale=True, have_amax=True, amax=self.amax) if fused_amax else None   # shared by wgrad and dgrad
+        dw = torch.empty_like(self.conv.weight)
+        summed = False
         if pre is not None and self.cin_p >= 8 and WGRAD_S16:
-            o.wgrad_s16(pre[0], o.shadow(self.x), self.dwp, pre[1], n=self.cout, cin=self.cin_p,
-                        what=self.name + ".wgrad", true_nc=self.cout * self.cin)            # shadow(x): the twin the forward conv left behind
+            summed = o.wgrad_s16(pre[0], o.shadow(self.x), self.dwp, pre[1], n=self.cout, cin=self.cin_p,
+                                 what=self.name + ".wgrad", true_nc=self.cout * self.cin, out_oihw=dw)   # shadow(x): the twin the forward conv left behind
         else:
             o.wgrad(self.dc, self.x, self.dwp, n=self.cout, cin=self.cin_p, ntaps=9, what=self.name + ".wgrad")
-        dw = torch.empty_like(self.conv.weight)
-        _chk(lib.ammc_unpack_conv_wgrad_f32(_ptr(self.dwp), self.cout, self.cin, 3, self.cin_p, _ptr(dw), s), "unpack")
+        if not summed:
+            _chk(lib.ammc_unpack_conv_wgrad_f32(_ptr(self.dwp), self.cout, self.cin, 3, self.cin_p, _ptr(dw), s), "unpack")
         grads[self.conv.weight] = dw
         if da is not None:
             w = self.conv.weight.detach()
@@ -907,15 +930,17 @@ class _Stream:
         _chk(lib.ammc_tanh_bwd_nhwc_f32(_ptr(dout), _ptr(self.out), self.B, self.cout, self.H, self.W, dp.pix0(),
                                         *dp.strides, 32, s), "tanh_bwd")
         grads[net.outc.bias] = o.chan_sum(dp, 32, self.scratch)[:self.cout]
+        dw = torch.empty_like(net.outc.weight)
+        summed = False
         if o.s16 and WGRAD_S16:
             pre = o.to_s16(dp, rescale=True, amax=self.outc_amax)
-            o.wgrad_s16(pre[0], o.shadow(self.u3), self.outc_dwp, pre[1], n=32, cin=64, what="outc.wgrad",
-                        true_nc=self.cout * 64)
+            summed = o.wgrad_s16(pre[0], o.shadow(self.u3), self.outc_dwp, pre[1], n=32, cin=64, what="outc.wgrad",
+                                 true_nc=self.cout * 64, out_oihw=dw)
         else:
             pre = None
             o.wgrad(dp.slice(0, 32), self.u3, self.outc_dwp, n=32, cin=64, ntaps=9, what="outc.wgrad")
-        dw = torch.empty_like(net.outc.weight)
-        _chk(lib.ammc_unpack_conv_wgrad_f32(_ptr(self.outc_dwp), self.cout, 64, 3, 64, _ptr(dw), s), "unpack")
+        if not summed:
+            _chk(lib.ammc_unpack_conv_wgrad_f32(_ptr(self.outc_dwp), self.cout, 64, 3, 64, _ptr(dw), s), "unpack")
         grads[net.outc.weight] = dw
         _chk(lib.ammc_pack_conv_dgrad_weight_f32(_ptr(net.outc.weight.detach()), self.cout, 64, 32, 64,
                                                  _ptr(self.outc_wdp), s), "pack_dgrad")

@@ -321,6 +321,16 @@ int ammc_conv_wgrad_f32(const AmmcWgradDesc* desc, void* stream);
  * a: it is one scalar on the result), divided out.  ntaps 9 (the stride-1 3x3 layers: halo-patch kernels), 16 (4x4,
  * a_step 1 | 2: PixelDiscriminator) or 4 (2x2, a_step 2: ConvTranspose); cin a power of two >= 8, n % 32 == 0. */
 int ammc_conv_wgrad_s16(const AmmcWgradDesc* desc, const float* g_inv_scale, void* stream);
+/* The 3x3 form with the split partials SUMMED INTO THE PARAMETER GRADIENT by a second kernel (round 5): every workgroup of
+ * the halo-patch weight-gradient kernel stores its tile of the packed gradient into the slab of its patch split
+ * (slabs: [splits][n][kpad] floats of caller workspace, plain stores) and a reduce kernel writes dw_oihw [cout][cin][3][3]
+ * (cout <= n, cin <= desc->cin: the unpadded channel counts) - replaces ammc_conv_wgrad_s16's fp32 atomics into a zeroed
+ * packed buffer + ammc_unpack_conv_wgrad_f32; fixed summation order, so deterministic.  desc->dw is not used.
+ * ammc_conv_wgrad_s16_slab_floats: the workspace this descriptor needs, or 0 when its kernel has no slab form (callers
+ * then use ammc_conv_wgrad_s16). */
+int64_t ammc_conv_wgrad_s16_slab_floats(const AmmcWgradDesc* desc);
+int ammc_conv_wgrad_s16_slabs(const AmmcWgradDesc* desc, const float* g_inv_scale, float* slabs, int64_t slab_floats,
+                              float* dw_oihw, int32_t cout, int32_t cin, void* stream);
 /* packed gradient -> the module's parameter layout */
 int ammc_unpack_conv_wgrad_f32(const float* packed, int32_t cout, int32_t cin, int32_t ksize, int32_t cin_p,
                                float* out_oihw, void* stream);

@@ -66,3 +66,23 @@ def test_wgrad_s16_vs_fp64(B, H, W, cin, n, gmag):
     (F.conv2d(a64, w, padding=1) * g64).sum().backward()
     err = float((dw.double().cpu() - w.grad).abs().max() / w.grad.abs().max())
     assert err <= 3e-6, err
+    # the slab form of the same launch (round 5): split partials stored as slabs and summed straight into the OIHW gradient
+    # - no atomics, no unpack; available exactly where the three-MFMA halo-patch kernel takes the shape.  Same 3e-6 against
+    # fp64, equal to the atomics form to summation order, and bit-identical between two launches (fixed summation order)
+    need = int(lib.ammc_conv_wgrad_s16_slab_floats(C.byref(d)))
+    takes = (W % 32 == 0 and H % 2 == 0 and ((cin % 64 == 0 and (n % 64 == 0 or (n == 32 and H % 4 == 0))) or
+                                             (cin <= 32 and n % 64 == 0 and H % 4 == 0)))
+    assert (need > 0) == takes, (need, takes)
+    if need > 0:
+        assert need % (n * kpad) == 0
+        outs = []
+        for _ in range(2):
+            slabs = torch.full((need + 64,), float("nan"), device=DEV)           # (every element that is read must have been written)
+            dws = torch.empty(n, cin, 3, 3, device=DEV)
+            _lib.check(lib.ammc_conv_wgrad_s16_slabs(C.byref(d), _ptr(inv), _ptr(slabs), need, _ptr(dws), n, cin, s), "wgrad slabs")
+            outs.append(dws)
+        assert torch.equal(outs[0], outs[1])
+        err_s = float((outs[0].double().cpu() - w.grad).abs().max() / w.grad.abs().max())
+        assert err_s <= 3e-6, err_s
+        assert float((outs[0] - dw).abs().max()) <= 2e-6 * float(dw.abs().max())
+        assert lib.ammc_conv_wgrad_s16_slabs(C.byref(d), _ptr(inv), _ptr(slabs), need - 1, _ptr(dws), n, cin, s) == -1   # AMMC_EINVAL
