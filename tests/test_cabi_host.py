@@ -45,6 +45,41 @@ def test_argument_errors_are_status_codes_not_aborts():
         _lib.check(-2, "x")
 
 
+def test_round5_entry_points_reject_bad_arguments_without_a_gpu():
+    """the entry points added in round 5 (include/ammc_hip.h): argument errors are decided before anything touches the
+    device, so they are checkable here"""
+    lib = _lib.load()
+    # memory_topk_f16r: workspace size, block count, null / misaligned / unsupported arguments
+    assert lib.ammc_codebook_f16_tiles_bytes(512, 8192) == 256 * 33 * 1024      # 256 tiles of (32 k-steps + 1 constants) KB
+    assert lib.ammc_codebook_f16_tiles_bytes(500, 8192) == 0 and lib.ammc_codebook_f16_tiles_bytes(512, 0) == 0
+    assert lib.ammc_memory_topk_f16r_blocks(0) == 0 and lib.ammc_memory_topk_f16r_blocks(262144) == 8192
+    assert lib.ammc_pack_codebook_f16_tiles(None, 512, 8192, None, None) == -1
+    assert lib.ammc_pack_codebook_f16_tiles(64, 500, 8192, 64, None) == -1       # d % 16
+    assert lib.ammc_pack_codebook_f16_tiles(64, 512, 8192, 72, None) == -1       # tiles not 16-byte aligned
+    args = [64, 64, 64, 1024, 512, 8192, 2, 64, 64, 64, 64, None]
+    assert lib.ammc_memory_topk_fwd_f16r(*([None] + args[1:])) == -1
+    for pos, val, want in ((3, 0, -1), (6, 0, -1), (6, 9000, -1), (4, 64, -2), (4, 1024, -2), (6, 5, -2), (0, 72, -1)):
+        bad = list(args)
+        bad[pos] = val
+        assert lib.ammc_memory_topk_fwd_f16r(*bad) == want, (pos, val)
+    # conv_first_s16_bs: batch-strided NCHW input
+    first = [64, 12 * 256 * 256, 16, 12, 256, 256, 64, None, None, 1, 64, 8, 8, 8, None, None]
+    assert lib.ammc_conv_first_s16_bs(*([None] + first[1:])) == -1
+    for pos, val, want in ((1, -1, -1), (3, 17, -2), (5, 250, -2), (9, 2, -2), (10, 72, -1), (11, 4, -1)):
+        bad = list(first)
+        bad[pos] = val
+        assert lib.ammc_conv_first_s16_bs(*bad) == want, (pos, val)
+    # weight-gradient slabs: no slab form -> 0 floats; the launch entry refuses null / short workspaces
+    d = _lib.AmmcWgradDesc()
+    assert lib.ammc_conv_wgrad_s16_slab_floats(None) == 0 and lib.ammc_conv_wgrad_s16_slab_floats(C.byref(d)) == 0
+    assert lib.ammc_conv_wgrad_s16_slabs(C.byref(d), None, None, 0, None, 64, 64, None) == -1
+    assert lib.ammc_scale_shift_act_s16_pool_supported(60, 256, 256, 258 * 64, 64, 258 * 64, 64, 64) == 0    # c % 8
+    assert lib.ammc_scale_shift_act_s16_pool_supported(64, 255, 256, 258 * 64, 64, 258 * 64, 64, 64) == 0   # odd height
+    assert lib.ammc_scale_shift_act_s16_pool_supported(64, 256, 256, 258 * 64, 64, 258 * 64, 64, 64) == 1
+    digests = lib.ammc_source_digests().decode()
+    assert "memory_topk_f16r.hip" in digests and "ammc_common.h" in digests
+
+
 def test_state_dict_schema_matches_reference():
     with open(os.path.join(GOLDEN, "param_counts.json")) as fp:
         pc = json.load(fp)

@@ -1,5 +1,12 @@
-"""The N>1 paths on CPU: world_size 2, gloo.  Covers the gradient reducer (bucketing, async
-all-reduce, in-place averaging), state broadcast and the batch sharding of inference."""
+"""The N>1 HOST LOGIC on CPU: world_size 2, gloo.
+
+What this tier proves: the gradient reducer's mechanics (bucketing, async all-reduce, in-place averaging, stage-fed
+buckets) on plain tensors and a toy torch module, state broadcast, the partition of whole batches over ranks, the
+statistics sync, and the scoping of the finite-vote collective to the data-parallel group.
+
+What it does NOT prove: a data-parallel step of the PRODUCT model - that needs the HIP library (there is no CPU path) and
+is covered on the GPU by tests/test_gpu_ddp.py (2 ranks sharing one GPU == the oracle on the whole batch; the RCCL
+world-of-one runs the real collectives) and tests/test_gpu_bench_ranks.py (bench.py's self-spawned ranks)."""
 import os
 import socket
 
