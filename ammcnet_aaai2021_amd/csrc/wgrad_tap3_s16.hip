@@ -30,6 +30,13 @@
 //   <4, 2, 1, 2> 128 x 64 channel tiles (N % 128 == 0)          <2, 2, 2, 2> 64 x 64, the two patch rows on different waves
 //   <1, 2, 4, 4> 32 gradient channels (the output layer)        <2, 1, 4, 4> Cin <= 32 (first layers, zero-padded block)
 // Needs W % 32 == 0, H % 2 == 0 (% 4 for the 4-row patches); wgrad_tap_s16_try falls back otherwise.
+//
+// ROLL (round 5, the two-row patches): a workgroup walks DOWN a 32-pixel column of the image and keeps the input halo
+// rows in a ring of four two-row groups - patch ty reads rows 2 ty - 1 .. 2 ty + 2 = groups ty and ty + 1, and while it is
+// contracted only group ty + 2 (two NEW rows) is fetched, not the four rows of the next patch's halo: 33 KB instead of
+// 51 KB of L2 -> LDS DMA per 64 x 64-channel patch, 49 instead of 67 KB per 128 x 64 one.  The kernel is fetch bound at
+// those sizes (a patch is 1.6 / 3.3 us of MFMAs: 8 / 5 TB/s summed over the chip).  A run of patches that crosses into
+// the next column loads that column's first two groups into the two free slots of the ring.
 #include "ammc_common.h"
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
@@ -50,6 +57,7 @@ struct WgradTap3Args {
   // launch at the memory side's ~1.3 TB/s for a <= 9.4-MB result, a memset of that buffer and an unpack launch)
   float* slabs;
   int query;                       // 1: launch nothing, return msplit * n * kpad (floats of slabs the launch would need)
+  int dbg;                         // AMMC_WGRAD_DBG (timing ablations, wrong results): 1 = no DMA inside the patch loop, 2 = no contraction, 4 = no epilogue
 };
 
 constexpr int W3_PW = 32, W3_HW = W3_PW + 2;                           // patch width, halo width
@@ -80,9 +88,10 @@ __device__ __forceinline__ f16x8u w3_frag(u32x2u a, u32x2u b) {
 // gradient, so a transposed A fragment - four of the 4.7 LDS reads a step costs - feeds six MFMAs instead of three:
 // 0.9 reads per MFMA instead of 1.4 (the kernel runs at 0.52 of the matrix pipe with its LDS reads at ~80 % of the MFMA
 // time).  288 accumulator registers per lane; the same 128 x 64 channel workgroup tile as <4, 2, 1, 2>.
-template <int NG, int NA, int NP, int PH, int GW = 1>
+template <int NG, int NA, int NP, int PH, int GW = 1, int ROLL = 0>
 __global__ __launch_bounds__(64 * NG * NA * NP, (GW == 2 ? 1 : 2)) void wgrad_tap3_s16_kernel(WgradTap3Args a) {
   static_assert((NG * NA * NP == 8 || (GW == 2 && NG * NA * NP == 4)) && (PH == 2 || PH == 4) && PH % NP == 0, "8 (4) waves");
+  static_assert(!ROLL || PH == 2, "the ring holds two-row groups");
   constexpr int W3_NT = 64 * NG * NA * NP;
   constexpr int W3_PH = PH, W3_PX = PH * W3_PW, W3_HPX = (PH + 2) * W3_HW, RPW = PH / NP;
   constexpr int W3_TN = 32 * NG * GW, W3_TC = 32 * NA;
@@ -92,6 +101,11 @@ __global__ __launch_bounds__(64 * NG * NA * NP, (GW == 2 ? 1 : 2)) void wgrad_ta
   constexpr int W3_AJ = (W3_HPX * W3_ASLOTS + W3_NT - 1) / W3_NT;        // (the last one partly padding)
   constexpr int W3_GSTAGE = W3_PX * W3_TN;                               // floats
   constexpr int W3_ASTAGE = W3_AJ * W3_NT * 4;                           // floats
+  // ROLL: a group = two halo rows = 68 pixels x TC channels, whole 64-piece wave instructions (68 ASLOTS % 64 == 0)
+  constexpr int W3_RPIECES = 2 * W3_HW * W3_ASLOTS;
+  constexpr int W3_RJ = (W3_RPIECES + W3_NT - 1) / W3_NT;                // DMA rounds of a group (the last: the first waves only)
+  constexpr int W3_AGRP = W3_RPIECES * 4;                                // floats
+  static_assert(!ROLL || W3_RPIECES % 64 == 0, "a group is whole wave instructions");
   static_assert(W3_PX * W3_GSLOTS % W3_NT == 0, "G pieces");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Gs = smem;                                             // [2][64 px][TN]
@@ -114,6 +128,7 @@ __global__ __launch_bounds__(64 * NG * NA * NP, (GW == 2 ? 1 : 2)) void wgrad_ta
   // DMA pieces: piece p -> image row p / SLOTS, physical slot p % SLOTS, which holds logical slot ps ^ swz(row)
   int g_off[W3_GJ], a_off[W3_AJ];
   bool a_pad[W3_AJ];                                            // this piece lies beyond the layer's input channels
+  int r_off[W3_RJ];                                             // ROLL: the pieces of a two-row group
 #pragma unroll
   for (int j = 0; j < W3_GJ; ++j) {
     const int p = j * W3_NT + tid;
@@ -128,6 +143,15 @@ __global__ __launch_bounds__(64 * NG * NA * NP, (GW == 2 ? 1 : 2)) void wgrad_ta
     const int hy = hp / W3_HW, hx = hp - hy * W3_HW;
     a_off[j] = (int)((int64_t)hy * d.a_rs + (int64_t)hx * d.a_ps) + c0 + 4 * ls;
     a_pad[j] = c0 + 4 * ls >= d.cin;                           // (slot = 4 elements: hi | lo halves of 8 channels per 2 slots)
+  }
+
+#pragma unroll
+  for (int j = 0; j < W3_RJ; ++j) {
+    int p = j * W3_NT + tid;
+    p = p < W3_RPIECES ? p : W3_RPIECES - 1;
+    const int hp = p / W3_ASLOTS, ls = (p % W3_ASLOTS) ^ w3_swz<W3_ARB>(hp & 3);     // (68 = 0 mod 4: the row's swizzle is the same in any group)
+    const int hy = hp / W3_HW, hx = hp - hy * W3_HW;
+    r_off[j] = (int)((int64_t)hy * d.a_rs + (int64_t)hx * d.a_ps) + c0 + 4 * ls;
   }
 
 #define W3_ISSUE(patch, stage)                                                                            \
@@ -148,6 +172,36 @@ __global__ __launch_bounds__(64 * NG * NA * NP, (GW == 2 ? 1 : 2)) void wgrad_ta
       const float* src_ = a_pad[j] ? d.zeros : ap_ + a_off[j];                                            \
       __builtin_amdgcn_global_load_lds(src_, adst_ + j * (W3_NT * 4), 16, 0, 0);                          \
     }                                                                                                     \
+  }
+
+  // ROLL: patches are numbered ty fastest (down a column), then tx, then the image
+#define W3_DECOMP(patch, b_, tx_, ty_)                                                                    \
+  int b_, tx_, ty_;                                                                                       \
+  {                                                                                                       \
+    int sp_ = (patch);                                                                                    \
+    ty_ = sp_ % a.tiles_y;                                                                                \
+    sp_ /= a.tiles_y;                                                                                     \
+    tx_ = sp_ % a.tiles_x, b_ = sp_ / a.tiles_x;                                                          \
+  }
+#define W3_ISSUE_G(b_, tx_, ty_, stage)                                                                   \
+  {                                                                                                       \
+    const float* gp_ = d.g + ((int64_t)(b_) * d.g_bs + (int64_t)((ty_) * W3_PH) * d.g_rs + (int64_t)((tx_) * W3_PW) * d.g_ps); \
+    float* gdst_ = Gs + (stage) * W3_GSTAGE + wave * 256;                                                 \
+    _Pragma("unroll") for (int j = 0; j < W3_GJ; ++j) {                                                   \
+      const float* src_ = gp_ + g_off[j];                                                                 \
+      __builtin_amdgcn_global_load_lds(src_, gdst_ + j * (W3_NT * 4), 16, 0, 0);                          \
+    }                                                                                                     \
+  }
+  // group `grp` of a column = halo rows 2 grp, 2 grp + 1 (image rows 2 grp - 1, 2 grp); the last round: the waves it has pieces for
+#define W3_ISSUE_GRP(b_, tx_, grp_, slot_)                                                                \
+  {                                                                                                       \
+    const float* ap_ = d.a + ((int64_t)(b_) * d.a_bs + (int64_t)((grp_) * 2) * d.a_rs + (int64_t)((tx_) * W3_PW) * d.a_ps); \
+    float* adst_ = As + (slot_) * W3_AGRP + wave * 256;                                                   \
+    _Pragma("unroll") for (int j = 0; j < W3_RJ; ++j)                                                     \
+      if (j * W3_NT + wave * 64 < W3_RPIECES) {                                                           \
+        const float* src_ = ap_ + r_off[j];                                                               \
+        __builtin_amdgcn_global_load_lds(src_, adst_ + j * (W3_NT * 4), 16, 0, 0);                        \
+      }                                                                                                   \
   }
 
   f32x16 acc[GW][9];
@@ -204,10 +258,12 @@ __global__ __launch_bounds__(64 * NG * NA * NP, (GW == 2 ? 1 : 2)) void wgrad_ta
 #define W3_AREAD(Y0, U, S)                                                                                    \
   {                                                                                                           \
     constexpr int y_ = (Y0) + (U) / 18, xh_ = ((U) / 9) & 1, t_ = (U) % 9;                                    \
-    constexpr int off_ = ((y_ + t_ / 3) * W3_HW + t_ % 3 + 16 * xh_) * W3_ARB;                                \
-    constexpr int k_ = (2 * (y_ + t_ / 3) + t_ % 3) & 3;                                                      \
+    constexpr int hr_ = y_ + t_ / 3;                          /* halo row; ROLL: rows 2, 3 live in the next group */ \
+    constexpr int off_ = ((ROLL ? (hr_ & 1) : hr_) * W3_HW + t_ % 3 + 16 * xh_) * W3_ARB;                     \
+    constexpr int k_ = (2 * hr_ + t_ % 3) & 3;                                                                \
     static_assert(off_ + 12 * W3_ARB < 65536, "ds offset");                                                   \
-    const uint32_t a1_ = abase + a_sw_x1[k_], a2_ = abase + a_sw_x2[k_];                                      \
+    const uint32_t ab_ = (ROLL && hr_ >= 2) ? abase_hi : abase;                                               \
+    const uint32_t a1_ = ab_ + a_sw_x1[k_], a2_ = ab_ + a_sw_x2[k_];                                          \
     ar[S][0] = w3_read_tr16<off_>(a1_);                                                                       \
     ar[S][1] = w3_read_tr16<off_ + 4 * W3_ARB>(a1_);                                                          \
     ar[S][2] = w3_read_tr16<off_ + 8 * W3_ARB>(a2_);                                                          \
@@ -265,28 +321,58 @@ __global__ __launch_bounds__(64 * NG * NA * NP, (GW == 2 ? 1 : 2)) void wgrad_ta
   constexpr int NH = 2 * RPW, NU = 18 * RPW;
   static_assert(RPW == 1 || RPW == 2, "rows per wave");
 
-  W3_ISSUE(p_begin, 0);
+  int ring = 0;                                                 // ROLL: the slot of the current patch's first group
+  if (ROLL) {
+    W3_DECOMP(p_begin, b0, tx0, ty0)
+    W3_ISSUE_G(b0, tx0, ty0, 0)
+    W3_ISSUE_GRP(b0, tx0, ty0, 0)
+    W3_ISSUE_GRP(b0, tx0, ty0 + 1, 1)
+  } else {
+    W3_ISSUE(p_begin, 0);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int pt = p_begin; pt < p_end; ++pt) {
     const int stage = (pt - p_begin) & 1;
-    if (pt + 1 < p_end) W3_ISSUE(pt + 1, stage ^ 1);
+    int adv = 1;
+    if (pt + 1 < p_end && !(a.dbg & 1)) {
+      if (ROLL) {
+        W3_DECOMP(pt + 1, b1, tx1, ty1)
+        W3_ISSUE_G(b1, tx1, ty1, stage ^ 1)
+        if (ty1 != 0) {                                  // the same column: two new rows
+          W3_ISSUE_GRP(b1, tx1, ty1 + 1, (ring + 2) & 3)
+        } else {                                         // the next column starts: its first two groups, into the two free slots
+          W3_ISSUE_GRP(b1, tx1, 0, (ring + 2) & 3)
+          W3_ISSUE_GRP(b1, tx1, 1, (ring + 3) & 3)
+          adv = 2;
+        }
+      } else {
+        W3_ISSUE(pt + 1, stage ^ 1);
+      }
+    }
     const uint32_t gst = g_base + (uint32_t)(stage * W3_GSTAGE * 4);
-    const uint32_t abase = a_base + (uint32_t)(stage * W3_ASTAGE * 4) + a_lane;
+    const uint32_t abase = a_base + (uint32_t)((ROLL ? ring * W3_AGRP : stage * W3_ASTAGE) * 4) + a_lane;
+    const uint32_t abase_hi = a_base + (uint32_t)((((ring + 1) & 3) * W3_AGRP) * 4) + a_lane;
     uint32_t ghi[GW], g1[GW], g2[GW];
 #pragma unroll
     for (int b = 0; b < GW; ++b) { ghi[b] = gst + g_lane_hi[b]; g1[b] = gst + g_lane_x1[b]; g2[b] = gst + g_lane_x2[b]; }
-    if (0 == wp) { W3_SEQ(0) }                           // (uniform per wave; the rows are literals in the offsets)
-    if (NP >= 2 && 1 == wp) { W3_SEQ((NP >= 2 ? RPW : 0)) }
-    if (NP == 4) {
-      if (2 == wp) { W3_SEQ((NP == 4 ? 2 * RPW : 0)) }
-      if (3 == wp) { W3_SEQ((NP == 4 ? 3 * RPW : 0)) }
+    if (!(a.dbg & 2)) {
+      if (0 == wp) { W3_SEQ(0) }                         // (uniform per wave; the rows are literals in the offsets)
+      if (NP >= 2 && 1 == wp) { W3_SEQ((NP >= 2 ? RPW : 0)) }
+      if (NP == 4) {
+        if (2 == wp) { W3_SEQ((NP == 4 ? 2 * RPW : 0)) }
+        if (3 == wp) { W3_SEQ((NP == 4 ? 3 * RPW : 0)) }
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    ring = (ring + adv) & 3;
   }
 #undef W3_ISSUE
+#undef W3_ISSUE_G
+#undef W3_ISSUE_GRP
+#undef W3_DECOMP
 #undef W3_AREAD
 #undef W3_GREAD
 #undef W3_STEP
@@ -294,6 +380,7 @@ __global__ __launch_bounds__(64 * NG * NA * NP, (GW == 2 ? 1 : 2)) void wgrad_ta
 #undef W3_SEQ
 
   // ---- add to the packed gradient: row = gradient channel (registers), column = tap * Cin + c (lanes) -------------
+  if (a.dbg & 4) return;
   const float inv = a.g_inv_scale ? a.g_inv_scale[0] : 1.f;
   const int c = c0 + 32 * wa + l31;
 #pragma unroll
@@ -313,14 +400,14 @@ __global__ __launch_bounds__(64 * NG * NA * NP, (GW == 2 ? 1 : 2)) void wgrad_ta
     }
 }
 
-template <int NG, int NA, int NP, int PH, int GW = 1>
+template <int NG, int NA, int NP, int PH, int GW = 1, int ROLL = 0>
 static int launch_wgrad_tap3(WgradTap3Args a, hipStream_t stream) {
   constexpr int W3_NT = 64 * NG * NA * NP;
   constexpr int TN = 32 * NG * GW, TC = 32 * NA;
   constexpr int AJ = ((PH + 2) * W3_HW * (TC / 4) + W3_NT - 1) / W3_NT;
-  constexpr size_t lds = (size_t)(2 * PH * W3_PW * TN + 2 * AJ * W3_NT * 4) * sizeof(float);
+  constexpr size_t lds = (size_t)(2 * PH * W3_PW * TN + (ROLL ? 4 * 2 * W3_HW * TC : 2 * AJ * W3_NT * 4)) * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = wgrad_tap3_s16_kernel<NG, NA, NP, PH, GW>;
+  auto kern = wgrad_tap3_s16_kernel<NG, NA, NP, PH, GW, ROLL>;
   if (!a.query) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
@@ -353,14 +440,18 @@ int wgrad_tap3_s16_try(const AmmcWgradDesc& d, const float* g_inv_scale, int kpa
   a.g_inv_scale = g_inv_scale;
   a.kpad = kpad;
   a.slabs = slabs, a.query = query;
+  static const int dbg = getenv("AMMC_WGRAD_DBG") ? atoi(getenv("AMMC_WGRAD_DBG")) : 0;
+  a.dbg = dbg;
   a.tiles_x = d.width / W3_PW;
   a.tiles_y = a.npatch = 0;                                       // set by the launcher (patch height)
   if (d.cin % 64 == 0) {
     // AMMC_WGRAD_GW: 2 = the four-wave form with two gradient blocks per wave (A/B; round 4)
     static const int gw = getenv("AMMC_WGRAD_GW") ? atoi(getenv("AMMC_WGRAD_GW")) : 1;
+    // AMMC_WGRAD_ROLL=0: every patch fetches its own four halo rows (the form before round 5; A/B)
+    static const int roll = getenv("AMMC_WGRAD_ROLL") ? atoi(getenv("AMMC_WGRAD_ROLL")) : 1;
     if (d.n % 128 == 0 && gw == 2) return launch_wgrad_tap3<2, 2, 1, 2, 2>(a, stream);
-    if (d.n % 128 == 0) return launch_wgrad_tap3<4, 2, 1, 2>(a, stream);
-    if (d.n % 64 == 0) return launch_wgrad_tap3<2, 2, 2, 2>(a, stream);
+    if (d.n % 128 == 0) return roll ? launch_wgrad_tap3<4, 2, 1, 2, 1, 1>(a, stream) : launch_wgrad_tap3<4, 2, 1, 2>(a, stream);
+    if (d.n % 64 == 0) return roll ? launch_wgrad_tap3<2, 2, 2, 2, 1, 1>(a, stream) : launch_wgrad_tap3<2, 2, 2, 2>(a, stream);
     if (d.n == 32 && d.height % 4 == 0) return launch_wgrad_tap3<1, 2, 4, 4>(a, stream);    // the output layer
     return -12345;
   }
@@ -369,29 +460,41 @@ int wgrad_tap3_s16_try(const AmmcWgradDesc& d, const float* g_inv_scale, int kpa
   return -12345;
 }
 
-// slabs [msplit][n][kpad] (k = tap * cin_p + c) -> OIHW [cout][cin][3][3]: one thread per output element sums its
-// `msplit` partial values in a fixed order (deterministic, unlike the atomics it replaces)
-__global__ __launch_bounds__(256) void reduce_unpack_wgrad_kernel(const float* __restrict__ slabs, int msplit, int n, int kpad,
-                                                                  int cout, int cin, int cin_p, float* __restrict__ out) {
+// slabs [msplit][n][kpad] (k = tap * cin_p + c) -> OIHW [cout][cin][3][3]: 64 consecutive elements of the packed row x
+// RU_G slab groups per workgroup; thread (e, g) sums the slabs m = g, g + RU_G, ... of element e with eight loads in
+// flight, the groups are added through LDS in a fixed order (deterministic, unlike the atomics it replaces).
+// (One thread per element walking all slabs - the first form - left the 64 -> 64 layers with 144 workgroups of serial
+// 512-deep chains: 75 MB in 31 us.)
+constexpr int RU_G = 4;
+__global__ __launch_bounds__(64 * RU_G) void reduce_unpack_wgrad_kernel(const float* __restrict__ slabs, int msplit, int n, int kpad,
+                                                                       int cout, int cin, int cin_p, float* __restrict__ out) {
+  __shared__ float part[RU_G][64];
   const int64_t total = (int64_t)cout * cin * 9;
-  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= total) return;
-  // threads of a warp walk the PACKED row (coalesced reads of every slab); the OIHW element is computed from it
-  const int o = (int)(gid / ((int64_t)cin * 9));
-  const int k = (int)(gid - (int64_t)o * cin * 9);              // k = tap * cin + c over the TRUE channels
+  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t gid = (int64_t)blockIdx.x * 64 + e;
+  const bool live = gid < total;
+  // threads of a wave walk the PACKED row (coalesced reads of every slab); the OIHW element is computed from it
+  const int64_t gi = live ? gid : 0;
+  const int o = (int)(gi / ((int64_t)cin * 9));
+  const int k = (int)(gi - (int64_t)o * cin * 9);               // k = tap * cin + c over the TRUE channels
   const int tap = k / cin, c = k - tap * cin;
-  const float* p = slabs + (int64_t)o * kpad + tap * cin_p + c;
   const int64_t stride = (int64_t)n * kpad;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int m = 0;
-  for (; m + 4 <= msplit; m += 4) {
-    s0 += p[(int64_t)m * stride];
-    s1 += p[(int64_t)(m + 1) * stride];
-    s2 += p[(int64_t)(m + 2) * stride];
-    s3 += p[(int64_t)(m + 3) * stride];
+  const float* p = slabs + (int64_t)o * kpad + tap * cin_p + c + g * stride;
+  const int64_t step = RU_G * stride;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int m = g;
+  for (; m + 7 * RU_G < msplit; m += 8 * RU_G) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] += p[(int64_t)u * step];
+    p += 8 * step;
   }
-  for (; m < msplit; ++m) s0 += p[(int64_t)m * stride];
-  out[((int64_t)o * cin + c) * 9 + tap] = (s0 + s1) + (s2 + s3);
+  for (; m < msplit; m += RU_G) {
+    s[0] += *p;
+    p += step;
+  }
+  part[g][e] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  __syncthreads();
+  if (g == 0 && live) out[((int64_t)o * cin + c) * 9 + tap] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
 }
 
 }  // namespace ammc_s16
@@ -421,7 +524,7 @@ extern "C" int ammc_conv_wgrad_s16_slabs(const AmmcWgradDesc* desc, const float*
   const int rc = wgrad_tap3_s16_try(d, g_inv_scale, kpad, (hipStream_t)stream, slabs, 0);
   if (rc != AMMC_OK) return rc == -12345 ? AMMC_EUNSUP : rc;
   const int64_t total = (int64_t)cout * cin * 9;
-  hipLaunchKernelGGL(reduce_unpack_wgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(reduce_unpack_wgrad_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64 * RU_G), 0, (hipStream_t)stream,
                      slabs, msplit, d.n, kpad, cout, cin, d.cin, dw_oihw);
   return ammc_launch_status();
 }

@@ -565,7 +565,8 @@ def run_train(args, rank, world, dev, dist, steps, warmup, with_cpu):
     vote, group = harness._watch_group(net)
     watch = harness._FiniteWatch(loss, group=group, vote=vote)
     loss.backward()
-    parity = train_parity(net, out, loss, fixture, with_grads=world == 1) if fixture else None
+    # (--no-secondary = a profiling pass: the fp64 oracle would run under the counters, tens of minutes of serialised launches)
+    parity = train_parity(net, out, loss, fixture, with_grads=world == 1 and not args.no_secondary) if fixture else None
     watch.step(opt)
     state["loss"] = loss.detach()
     del out, loss

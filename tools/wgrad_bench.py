@@ -33,15 +33,23 @@ d.g, d.a, d.dw, d.zeros = G16.pix0(), A16.tap0(), _ptr(dwp), _ptr(zeros)
 d.batch, d.height, d.width, d.n, d.cin, d.ntaps, d.a_step = B, H, W, n, cin, 9, 1
 d.g_bs, d.g_rs, d.g_ps = G16.strides
 d.a_bs, d.a_rs, d.a_ps = A16.strides
+# the training path's form (train.py: _Ops.wgrad_s16): partials as slabs + the fixed-order reduce into OIHW; WGRAD_SLABS=0: atomics
+need = int(lib.ammc_conv_wgrad_s16_slab_floats(C.byref(d))) if os.environ.get("WGRAD_SLABS", "1") != "0" else 0
+if need:
+    slabs = torch.empty(need, device=dev)
+    out = torch.empty(n, cin, 3, 3, device=dev)
+    call = lambda: lib.ammc_conv_wgrad_s16_slabs(C.byref(d), None, _ptr(slabs), need, _ptr(out), n, cin, s)
+else:
+    call = lambda: lib.ammc_conv_wgrad_s16(C.byref(d), None, s)
 for _ in range(3):
-    _lib.check(lib.ammc_conv_wgrad_s16(C.byref(d), None, s), "wgrad")
+    _lib.check(call(), "wgrad")
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(reps):
-    lib.ammc_conv_wgrad_s16(C.byref(d), None, s)
+    call()
 e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / reps
 fl = 2.0 * B * H * W * n * cin * 9
-print(f"B={B} {H}x{W} {cin}->{n}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF algorithmic  ({3 * fl / us / 1e6 / 2500 * 100:.1f}% of the f16 MFMA issue peak with 3 MFMAs)")
+print(f"B={B} {H}x{W} {cin}->{n} ({'slabs + reduce' if need else 'atomics'}): {us:8.1f} us  {fl / us / 1e6:7.1f} TF algorithmic  ({3 * fl / us / 1e6 / 2500 * 100:.1f}% of the f16 MFMA issue peak with 3 MFMAs)")
