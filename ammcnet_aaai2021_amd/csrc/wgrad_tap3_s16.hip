@@ -37,6 +37,13 @@
 // 51 KB of L2 -> LDS DMA per 64 x 64-channel patch, 49 instead of 67 KB per 128 x 64 one.  The kernel is fetch bound at
 // those sizes (a patch is 1.6 / 3.3 us of MFMAs: 8 / 5 TB/s summed over the chip).  A run of patches that crosses into
 // the next column loads that column's first two groups into the two free slots of the ring.
+//
+// Measured and removed again (round 5, profiles/r05_wgrad_af_ab.txt; the code is in the history): the three taps of a
+// filter row sharing SIX transposed reads (tap 1 = a 16-bit funnel shift of tap 0's registers, tap 2 = the same
+// registers one further) instead of twelve - bit-identical results, 43 % fewer LDS read instructions, the same time
+// within 1 % on every layer shape: the LDS read port is not what the kernel waits for.  Its matrix pipe is 0.65 busy in
+// CYCLES (PMC) at a clock the power cap holds near 1.7 GHz; the rest is the per-patch `vmcnt(0)` + barrier and the
+// epilogue (AMMC_WGRAD_DBG ablations).
 #include "ammc_common.h"
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
@@ -80,25 +87,6 @@ __device__ __forceinline__ f16x8u w3_frag(u32x2u a, u32x2u b) {
   return __builtin_bit_cast(f16x8u, v);
 }
 
-// AF = 1: the three taps of one filter row share their reads.  A lane's fragment of tap s is eight consecutive pixels
-// starting at pixel s of the window, two per register: tap 1 is a 16-bit funnel shift of taps 0's registers and the next
-// one (v_alignbit_b32), tap 2 the same registers one further - so a filter row costs SIX transposed reads (pixels 0-11 of
-// one plane, 8-19 of the other) instead of twelve, and a half-row 18 + 6 instead of 36 + 6: the LDS read port is what this
-// kernel runs against.
-__device__ __forceinline__ f16x8u w3_frag_s1(u32x2u a, u32x2u b, u32x2u c) {
-  u32x4u v;
-  v[0] = __builtin_amdgcn_alignbit(a[1], a[0], 16);
-  v[1] = __builtin_amdgcn_alignbit(b[0], a[1], 16);
-  v[2] = __builtin_amdgcn_alignbit(b[1], b[0], 16);
-  v[3] = __builtin_amdgcn_alignbit(c[0], b[1], 16);
-  return __builtin_bit_cast(f16x8u, v);
-}
-__device__ __forceinline__ f16x8u w3_frag_s2(u32x2u a, u32x2u b, u32x2u c) {
-  u32x4u v;
-  v[0] = a[1]; v[1] = b[0]; v[2] = b[1]; v[3] = c[0];
-  return __builtin_bit_cast(f16x8u, v);
-}
-
 // NG x NA x NP = 8 waves: NG 32-channel blocks of the gradient, NA of the input, NP groups of image rows of the PH-row
 // patch (waves of different groups add their parts to the same outputs).  PH = 4 with one row per wave serves the thin
 // operands: 32 gradient channels (the output layer) or 16 / 8 input channels (the first layers; channels beyond Cin
@@ -107,7 +95,7 @@ __device__ __forceinline__ f16x8u w3_frag_s2(u32x2u a, u32x2u b, u32x2u c) {
 // gradient, so a transposed A fragment - four of the 4.7 LDS reads a step costs - feeds six MFMAs instead of three:
 // 0.9 reads per MFMA instead of 1.4 (the kernel runs at 0.52 of the matrix pipe with its LDS reads at ~80 % of the MFMA
 // time).  288 accumulator registers per lane; the same 128 x 64 channel workgroup tile as <4, 2, 1, 2>.
-template <int NG, int NA, int NP, int PH, int GW = 1, int ROLL = 0, int AF = 0>
+template <int NG, int NA, int NP, int PH, int GW = 1, int ROLL = 0>
 __global__ __launch_bounds__(64 * NG * NA * NP, (GW == 2 ? 1 : 2)) void wgrad_tap3_s16_kernel(WgradTap3Args a) {
   static_assert((NG * NA * NP == 8 || (GW == 2 && NG * NA * NP == 4)) && (PH == 2 || PH == 4) && PH % NP == 0, "8 (4) waves");
   static_assert(!ROLL || PH == 2, "the ring holds two-row groups");
@@ -273,7 +261,6 @@ __global__ __launch_bounds__(64 * NG * NA * NP, (GW == 2 ? 1 : 2)) void wgrad_ta
   // everything issued up to A(U) and tolerates what was issued after it.  Issue order around a boundary:
   //   ... A(t7) [step t5, before its wait], G(next) [step t5, after it], A(t8) [t6], A(next t0) [t7], A(next t1) [t8] ...
   u32x2u ar[3][4], graw[GW][2][6];
-  u32x2u ag[2][6];                                              // AF: [set][plane 1: px 0-3, 4-7, 8-11 | plane 2: px 8-11, 12-15, 16-19]
   f16x8u gf_hi[GW], gf_x1[GW], gf_x2[GW];
 #define W3_AREAD(Y0, U, S)                                                                                    \
   {                                                                                                           \
@@ -338,67 +325,7 @@ __global__ __launch_bounds__(64 * NG * NA * NP, (GW == 2 ? 1 : 2)) void wgrad_ta
     W3_STEP9(Y0, 0) W3_STEP9(Y0, 9)                                                                           \
     if (RPW == 2) { W3_STEP9(Y0, (RPW == 2 ? 18 : 0)) W3_STEP9(Y0, (RPW == 2 ? 27 : 9)) }                     \
   }
-  // ---- AF: a group = one filter row of one half-row (three taps, six reads, nine MFMAs per gradient block) ----------
-#define W3_AGREAD(Y0, G, S)                                                                                   \
-  {                                                                                                           \
-    constexpr int y_ = (Y0) + (G) / 6, xh_ = ((G) / 3) & 1, hr_ = y_ + (G) % 3;                               \
-    constexpr int off_ = ((ROLL ? (hr_ & 1) : hr_) * W3_HW + 16 * xh_) * W3_ARB;                              \
-    constexpr int k_ = (2 * hr_) & 3;                                                                         \
-    static_assert(off_ + 16 * W3_ARB < 65536, "ds offset");                                                   \
-    const uint32_t ab_ = (ROLL && hr_ >= 2) ? abase_hi : abase;                                               \
-    const uint32_t a1_ = ab_ + a_sw_x1[k_], a2_ = ab_ + a_sw_x2[k_];                                          \
-    ag[S][0] = w3_read_tr16<off_>(a1_);                                                                       \
-    ag[S][1] = w3_read_tr16<off_ + 4 * W3_ARB>(a1_);                                                          \
-    ag[S][2] = w3_read_tr16<off_ + 8 * W3_ARB>(a1_);                                                          \
-    ag[S][3] = w3_read_tr16<off_ + 8 * W3_ARB>(a2_);                                                          \
-    ag[S][4] = w3_read_tr16<off_ + 12 * W3_ARB>(a2_);                                                         \
-    ag[S][5] = w3_read_tr16<off_ + 16 * W3_ARB>(a2_);                                                         \
-  }
-#define W3_TAP3(T, AX1, AX2)                                                                                  \
-  {                                                                                                           \
-    const f16x8u ax1_ = (AX1), ax2_ = (AX2);                                                                  \
-    const f16x8u ahi_ = upper ? ax2_ : ax1_;                                                                  \
-    _Pragma("unroll") for (int b_ = 0; b_ < GW; ++b_)                                                         \
-      acc[b_][T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf_hi[b_], ahi_, acc[b_][T], 0, 0, 0);              \
-    _Pragma("unroll") for (int b_ = 0; b_ < GW; ++b_)                                                         \
-      acc[b_][T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf_x1[b_], ax1_, acc[b_][T], 0, 0, 0);              \
-    _Pragma("unroll") for (int b_ = 0; b_ < GW; ++b_)                                                         \
-      acc[b_][T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf_x2[b_], ax2_, acc[b_][T], 0, 0, 0);              \
-  }
-  // waits are counted as in W3_STEP: group G needs everything issued up to A(G); issued after it: A(G + 1) (at the top
-  // of this group) and, in the last group of a half-row, the G reads of the next half-row (issued in the middle group,
-  // behind its wait)
-#define W3_GSTEP(Y0, G)                                                                                       \
-  {                                                                                                           \
-    constexpr int r_ = (G) % 3, hh_ = (G) / 3, S_ = (G) & 1;                                                  \
-    constexpr bool nxt_ = hh_ + 1 < NH;                                                                       \
-    if ((G) + 1 < NGR) W3_AGREAD(Y0, ((G) + 1 < NGR ? (G) + 1 : 0), (((G) + 1) & 1))                          \
-    constexpr int cnt_ = ((G) + 1 < NGR ? 6 : 0) + ((r_ == 2 && nxt_) ? 6 * GW : 0);                          \
-    __builtin_amdgcn_s_waitcnt(0xC07F | ((cnt_ < 15 ? cnt_ : 15) << 8));                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                                        \
-    if (r_ == 0) {                                                                                            \
-      _Pragma("unroll") for (int b_ = 0; b_ < GW; ++b_) {                                                     \
-        gf_hi[b_] = w3_frag(graw[b_][hh_ & 1][0], graw[b_][hh_ & 1][1]);                                      \
-        gf_x1[b_] = w3_frag(graw[b_][hh_ & 1][2], graw[b_][hh_ & 1][3]) * cg;                                 \
-        gf_x2[b_] = w3_frag(graw[b_][hh_ & 1][4], graw[b_][hh_ & 1][5]) * cg;                                 \
-      }                                                                                                       \
-    }                                                                                                         \
-    if (r_ == 1 && nxt_) W3_GREAD(Y0, (nxt_ ? hh_ + 1 : 0), ((hh_ + 1) & 1))                                  \
-    W3_TAP3(3 * r_ + 0, w3_frag(ag[S_][0], ag[S_][1]), w3_frag(ag[S_][3], ag[S_][4]))                         \
-    W3_TAP3(3 * r_ + 1, w3_frag_s1(ag[S_][0], ag[S_][1], ag[S_][2]), w3_frag_s1(ag[S_][3], ag[S_][4], ag[S_][5])) \
-    W3_TAP3(3 * r_ + 2, w3_frag_s2(ag[S_][0], ag[S_][1], ag[S_][2]), w3_frag_s2(ag[S_][3], ag[S_][4], ag[S_][5])) \
-    __builtin_amdgcn_sched_barrier(0);                                                                        \
-  }
-#define W3_GSTEP6(Y0, G) W3_GSTEP(Y0, G) W3_GSTEP(Y0, (G) + 1) W3_GSTEP(Y0, (G) + 2) W3_GSTEP(Y0, (G) + 3)    \
-  W3_GSTEP(Y0, (G) + 4) W3_GSTEP(Y0, (G) + 5)
-#define W3_SEQ_AF(Y0)                                                                                         \
-  {                                                                                                           \
-    W3_GREAD(Y0, 0, 0)                                                                                        \
-    W3_AGREAD(Y0, 0, 0)                                                                                       \
-    W3_GSTEP6(Y0, 0)                                                                                          \
-    if (RPW == 2) { W3_GSTEP6(Y0, (RPW == 2 ? 6 : 0)) }                                                       \
-  }
-  constexpr int NH = 2 * RPW, NU = 18 * RPW, NGR = 6 * RPW;
+  constexpr int NH = 2 * RPW, NU = 18 * RPW;
   static_assert(RPW == 1 || RPW == 2, "rows per wave");
 
   int ring = 0;                                                 // ROLL: the slot of the current patch's first group
@@ -438,14 +365,12 @@ __global__ __launch_bounds__(64 * NG * NA * NP, (GW == 2 ? 1 : 2)) void wgrad_ta
 #pragma unroll
     for (int b = 0; b < GW; ++b) { ghi[b] = gst + g_lane_hi[b]; g1[b] = gst + g_lane_x1[b]; g2[b] = gst + g_lane_x2[b]; }
     if (!(a.dbg & 2)) {
-#define W3_ROWS(Y0) { if (AF) W3_SEQ_AF(Y0) else W3_SEQ(Y0) }
-      if (0 == wp) { W3_ROWS(0) }                        // (uniform per wave; the rows are literals in the offsets)
-      if (NP >= 2 && 1 == wp) { W3_ROWS((NP >= 2 ? RPW : 0)) }
+      if (0 == wp) { W3_SEQ(0) }                         // (uniform per wave; the rows are literals in the offsets)
+      if (NP >= 2 && 1 == wp) { W3_SEQ((NP >= 2 ? RPW : 0)) }
       if (NP == 4) {
-        if (2 == wp) { W3_ROWS((NP == 4 ? 2 * RPW : 0)) }
-        if (3 == wp) { W3_ROWS((NP == 4 ? 3 * RPW : 0)) }
+        if (2 == wp) { W3_SEQ((NP == 4 ? 2 * RPW : 0)) }
+        if (3 == wp) { W3_SEQ((NP == 4 ? 3 * RPW : 0)) }
       }
-#undef W3_ROWS
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -460,11 +385,6 @@ __global__ __launch_bounds__(64 * NG * NA * NP, (GW == 2 ? 1 : 2)) void wgrad_ta
 #undef W3_STEP
 #undef W3_STEP9
 #undef W3_SEQ
-#undef W3_SEQ_AF
-#undef W3_GSTEP6
-#undef W3_GSTEP
-#undef W3_TAP3
-#undef W3_AGREAD
 
   // ---- add to the packed gradient: row = gradient channel (registers), column = tap * Cin + c (lanes) -------------
   if (a.dbg & 4) return;
@@ -487,15 +407,14 @@ __global__ __launch_bounds__(64 * NG * NA * NP, (GW == 2 ? 1 : 2)) void wgrad_ta
     }
 }
 
-template <int NG, int NA, int NP, int PH, int GW = 1, int ROLL = 0, int AF = 0>
+template <int NG, int NA, int NP, int PH, int GW = 1, int ROLL = 0>
 static int launch_wgrad_tap3(WgradTap3Args a, hipStream_t stream) {
   constexpr int W3_NT = 64 * NG * NA * NP;
   constexpr int TN = 32 * NG * GW, TC = 32 * NA;
   constexpr int AJ = ((PH + 2) * W3_HW * (TC / 4) + W3_NT - 1) / W3_NT;
-  // (+ 2 pixel rows: the last read of a filter row's second plane covers pixels 16-19 of a 34-pixel halo row)
-  constexpr size_t lds = (size_t)(2 * PH * W3_PW * TN + (ROLL ? 4 * 2 * W3_HW * TC : 2 * AJ * W3_NT * 4) + (AF ? 2 * TC : 0)) * sizeof(float);
+  constexpr size_t lds = (size_t)(2 * PH * W3_PW * TN + (ROLL ? 4 * 2 * W3_HW * TC : 2 * AJ * W3_NT * 4)) * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = wgrad_tap3_s16_kernel<NG, NA, NP, PH, GW, ROLL, AF>;
+  auto kern = wgrad_tap3_s16_kernel<NG, NA, NP, PH, GW, ROLL>;
   if (!a.query) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
@@ -538,10 +457,6 @@ int wgrad_tap3_s16_try(const AmmcWgradDesc& d, const float* g_inv_scale, int kpa
     // AMMC_WGRAD_ROLL=0: every patch fetches its own four halo rows (the form before round 5; A/B)
     static const int roll = getenv("AMMC_WGRAD_ROLL") ? atoi(getenv("AMMC_WGRAD_ROLL")) : 1;
     if (d.n % 128 == 0 && gw == 2) return launch_wgrad_tap3<2, 2, 1, 2, 2>(a, stream);
-    // AMMC_WGRAD_AF=0: four transposed reads per tap (the form before the shared filter-row reads; A/B)
-    static const int af = getenv("AMMC_WGRAD_AF") ? atoi(getenv("AMMC_WGRAD_AF")) : 1;
-    if (d.n % 128 == 0 && roll && af) return launch_wgrad_tap3<4, 2, 1, 2, 1, 1, 1>(a, stream);
-    if (d.n % 64 == 0 && roll && af) return launch_wgrad_tap3<2, 2, 2, 2, 1, 1, 1>(a, stream);
     if (d.n % 128 == 0) return roll ? launch_wgrad_tap3<4, 2, 1, 2, 1, 1>(a, stream) : launch_wgrad_tap3<4, 2, 1, 2>(a, stream);
     if (d.n % 64 == 0) return roll ? launch_wgrad_tap3<2, 2, 2, 2, 1, 1>(a, stream) : launch_wgrad_tap3<2, 2, 2, 2>(a, stream);
     if (d.n == 32 && d.height % 4 == 0) return launch_wgrad_tap3<1, 2, 4, 4>(a, stream);    // the output layer
