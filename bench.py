@@ -606,10 +606,12 @@ def run_train(args, rank, world, dev, dist, steps, warmup, with_cpu):
             peak = PEAK_F16_MFMA_TFLOPS if s16 else PEAK_F32_MFMA_TFLOPS
             ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
             traffic, tsrc = train_traffic(name, batch, args.size)
+            busy, busy_src = pmc_busy(name, "train") if (batch, args.size, s16) == (32, 256, True) else (None, None)
             roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc,
                     "mfma_issue_frac": round((3.0 if s16 else 1.0) * ach / peak, 4),
                     "power_ceiling": power_ceiling("wgrad_tap3_s16", 3.0 * ach) if s16 else None,
+                    "mfma_busy_frac": busy, "mfma_busy_source": busy_src,
                     "flops_per_launch": f["flops"] / f["launches"], "avg_launch_us": round(1e3 * f["ms"] / f["launches"], 2),
                     "launches_per_step": f["launches"], "share_of_step": round(f["ms"] / (1e3 * elapsed / steps), 4)}
     if rank != 0:

@@ -86,3 +86,16 @@ def test_wgrad_s16_vs_fp64(B, H, W, cin, n, gmag):
         assert err_s <= 3e-6, err_s
         assert float((outs[0] - dw).abs().max()) <= 2e-6 * float(dw.abs().max())
         assert lib.ammc_conv_wgrad_s16_slabs(C.byref(d), _ptr(inv), _ptr(slabs), need - 1, _ptr(dws), n, cin, s) == -1   # AMMC_EINVAL
+
+
+def test_per_patch_halo_form_still_passes():
+    """`AMMC_WGRAD_ROLL=0` (the A/B switch of the rolling input halo, read once per process): the per-patch halo form of the
+    same kernels against the same fp64 references, in a child process"""
+    import os
+    import subprocess
+    import sys
+    if "AMMC_WGRAD_ROLL" in os.environ:
+        pytest.skip("already inside a run with the switch set")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_wgrad_s16_vs_fp64"],
+                       env=dict(os.environ, AMMC_WGRAD_ROLL="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
