@@ -165,3 +165,35 @@ def test_gan_step_matches_oracle_autograd():
     # (tools/debug_gan_grads2.py prints the per-tensor table; the oracle's own fp32 vs fp64 runs show the same
     # kind of jump one layer later).  A wrong formula gives errors >= 1e-1 on every tensor.
     assert errs.max() <= 3e-2 and np.median(errs) <= 1.5e-2 and errs.min() <= 1e-5, (errs.max(), np.median(errs))
+
+
+def test_s16_range_guard_of_the_discriminator():
+    """activations beyond the half range (65504) would turn the S16 patch map non-finite: the inference forward notices,
+    recomputes on the exact-fp32 kernels and counts the fallback; "defer" leaves the verdict on the device; with autograd
+    the verdict lands in `last_overflow` for the trainer (harness.train_step_gan refuses the step on it)"""
+    net, sd = _disc()
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd["net.0.weight"] *= 3e5                                            # first layer's outputs ~1e5-1e6
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    x = S.hashed_uniform("d-guard", (2, 3, 64, 64)).to(DEV)
+    with torch.no_grad():
+        want = O.pixel_discriminator({k: v.double() for k, v in sd.items()}, x.double().cpu())
+        assert float(want.abs().max()) > 0 and torch.isfinite(want).all()
+        got = net(x)
+        assert net.s16_fallbacks == 1 and torch.isfinite(got).all()
+        assert rel_err(got.cpu(), want) <= 1e-5                          # the fp32 kernels' answer
+        net.s16_guard = "defer"
+        raw = net(x)
+        assert int(net.last_overflow) == 1 and not torch.isfinite(raw).all() and net.s16_fallbacks == 1
+        net.s16_guard = False
+        net(x)
+        assert net.last_overflow is None
+        del net.s16_guard
+    net.train()
+    out = net(x.requires_grad_(True))                                    # autograd path: verdict only, no recomputation
+    assert int(net.last_overflow) == 1 and not torch.isfinite(out).all()
+    small, _ = _disc()                                                   # ordinary magnitudes: nothing fires
+    with torch.no_grad():
+        small.eval()(x.detach())
+    assert getattr(small, "s16_fallbacks", 0) == 0

@@ -54,3 +54,29 @@ def test_flownet2sd_interface():
         net.train()(torch.zeros(1, 3, 2, 64, 64, device=DEV))
     with pytest.raises(NotImplementedError):
         FlowNet2SD(batchNorm=True)
+
+
+def test_s16_range_guard_of_flownet():
+    """an activation beyond the half range inside the frozen estimator (here: a first layer scaled by 1e5) sets the sticky
+    device flag of the S16 kernels; the forward reads it once, recomputes the batch on the exact-fp32 kernels and counts
+    the fallback - the flows equal the fp32 model's, not NaN; "defer" hands the flag to the trainer instead"""
+    net, sd = _net()
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd["conv0.0.weight"] *= 1e5
+    net.load_state_dict(sd, strict=True)
+    x = (S.hashed_uniform("flow-guard", (1, 3, 2, 64, 128)) + 1) * 127.5
+    ref = FlowNet2SD()
+    ref.load_state_dict(sd, strict=True)
+    ref = ref.to(DEV).eval()
+    ref.precision = "fp32"
+    want = ref(x.to(DEV))
+    assert torch.isfinite(want).all()
+    got = net(x.to(DEV))
+    assert net.s16_fallbacks == 1 and torch.equal(got, want)             # the same fp32 kernels, the same launches
+    net.s16_guard = "defer"
+    net(x.to(DEV))
+    assert int(net.last_overflow) != 0 and net.s16_fallbacks == 1
+    del net.s16_guard
+    plain, _ = _net()                                                    # ordinary weights: the flag stays clear
+    plain(x.to(DEV))
+    assert getattr(plain, "s16_fallbacks", 0) == 0

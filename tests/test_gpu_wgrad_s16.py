@@ -27,7 +27,9 @@ DEV = "cuda:0"
                                                # its 4-row-patch forms: 32 gradient channels (output layer), 8 / 16 / 32 input
                                                # channels (first layers; the missing channels come from the zero buffer)
                                                (2, 16, 32, 64, 32, 1e-5), (2, 8, 64, 16, 64, 1.0), (1, 4, 32, 8, 128, 1e-3),
-                                               (3, 12, 32, 32, 64, 1.0), (1, 20, 96, 128, 32, 1.0)])
+                                               (3, 12, 32, 32, 64, 1.0), (1, 20, 96, 128, 32, 1.0),
+                                               # rolling halo: one-patch columns (every patch starts a column), runs that end mid-column
+                                               (2, 2, 64, 64, 64, 1.0), (3, 2, 96, 128, 128, 1e-4), (1, 22, 32, 64, 64, 1.0)])
 def test_wgrad_s16_vs_fp64(B, H, W, cin, n, gmag):
     lib = _lib.load()
     s = torch.cuda.current_stream().cuda_stream
