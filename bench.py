@@ -622,7 +622,10 @@ def run_train(args, rank, world, dev, dist, steps, warmup, with_cpu):
         "metric": "clips/sec, 256x256x4 dual-stream clips (twostream forward + backward + Adam, training)",
         "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": steps, "warmup": max(warmup, 1),
         "ms_per_step": round(1e3 * elapsed / steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if net._train_engine.precision == "fp32" else "f32-equivalent: (hi,lo) f16 split MFMA for the 3x3 convolutions, f32 elsewhere",
+        "dtype": "f32" if net._train_engine.precision == "fp32" else (
+            "f32-equivalent: (hi,lo) f16 split MFMA for the 3x3 convolutions, f32 elsewhere" +
+            ("; AMMC_WGRAD_G11=1: the weight gradients take their gradient operand at 11 bits (NOT f32-equivalent)"
+             if os.environ.get("AMMC_WGRAD_G11", "0") not in ("", "0") else "")),
         "data": "synthetic",
         "config": {"workload": "Ped2 dual-stream + 256-slot memory + AMFT, batch 32 per GPU, fwd+bwd+Adam "
                                "(BASELINE.json configs[2]; configs[3] with --gpus 8)",

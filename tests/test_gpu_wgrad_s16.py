@@ -67,7 +67,16 @@ def test_wgrad_s16_vs_fp64(B, H, W, cin, n, gmag):
     w = torch.zeros(n, cin, 3, 3, dtype=torch.float64, requires_grad=True)
     (F.conv2d(a64, w, padding=1) * g64).sum().backward()
     err = float((dw.double().cpu() - w.grad).abs().max() / w.grad.abs().max())
-    assert err <= 3e-6, err
+    # AMMC_WGRAD_G11=1 (opt-in; the child run below): the rolling-halo instances take the GRADIENT operand with its 11-bit
+    # hi half, two MFMAs per product block (wgrad_tap3_s16.hip) - a relative 2^-12 rounding of every g, ~1e-4 of max |dw|
+    # on these random operands; the default keeps all three products: 3e-6
+    import os
+    g11 = (os.environ.get("AMMC_WGRAD_G11", "0") != "0" and os.environ.get("AMMC_WGRAD_ROLL", "1") != "0"
+           and cin % 64 == 0 and n % 64 == 0 and W % 32 == 0 and H % 2 == 0)
+    tol = 3e-4 if g11 else 3e-6
+    assert err <= tol, (err, tol)
+    if g11:
+        assert err >= 3e-6, err                       # (the switch did switch)
     # the slab form of the same launch (round 5): split partials stored as slabs and summed straight into the OIHW gradient
     # - no atomics, no unpack; available exactly where the three-MFMA halo-patch kernel takes the shape.  Same 3e-6 against
     # fp64, equal to the atomics form to summation order, and bit-identical between two launches (fixed summation order)
@@ -85,9 +94,23 @@ def test_wgrad_s16_vs_fp64(B, H, W, cin, n, gmag):
             outs.append(dws)
         assert torch.equal(outs[0], outs[1])
         err_s = float((outs[0].double().cpu() - w.grad).abs().max() / w.grad.abs().max())
-        assert err_s <= 3e-6, err_s
+        assert err_s <= tol, (err_s, tol)
         assert float((outs[0] - dw).abs().max()) <= 2e-6 * float(dw.abs().max())
         assert lib.ammc_conv_wgrad_s16_slabs(C.byref(d), _ptr(inv), _ptr(slabs), need - 1, _ptr(dws), n, cin, s) == -1   # AMMC_EINVAL
+
+
+def test_two_product_form_of_the_gradient_operand():
+    """`AMMC_WGRAD_G11=1` (opt-in): the gradient operand with its hi half only, two MFMAs per product block - the same
+    launches within 3e-4 of fp64 (and measurably NOT at 3e-6: the switch did switch), in a child process (the switch is
+    read once per process)"""
+    import os
+    import subprocess
+    import sys
+    if "AMMC_WGRAD_G11" in os.environ or "AMMC_WGRAD_ROLL" in os.environ:
+        pytest.skip("already inside a run with a switch set")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_wgrad_s16_vs_fp64"],
+                       env=dict(os.environ, AMMC_WGRAD_G11="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_per_patch_halo_form_still_passes():
@@ -96,8 +119,8 @@ def test_per_patch_halo_form_still_passes():
     import os
     import subprocess
     import sys
-    if "AMMC_WGRAD_ROLL" in os.environ:
-        pytest.skip("already inside a run with the switch set")
+    if "AMMC_WGRAD_ROLL" in os.environ or "AMMC_WGRAD_G11" in os.environ:
+        pytest.skip("already inside a run with a switch set")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_wgrad_s16_vs_fp64"],
                        env=dict(os.environ, AMMC_WGRAD_ROLL="0"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
