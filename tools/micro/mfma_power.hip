@@ -1,7 +1,9 @@
 // What MFMA rate does the board sustain at its power cap?  Register-resident fp16 operands, no memory traffic inside
 // the loop: 2 waves per SIMD on every CU issue v_mfma_f32_32x32x16_f16 (or 16x16x32) back to back on 8 independent
 // accumulators, rotating through 2 x 4 distinct operand fragments so that consecutive instructions see different data
-// (as in a real GEMM).  Operand data: random in [-1, 1] | random with half the A elements zero (post-ReLU) | constant.
+// (as in a real GEMM).  Operand data: random in [-1, 1] | random with half the A elements zero (post-ReLU) | constant |
+// (round 5, `./mfma_power 2 new`) random with the low 5 / 6 / 8 mantissa bits of the B operand - or of both - zero: what a
+// lo half rounded to 6 / 5 / 3 significant bits would cost the matrix pipe.
 // Board power and shader clock are sampled from the amdgpu hwmon files of this process's GPU while it runs.
 //     hipcc --offload-arch=gfx950 -O3 -o mfma_power tools/micro/mfma_power.hip && ./mfma_power [seconds per case]
 #include <hip/hip_runtime.h>
@@ -155,19 +157,32 @@ int main(int argc, char** argv) {
   float* out;
   hipMalloc(&src, n * sizeof(f16x8));
   hipMalloc(&out, 256 * 512 * sizeof(float));
-  for (int mode = 0; mode < 5; ++mode) {
+  const bool only_new = argc > 2 && !strcmp(argv[2], "new");
+  for (int mode = only_new ? 5 : 0; mode < (only_new ? 10 : 5); ++mode) {
     srand(1234);
+    // modes 5..9: 0 = reference (random), then the low `zb` mantissa bits cleared in B (planes 2..5) or in both operands
+    const int zb = mode == 6 ? 5 : mode == 7 ? 6 : mode == 8 ? 8 : mode == 9 ? 6 : 0;
     for (size_t i = 0; i < n; ++i)
       for (int k = 0; k < 8; ++k) {
         float v = mode == 2 ? 0.5f : (float)rand() / RAND_MAX * 2.f - 1.f;
         if (mode == 1 && (i / 131072 == 0 || i / 131072 == 6) && (rand() & 1)) v = 0.f;    // the A fragments: half zeros
         if (mode == 3 && (i / 131072 >= 2 && i / 131072 <= 5) && (rand() & 1)) v = 0.f;    // the B fragments: half zeros
         if (mode == 4 && (rand() & 1)) v = 0.f;                                            // both
-        h[i][k] = (_Float16)v;
+        _Float16 hv = (_Float16)v;
+        if (zb && (mode == 9 || (i / 131072 >= 2 && i / 131072 <= 5))) {
+          unsigned short bits;
+          memcpy(&bits, &hv, 2);
+          bits &= (unsigned short)~((1u << zb) - 1u);
+          memcpy(&hv, &bits, 2);
+        }
+        h[i][k] = hv;
       }
     hipMemcpy(src, h.data(), n * sizeof(f16x8), hipMemcpyHostToDevice);
     const char* tag = mode == 0 ? "random operands" : mode == 1 ? "random, half of A zero" : mode == 2 ? "constant operands"
-                      : mode == 3 ? "random, half of B zero" : "random, half of A and of B zero";
+                      : mode == 3 ? "random, half of B zero" : mode == 4 ? "random, half of A and of B zero"
+                      : mode == 5 ? "random operands (reference)" : mode == 6 ? "random, low 5 mantissa bits of B zero"
+                      : mode == 7 ? "random, low 6 mantissa bits of B zero" : mode == 8 ? "random, low 8 mantissa bits of B zero"
+                      : "random, low 6 mantissa bits of A and B zero";
     char name[128];
     snprintf(name, sizeof name, "v_mfma_f32_32x32x16_f16, %s", tag);
     run_case<0>(name, src, out, seconds, hw);
