@@ -230,3 +230,46 @@ def test_bench_defaults_the_rccl_channel_cap_for_training_ranks_only():
         assert b.default_rccl_channels(mode, share, env) is None and env == {}
     topo = b.host_topology()
     assert topo and all(len(v) >= 1 for v in topo.values())
+
+
+def test_header_compiles_as_c_and_agrees_with_the_ctypes_mirror(tmp_path):
+    """the boundary is a C ABI: include/ammc_hip.h must compile as plain C99 (what a cgo / JNI / FFI binding of the
+    reference's side would include), a C program must link against the library and get status codes back, and the two
+    descriptor structs must have the size and field offsets `_lib.py` mirrors with ctypes (a silent disagreement would
+    scramble every launch)"""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no C compiler")
+    lib = _lib.load()
+    fields = {"AmmcConvDesc": [f[0] for f in _lib.AmmcConvDesc._fields_],
+              "AmmcWgradDesc": [f[0] for f in _lib.AmmcWgradDesc._fields_]}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "ammc_hip.h"', 'int main(void) {',
+             '  printf("abi %d\\n", ammc_abi_version());',
+             '  printf("einval %d\\n", ammc_conv_gemm_f32(NULL, NULL));',
+             '  printf("blocks %d\\n", ammc_memory_topk_blocks(129));',
+             '  printf("err %s\\n", ammc_error_string(-2));']
+    for name, fl in fields.items():
+        lines.append(f'  printf("sizeof {name} %zu\\n", sizeof({name}));')
+        for f in fl:
+            lines.append(f'  printf("off {name}.{f} %zu\\n", offsetof({name}, {f}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "cabi.c"
+    src.write_text("\n".join(lines) + "\n")
+    libdir = os.path.dirname(_lib.LIB_PATH) if hasattr(_lib, "LIB_PATH") else os.path.join(ROOT, "ammcnet_aaai2021_amd")
+    exe = tmp_path / "cabi"
+    cmd = [gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src),
+           "-o", str(exe), "-L", libdir, "-lammc_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = dict(ln.rsplit(" ", 1) for ln in out.stdout.strip().splitlines() if not ln.startswith("err "))
+    assert int(got["abi"]) == _lib.ABI_VERSION == lib.ammc_abi_version()
+    assert int(got["einval"]) == -1 and int(got["blocks"]) == 5
+    assert "err unsupported" in out.stdout or "err " in out.stdout
+    for name, cls in (("AmmcConvDesc", _lib.AmmcConvDesc), ("AmmcWgradDesc", _lib.AmmcWgradDesc)):
+        assert int(got[f"sizeof {name}"]) == C.sizeof(cls), name
+        for f in fields[name]:
+            assert int(got[f"off {name}.{f}"]) == getattr(cls, f).offset, (name, f)
