@@ -25,7 +25,8 @@
 // The 16-byte slot index s = 2 * group + plane of pixel row m is stored XOR-swizzled by m & 3 (w3_swz): a transposed
 // read touches four consecutive rows x four groups of one plane, which the swizzle spreads over all sixteen 16-byte
 // bank slots for any start row - conflict free for every tap.
-// One workgroup of 8 waves per CU; split over patches, fp32 atomics into the packed gradient.
+// One workgroup of 8 waves per CU; split over patches; the partial tiles go out as slabs (round 5, WgradTap3Args::slabs)
+// or as fp32 atomics into the packed gradient.
 // Variants <NG, NA, NP, PH> (32-channel blocks of the gradient / of the input, row groups, patch rows):
 //   <4, 2, 1, 2> 128 x 64 channel tiles (N % 128 == 0)          <2, 2, 2, 2> 64 x 64, the two patch rows on different waves
 //   <1, 2, 4, 4> 32 gradient channels (the output layer)        <2, 1, 4, 4> Cin <= 32 (first layers, zero-padded block)
@@ -34,9 +35,10 @@
 // ROLL (round 5, the two-row patches): a workgroup walks DOWN a 32-pixel column of the image and keeps the input halo
 // rows in a ring of four two-row groups - patch ty reads rows 2 ty - 1 .. 2 ty + 2 = groups ty and ty + 1, and while it is
 // contracted only group ty + 2 (two NEW rows) is fetched, not the four rows of the next patch's halo: 33 KB instead of
-// 51 KB of L2 -> LDS DMA per 64 x 64-channel patch, 49 instead of 67 KB per 128 x 64 one.  The kernel is fetch bound at
-// those sizes (a patch is 1.6 / 3.3 us of MFMAs: 8 / 5 TB/s summed over the chip).  A run of patches that crosses into
-// the next column loads that column's first two groups into the two free slots of the ring.
+// 51 KB of L2 -> LDS DMA per 64 x 64-channel patch, 49 instead of 67 KB per 128 x 64 one (PMC: 2.06 -> 1.38 GB and 509 ->
+// 419 MB per launch).  Worth 1.5-4 % per layer: the kernel runs at the power cap and those bytes are that share of its
+// energy - it was not waiting for them.  A run of patches that crosses into the next column loads that column's first two
+// groups into the two free slots of the ring.
 //
 // G11 (round 5, opt-in: AMMC_WGRAD_G11=1): the gradient operand with its hi half only, (GH | GH) * (AH | AH) +
 // (GH'[8-15] | GH'[0-7]) * (AL[8-15] | AL[0-7]) - the second product's fragments are lane selects of the cross fragments
