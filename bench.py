@@ -17,6 +17,8 @@ Besides the contract fields the JSON line carries
 and, at N = 1 (each outside the headline's timed region; --no-secondary skips them):
   fp32_exact      the same workload on the exact-fp32 MFMA kernels (`model.precision = "fp32"`)
   train           BASELINE.json configs[2]: batch 32, forward + backward + Adam           (alone: --mode train)
+  train_wgrad_g11 the same leg in a child process with the OPT-IN two-product weight gradients (AMMC_WGRAD_G11=1), its own
+                  fixture parity and fp64-truth verdict; reported beside `train`, never instead of it
   train_gan       the reference's whole joint G / D iteration with FlowNet2-SD, batch 32   (alone: --mode train_gan)
   stress_memory   BASELINE.json configs[4]: 8192 slots x 512-d memory addressing, fp16 MFMA (alone: --mode stress)
 """
@@ -493,6 +495,32 @@ def train_vs_fp64(net, d, cfg):
             "worst": [f"{r['name']} e {r['e_hip']:.2e} (ref {r['e_ref']:.2e}) norm {r['norm_hip']:.2e}" for r in worst],
             "failing": bad, "ok": bool(not bad and (not ratios or ratios[len(ratios) // 2] <= 1.5))}
 
+
+
+def train_wgrad_g11_leg():
+    """The opt-in form of the 3x3 weight gradients (AMMC_WGRAD_G11=1: the gradient operand at 11 bits, two MFMAs per
+    product block) as its OWN line of the same run: `bench.py --mode train` in a child process (the
+    switch is read once per process) with the same fixture parity and the same fp64-truth gates.  NOT the `train` leg's
+    arithmetic and not f32-equivalent on an isolated layer - reported beside it, never instead of it."""
+    import subprocess
+    env = dict(os.environ, AMMC_WGRAD_G11="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "train", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"]
+    t0 = time.perf_counter()
+    try:
+        out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    except Exception as e:                                   # (a leg beside the contract's lines: never fails the bench)
+        return {"error": repr(e)[:300]}
+    par = rec.get("parity") or {}
+    v64 = par.get("vs_fp64") or {}
+    return {"what": "AMMC_WGRAD_G11=1 in a child process: 3x3 weight gradients with the gradient operand's hi half only "
+                    "(opt-in; the `train` leg above is the default three-product arithmetic)",
+            "ms_per_step": rec.get("ms_per_step"), "value": rec.get("value"), "unit": rec.get("unit"), "steps": rec.get("steps"),
+            "leg_seconds": round(time.perf_counter() - t0, 1), "dtype": rec.get("dtype"), "parity_ok": par.get("ok"), "parity_loss_rel": rec.get("parity_loss_rel"),
+            "vs_fp64": {k: v64.get(k) for k in ("grad_norm_rel", "reference_grad_norm_rel", "grad_l2_rel", "reference_grad_l2_rel",
+                                                "ratio_hip_over_reference", "failing", "ok")}}
 
 def train_traffic(kernel: str, batch: int, size: int):
     """HBM-side bytes per launch of the training step's dominant kernel family from the committed PMC passes of
@@ -1279,6 +1307,8 @@ def run_infer(args, rank, world, dev, dist):
             rc = 3
         del t
         torch.cuda.empty_cache()
+        if os.environ.get("AMMC_WGRAD_G11", "0") in ("", "0"):
+            line["train_wgrad_g11"] = train_wgrad_g11_leg()
         gan = run_train_gan(args, dev, steps=5, warmup=2)
         line["train_gan"] = gan
         if gan["parity"] is not None and not gan["parity"]["ok"]:
@@ -1299,6 +1329,7 @@ def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args))
+    t_start = time.perf_counter()
     rank, world, dev, dist = init_ranks(args)
     rc = 0
     if args.mode == "train":
@@ -1322,6 +1353,7 @@ def main():
             args.batch = 16
         line, rc = run_infer(args, rank, world, dev, dist)
     if rank == 0:
+        line["bench_seconds"] = round(time.perf_counter() - t_start, 1)      # this process, imports excluded
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
