@@ -70,6 +70,7 @@ SIGNATURES = {
     "ammc_memory_topk_blocks": (C.c_int, [_i32]),
     "ammc_memory_topk_fwd_f32": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
     "ammc_pack_codebook_s16": (C.c_int, [_p, _i32, _i32, _p, _p]),
+    "ammc_pack_codebook_s16_guarded": (C.c_int, [_p, _i32, _i32, _p, _p, _p]),
     "ammc_memory_topk_fwd_s16": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
     "ammc_sum_partials_f32": (C.c_int, [_p, _i32, _f32, _p, _p]),
     "ammc_conv_gemm_s16": (C.c_int, [C.POINTER(AmmcConvDesc), _p]),
@@ -82,6 +83,7 @@ SIGNATURES = {
     "ammc_conv_gemm_s16_variant": (C.c_int, [C.POINTER(AmmcConvDesc), C.c_char_p, _i32]),
     "ammc_conv_gemm_s16_stats_rows": (C.c_int, [C.POINTER(AmmcConvDesc)]),
     "ammc_split_rows_f32": (C.c_int, [_p, _i64, _p, _p]),
+    "ammc_split_rows_guarded_f32": (C.c_int, [_p, _i64, _p, _p, _p]),
     "ammc_absmax_bits_f32": (C.c_int, [_p, _i64, _p, _p]),
     "ammc_split_rows_scaled_f32": (C.c_int, [_p, _i64, _p, _p, _p, _i32, _p]),
     "ammc_nchw_to_s16_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _i64, _i64, _i64, _i32, _p]),

@@ -485,9 +485,10 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(ConvArgs a) {
   *reinterpret_cast<f16x8*>(yp + 4) = lo;
 }
 
-// fp32 [rows][cols] (cols % 8 == 0) -> S16 groups [8 hi | 8 lo], same shape in bytes
+// fp32 [rows][cols] (cols % 8 == 0) -> S16 groups [8 hi | 8 lo], same shape in bytes.  `range_flag` (may be null): raised
+// (sticky, like the S16 epilogues' overflow flag) when a value does not fit the hi half - |v| > 65504 or not finite
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, int64_t ngroups,
-                                                         float* __restrict__ dst) {
+                                                         float* __restrict__ dst, int* __restrict__ range_flag) {
   const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (g >= ngroups) return;
   const f32x4 a0 = *reinterpret_cast<const f32x4*>(src + g * 8);
@@ -495,6 +496,12 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
   float v[8];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { v[i] = a0[i]; v[4 + i] = a1[i]; }
+  if (range_flag) {
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bad |= !(fabsf(v[i]) <= 65504.f);
+    if (bad) atomicOr(range_flag, 1);
+  }
   f16x8 hi, lo;
   split8(v, hi, lo);
   *reinterpret_cast<f16x8*>(dst + g * 8) = hi;
@@ -742,10 +749,15 @@ extern "C" int ammc_conv_gemm_s16_stats_rows(const AmmcConvDesc* desc) {
   return (strstr(label, "+stats") || strstr(label, "+bnbwd")) ? conv_tap_s16_stat_rows(d) : 0;
 }
 
-extern "C" int ammc_split_rows_f32(const float* src, int64_t count, float* dst, void* stream) {
+extern "C" int ammc_split_rows_guarded_f32(const float* src, int64_t count, float* dst, int32_t* range_flag, void* stream) {
   if (!src || !dst || count <= 0 || (count & 7) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return AMMC_EINVAL;
-  hipLaunchKernelGGL(split_rows_kernel, dim3(nblk(count >> 3)), dim3(256), 0, (hipStream_t)stream, src, count >> 3, dst);
+  hipLaunchKernelGGL(split_rows_kernel, dim3(nblk(count >> 3)), dim3(256), 0, (hipStream_t)stream, src, count >> 3, dst,
+                     range_flag);
   return ammc_launch_status();
+}
+
+extern "C" int ammc_split_rows_f32(const float* src, int64_t count, float* dst, void* stream) {
+  return ammc_split_rows_guarded_f32(src, count, dst, nullptr, stream);
 }
 
 extern "C" int ammc_absmax_bits_f32(const float* src, int64_t count, int32_t* out_bits, void* stream) {

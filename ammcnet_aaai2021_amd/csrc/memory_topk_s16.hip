@@ -281,15 +281,21 @@ __global__ __launch_bounds__(256 * RT, 2) void memory_topk_s16_kernel(
 }
 
 // [d][m] fp32 -> [d/8][hi | lo][mpad][8] halfs (slots >= m zero)
+// `range_flag` (may be null) is raised when an entry does not fit the hi half (|v| > 65504 or not finite): such a slot would
+// read as inf / NaN in the S16 image - a NaN distance is never inserted, a -inf distance WINS - so the caller must take
+// the fp32 kernel for this codebook (engine.py does).  The reference's EMA update produces exactly that from its own
+// initial state: a slot no row has hit yet sits at embed = 0.99^t e0 / ~1e-5 (models/unet.py:277-280, 298-309).
 __global__ __launch_bounds__(256) void pack_codebook_s16_kernel(const float* __restrict__ e_dm, int d, int m, int mpad,
-                                                                _Float16* __restrict__ out) {
+                                                                _Float16* __restrict__ out, int* __restrict__ range_flag) {
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (gid >= (int64_t)(d >> 3) * mpad) return;
   const int s = (int)(gid % mpad), kb = (int)(gid / mpad);
   h16x8 hi, lo;
+  bool bad = false;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const float v = s < m ? e_dm[(int64_t)(kb * 8 + i) * m + s] : 0.f;
+    bad |= !(fabsf(v) <= 65504.f);
     const _Float16 hv = (_Float16)v;
     hi[i] = hv;
     lo[i] = (_Float16)((v - (float)hv) * S_LO_SCALE);
@@ -298,6 +304,7 @@ __global__ __launch_bounds__(256) void pack_codebook_s16_kernel(const float* __r
   // load (interleaved [8 hi | 8 lo] rows made every load touch twice the cache lines it used)
   *reinterpret_cast<h16x8*>(out + ((int64_t)(2 * kb) * mpad + s) * 8) = hi;
   *reinterpret_cast<h16x8*>(out + ((int64_t)(2 * kb + 1) * mpad + s) * 8) = lo;
+  if (bad && range_flag) atomicOr(range_flag, 1);
 }
 
 template <int K>
@@ -324,13 +331,18 @@ int launch_topk_s16(const float* x, const void* e_s16, const float* e_md, const 
 }  // namespace ammc_impl
 using namespace ammc_impl;
 
-extern "C" int ammc_pack_codebook_s16(const float* embed_dm, int32_t d, int32_t m, void* e_s16, void* stream) {
+extern "C" int ammc_pack_codebook_s16_guarded(const float* embed_dm, int32_t d, int32_t m, void* e_s16, int32_t* range_flag,
+                                              void* stream) {
   if (!embed_dm || !e_s16 || d <= 0 || (d % 8) || m <= 0) return AMMC_EINVAL;
   const int mpad = (m + 31) / 32 * 32;
   const int64_t total = (int64_t)(d >> 3) * mpad;
   hipLaunchKernelGGL(pack_codebook_s16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     embed_dm, d, m, mpad, reinterpret_cast<_Float16*>(e_s16));
+                     embed_dm, d, m, mpad, reinterpret_cast<_Float16*>(e_s16), range_flag);
   return ammc_launch_status();
+}
+
+extern "C" int ammc_pack_codebook_s16(const float* embed_dm, int32_t d, int32_t m, void* e_s16, void* stream) {
+  return ammc_pack_codebook_s16_guarded(embed_dm, d, m, e_s16, nullptr, stream);
 }
 
 // same workgroup geometry as ammc_memory_topk_fwd_f32: diff_partial has ammc_memory_topk_blocks(n) entries

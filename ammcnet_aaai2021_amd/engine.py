@@ -148,13 +148,18 @@ class _Packer:
         self.lib = _lib.load()
         self.device = device
         self.s16 = s16                  # filters as (hi, lo) half pairs for ammc_conv_gemm_s16
+        # range verdicts of the S16 packs (round 6): [0] = a packed filter beyond the half range, [1..] = one per codebook
+        # (`codebook_s16`); read ONCE per parameter version by EvalEngine._ensure_packs
+        self.flags = torch.zeros(8, device=device, dtype=torch.int32) if s16 else None
+        self.nflags = 1
 
     def _split(self, t: torch.Tensor) -> torch.Tensor:
         """packed filter [N][Kpad] -> S16"""
         if not self.s16:
             return t
         out = torch.empty_like(t)
-        _lib.check(self.lib.ammc_split_rows_f32(_ptr(t), t.numel(), _ptr(out), self.stream()), "split_rows")
+        _lib.check(self.lib.ammc_split_rows_guarded_f32(_ptr(t), t.numel(), _ptr(out), self.flags.data_ptr(), self.stream()),
+                   "split_rows")
         return out
 
     def stream(self) -> int:
@@ -216,13 +221,18 @@ class _Packer:
                    "pack_codebook")
         return e_md, enorm
 
-    def codebook_s16(self, embed: torch.Tensor) -> torch.Tensor:
-        """[d/8][mpad][8 hi | 8 lo] halfs: the slot operand of `ammc_memory_topk_fwd_s16`"""
+    def codebook_s16(self, embed: torch.Tensor) -> Tuple[torch.Tensor, int]:
+        """[d/8][mpad][8 hi | 8 lo] halfs: the slot operand of `ammc_memory_topk_fwd_s16`, and the index of its range
+        verdict in `self.flags` (raised when a slot does not fit the half range: the reference's from-scratch EMA state
+        holds |embed| ~ 1e5 in every slot no row has hit yet, models/unet.py:277-280, 298-309)"""
         d, m = embed.shape
         mpad = (m + 31) // 32 * 32
         out = torch.empty((d // 8, mpad, 16), device=self.device, dtype=torch.float16)
-        _lib.check(self.lib.ammc_pack_codebook_s16(_ptr(embed), d, m, out.data_ptr(), self.stream()), "pack_codebook_s16")
-        return out
+        fi = self.nflags
+        self.nflags += 1
+        _lib.check(self.lib.ammc_pack_codebook_s16_guarded(_ptr(embed), d, m, out.data_ptr(),
+                                                           self.flags.data_ptr() + 4 * fi, self.stream()), "pack_codebook_s16")
+        return out, fi
 
 
 class _DoubleConvPack:
@@ -263,10 +273,10 @@ class _StreamPack:
             enc_w, _ = pk.conv(q.enc.weight, 1)
             dec_w, _ = pk.conv(q.dec.weight, 1)
             e_md, enorm = pk.codebook(q.quantize.embed)
+            e_s16, e_flag = pk.codebook_s16(q.quantize.embed) if (pk.s16 and q.quantize.dim == 64) else (None, None)
             self.vq = dict(enc_w=enc_w, enc_b=q.enc.bias.detach(), dec_w=dec_w, dec_b=q.dec.bias.detach(),
                            embed=q.quantize.embed, e_md=e_md, enorm=enorm, d=q.quantize.dim,
-                           m=q.quantize.n_embed, k=q.quantize.k,
-                           e_s16=pk.codebook_s16(q.quantize.embed) if (pk.s16 and q.quantize.dim == 64) else None)
+                           m=q.quantize.n_embed, k=q.quantize.k, e_s16=e_s16, e_s16_flag=e_flag)
 
 
 class _Builder:
@@ -532,8 +542,10 @@ class StreamGraph:
         self.x4q = bld.act(B, h, w, 512)
         if bld.s16:              # the gathered fp32 rows become the S16 operand of `dec`
             qk_s = bld.act(B, h, w, k * d, halo=0)
-            bld.plan.add(lib.ammc_split_rows_f32, _ptr(self.qk.buf), n * k * d, _ptr(qk_s.buf), name="vq.split",
-                         nbytes=8.0 * n * k * d, kernel="split_rows")
+            # (guarded: a gathered slot beyond the half range - an un-hit slot of a from-scratch codebook picked as second
+            # neighbour - raises the plan's range flag HERE, not only if the `dec` epilogue downstream happens to see inf)
+            bld.plan.add(lib.ammc_split_rows_guarded_f32, _ptr(self.qk.buf), n * k * d, _ptr(qk_s.buf), bld.overflow.data_ptr(),
+                         name="vq.split", nbytes=8.0 * n * k * d, kernel="split_rows")
             self.qk_op = qk_s
         else:
             self.qk_op = self.qk
@@ -581,6 +593,8 @@ class EvalEngine:
         self._plans: Dict[Tuple, dict] = {}
         self._arenas: Dict[Tuple, Tuple[int, List[torch.Tensor]]] = {}
         self._timed = False          # bench.py: bracket every launch with HIP events
+        self.memory_fp32_routed = 0  # codebooks of the current packs that do not fit the half range (looked up in fp32)
+        self.weights_out_of_range = False
         self.use_graph = USE_GRAPH   # replay one captured hipGraph per forward (AMMC_GRAPH=0: ~100 eager launches)
         self.timings = []
 
@@ -609,6 +623,22 @@ class EvalEngine:
         self._pack_version = ver
         self._plans.clear()               # plans hold pointers to the old packs
         self._arenas.clear()
+        # Range verdicts of the S16 packs: ONE small read per parameter version (packing is rare in evaluation).
+        #  * a codebook with an entry beyond the half range (the reference's from-scratch EMA state: every slot no row has hit
+        #    yet, ~1e5 x N(0, 1) for the first ~150 training steps) is looked up by the fp32 kernel - the memory block only
+        #    (0.07 of 6.3 ms per step): nothing else of the S16 plan changes and no batch is re-run;
+        #  * a FILTER beyond the half range cannot be represented at all: every forward reports overflow and the guard
+        #    evaluates on the exact-fp32 plans (`overflowed` / `take_overflow`).
+        self.memory_fp32_routed = 0
+        self.weights_out_of_range = False
+        if pk.flags is not None:
+            verdicts = pk.flags.tolist()
+            self.weights_out_of_range = bool(verdicts[0])
+            for sp in self._packs.values():
+                vq = getattr(sp, "vq", None)
+                if vq and vq.get("e_s16_flag") is not None and verdicts[vq["e_s16_flag"]]:
+                    vq["e_s16"] = None
+                    self.memory_fp32_routed += 1
 
     # ---- plans ----------------------------------------------------------------------
     def _build(self, B, H, W, device) -> dict:
@@ -679,6 +709,8 @@ class EvalEngine:
         flag = self._last.get("overflow")
         if flag is None:
             return False
+        if self.weights_out_of_range:          # a filter that has no S16 image: every batch goes to the fp32 plans
+            return True
         ev = self._last.get("flag_event")
         if ev is not None:                     # copied to pinned memory ahead of the output layers (`_launch_all`)
             ev.synchronize()
@@ -695,7 +727,7 @@ class EvalEngine:
         flag = self._last.get("overflow")
         if flag is None:
             return None
-        out = flag.to(torch.float32)
+        out = flag.to(torch.float32) if not self.weights_out_of_range else torch.ones(1, device=flag.device)
         flag.zero_()
         return out
 

@@ -103,9 +103,13 @@ def main(argv=None):
             return rec, st, lens
         staged_loop(sources[:max(world, 1)])                                     # warm-up: plans, packs, pinned pools
         torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
         t0 = time.time()
         rec, st, lens = staged_loop(sources)
         torch.cuda.synchronize()
+        if world > 1:                     # the clock stops when the SLOWEST rank is done: fps = all ranks' frames / that time
+            torch.distributed.barrier()
         used = time.time() - t0
         staged = {"host_read_s": round(st.host_seconds, 3), "uploaded_MB": round(st.bytes_uploaded / 2**20, 1),
                   "staging": "streamed: overlapped with the scoring loop (total_time_s covers it)"}

@@ -152,6 +152,46 @@ def make_twostream_state(in_channel=(12, 6), out_channel=(3, 2), embed_dim=64, n
     return sd
 
 
+def _fill_from_scratch(key: str, shape, tag: str, sd) -> torch.Tensor:
+    leaf = key.rsplit(".", 1)[-1]
+    t = f"{tag}:{key}"
+    if leaf == "num_batches_tracked":
+        return torch.tensor(0, dtype=torch.int64)
+    if leaf == "running_mean":
+        return torch.zeros(shape)
+    if leaf == "running_var":
+        return torch.ones(shape)
+    if leaf == "cluster_size":
+        return torch.zeros(shape)
+    if leaf == "embed":
+        return hashed_normal(t, shape, 1.0)
+    if leaf == "embed_avg":
+        return sd[key.replace("embed_avg", "embed")].clone()
+    if len(shape) == 1:
+        parent = key.rsplit(".", 2)[-2]
+        if parent in ("1", "4"):                             # BatchNorm2d: gamma ~ N(1, 0.02), beta = 0
+            return 1.0 + hashed_normal(t, shape, 0.02) if leaf == "weight" else torch.zeros(shape)
+        wshape = sd[key[:-4] + "weight"].shape               # conv bias: torch's default U(-1/sqrt(fan_in), +), untouched by the init
+        fan_in = wshape[1] * wshape[2] * wshape[3]           # (ConvTranspose2d [Cin, Cout, 2, 2]: torch takes dim 1 here as well)
+        b = 1.0 / fan_in ** 0.5
+        return hashed_uniform(t, shape, -b, b)
+    return hashed_normal(t, shape, 0.02)                     # Conv2d / ConvTranspose2d weights ~ N(0, 0.02)
+
+
+def make_from_scratch_state(in_channel=(12, 6), out_channel=(3, 2), embed_dim=64, n_embed=256, k=2,
+                            tag="ammc-scratch") -> "OrderedDict[str, torch.Tensor]":
+    """The state the reference's training starts from when no checkpoint is given, with its
+    random draws replaced by the hash filler of the same distributions: `generator.apply(weights_init_normal)`
+    (utils/utils.py:328-334, 342: Conv* weights ~ N(0, 0.02), BatchNorm2d gamma ~ N(1, 0.02), beta = 0) over torch's
+    default construction (conv biases U(+-1/sqrt(fan_in)), running statistics 0 / 1) and `Quantize_topk.__init__`
+    (models/unet.py:277-280: embed ~ N(0, 1), **cluster_size = 0, embed_avg = embed**).  tests/golden/make_golden.py
+    (`from_scratch`) checks structure and distribution parameters against a model the reference initialised itself."""
+    sd = OrderedDict()
+    for key, shape in twostream_schema(in_channel, out_channel, embed_dim, n_embed, k):
+        sd[key] = _fill_from_scratch(key, shape, tag, sd)
+    return sd
+
+
 def make_unet_state(cin=12, cout=3, tag="ammc-unet") -> "OrderedDict[str, torch.Tensor]":
     sd = OrderedDict()
     for key, shape in unet_schema("", cin, cout):

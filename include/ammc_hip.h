@@ -181,6 +181,12 @@ int ammc_memory_topk_fwd_f32(const float* x, const float* embed_dm, const float*
  * the fp32 entry).  e_s16 = ammc_pack_codebook_s16(embed [d][m]): [d/8][hi | lo][mpad][8] halfs (opaque to callers), mpad = m rounded up
  * to 32; enorm / embed_md from ammc_pack_codebook_f32; diff_partial has ammc_memory_topk_blocks(n) entries. */
 int ammc_pack_codebook_s16(const float* embed_dm, int32_t d, int32_t m, void* e_s16, void* stream);
+/* ... and with a range verdict: *range_flag (device int32, zeroed by the caller, sticky) is raised when an entry of the
+ * codebook does not fit the hi half (|v| > 65504 or not finite).  The reference's own EMA update (models/unet.py:298-309)
+ * produces such entries from its initial state (:277-280: cluster_size = 0): a slot no row has hit yet sits at
+ * embed = 0.99^t e0 / ~1e-5 ~ 1e5 x N(0, 1) for the first ~150 training steps.  A flagged codebook must be looked up with
+ * ammc_memory_topk_fwd_f32 (an inf / NaN slot of the S16 image corrupts the ranking). */
+int ammc_pack_codebook_s16_guarded(const float* embed_dm, int32_t d, int32_t m, void* e_s16, int32_t* range_flag, void* stream);
 int ammc_memory_topk_fwd_s16(const float* x, const void* e_s16, const float* embed_md, const float* enorm, int32_t n,
                              int32_t d, int32_t m, int32_t k, int32_t* idx_topk, float* q_topk, float* q_one,
                              float* diff_partial, void* stream);
@@ -239,6 +245,10 @@ int ammc_conv_gemm_s16_variant(const AmmcConvDesc* desc, char* out, int32_t out_
 int ammc_conv_gemm_s16_stats_rows(const AmmcConvDesc* desc);
 /* fp32 -> S16, count elements (multiple of 8): packed filters, gathered codebook rows */
 int ammc_split_rows_f32(const float* src, int64_t count, float* dst, void* stream);
+/* ... and with a range verdict: *range_flag (device int32, sticky; the same flag the S16 epilogues raise through
+ * AmmcConvDesc.overflow_flag) is raised when a value does not fit the hi half (|v| > 65504 or not finite): the S16 image
+ * would hold inf there.  range_flag may be NULL (= ammc_split_rows_f32). */
+int ammc_split_rows_guarded_f32(const float* src, int64_t count, float* dst, int32_t* range_flag, void* stream);
 /* Gradient tensors as S16 operands (what autograd derives for the 3x3 convs, train_helper.py:337-339): the largest
  * |v| of the tensor as its fp32 bit pattern (atomicMax into one of the 256 slots out_bits[0..256), zeroed by the
  * caller; the consumer takes the maximum of the slots), then the split of

@@ -154,18 +154,22 @@ def unet_forward(sd: State, x: torch.Tensor, training: bool = False, prefix: str
     return torch.tanh(y)
 
 
-def unetmem_forward(sd: State, x: torch.Tensor, k: int, training: bool = False, prefix: str = ""):
-    """`UNetMem_v7.forward` (models/unet.py:924-937)."""
+def unetmem_forward(sd: State, x: torch.Tensor, k: int, training: bool = False, prefix: str = "",
+                    force_idx: torch.Tensor = None, want_idx: bool = False):
+    """`UNetMem_v7.forward` (models/unet.py:924-937).  `force_idx` / `want_idx`: test instrumentation, see `quantize_topk`
+    (with `want_idx` the lookups [N, k] are returned as a fourth value)."""
     p = prefix
     x1 = double_conv(sd, f"{p}inc.conv.conv", x, training)
     x2 = down(sd, f"{p}down1", x1, training)
     x3 = down(sd, f"{p}down2", x2, training)
     x4 = down(sd, f"{p}down3", x3, training)
-    x4, diff, q_one, _ = vq_block(sd, f"{p}vq_down3", x4, k, training)
+    x4, diff, q_one, idxk = vq_block(sd, f"{p}vq_down3", x4, k, training, force_idx)
     y = up(sd, f"{p}up1", x4, x3, training)
     y = up(sd, f"{p}up2", y, x2, training)
     y = up(sd, f"{p}up3", y, x1, training)
     y = F.conv2d(y, sd[f"{p}outc.weight"], sd[f"{p}outc.bias"], padding=1)
+    if want_idx:
+        return torch.tanh(y), diff, q_one, idxk.reshape(-1, k).detach()
     return torch.tanh(y), diff, q_one
 
 

@@ -115,6 +115,29 @@ def twostream_eval(ref, hw, batch, n_embed, name, full, rows=None, q_step=1, gri
     print(name, {k: getattr(v, "shape", None) for k, v in list(out.items())[:8]})
 
 
+def lookup_hooks(net, sd, picked):
+    """Which slots the reference's own memory lookups picked (`Quantize_topk.forward` returns the gathered rows only: each
+    is matched bit for bit against the pre-update codebook).  The fp64 truth of tests/truth.py is evaluated on the same
+    piecewise-smooth branch.  Fills `picked[stream] = int16 [N, k]` when the forward runs; returns the hook handles."""
+    def grab(stream):
+        def fn(mod, inp, outp):
+            e0 = sd[f"{stream}.vq_down3.quan.quantize.embed"]                     # [D, M], the codebook before the EMA update
+            rows = outp[0].detach().reshape(-1, mod.k, mod.dim)
+            d2 = torch.cdist(rows.reshape(-1, mod.dim), e0.t().contiguous())
+            ix = d2.argmin(1)
+            assert torch.equal(e0.t()[ix], rows.reshape(-1, mod.dim)), "gathered rows are not codebook rows"
+            picked[stream] = ix.reshape(-1, mod.k).to(torch.int16).numpy()
+        return fn
+    return [getattr(net, st).vq_down3.quan.quantize.register_forward_hook(grab(st)) for st in ("rgb", "op")]
+
+
+def dense(g: torch.Tensor, n: int = 4096) -> np.ndarray:
+    """`n` strided entries of a gradient (the whole tensor when smaller): the positions of `gs4k.*` / make_fp64_truth.py"""
+    # (.clone(): for a tensor of <= n entries the slice is a VIEW of the gradient - a later backward that accumulates into
+    # the same .grad would rewrite the recorded numbers)
+    return g.detach().flatten()[:: max(1, g.numel() // n)][:n].clone().numpy()
+
+
 def twostream_train(ref, hw, batch, name, out_step=1, rows=None, dense_samples=0):
     """`rows`: batch rows of the strided frames that are kept (all when None) - the batch-32 fixture of the training
     benchmark's own shape stays a few hundred KB"""
@@ -128,17 +151,7 @@ def twostream_train(ref, hw, batch, name, out_step=1, rows=None, dense_samples=0
     # only: each is matched bit for bit against the pre-update codebook) - the fp64 truth of test_gpu_train.py is
     # evaluated on the same piecewise-smooth branch
     picked = {}
-
-    def grab(stream):
-        def fn(mod, inp, outp):
-            e0 = sd[f"{stream}.vq_down3.quan.quantize.embed"]                     # [D, M], the codebook before the EMA update
-            rows = outp[0].detach().reshape(-1, mod.k, mod.dim)
-            d2 = torch.cdist(rows.reshape(-1, mod.dim), e0.t().contiguous())
-            ix = d2.argmin(1)
-            assert torch.equal(e0.t()[ix], rows.reshape(-1, mod.dim)), "gathered rows are not codebook rows"
-            picked[stream] = ix.reshape(-1, mod.k).to(torch.int16).numpy()
-        return fn
-    hooks = [getattr(net, st).vq_down3.quan.quantize.register_forward_hook(grab(st)) for st in ("rgb", "op")] if dense_samples else []
+    hooks = lookup_hooks(net, sd, picked) if dense_samples else []
     rgb, op, (rd, od), _ = net(rgb_x, op_x)
     for h_ in hooks:
         h_.remove()
@@ -157,7 +170,7 @@ def twostream_train(ref, hw, batch, name, out_step=1, rows=None, dense_samples=0
         if dense_samples:
             # round 5: 4096 strided entries per gradient (whole tensor when smaller) - the reference's own fp32 noise
             # against the fp64 truth of make_fp64_truth.py is measured on these (e_ref of test_gpu_train.py)
-            out[f"gs4k.{k}"] = g.flatten()[:: max(1, g.numel() // dense_samples)][:dense_samples].contiguous().numpy()
+            out[f"gs4k.{k}"] = dense(g, dense_samples)
     params = dict(net.named_parameters())
     for k, v in net.state_dict().items():
         if k in params:
@@ -391,7 +404,11 @@ def gan_iteration(ref, batch, name):
     F2 = flow_models.FlowNet2SD().eval()
     F2.load_state_dict(S.make_flownet2sd_state(), strict=True)
     rgb_x, op_x, rgb_t, op_t = S.make_clips(batch, 256, 256, tag=name)
+    picked = {}
+    hooks = lookup_hooks(G, S.make_twostream_state(**cfg), picked)
     rgb_out, op_out, (rd, od), _ = G(rgb_x, op_x)
+    for h_ in hooks:
+        h_.remove()
     last = rgb_t                                     # `rgb_input_last = rgb[:, -1]` IS the target frame (train_helper.py:299)
     with torch.no_grad():
         fp = F2((torch.cat([last.unsqueeze(2), rgb_out.detach().unsqueeze(2)], 2) * 0.5 + 0.5) * 255.0) / 255.0
@@ -414,19 +431,140 @@ def gan_iteration(ref, batch, name):
     out.update({"term." + k: np.float64(v.item()) for k, v in terms.items()})
     for k, p in D.named_parameters():
         out["dgn." + k] = np.float64(p.grad.double().norm().item())
+        out["dgs4k." + k] = dense(p.grad)
     G.zero_grad()
     g_loss.backward()
+    # round 6: 4096 strided entries per gradient of both networks and the lookups the reference made - its own fp32 noise
+    # against the fp64 truth on ITS branch (tests/truth.py) is what the HIP gradients' entry-by-entry gate is set from
     for k, p in G.named_parameters():
         out["ggn." + k] = np.float64(p.grad.double().norm().item())
+        out["ggs4k." + k] = dense(p.grad)
+    for st, ix in picked.items():
+        out[f"idx.{st}"] = ix
     out["flow_pred_absmax"] = np.float64(fp.abs().max().item())
     out["cfg"] = np.array(json.dumps(dict(hw=256, batch=batch, tag=name, lams=lam, **cfg)))
     np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
     print(name, {k: float(v) for k, v in out.items() if k.endswith("loss") or k.startswith("term.")})
 
 
+def load_ref_utils():
+    """the reference's `Code/utils/utils.py` as a module (its `weights_init_normal`, :328-334); torchvision, cv2, png are
+    absent here and only touched by its plotting helpers: stubbed"""
+    import importlib
+    for name in ("torchvision", "torchvision.utils", "cv2", "png"):
+        if name not in sys.modules:
+            try:
+                importlib.import_module(name)
+            except Exception:
+                sys.modules[name] = types.ModuleType(name)
+    if not hasattr(sys.modules["torchvision.utils"], "make_grid"):
+        sys.modules["torchvision.utils"].make_grid = lambda *a, **k: None
+    pkg = types.ModuleType("ref_utils_pkg")
+    pkg.__path__ = [f"{REF}/utils"]
+    sys.modules["ref_utils_pkg"] = pkg
+    return importlib.import_module("ref_utils_pkg.utils")
+
+
+def from_scratch(ref, name="twostream_64_b2_from_scratch", hw=64, batch=2, steps=3, lr=2e-4):
+    """Round 6 (review: "the reference's from-scratch state has never gone through the kernels").  The reference model
+    from ITS OWN init path - `get_twostream(...)` then `generator.apply(weights_init_normal)` (utils/utils.py:328-334, 342),
+    `Quantize_topk.__init__` (models/unet.py:277-280: cluster_size = 0, embed_avg = embed) - with the random draws
+    replaced by the hash filler of the same distributions (`synthetic.make_from_scratch_state`; structure, constants and
+    distribution parameters are asserted against the reference-initialised model first), then `steps` optimisation steps
+    (Adam, the G-only objective of `twostream_train`) and an eval forward.  Recorded per step: loss, commit terms, the
+    three EMA buffers of both memories (the slots NOT hit so far sit at embed = 0.99^t e0 / ~1e-5: models/unet.py:298-309),
+    the lookups; of the eval forward: frames, commit scalars, quantised maps, lookups, per-sample PSNR inputs."""
+    cfg = dict(in_channel=(12, 6), out_channel=(3, 2), embed_dim=64, n_embed=256, k=2)
+    ru = load_ref_utils()
+    torch.manual_seed(0)
+    net = ref.get_twostream(cfg["in_channel"], cfg["out_channel"], 64, 256, 2)
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    net.apply(ru.weights_init_normal)
+    own = net.state_dict()
+    sd = S.make_from_scratch_state(**cfg)
+    assert list(own.keys()) == list(sd.keys())
+    for k, v in own.items():
+        f = sd[k]
+        assert tuple(v.shape) == tuple(f.shape) and v.dtype == f.dtype, k
+        leaf = k.rsplit(".", 1)[-1]
+        touched = not torch.equal(v, before[k])
+        if leaf in ("running_mean", "running_var", "num_batches_tracked", "cluster_size") or \
+                (leaf == "bias" and own[k[:-4] + "weight"].dim() == 1):
+            assert torch.equal(v, f), k                                    # constants: 0 / 1 / 0 / 0, BatchNorm beta = 0
+        elif leaf == "embed_avg":
+            assert torch.equal(v, own[k.replace("embed_avg", "embed")]) and torch.equal(f, sd[k.replace("embed_avg", "embed")]), k
+        elif leaf == "embed":
+            assert abs(float(v.std()) - 1.0) < 0.02 and abs(float(f.std()) - 1.0) < 0.02, k
+        elif leaf == "weight" and v.dim() == 1:                            # BatchNorm gamma ~ N(1, 0.02)
+            assert touched and abs(float(v.mean()) - 1) < 0.01 and abs(float(f.mean()) - 1) < 0.01 and float(f.std()) < 0.03, k
+        elif leaf == "weight":                                             # every conv / transposed-conv filter ~ N(0, 0.02)
+            assert touched and abs(float(v.std()) - 0.02) < 2e-3 and abs(float(f.std()) - 0.02) < 2e-3, (k, float(v.std()), float(f.std()))
+        else:                                                              # conv biases: torch's default, untouched by the init
+            assert leaf == "bias" and not touched, k
+            w = own[k[:-4] + "weight"]
+            b = 1.0 / float(w.shape[1] * w.shape[2] * w.shape[3]) ** 0.5     # (what the reference's draw is bounded by - checked:)
+            assert float(v.abs().max()) <= b * (1 + 1e-6) and float(f.abs().max()) <= b * (1 + 1e-6), (k, b)
+            assert v.numel() < 32 or (float(v.abs().max()) >= 0.8 * b and float(f.abs().max()) >= 0.8 * b), (k, b)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=lr)
+    out = {}
+    picked = {}
+    hooks = None
+    for t in range(steps):
+        rgb_x, op_x, rgb_t, op_t = S.make_clips(batch, hw, hw, tag=f"{name}:{t}")
+        pre = {k: v.clone() for k, v in net.state_dict().items()}
+        hooks = lookup_hooks(net, pre, picked)
+        rgb, op, (rd, od), _ = net(rgb_x, op_x)
+        for h_ in hooks:
+            h_.remove()
+        loss = torch.norm(rgb - rgb_t, p=2, dim=1).mean() + torch.norm(op - op_t, p=2, dim=1).mean() + (rd + od).sum()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        out[f"step{t}.loss"] = np.float64(loss.item())
+        out[f"step{t}.rgb_diff"], out[f"step{t}.op_diff"] = rd.detach().numpy(), od.detach().numpy()
+        for st in ("rgb", "op"):
+            out[f"step{t}.idx.{st}"] = picked[st]
+            q = getattr(net, st).vq_down3.quan.quantize
+            for b_ in ("embed", "cluster_size", "embed_avg"):
+                out[f"step{t}.{st}.{b_}"] = getattr(q, b_).detach().numpy().copy()
+    # eval forward from the trained state: the codebook now holds slots no row has hit (|embed| ~ 1e5)
+    net.eval()
+    rgb_x, op_x, rgb_t, op_t = S.make_clips(batch, hw, hw, tag=f"{name}:eval")
+    hooks = lookup_hooks(net, {k: v.clone() for k, v in net.state_dict().items()}, picked)
+    with torch.no_grad():
+        rgb, op, (rd, od), (rq, oq) = net(rgb_x, op_x)
+    for h_ in hooks:
+        h_.remove()
+    out.update({"eval.rgb": rgb.numpy(), "eval.op": op.numpy(), "eval.rgb_diff": rd.numpy(), "eval.op_diff": od.numpy(),
+                "eval.rgb_q": rq.numpy(), "eval.op_q": oq.numpy(), "eval.idx.rgb": picked["rgb"], "eval.idx.op": picked["op"]})
+    fin = net.state_dict()
+    for st in ("rgb", "op"):
+        e = fin[f"{st}.vq_down3.quan.quantize.embed"]
+        cs = fin[f"{st}.vq_down3.quan.quantize.cluster_size"]
+        out[f"final.{st}.slots_never_hit"] = np.int64(int((cs == 0).sum()))
+        out[f"final.{st}.embed_absmax"] = np.float64(float(e.abs().max()))
+    # a few final parameters (Adam moved every one of them three times) as a check on the whole trajectory
+    for k in ("rgb.inc.conv.conv.0.weight", "op.outc.weight", "bridge.O2F.conv.3.weight", "rgb.vq_down3.quan.enc.weight",
+              "rgb.up2.up.weight", "op.down3.mpconv.1.conv.1.weight"):
+        out["final." + k] = dense(fin[k], 512)
+    out["cfg"] = np.array(json.dumps(dict(hw=hw, batch=batch, steps=steps, lr=lr, tag=name, **cfg)))
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    print(name, {k: (float(v) if np.ndim(v) == 0 else v.shape) for k, v in out.items() if k.startswith(("final.", "step")) and "idx" not in k and "embed" not in k[6:] and "cluster" not in k})
+    print({k: float(out[k]) for k in out if k.endswith(("slots_never_hit", "embed_absmax"))})
+
+
 def main():
     torch.set_num_threads(8)
     ref = load_ref_unet()
+    if len(sys.argv) > 1 and sys.argv[1] == "from_scratch":
+        from_scratch(ref)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "train_small":
+        twostream_train(ref, 64, 2, "twostream_64_b2_train", dense_samples=4096)
+        twostream_train(ref, 256, 2, "twostream_256_b2_train", out_step=4, dense_samples=4096)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "gan":
         # the joint G / D iteration at the training benchmark's frame size: batch 2 (the -m gpu test) or 32 (what
         # bench.py's train_gan leg times; ~35 GB, several minutes)
@@ -447,13 +585,14 @@ def main():
     twostream_eval(ref, 256, 2, 256, "twostream_256_b2_eval", full=False)
     # the benchmark's own workload (BASELINE.json configs[1]): batch 16, 256x256, 2000 slots
     twostream_eval(ref, 256, 16, 2000, "twostream_256_b16_m2000_eval", full=False, rows=(0, 7, 15), q_step=4, grid=8)
-    twostream_train(ref, 64, 2, "twostream_64_b2_train")
+    twostream_train(ref, 64, 2, "twostream_64_b2_train", dense_samples=4096)
     # the training benchmark's frame size (BASELINE.json configs[2] shape at batch 2): loss, strided outputs, every
     # gradient's norm + 64 samples, post-step buffers
-    twostream_train(ref, 256, 2, "twostream_256_b2_train", out_step=4)
+    twostream_train(ref, 256, 2, "twostream_256_b2_train", out_step=4, dense_samples=4096)
     score_fusion_golden()
     discriminator_and_losses()
     flownet2sd_golden()
+    from_scratch(ref)
 
 
 

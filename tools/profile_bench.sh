@@ -14,7 +14,7 @@ cd "$GRAFT_REPO_ROOT"
 # per-kernel statistics of the training step: one HIP stream (kernels of the two network streams running concurrently
 # stretch each other's durations; exported here, in the shell, not as an `env` hop under rocprofv3)
 case "$MODE" in train|train_gan) export AMMC_TWO_STREAMS=0;; infer) export AMMC_EVAL_LANES=0;; esac
-ARGS="--mode $MODE --steps 5 --warmup 2 --no-cpu-baseline --no-secondary $*"
+ARGS="--mode $MODE --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-grad-check $*"
 echo "python3 bench.py $ARGS" > $OUT/command.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 bench.py $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- python3 bench.py $ARGS > $OUT/pmc_fetch.log 2>&1

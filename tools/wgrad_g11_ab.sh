@@ -10,7 +10,7 @@ for shape in "32 256 256 64 64" "32 128 128 128 128" "32 64 64 256 256" "32 32 3
 done
 for g in 0 1 0 1; do
   echo "== train step, AMMC_WGRAD_G11=$g"
-  AMMC_WGRAD_G11=$g python bench.py --mode train --steps 8 --warmup 3 --no-secondary --no-cpu-baseline 2>/dev/null | python -c "import sys, json; d = json.loads(sys.stdin.readlines()[-1]); print(d.get('ms_per_step'), d.get('train', {}).get('parity', {}).get('ok'))"
+  AMMC_WGRAD_G11=$g python bench.py --mode train --steps 8 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys, json; d = json.loads(sys.stdin.readlines()[-1]); print(d.get('ms_per_step'), (d.get('parity') or {}).get('ok'), ((d.get('parity') or {}).get('vs_fp64') or {}).get('ok'))"
 done
 for g in 0 1; do
   echo "== gradients against the fp64 truth, AMMC_WGRAD_G11=$g"

@@ -9,5 +9,5 @@ for shape in "32 256 256 64 64" "32 256 256 128 64" "32 128 128 128 128" "32 128
 done
 for roll in 0 1 0 1; do
   echo "== train step, AMMC_WGRAD_ROLL=$roll"
-  AMMC_WGRAD_ROLL=$roll python bench.py --mode train --steps 8 --warmup 3 --no-secondary --no-cpu-baseline | python -c "import sys, json; d = json.loads(sys.stdin.readlines()[-1]); print(d.get('ms_per_step'), d.get('train', {}).get('parity', {}).get('ok'))"
+  AMMC_WGRAD_ROLL=$roll python bench.py --mode train --steps 8 --warmup 3 --no-cpu-baseline | python -c "import sys, json; d = json.loads(sys.stdin.readlines()[-1]); print(d.get('ms_per_step'), (d.get('parity') or {}).get('ok'), ((d.get('parity') or {}).get('vs_fp64') or {}).get('ok'))"
 done
