@@ -71,6 +71,8 @@ SIGNATURES = {
     "ammc_memory_topk_fwd_f32": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
     "ammc_pack_codebook_s16": (C.c_int, [_p, _i32, _i32, _p, _p]),
     "ammc_pack_codebook_s16_guarded": (C.c_int, [_p, _i32, _i32, _p, _p, _p]),
+    "ammc_memory_block_s16": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p,
+                                         _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "ammc_memory_topk_fwd_s16": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
     "ammc_sum_partials_f32": (C.c_int, [_p, _i32, _f32, _p, _p]),
     "ammc_conv_gemm_s16": (C.c_int, [C.POINTER(AmmcConvDesc), _p]),

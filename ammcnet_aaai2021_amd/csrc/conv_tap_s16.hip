@@ -747,6 +747,7 @@ __device__ __forceinline__ void conv_tap_s16_tile(const TapArgs& a, const int vb
           for (int k = 0; k < 8; ++k) {
             float t = TAP_ACC16(pt, 2 * u + (k >> 2), k & 3) * sc[k] + sh[k];
             if (d.act == AMMC_ACT_RELU) t = t > 0.f ? t : 0.f;
+            else if (d.act == AMMC_ACT_LRELU) t = t > 0.f ? t : 0.1f * t;
             v[k] = t;
           }
           if (d.res) {
@@ -968,6 +969,7 @@ __device__ __forceinline__ void conv_tap_s16_tile(const TapArgs& a, const int vb
         for (int k = 0; k < 8; ++k) {
           float t = TAP_ACC(i, j, 8 * o + k) * sc[k] + sh[k];
           if (d.act == AMMC_ACT_RELU) t = t > 0.f ? t : 0.f;
+          else if (d.act == AMMC_ACT_LRELU) t = t > 0.f ? t : 0.1f * t;
           v[k] = t;
         }
         if (d.res) {
@@ -1088,7 +1090,10 @@ int conv_tap_s16_try(const AmmcConvDesc& d, int kpad, hipStream_t stream, char* 
   constexpr int TAP_SKIP = -12345;
   if (!mode) return TAP_SKIP;
   if (d.ntaps != 9 || d.up != 1 || d.x_step > 1) return TAP_SKIP;
-  if (d.act == AMMC_ACT_LRELU) return TAP_SKIP;           // (FlowNet2-SD / discriminator layers: the implicit-GEMM kernel's epilogue has it)
+  // (round 6: LeakyReLU(0.1) in the epilogues - FlowNet2-SD's stride-1 3x3 layers at 128x128 ... 32x32 take the halo-patch
+  // kernels; AMMC_TAP_LRELU=0 sends them back to the implicit GEMM for A/Bs)
+  static const int tap_lrelu = getenv("AMMC_TAP_LRELU") ? atoi(getenv("AMMC_TAP_LRELU")) : 1;
+  if (d.act == AMMC_ACT_LRELU && (!tap_lrelu || d.y_f32)) return TAP_SKIP;      // (the S16-output epilogues have it; fp32 outputs: the GEMM kernel)
   if (d.cin % 32 || d.width % T_TW || d.height % T_TH) return TAP_SKIP;
   if (d.n != 32 && d.n != 64 && d.n % 128) return TAP_SKIP;
   if (d.n == 32 && !d.y_f32) return TAP_SKIP;

@@ -328,8 +328,402 @@ int launch_topk_s16(const float* x, const void* e_s16, const float* e_md, const 
   return ammc_launch_status();
 }
 
+
+// ======================================================================================================================
+// Round 6: the WHOLE memory block of the inference path as ONE launch (`enc_quan_dec_res_topk.forward`, reference
+// Code/models/unet.py:318-331, 379-387): enc 1x1 (C -> 64, + bias) -> distance GEMM + top-2 (the kernel above) -> gather ->
+// dec 1x1 (128 -> C, + bias) -> `out += x` for a 64-pixel tile, one workgroup (8 waves) per tile.  Until round 5 this was
+// five launches per stream (conv_gemm_s16 1x1, memory_topk_s16, sum_partials, split_rows, conv_gemm_s16 1x1): ~95 us of
+// kernel time for ~9 us of MFMAs, every stage latency-bound on its own (16384 rows = 256 tiles, one wave of workgroups).
+// Now z, the N x M distances, the gathered rows and their S16 re-encoding never leave the CU:
+//   A  waves 0-3: z = x4 . Wenc for a 32-pixel x 32-channel tile each, K = C sequential (fragments straight from L2: the
+//      pixel's S16 groups and the filter row's are 32 contiguous bytes per lane and k-step), written to LDS as the fp32
+//      copy + S16 image the distance sweep reads - the SAME k order, accumulator pair and epilogue expression as
+//      conv_gemm_s16's 1x1 path, so z (and with it every lookup) is bit-identical to the five-launch chain;
+//   B  the distance sweep / top-2 / merge of memory_topk_s16_kernel<2, true, 2>, unchanged;
+//   C  gather: q_topk (optional), q_one, commit partial exactly as above (same thread -> element map: the same partials),
+//      plus the S16 image of the gathered rows in LDS (XOR-swizzled 16-byte slots);
+//   D  every wave: out[64 pixels x 64 channels] = qk . Wdec + bias + x4 (the S16 residual), split, 32-byte S16 stores;
+//   E  the LAST workgroup to arrive sums the commit partials in sum_partials_kernel's order (agent-scope release / acquire
+//      around one atomic counter; the counter is left at zero for the next launch).
+struct MemBlockArgs {
+  const float* x; int64_t x_bs, x_rs, x_ps;       // S16 activation [B][h][w][C] (interior pixel 0)
+  float* y; int64_t y_bs, y_rs, y_ps;             // S16 output, same geometry
+  const float* enc_w; const float* enc_b;         // S16 [64][C] (k-major rows), fp32 [64]
+  const float* dec_w; const float* dec_b;         // S16 [C][128], fp32 [C]
+  const h16x8* e_s16; const float* e_md; const float* enorm;
+  int n, hw, w, m, mpad, nparts;
+  int* idx; float* q_topk; float* q_one;
+  float* diff_partial; float* diff; int* counter; float inv_count;
+  int* overflow_flag;
+};
+
+template <int C>
+__global__ __launch_bounds__(512, 2) void memory_block_s16_kernel(MemBlockArgs a) {
+  constexpr int K = 2, RT = 2, SBR = 64, NT = 512, NW = 8;
+  static_assert(C == 512, "8 waves x 64 output channels");
+  __shared__ __attribute__((aligned(16))) float xs[SBR * SD];            // fp32 z, swizzled 16-B slots
+  // one region, two lives (64 KB of static LDS is the limit): the S16 image of z + the candidate lists during the sweep,
+  // then - both dead behind the merge's barrier - the S16 image of the gathered rows [64][128 ch], swizzled 16-B slots
+  constexpr int CROW = 2 * NW * K + 1;
+  __shared__ __attribute__((aligned(16))) float region[SBR * SD + 2 * SBR * CROW];
+  _Float16* xh = reinterpret_cast<_Float16*>(region);                    // [64][128 halfs]: row = 8 hi slots | 8 lo slots
+  float* cand_v = region + SBR * SD;
+  int* cand_i = reinterpret_cast<int*>(cand_v + SBR * CROW);
+  float* qs = region;
+  static_assert(SBR * SD + 2 * SBR * CROW >= SBR * 2 * SD, "the gathered rows fit the region");
+  __shared__ float xx[SBR];
+  __shared__ int best[SBR * K];
+  __shared__ float red[NT];
+  __shared__ double dred[256];
+  __shared__ float ens[2048];
+  __shared__ int is_last;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int r0 = blockIdx.x * SBR;
+  const int n = a.n, m = a.m, mpad = a.mpad;
+  const int pl31 = (l31 & 19) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);     // MFMA row -> filter: bits 2 and 3 swapped (conv_gemm_s16.hip)
+  for (int i = tid; i < m; i += NT) ens[i] = a.enorm[i];
+
+  // pixel offsets of this lane's two tile rows (rows beyond n: the last row's pixel, results dropped)
+  int64_t pix_in[RT], pix_out[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    int r = r0 + 32 * rt + l31;
+    r = r < n ? r : n - 1;
+    const int b = r / a.hw, rem = r - b * a.hw, yy = rem / a.w, xq = rem - yy * a.w;
+    pix_in[rt] = (int64_t)b * a.x_bs + (int64_t)yy * a.x_rs + (int64_t)xq * a.x_ps;
+    pix_out[rt] = (int64_t)b * a.y_bs + (int64_t)yy * a.y_rs + (int64_t)xq * a.y_ps;
+  }
+
+  // ---- A: enc 1x1 ------------------------------------------------------------------------------------------------------------
+  if (wave < 4) {
+    const int pt = wave & 1, ct = wave >> 1;
+    const float* px = a.x + pix_in[pt] + 8 * h;
+    const float* fw = a.enc_w + (int64_t)(ct * 32 + pl31) * C + 8 * h;
+    f32x16 hh, xa;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { hh[r] = 0.f; xa[r] = 0.f; }
+#pragma unroll 8
+    for (int t = 0; t < C / 16; ++t) {
+      const h16x8 ah = *reinterpret_cast<const h16x8*>(px + 16 * t), al = *reinterpret_cast<const h16x8*>(px + 16 * t + 4);
+      const h16x8 bh = *reinterpret_cast<const h16x8*>(fw + 16 * t), bl = *reinterpret_cast<const h16x8*>(fw + 16 * t + 4);
+      hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, hh, 0, 0, 0);
+      xa = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, xa, 0, 0, 0);
+      xa = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, xa, 0, 0, 0);
+    }
+    const int row = 32 * pt + l31;
+    const bool live = r0 + row < n;
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const int c0 = ct * 32 + 8 * (2 * o + h);
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.enc_b + c0), s1 = *reinterpret_cast<const f32x4*>(a.enc_b + c0 + 4);
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = hh[8 * o + k] + xa[8 * o + k] * S_LO_INV;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[k] += s0[k]; v[4 + k] += s1[k]; }
+      if (!live) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = 0.f;
+      }
+      const int kg = c0 >> 3;
+      *reinterpret_cast<f32x4*>(xs + row * SD + (((2 * kg) ^ (row & 15)) << 2)) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(xs + row * SD + (((2 * kg + 1) ^ (row & 15)) << 2)) = f32x4{v[4], v[5], v[6], v[7]};
+      ammc_u4 hi, lo;
+      ammc_s16_split8(v, hi, lo);
+      *reinterpret_cast<ammc_u4*>(xh + row * 2 * SD + ((kg ^ (row & 15)) << 3)) = hi;
+      *reinterpret_cast<ammc_u4*>(xh + row * 2 * SD + (((8 + kg) ^ (row & 15)) << 3)) = lo;
+    }
+  }
+  __syncthreads();
+  if (tid < SBR) {
+    float s = 0.f;
+    for (int sl = 0; sl < SD / 4; ++sl) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xs + tid * SD + ((sl ^ (tid & 15)) << 2));
+      s += v[0] * v[0];
+      s += v[1] * v[1];
+      s += v[2] * v[2];
+      s += v[3] * v[3];
+    }
+    xx[tid] = s;
+  }
+  __syncthreads();
+
+  // ---- B: distances + running top-2 (memory_topk_s16_kernel<2, true, 2>'s sweep) ---------------------------------------------
+  {
+    float bv[RT][K];
+    int bi[RT][K];
+    float xnorm[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) { bv[rt][j] = INFINITY; bi[rt][j] = 0x7fffffff; }
+      xnorm[rt] = xx[l31 + 32 * rt];
+    }
+    h16x8 bh[RT][4], bx[RT][4], bl2[RT][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int kg = 2 * t + h, row = l31 + 32 * rt;
+        bh[rt][t] = *reinterpret_cast<const h16x8*>(xh + row * 2 * SD + ((kg ^ (row & 15)) << 3));
+        const h16x8 bl = *reinterpret_cast<const h16x8*>(xh + row * 2 * SD + (((8 + kg) ^ (row & 15)) << 3));
+        bx[rt][t] = bh[rt][t] * (_Float16)S_LO_INV;
+        bl2[rt][t] = bl * (_Float16)S_LO_INV;
+      }
+    const int ntile = mpad >> 5;
+    const h16x8* e_s16 = a.e_s16;
+#define F_LOAD(dst_h, dst_l, tile_)                                                                    \
+  {                                                                                                    \
+    const int tl_ = (tile_) < ntile ? (tile_) : ntile - 1;                                             \
+    const h16x8* ep_ = e_s16 + ((int64_t)(2 * h) * mpad + (tl_ << 5) + l31);                           \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                    \
+      dst_h[t] = ep_[(int64_t)(4 * t) * mpad];                                                         \
+      dst_l[t] = ep_[(int64_t)(4 * t + 1) * mpad];                                                     \
+    }                                                                                                  \
+  }
+#define F_TILES(src_h, src_l, tile_)                                                                   \
+  {                                                                                                    \
+    f32x16 acc[RT];                                                                                    \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                  \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;                                 \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                    \
+      _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                \
+        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src_h[t], bh[rt][t], acc[rt], 0, 0, 0);       \
+      _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                \
+        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src_l[t], bx[rt][t], acc[rt], 0, 0, 0);       \
+      _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                \
+        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(src_h[t], bl2[rt][t], acc[rt], 0, 0, 0);      \
+    }                                                                                                  \
+    if ((tile_) < ntile) {                                                                             \
+      const int s0_ = (tile_) << 5;                                                                    \
+      float en_[16];                                                                                   \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                 \
+        const int s = s0_ + (r & 3) + 8 * (r >> 2) + 4 * h;                                            \
+        const int sc = s < m ? s : m - 1;                                                              \
+        en_[r] = s < m ? ens[sc] : INFINITY;                                                           \
+      }                                                                                                \
+      _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                               \
+          const float dist = (xnorm[rt] - 2.f * acc[rt][r]) + en_[r];                                  \
+          s_topk_insert_ordered<K>(bv[rt], bi[rt], dist, s0_ + (r & 3) + 8 * (r >> 2) + 4 * h);        \
+        }                                                                                              \
+    }                                                                                                  \
+  }
+    {
+      h16x8 ah0[4], al0[4], ah1[4], al1[4];
+      int tile = wave;
+      F_LOAD(ah0, al0, tile)
+      while (tile < ntile) {
+        F_LOAD(ah1, al1, tile + 8)
+        __builtin_amdgcn_sched_barrier(0);
+        F_TILES(ah0, al0, tile)
+        tile += 8;
+        if (tile >= ntile) break;
+        F_LOAD(ah0, al0, tile + 8)
+        __builtin_amdgcn_sched_barrier(0);
+        F_TILES(ah1, al1, tile)
+        tile += 8;
+      }
+    }
+#undef F_LOAD
+#undef F_TILES
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const int o = (l31 + 32 * rt) * CROW + (wave * 2 + h) * K + j;
+        cand_v[o] = bv[rt][j];
+        cand_i[o] = bi[rt][j];
+      }
+  }
+  __syncthreads();
+  if (tid < SBR) {
+    float v[K];
+    int ix[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { v[j] = INFINITY; ix[j] = 0x7fffffff; }
+    for (int c = 0; c < 2 * NW * K; ++c) s_topk_insert<K>(v, ix, cand_v[tid * CROW + c], cand_i[tid * CROW + c]);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      best[tid * K + j] = ix[j];
+      if (r0 + tid < n) a.idx[(int64_t)(r0 + tid) * K + j] = ix[j];
+    }
+  }
+  __syncthreads();
+
+  // ---- C: gather + commit distance (the map of memory_topk_s16_kernel: the same partial sums), S16 image of the rows -------------
+  float part = 0.f;
+  constexpr int slots16 = SD / 4;
+  const int half = tid >> 8, t8 = tid & 255;
+  for (int p = t8; p < 32 * K * slots16; p += 256) {
+    const int sl = p % slots16;
+    const int rj = p / slots16;
+    const int j = rj % K, row = 32 * half + rj / K;
+    if (r0 + row >= n) continue;
+    const int s = best[row * K + j];
+    const f32x4 e = *reinterpret_cast<const f32x4*>(a.e_md + (int64_t)s * SD + sl * 4);
+    if (a.q_topk) *reinterpret_cast<f32x4*>(a.q_topk + ((int64_t)(r0 + row) * K + j) * SD + sl * 4) = e;
+    if (j == 0) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + row * SD + ((sl ^ (row & 15)) << 2));
+      f32x4 q1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float df = e[i] - xv[i];
+        part += df * df;
+        q1[i] = xv[i] + df;
+      }
+      if (a.q_one) *reinterpret_cast<f32x4*>(a.q_one + (int64_t)(r0 + row) * SD + sl * 4) = q1;
+    }
+  }
+  // (row, neighbour, group of 8 channels): 64 x 2 x 8 items; slot s of a 512-byte row lives at s ^ (row & 31)
+  for (int p = tid; p < SBR * K * (SD / 8); p += NT) {
+    const int g = p & 7, j = (p >> 3) & 1, row = p >> 4;
+    const int s = r0 + row < n ? best[row * K + j] : 0;
+    const float* ep = a.e_md + (int64_t)s * SD + g * 8;
+    const f32x4 e0 = *reinterpret_cast<const f32x4*>(ep), e1 = *reinterpret_cast<const f32x4*>(ep + 4);
+    const float v[8] = {e0[0], e0[1], e0[2], e0[3], e1[0], e1[1], e1[2], e1[3]};
+    ammc_u4 hi, lo;
+    ammc_s16_split8(v, hi, lo);
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bad |= !(fabsf(v[k]) <= 65504.f);
+    if (bad && a.overflow_flag) atomicOr(a.overflow_flag, 1);            // (a gathered slot beyond the half range: split_rows' verdict)
+    const int kg = j * 8 + g;                                             // channel group of the 128-channel row
+    *reinterpret_cast<ammc_u4*>(qs + row * 2 * SD + (((2 * kg) ^ (row & 31)) << 2)) = hi;
+    *reinterpret_cast<ammc_u4*>(qs + row * 2 * SD + (((2 * kg + 1) ^ (row & 31)) << 2)) = lo;
+  }
+  red[tid] = part;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t8 < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (t8 == 0 && (int)blockIdx.x * RT + half < a.nparts) a.diff_partial[blockIdx.x * RT + half] = red[tid];
+
+  // ---- D: dec 1x1 + bias + residual, S16 out: wave = 64 output channels x 64 pixels ------------------------------------------------
+  {
+    f32x16 hh[RT][2], xa[RT][2];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { hh[rt][c][r] = 0.f; xa[rt][c][r] = 0.f; }
+    const float* fw0 = a.dec_w + (int64_t)(wave * 64 + pl31) * (2 * SD) + 8 * h;
+#pragma unroll
+    for (int t = 0; t < (2 * SD) / 16; ++t) {
+      const int g = 2 * t + h;
+      h16x8 ah[RT], al[RT], bh[2], bl[2];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const int row = 32 * rt + l31;
+        ah[rt] = *reinterpret_cast<const h16x8*>(qs + row * 2 * SD + (((2 * g) ^ (row & 31)) << 2));
+        al[rt] = *reinterpret_cast<const h16x8*>(qs + row * 2 * SD + (((2 * g + 1) ^ (row & 31)) << 2));
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        bh[c] = *reinterpret_cast<const h16x8*>(fw0 + (int64_t)c * 32 * (2 * SD) + 16 * t);
+        bl[c] = *reinterpret_cast<const h16x8*>(fw0 + (int64_t)c * 32 * (2 * SD) + 16 * t + 4);
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          hh[rt][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[c], ah[rt], hh[rt][c], 0, 0, 0);
+          xa[rt][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[c], ah[rt], xa[rt][c], 0, 0, 0);
+          xa[rt][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[c], al[rt], xa[rt][c], 0, 0, 0);
+        }
+    }
+    bool bad = false;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      if (r0 + 32 * rt + l31 >= n) continue;
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+          const int c0 = wave * 64 + c * 32 + 8 * (2 * o + h);
+          const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.dec_b + c0), s1 = *reinterpret_cast<const f32x4*>(a.dec_b + c0 + 4);
+          float v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = hh[rt][c][8 * o + k] + xa[rt][c][8 * o + k] * S_LO_INV;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { v[k] += s0[k]; v[4 + k] += s1[k]; }
+          const float* rp = a.x + pix_in[rt] + c0;
+          const h16x8 rh = *reinterpret_cast<const h16x8*>(rp), rl = *reinterpret_cast<const h16x8*>(rp + 4);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] += (float)rh[k] + (float)rl[k] * S_LO_INV;
+          ammc_u4 hi, lo;
+          ammc_s16_split8(v, hi, lo);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) bad |= !(fabsf(v[k]) <= 65504.f);
+          float* yp = a.y + pix_out[rt] + c0;
+          *reinterpret_cast<ammc_u4*>(yp) = hi;
+          *reinterpret_cast<ammc_u4*>(yp + 4) = lo;
+        }
+    }
+    if (bad && a.overflow_flag) atomicOr(a.overflow_flag, 1);
+  }
+
+  // ---- E: the last workgroup sums the commit partials (sum_partials_kernel's expressions, operation for operation) -------------
+  __threadfence();                                             // release: this workgroup's partials before its arrival
+  __syncthreads();
+  if (tid == 0) is_last = atomicAdd(a.counter, 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (is_last) {
+    __threadfence();                                           // acquire
+    if (tid < 256) {
+      double s = 0.0;
+      for (int i = tid; i < a.nparts; i += 256)
+        s += (double)__hip_atomic_load(a.diff_partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      dred[tid] = s;
+    }
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) dred[tid] += dred[tid + o];
+      __syncthreads();
+    }
+    if (tid == 0) {
+      a.diff[0] = (float)(dred[0] * (double)a.inv_count);
+      __hip_atomic_store(a.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 }  // namespace ammc_impl
 using namespace ammc_impl;
+
+extern "C" int ammc_memory_block_s16(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, float* y, int64_t y_bs, int64_t y_rs,
+                                     int64_t y_ps, int32_t batch, int32_t h, int32_t w, int32_t c, const float* enc_w,
+                                     const float* enc_b, const void* e_s16, const float* embed_md, const float* enorm, int32_t d,
+                                     int32_t m, int32_t k, const float* dec_w, const float* dec_b, int32_t* idx_topk,
+                                     float* q_topk, float* q_one, float* diff_partial, float* diff, int32_t* counter,
+                                     int32_t* overflow_flag, void* stream) {
+  if (!x || !y || !enc_w || !enc_b || !e_s16 || !embed_md || !enorm || !dec_w || !dec_b || !idx_topk || !diff_partial || !diff ||
+      !counter)
+    return AMMC_EINVAL;
+  if (batch <= 0 || h <= 0 || w <= 0 || m <= 0 || k <= 0 || k > m) return AMMC_EINVAL;
+  if ((x_bs | x_rs | x_ps | y_bs | y_rs | y_ps) & 7) return AMMC_EINVAL;
+  if ((((uintptr_t)x | (uintptr_t)y) & 31) || (((uintptr_t)enc_w | (uintptr_t)dec_w | (uintptr_t)enc_b | (uintptr_t)dec_b) & 15))
+    return AMMC_EINVAL;
+  if (d != SD || k != 2 || c != 512 || m > 2048) return AMMC_EUNSUP;       // the shipped block's shape; else the five-launch chain
+  const int64_t n64 = (int64_t)batch * h * w;
+  if (n64 >= (1LL << 31)) return AMMC_EUNSUP;
+  MemBlockArgs a;
+  a.x = x; a.x_bs = x_bs; a.x_rs = x_rs; a.x_ps = x_ps;
+  a.y = y; a.y_bs = y_bs; a.y_rs = y_rs; a.y_ps = y_ps;
+  a.enc_w = enc_w; a.enc_b = enc_b; a.dec_w = dec_w; a.dec_b = dec_b;
+  a.e_s16 = reinterpret_cast<const h16x8*>(e_s16); a.e_md = embed_md; a.enorm = enorm;
+  a.n = (int)n64; a.hw = h * w; a.w = w; a.m = m; a.mpad = (m + 31) / 32 * 32; a.nparts = (a.n + 31) / 32;
+  a.idx = idx_topk; a.q_topk = q_topk; a.q_one = q_one;
+  a.diff_partial = diff_partial; a.diff = diff; a.counter = counter; a.inv_count = 1.f / ((float)a.n * (float)SD);
+  a.overflow_flag = overflow_flag;
+  hipLaunchKernelGGL(memory_block_s16_kernel<512>, dim3((a.n + 63) / 64), dim3(512), 0, (hipStream_t)stream, a);
+  return ammc_launch_status();
+}
 
 extern "C" int ammc_pack_codebook_s16_guarded(const float* embed_dm, int32_t d, int32_t m, void* e_s16, int32_t* range_flag,
                                               void* stream) {

@@ -141,6 +141,10 @@ class Plan:
         return [(m, e0.elapsed_time(e1)) for m, (e0, e1) in zip(self.meta, evs)]
 
 
+# the memory block of an S16 plan as one launch (ammc_memory_block_s16); AMMC_FUSED_MEMORY=0: the five-launch chain (A/Bs)
+FUSED_MEMORY = os.environ.get("AMMC_FUSED_MEMORY", "1") != "0"
+
+
 class _Packer:
     """weight pre-packing through the C ABI"""
 
@@ -516,15 +520,31 @@ class StreamGraph:
         B, h, w = self.B, self.hs[3], self.ws[3]
         n, d, m, k = B * h * w, v["d"], v["m"], v["k"]
         lib = bld.lib
-        self.z = bld.act(B, h, w, d, halo=0)
-        bld.conv(self.x4, v["enc_w"], self.z, ntaps=1, cin=512, n=d, shift=v["enc_b"], name="vq.enc", y_f32=True)
         self.idx = torch.zeros((n, k), device=bld.device, dtype=torch.int32)
-        self.qk = bld.act(B, h, w, k * d, halo=0)
         self.q_one = bld.buf(B, h, w, d)
         nblk = lib.ammc_memory_topk_blocks(n)
         self.diff_part = bld.buf(nblk)
         self.diff = bld.buf(1)
         bld.plan.keep.extend([self.idx, v["embed"], v["e_md"], v["enorm"]])
+        if (bld.s16 and v.get("e_s16") is not None and FUSED_MEMORY and (d, k) == (64, 2) and m <= 2048 and
+                self.x4.c == 512 and self.x4.c_off == 0 and os.environ.get("AMMC_MEMORY_S16", "1") != "0"):
+            # round 6: the whole block as ONE launch (csrc/memory_topk_s16.hip, `memory_block_s16_kernel`): z, the n x m
+            # distances, the gathered rows and their S16 re-encoding never leave the CU; bit-identical to the chain below
+            self.x4q = bld.act(B, h, w, 512)
+            counter = torch.zeros(1, device=bld.device, dtype=torch.int32)      # the last workgroup leaves it at zero
+            bld.plan.keep.extend([v["e_s16"], v["enc_w"], v["enc_b"], v["dec_w"], v["dec_b"], counter])
+            bld.plan.add(lib.ammc_memory_block_s16, self.x4.pix0(), *self.x4.strides, self.x4q.pix0(), *self.x4q.strides,
+                         B, h, w, 512, _ptr(v["enc_w"]), _ptr(v["enc_b"]), v["e_s16"].data_ptr(), _ptr(v["e_md"]),
+                         _ptr(v["enorm"]), d, m, k, _ptr(v["dec_w"]), _ptr(v["dec_b"]), self.idx.data_ptr(), None,
+                         _ptr(self.q_one), _ptr(self.diff_part), _ptr(self.diff), counter.data_ptr(),
+                         bld.overflow.data_ptr(), name="vq.block",
+                         flops=2.0 * n * (512 * d + d * m + k * d * 512), nbytes=4.0 * n * (512 + 512 + 512 + k + d),
+                         kernel="memory_block_s16")
+            self.bottom = self.x4q
+            return
+        self.z = bld.act(B, h, w, d, halo=0)
+        bld.conv(self.x4, v["enc_w"], self.z, ntaps=1, cin=512, n=d, shift=v["enc_b"], name="vq.enc", y_f32=True)
+        self.qk = bld.act(B, h, w, k * d, halo=0)
         if v.get("e_s16") is not None and os.environ.get("AMMC_MEMORY_S16", "1") != "0":
             # S16 plans: the distance GEMM in fp32-equivalent split-fp16 arithmetic (csrc/memory_topk_s16.hip)
             bld.plan.keep.append(v["e_s16"])

@@ -191,6 +191,22 @@ int ammc_memory_topk_fwd_s16(const float* x, const void* e_s16, const float* emb
                              int32_t d, int32_t m, int32_t k, int32_t* idx_topk, float* q_topk, float* q_one,
                              float* diff_partial, void* stream);
 
+/* The whole memory block of the inference path as ONE launch (`enc_quan_dec_res_topk.forward`, models/unet.py:318-331,
+ * 379-387): enc 1x1 (c -> d, + enc_b) -> distances + top-k (ammc_memory_topk_fwd_s16's arithmetic) -> gather -> dec 1x1
+ * (k d -> c, + dec_b) -> += x, for 64-pixel tiles; z, the n x m distances and the gathered rows never leave the CU.
+ * x / y: S16 activations [batch][h][w][c] (pointer to interior pixel 0, strides in floats); enc_w [d][c], dec_w [c][k d]:
+ * ammc_pack_conv_weight_f32 (ksize 1) + ammc_split_rows_f32; e_s16 / embed_md / enorm as for ammc_memory_topk_fwd_s16.
+ * Outputs: y, idx_topk [n][k], q_one [n][d] (may be NULL), q_topk [n][k d] fp32 (may be NULL), diff[0] = commit
+ * distance (the LAST workgroup sums diff_partial[ammc_memory_topk_blocks(n)] in ammc_sum_partials_f32's order; *counter
+ * is a device int32 the caller zeroes ONCE - the kernel leaves it at zero), *overflow_flag raised like the S16 epilogues
+ * and ammc_split_rows_guarded_f32 do.  Bit-identical to the five-launch chain it replaces (same k order and expressions).
+ * Shapes: d = 64, k = 2, c = 512, m <= 2048 (the shipped block; otherwise AMMC_EUNSUP: use the chain). */
+int ammc_memory_block_s16(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, float* y, int64_t y_bs, int64_t y_rs,
+                          int64_t y_ps, int32_t batch, int32_t h, int32_t w, int32_t c, const float* enc_w, const float* enc_b,
+                          const void* e_s16, const float* embed_md, const float* enorm, int32_t d, int32_t m, int32_t k,
+                          const float* dec_w, const float* dec_b, int32_t* idx_topk, float* q_topk, float* q_one,
+                          float* diff_partial, float* diff, int32_t* counter, int32_t* overflow_flag, void* stream);
+
 /* diff = sum(partials) / count, fixed order (deterministic) */
 int ammc_sum_partials_f32(const float* partial, int32_t nparts, float inv_count, float* out, void* stream);
 

@@ -54,9 +54,37 @@ def double_conv(sd: State, p: str, x: torch.Tensor, training: bool = False) -> t
     return x
 
 
-def down(sd: State, p: str, x: torch.Tensor, training: bool = False) -> torch.Tensor:
-    """MaxPool2d(2) then double_conv   (models/unet.py:33-41)."""
-    return double_conv(sd, f"{p}.mpconv.1.conv", F.max_pool2d(x, 2), training)
+def maxpool2x2_routes(x: torch.Tensor):
+    """MaxPool2d(2) (floor mode) and WHICH element of each window it took: (pooled, routes [B,C,h,w] int64 in 0..3, window
+    position row-major, the first maximum as F.max_pool2d takes it)"""
+    b, c, hh, ww = x.shape
+    y, flat = F.max_pool2d(x, 2, return_indices=True)
+    iy, ix = flat // ww, flat % ww
+    return y, (iy & 1) * 2 + (ix & 1)
+
+
+def maxpool2x2_forced(x: torch.Tensor, routes: torch.Tensor) -> torch.Tensor:
+    """TEST INSTRUMENTATION (no counterpart in the reference, like `quantize_topk(force_idx=...)`): the pooling with its
+    routes prescribed - element `routes[b,c,i,j]` (0..3, row-major) of window (i, j).  A 2x2 window whose two largest
+    values tie within rounding noise is the path's second discontinuity: which one an fp32-accurate evaluation takes is
+    noise, and the gradient follows it to another pixel.  The fp64 truth of tests/truth.py takes the routes of the
+    evaluation under test where that evaluation records them (the HIP training engine does: one byte per pooled element)."""
+    b, c, hh, ww = x.shape
+    h, w = hh // 2, ww // 2
+    win = x[..., :2 * h, :2 * w].reshape(b, c, h, 2, w, 2).permute(0, 1, 2, 4, 3, 5).reshape(b, c, h, w, 4)
+    return win.gather(-1, routes.to(device=x.device, dtype=torch.int64).unsqueeze(-1)).squeeze(-1)
+
+
+def down(sd: State, p: str, x: torch.Tensor, training: bool = False, force_pool: torch.Tensor = None, aux: dict = None) -> torch.Tensor:
+    """MaxPool2d(2) then double_conv   (models/unet.py:33-41).  `force_pool` / `aux`: test instrumentation - the pooling
+    routes to take (`maxpool2x2_forced`) / a dict that receives the routes this evaluation took under `"<p>.pool"`."""
+    if force_pool is not None:
+        pooled = maxpool2x2_forced(x, force_pool)
+    elif aux is not None:
+        pooled, aux[f"{p}.pool"] = maxpool2x2_routes(x)
+    else:
+        pooled = F.max_pool2d(x, 2)
+    return double_conv(sd, f"{p}.mpconv.1.conv", pooled, training)
 
 
 def up(sd: State, p: str, x1: torch.Tensor, x2: torch.Tensor, training: bool = False) -> torch.Tensor:
@@ -184,11 +212,15 @@ def twostream_forward(sd: State, rgb_x: torch.Tensor, op_x: torch.Tensor, k: int
     """
     aux = {}
 
+    fi = force_idx or {}                  # test instrumentation: {"rgb": idx [N, k], "op": ..., "pool": {"rgb.down1": routes, ...}}
+    fpool = fi.get("pool") or {}
+    pools = {} if want_aux else None
+
     def enc(p, x):
         x1 = double_conv(sd, f"{p}.inc.conv.conv", x, training)
-        x2 = down(sd, f"{p}.down1", x1, training)
-        x3 = down(sd, f"{p}.down2", x2, training)
-        x4 = down(sd, f"{p}.down3", x3, training)
+        x2 = down(sd, f"{p}.down1", x1, training, fpool.get(f"{p}.down1"), pools)
+        x3 = down(sd, f"{p}.down2", x2, training, fpool.get(f"{p}.down2"), pools)
+        x4 = down(sd, f"{p}.down3", x3, training, fpool.get(f"{p}.down3"), pools)
         return x1, x2, x3, x4
 
     def dec(p, x4, x3, x2, x1):
@@ -202,7 +234,6 @@ def twostream_forward(sd: State, rgb_x: torch.Tensor, op_x: torch.Tensor, k: int
 
     r1, r2, r3, r4 = enc("rgb", rgb_x)
     aux.update({"rgb.x1": r1, "rgb.x2": r2, "rgb.x3": r3, "rgb.x4": r4})
-    fi = force_idx or {}                  # test instrumentation: {"rgb": idx [N, k], "op": ...}, see quantize_topk
     r4q, rgb_diff, rgb_q, rgb_idx = vq_block(sd, "rgb.vq_down3", r4, k, training, fi.get("rgb"))
     o1, o2, o3, o4 = enc("op", op_x)
     aux.update({"op.x1": o1, "op.x2": o2, "op.x3": o3, "op.x4": o4})
@@ -213,6 +244,9 @@ def twostream_forward(sd: State, rgb_x: torch.Tensor, op_x: torch.Tensor, k: int
     rgb = dec("rgb", r4b, r3, r2, r1)
     op = dec("op", o4b, o3, o2, o1)
     out = (torch.tanh(rgb), torch.tanh(op), (rgb_diff, op_diff), (rgb_q, op_q))
+    if want_aux:
+        # the routes actually taken: the forced ones where given, else this evaluation's own ("<stream>.down<i>.pool" -> "<stream>.down<i>")
+        aux["pool"] = {**{k[:-5]: v for k, v in pools.items()}, **{k: v for k, v in fpool.items()}}
     return out + (aux,) if want_aux else out
 
 

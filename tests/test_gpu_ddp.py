@@ -44,7 +44,7 @@ def _worker(rank, world, port, q):
     torch.cuda.synchronize()
     ok, detail = True, ""
     # the lookups every rank made (the truth is evaluated on the branch the HIP ranks took: tests/truth.py)
-    mine = {p: v.cpu() for p, v in T.hip_lookups(net).items()}
+    mine = T.branch_to(T.hip_lookups(net), "cpu")
     every = [None] * world
     dist.all_gather_object(every, mine)
     if rank == 0:
@@ -113,14 +113,14 @@ def _worker_sync(rank, world, port, q):
     ncoll = net._train_engine._last["ops"].collectives
     if ncoll != 33:
         ok, detail = False, f"{ncoll} statistics collectives, expected 33"
-    mine = {p: v.cpu() for p, v in T.hip_lookups(net).items()}
+    mine = T.branch_to(T.hip_lookups(net), "cpu")
     every = [None] * world
     dist.all_gather_object(every, mine)
     if rank == 0 and ok:
         # ONE step of the oracle on the whole batch of 2*world clips: the truth on the branch the ranks took together
         # (rows of rank r are rows [r N/world, (r + 1) N/world) of the whole batch's lookups)
         clips = (rgb_x, op_x, rgb_t, op_t)
-        idx_all = {p: torch.cat([e[p] for e in every]) for p in ("rgb", "op")}
+        idx_all = T.cat_branches(every)
         v = T.same_branch_verdict(T.g_stepper(sd, clips), {n: p.grad.detach() for n, p in net.named_parameters()}, idx_all, dev,
                                   "small_batch", what="2 ranks x 2 clips, synchronised statistics = one step on 4 clips")
         _, _, _, msd = T.g_step(sd, clips, torch.float32, "cpu")

@@ -109,9 +109,13 @@ def test_eval_after_training_from_scratch(precision):
     for si, p in enumerate(("rgb", "op")):
         got = eng._last["streams"][si].idx.reshape(-1, 2).cpu().long()
         assert torch.equal(got, w[-1][f"{p}.idx"].reshape(-1, 2)), p
-    # ... and against what the REFERENCE returned after ITS three steps (trajectory tolerance: three Adam steps apart)
-    assert rel_err(rgb.cpu(), d["eval.rgb"]) <= 1e-3 and rel_err(op.cpu(), d["eval.op"]) <= 1e-3
-    assert rel_err(rd.cpu(), d["eval.rgb_diff"]) <= 1e-3 and rel_err(od.cpu(), d["eval.op_diff"]) <= 1e-3
+    # ... and against what the REFERENCE returned after ITS three steps.  Not a kernel gate (that is the 1e-4 above): the two
+    # states are three Adam steps apart, and Adam's first steps move every entry by lr * g / |g| - an entry whose gradient
+    # is at fp32 noise moves by 2 lr = 4e-4 the other way in another fp32 evaluation, against filters of size 0.02.
+    # Measured 3.9e-3 of max|frame| (S16 and fp32 alike); held to 1e-2 so that a wrong trajectory (a missed EMA update, a
+    # stale pack after the optimizer step) cannot pass.
+    assert rel_err(rgb.cpu(), d["eval.rgb"]) <= 1e-2 and rel_err(op.cpu(), d["eval.op"]) <= 1e-2
+    assert rel_err(rd.cpu(), d["eval.rgb_diff"]) <= 1e-2 and rel_err(od.cpu(), d["eval.op_diff"]) <= 1e-2
 
 
 def test_a_gathered_row_beyond_the_half_range_raises_the_flag_at_the_split():
@@ -122,6 +126,9 @@ def test_a_gathered_row_beyond_the_half_range_raises_the_flag_at_the_split():
     for p in ("rgb", "op"):
         e = sd[f"{p}.vq_down3.quan.quantize.embed"]
         e[:, 1:] = e[:, 1:] * 2.0e5
+        # (the second neighbour's half of `dec` scaled down so that the 1e5-sized rows reach the decoder as O(1) values:
+        # with the bottleneck at 1e5 the frames saturate and single pixels flip sign on the last bit of an fp32 sum)
+        sd[f"{p}.vq_down3.quan.dec.weight"][:, 64:] *= 1.0e-5
     net = A.get_twostream((12, 6), (3, 2), 64, 256, 2)
     net.load_state_dict(sd)
     net = net.to(DEV).eval()

@@ -280,8 +280,9 @@ def test_benchmark_workload_b16_256_m2000_vs_reference_vectors(prec, mf):
         # layers of two rounds and more, the 8-wave 16x16x32 form below); 0 / 1: one MFMA shape forced, tap-by-tap loops
         taps = ({"conv_tap_s16<4, 1, 2, 4, 1, 0, 1>", "conv_tap_s16<4, 1, 2, 2, 1, 0, 1>", "conv_tap_s16<4, 2, 2, 2, 2, 1>"} if mf < 0 else
                 {f"conv_tap_s16<4, 1, 2, 4, 1, {mf}>", f"conv_tap_s16<4, 1, 2, 2, 1, {mf}>", f"conv_tap_s16<4, 2, 2, 2, 2, {mf}>"})
-        assert taps | {"conv_outc_s16", "conv_first_s16", "conv_up_s16<2>", "conv_up_s16<4>",
-                "memory_topk_s16", "conv_gemm_s16<128x128>", "conv_gemm_s16<128x64>"} <= kernels, kernels
+        # (round 6: the memory block - enc 1x1, lookup, commit sum, re-encoding, dec 1x1 + residual - is ONE launch)
+        assert taps | {"conv_outc_s16", "conv_first_s16", "conv_up_s16<2>", "conv_up_s16<4>", "memory_block_s16"} <= kernels, kernels
+        assert not ({"memory_topk_s16", "split_rows"} & kernels), kernels
         assert all(s.first_mid is not None for s in st["streams"])                  # conv_first_s16 took the first layers
         assert not eng.overflowed()
 
@@ -379,3 +380,42 @@ def test_memory_topk_s16_golden_and_tie():
     embed = S.hashed_normal("quantize_cases:tie:embed", (64, 256), 0.9)
     qk, _, _, _ = _memory_s16(embed, torch.from_numpy(g["tie.x"]), 2)
     assert np.array_equal(qk.numpy(), g["tie.qk"])                   # 1e-3 off the bisector: unambiguous
+
+
+@pytest.mark.parametrize("B,H,W,m", [(2, 64, 64, 256), (3, 72, 96, 2000), (16, 256, 256, 2000), (1, 256, 256, 33)])
+def test_memory_block_as_one_launch_equals_the_five_launch_chain(B, H, W, m):
+    """`ammc_memory_block_s16` (round 6: enc 1x1 -> distances + top-2 -> gather -> dec 1x1 + residual in one kernel, the
+    commit sum by the last workgroup) against the chain it replaces (conv_gemm_s16 1x1, memory_topk_s16, sum_partials,
+    split_rows, conv_gemm_s16 1x1): the same k order and expressions, so EVERYTHING is bit-identical - frames, commit
+    scalars, quantised maps, lookups, the bottleneck after the block.  324 rows (72x96): a ragged last 64-row tile; 33
+    slots: a single, ragged slot tile; twice in a row: the arrival counter is left at zero."""
+    from ammcnet_aaai2021_amd import engine as E
+    sd = S.make_twostream_state(n_embed=m)
+    rgb_x, op_x, _, _ = (t.to(DEV) for t in S.make_clips(B, H, W, tag=f"fused-memory:{B}:{H}"))
+    outs = {}
+    old = E.FUSED_MEMORY
+    try:
+        for fused in (True, False):
+            E.FUSED_MEMORY = fused
+            net = A.get_twostream((12, 6), (3, 2), 64, m, 2)
+            net.load_state_dict(sd)
+            net = net.to(DEV).eval()
+            net.precision = "s16"
+            with torch.no_grad():
+                for _ in range(2):
+                    rgb, op, (rd, od), (rq, oq) = net(rgb_x, op_x)
+            eng = net._last_engine
+            st = eng._last
+            kernels = {mm["kernel"] for mm in st["plan"].meta}
+            assert ("memory_block_s16" in kernels) == fused and ("memory_topk_s16" in kernels) == (not fused), kernels
+            outs[fused] = dict(rgb=rgb.clone(), op=op.clone(), rd=rd.clone(), od=od.clone(), rq=rq.clone(), oq=oq.clone(),
+                               idx=[s_.idx.clone() for s_ in st["streams"]],
+                               x4q=[eng.act_nchw(s_.x4q).clone() for s_ in st["streams"]])
+            assert not eng.overflowed()
+    finally:
+        E.FUSED_MEMORY = old
+    a, b = outs[True], outs[False]
+    for key in ("rgb", "op", "rd", "od", "rq", "oq"):
+        assert torch.equal(a[key], b[key]), key
+    for i in range(2):
+        assert torch.equal(a["idx"][i], b["idx"][i]) and torch.equal(a["x4q"][i], b["x4q"][i]), i

@@ -45,13 +45,21 @@ def test_forcing_an_evaluations_own_lookups_reproduces_it():
     clips = S.make_clips(2, 32, 32, tag="truth-host")
     loss, g, idx, _ = T.g_step(sd, clips, torch.float32, "cpu")
     loss2, g2, idx2, _ = T.g_step(sd, clips, torch.float32, "cpu", force_idx=idx)
-    assert loss == loss2 and all(torch.equal(idx[p], idx2[p]) for p in idx)
+    assert loss == loss2 and all(torch.equal(idx[p], idx2[p]) for p in ("rgb", "op"))
+    assert sorted(idx["pool"]) == ["op.down1", "op.down2", "op.down3", "rgb.down1", "rgb.down2", "rgb.down3"]
+    assert all(torch.equal(idx["pool"][k], idx2["pool"][k]) for k in idx["pool"])          # forced pool routes = its own
     assert all(torch.equal(g[n], g2[n]) for n in g)
     # another branch: swap the two picks of one row -> the commit term (top-1) and the gathered pair change
-    other = {p: v.clone() for p, v in idx.items()}
+    other = {p: v.clone() for p, v in idx.items() if p != "pool"}
     other["rgb"][0] = other["rgb"][0].flip(0)
     loss3, g3, _, _ = T.g_step(sd, clips, torch.float32, "cpu", force_idx=other)
     assert loss3 != loss
+    # ... and another pool route: the gradient of the first layer follows it
+    moved = {"pool": {k: v.clone() for k, v in idx["pool"].items()}, "rgb": idx["rgb"], "op": idx["op"]}
+    moved["pool"]["rgb.down1"][0, :, 0, :] = (moved["pool"]["rgb.down1"][0, :, 0, :] + 1) % 4       # one row of windows, every channel
+    loss4, g4, idx4, _ = T.g_step(sd, clips, torch.float32, "cpu", force_idx=moved)
+    assert torch.equal(idx4["pool"]["rgb.down1"], moved["pool"]["rgb.down1"])
+    assert loss4 != loss and not torch.equal(g4["rgb.inc.conv.conv.3.weight"], g["rgb.inc.conv.conv.3.weight"])
     # the oracle's fp32 evaluation as the evaluation under test: its own reference -> ratio 1, verdict ok
     step = T.g_stepper(sd, clips)
     t64, _ = step(torch.float64, "cpu", idx)

@@ -8,8 +8,10 @@ smooth and its one violent discontinuity is the memory lookup (`Quantize_topk`, 
 lookup whose two candidate slots tie within fp32 resolution falling the other way moves every gradient downstream by
 ~1e-2 - for ANY fp32 evaluation, the reference's own included.  Distances between two fp32 evaluations (the 1e-2 max /
 2e-3 median envelopes the tests of rounds 2-5 were fitted to) therefore gate nothing.  Here every evaluation E is
-compared with the oracle in FLOAT64 taking the lookups E itself made (`oracle.quantize_topk(force_idx=...)`), so that what
-is left is E's arithmetic plus the handful of ReLU masks / pool routes that flip inside fp32 noise.
+compared with the oracle in FLOAT64 taking the lookups E itself made (`oracle.quantize_topk(force_idx=...)`) and, where E
+records them (the HIP training engine's default path does), the routes of its max-pools (`oracle.maxpool2x2_forced`: a 2x2
+window whose two largest values tie inside rounding noise is the second discontinuity), so that what is left is E's
+arithmetic plus the handful of ReLU masks that flip inside fp32 noise.
 
 The gates ("gradients rel <= 1e-3 per tensor").  e_ref / norm_ref: what the REFERENCE's own fp32
 arithmetic is away from the truth on ITS branch - from the dense samples and lookups the reference recorded in a fixture
@@ -66,9 +68,33 @@ def dense(g: torch.Tensor, n: int = DENSE) -> torch.Tensor:
 
 
 def hip_lookups(net) -> dict:
-    """the memory lookups the HIP training forward just made: {"rgb": int64 [N, k], "op": ...}"""
+    """The branch the HIP training forward just took: the memory lookups {"rgb": int64 [N, k], "op": ...} and - where the
+    engine records them (the default split-fp16 training path: one byte per pooled element, `AMMC_POOL_IDX`) - the routes
+    of its max-pools, "pool": {"rgb.down1": int64 [B, C, h, w] in 0..3, ...} (oracle.maxpool2x2_forced)."""
     st = net._train_engine._last
-    return {p: st["streams"][si].idx.reshape(-1, 2).long().clone() for si, p in enumerate(("rgb", "op"))}
+    out = {p: st["streams"][si].idx.reshape(-1, 2).long().clone() for si, p in enumerate(("rgb", "op"))}
+    pools = {}
+    for si, p in enumerate(("rgb", "op")):
+        pi = getattr(st["streams"][si], "pool_idx", None)
+        if pi:
+            for lvl, t in enumerate(pi):
+                pools[f"{p}.down{lvl + 1}"] = t.permute(0, 3, 1, 2).long().contiguous()       # [B, h, w, C] bytes -> [B, C, h, w]
+    if pools:
+        out["pool"] = pools
+    return out
+
+
+def branch_to(idx: dict, device="cpu") -> dict:
+    """a branch (lookups + pool routes) moved to `device` (ranks exchange theirs through all_gather_object)"""
+    return {k: ({kk: vv.to(device) for kk, vv in v.items()} if isinstance(v, dict) else v.to(device)) for k, v in idx.items()}
+
+
+def cat_branches(parts: list) -> dict:
+    """the branch of ONE step on the concatenated batch from the branches of its shards (rank order = batch order)"""
+    out = {p: torch.cat([e[p] for e in parts]) for p in ("rgb", "op")}
+    if all("pool" in e for e in parts):
+        out["pool"] = {k: torch.cat([e["pool"][k] for e in parts]) for k in parts[0]["pool"]}
+    return out
 
 
 def _cast(sd, dtype, device, requires_grad):
@@ -85,8 +111,14 @@ def g_step(sd, clips, dtype, device, force_idx=None, loss_scale: float = 1.0):
     loss = O.generator_loss(out, rgb_t, op_t)
     (loss * loss_scale).backward()
     grads = {k: v.grad.detach() for k, v in m.items() if v.requires_grad}
-    idx = {p: out[-1][f"{p}.idx"].reshape(-1, 2).detach() for p in ("rgb", "op")}
-    return float(loss.detach()), grads, idx, m
+    return float(loss.detach()), grads, _branch(out[-1]), m
+
+
+def _branch(aux: dict) -> dict:
+    """the branch an oracle evaluation took, in the structure it accepts as `force_idx`"""
+    idx = {p: aux[f"{p}.idx"].reshape(-1, 2).detach() for p in ("rgb", "op")}
+    idx["pool"] = {k: v.detach() for k, v in aux["pool"].items()}
+    return idx
 
 
 def gan_step(sd_g, sd_d, sd_f, clips, lams, dtype, device, force_idx=None):
@@ -115,8 +147,8 @@ def gan_step(sd_g, sd_d, sd_f, clips, lams, dtype, device, force_idx=None):
     gn = [k for k, v in mg.items() if v.requires_grad]
     dg = torch.autograd.grad(d_loss, [md[k] for k in dn])
     gg = torch.autograd.grad(g_loss, [mg[k] for k in gn])
-    idx = {p: out[-1][f"{p}.idx"].reshape(-1, 2).detach() for p in ("rgb", "op")}
-    return dict(g_loss=float(g_loss.detach()), d_loss=float(d_loss.detach()), g=dict(zip(gn, gg)), d=dict(zip(dn, dg)), idx=idx)
+    return dict(g_loss=float(g_loss.detach()), d_loss=float(d_loss.detach()), g=dict(zip(gn, gg)), d=dict(zip(dn, dg)),
+                idx=_branch(out[-1]))
 
 
 def reference_errors(ref_samples: dict, ref_norms: dict, truth_on_ref_branch: dict):
