@@ -71,6 +71,7 @@ SIGNATURES = {
     "ammc_memory_topk_fwd_f32": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
     "ammc_pack_codebook_s16": (C.c_int, [_p, _i32, _i32, _p, _p]),
     "ammc_pack_codebook_s16_guarded": (C.c_int, [_p, _i32, _i32, _p, _p, _p]),
+    "ammc_pack_frag_rows_s16": (C.c_int, [_p, _i32, _i32, _p, _p]),
     "ammc_memory_block_s16": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p,
                                          _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "ammc_memory_topk_fwd_s16": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),

@@ -336,42 +336,68 @@ int launch_topk_s16(const float* x, const void* e_s16, const float* e_md, const 
 // five launches per stream (conv_gemm_s16 1x1, memory_topk_s16, sum_partials, split_rows, conv_gemm_s16 1x1): ~95 us of
 // kernel time for ~9 us of MFMAs, every stage latency-bound on its own (16384 rows = 256 tiles, one wave of workgroups).
 // Now z, the N x M distances, the gathered rows and their S16 re-encoding never leave the CU:
-//   A  waves 0-3: z = x4 . Wenc for a 32-pixel x 32-channel tile each, K = C sequential (fragments straight from L2: the
-//      pixel's S16 groups and the filter row's are 32 contiguous bytes per lane and k-step), written to LDS as the fp32
-//      copy + S16 image the distance sweep reads - the SAME k order, accumulator pair and epilogue expression as
-//      conv_gemm_s16's 1x1 path, so z (and with it every lookup) is bit-identical to the five-launch chain;
-//   B  the distance sweep / top-2 / merge of memory_topk_s16_kernel<2, true, 2>, unchanged;
-//   C  gather: q_topk (optional), q_one, commit partial exactly as above (same thread -> element map: the same partials),
-//      plus the S16 image of the gathered rows in LDS (XOR-swizzled 16-byte slots);
-//   D  every wave: out[64 pixels x 64 channels] = qk . Wdec + bias + x4 (the S16 residual), split, 32-byte S16 stores;
-//   E  the LAST workgroup to arrive sums the commit partials in sum_partials_kernel's order (agent-scope release / acquire
-//      around one atomic counter; the counter is left at zero for the next launch).
+//   A  z = x4 . Wenc: the pixel tile and the filters travel L2 -> LDS by LDS-DMA in 64-channel chunks (three stages, two
+//      chunks in flight, one barrier per chunk; lanes of a DMA read consecutive 16-byte pieces - fragments fetched per lane
+//      straight from L2, one cache line per lane and instruction, kept the CU's vector-memory path busy for 23 us); waves
+//      0-3 contract a 32-pixel x 32-channel tile each, K sequential - the SAME k order, accumulator pair and epilogue
+//      expression as conv_gemm_s16's 1x1 path, so z (and with it every lookup) is bit-identical to the five-launch chain;
+//   B  the distance sweep / top-2 of memory_topk_s16_kernel<2, true, 2>, unchanged; the 32 partial lists of a row are
+//      merged by eight lanes (the order is total - value, then slot - so the result does not depend on the merge tree);
+//   C  gather: q_topk (optional), q_one, commit partial with the thread -> element map and the summation tree of the
+//      kernel above (the same partials, bit for bit), plus the S16 image of the gathered rows in LDS;
+//   D  every wave: out[64 pixels x 64 channels] = qk . Wdec, the filters pre-packed FRAGMENT-major
+//      (ammc_pack_frag_rows_s16: a lane's fragment loads are 512 contiguous bytes per half wave); the accumulator tile
+//      turns through a wave-private LDS tile so that bias + residual + split + store run with eight lanes per pixel on
+//      256 contiguous bytes (one pixel per lane cost 16 cache lines per store instruction: 8 us);
+//   E  the LAST workgroup to arrive sums the commit partials in sum_partials_kernel's order.  No release fence:
+//      `__threadfence()` is `buffer_wbl2 sc1` on gfx950 - a write-back of the XCD's whole L2, by every wave of every
+//      workgroup (the first form spent ~70 us there).  The partials are agent-scope atomic stores (write-through),
+//      completed (vmcnt(0)) before the workgroup's barrier, behind which one thread bumps the arrival counter with a
+//      relaxed agent-scope atomic; the last workgroup reads them with agent-scope atomic loads and leaves the counter at 0.
+// (profiling only) AMMC_MB_STAMPS=1: workgroups 0 / 100 write the cycle counter at every phase boundary into this buffer
+__device__ unsigned long long g_mb_stamps[2][16];
+#define MB_STAMP(i)                                                                                  \
+  if (a.stamps && (blockIdx.x == 0 || blockIdx.x == 100) && tid == 0)                               \
+    g_mb_stamps[blockIdx.x ? 1 : 0][i] = __builtin_readcyclecounter();
+
 struct MemBlockArgs {
   const float* x; int64_t x_bs, x_rs, x_ps;       // S16 activation [B][h][w][C] (interior pixel 0)
   float* y; int64_t y_bs, y_rs, y_ps;             // S16 output, same geometry
   const float* enc_w; const float* enc_b;         // S16 [64][C] (k-major rows), fp32 [64]
-  const float* dec_w; const float* dec_b;         // S16 [C][128], fp32 [C]
+  const float* dec_wf; const float* dec_b;        // S16 [C][128] FRAGMENT-major (ammc_pack_frag_rows_s16), fp32 [C]
   const h16x8* e_s16; const float* e_md; const float* enorm;
   int n, hw, w, m, mpad, nparts;
   int* idx; float* q_topk; float* q_one;
   float* diff_partial; float* diff; int* counter; float inv_count;
   int* overflow_flag;
+  int stamps;
 };
+
+// one 16-byte LDS-DMA per lane: global `src` (a full address per lane) -> LDS byte `lds_byte` (wave-uniform) + 16 lane.
+// asm, because the builtin makes hipcc's waitcnt pass drain both counters in front of every later LDS read (DESIGN.md
+// section 8, pitfall 9); M0 saved / restored inside the statement, s_nop 4: the SGPR may have just been written.
+__device__ __forceinline__ void mb_dma16(const float* src, unsigned lds_byte) {
+  unsigned keep;
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(lds_byte) : "memory");
+}
+
+constexpr int MB_STG = 8192;                       // floats per stage of phase A: x chunk [64 px][64 ch] | filter chunk [64][64]
+constexpr int MB_DYN_FLOATS = 3 * MB_STG;          // 96 KB of dynamic LDS
 
 template <int C>
 __global__ __launch_bounds__(512, 2) void memory_block_s16_kernel(MemBlockArgs a) {
   constexpr int K = 2, RT = 2, SBR = 64, NT = 512, NW = 8;
-  static_assert(C == 512, "8 waves x 64 output channels");
-  __shared__ __attribute__((aligned(16))) float xs[SBR * SD];            // fp32 z, swizzled 16-B slots
-  // one region, two lives (64 KB of static LDS is the limit): the S16 image of z + the candidate lists during the sweep,
-  // then - both dead behind the merge's barrier - the S16 image of the gathered rows [64][128 ch], swizzled 16-B slots
+  static_assert(C == 512, "8 waves x 64 output channels; 8 chunks of 64 input channels");
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
+  // lives of the three 32-KB stages: A: DMA stages 0 / 1 / 2.  B: xs + xh in stage 2, the candidate lists in stage 0.
+  // C, D: the gathered rows' S16 image in stage 1.  D epilogue: wave-private 8-KB tiles in stages 0 (waves 0-3) and 2 (4-7).
+  float* xs = dyn + 2 * MB_STG;                                             // fp32 z [64][64], swizzled 16-B slots
+  _Float16* xh = reinterpret_cast<_Float16*>(dyn + 2 * MB_STG + 4096);      // S16 image of z: row = 8 hi slots | 8 lo slots
   constexpr int CROW = 2 * NW * K + 1;
-  __shared__ __attribute__((aligned(16))) float region[SBR * SD + 2 * SBR * CROW];
-  _Float16* xh = reinterpret_cast<_Float16*>(region);                    // [64][128 halfs]: row = 8 hi slots | 8 lo slots
-  float* cand_v = region + SBR * SD;
-  int* cand_i = reinterpret_cast<int*>(cand_v + SBR * CROW);
-  float* qs = region;
-  static_assert(SBR * SD + 2 * SBR * CROW >= SBR * 2 * SD, "the gathered rows fit the region");
+  float* cand_v = dyn;
+  int* cand_i = reinterpret_cast<int*>(dyn + SBR * CROW);
+  float* qs = dyn + MB_STG;                                                 // S16 image of the gathered rows [64][128 ch]
   __shared__ float xx[SBR];
   __shared__ int best[SBR * K];
   __shared__ float red[NT];
@@ -384,60 +410,104 @@ __global__ __launch_bounds__(512, 2) void memory_block_s16_kernel(MemBlockArgs a
   const int r0 = blockIdx.x * SBR;
   const int n = a.n, m = a.m, mpad = a.mpad;
   const int pl31 = (l31 & 19) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);     // MFMA row -> filter: bits 2 and 3 swapped (conv_gemm_s16.hip)
+  MB_STAMP(0)
   for (int i = tid; i < m; i += NT) ens[i] = a.enorm[i];
 
-  // pixel offsets of this lane's two tile rows (rows beyond n: the last row's pixel, results dropped)
-  int64_t pix_in[RT], pix_out[RT];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    int r = r0 + 32 * rt + l31;
+  auto pix_of = [&](int row, int& pin, int& pout) {                        // (rows beyond n: the last row's pixel, results dropped)
+    int r = r0 + row;
     r = r < n ? r : n - 1;
     const int b = r / a.hw, rem = r - b * a.hw, yy = rem / a.w, xq = rem - yy * a.w;
-    pix_in[rt] = (int64_t)b * a.x_bs + (int64_t)yy * a.x_rs + (int64_t)xq * a.x_ps;
-    pix_out[rt] = (int64_t)b * a.y_bs + (int64_t)yy * a.y_rs + (int64_t)xq * a.y_ps;
-  }
+    pin = (int)((int64_t)b * a.x_bs + (int64_t)yy * a.x_rs + (int64_t)xq * a.x_ps);
+    pout = (int)((int64_t)b * a.y_bs + (int64_t)yy * a.y_rs + (int64_t)xq * a.y_ps);
+  };
 
   // ---- A: enc 1x1 ------------------------------------------------------------------------------------------------------------
-  if (wave < 4) {
-    const int pt = wave & 1, ct = wave >> 1;
-    const float* px = a.x + pix_in[pt] + 8 * h;
-    const float* fw = a.enc_w + (int64_t)(ct * 32 + pl31) * C + 8 * h;
+  {
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)dyn;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    // a DMA instruction fills 4 rows x 16 pieces; lane = (row in the group, LDS position); the piece it FETCHES is
+    // position ^ (row & 15), so that a fragment read (32 rows, one piece) meets every bank once per 16 lanes
+    const int drow0 = (uwave * 2) * 4 + (lane >> 4), drow1 = drow0 + 4, dpos = lane & 15;
+    int pin0, pin1, unused;
+    pix_of(drow0, pin0, unused);
+    pix_of(drow1, pin1, unused);
+    const float* sx0 = a.x + pin0 + 4 * (dpos ^ (drow0 & 15));
+    const float* sx1 = a.x + pin1 + 4 * (dpos ^ (drow1 & 15));
+    const float* sw0 = a.enc_w + (int64_t)drow0 * C + 4 * (dpos ^ (drow0 & 15));
+    const float* sw1 = a.enc_w + (int64_t)drow1 * C + 4 * (dpos ^ (drow1 & 15));
+    const unsigned dst0 = lds0 + 4u * (unsigned)(uwave * 512);              // this wave's two 1-KB pieces of a 16-KB operand chunk
+#define MB_ISSUE(c, st)                                                                             \
+  {                                                                                                 \
+    mb_dma16(sx0 + (c) * 64, dst0 + 4u * (unsigned)((st) * MB_STG));                                \
+    mb_dma16(sx1 + (c) * 64, dst0 + 4u * (unsigned)((st) * MB_STG + 256));                          \
+    mb_dma16(sw0 + (c) * 64, dst0 + 4u * (unsigned)((st) * MB_STG + 4096));                         \
+    mb_dma16(sw1 + (c) * 64, dst0 + 4u * (unsigned)((st) * MB_STG + 4096 + 256));                   \
+  }
+    const int pt = wave & 1, ct = (wave >> 1) & 1;
+    const int xrow = 32 * pt + l31, frow = 32 * ct + pl31;
+    const int swz = xrow & 15, swzb = frow & 15;
     f32x16 hh, xa;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { hh[r] = 0.f; xa[r] = 0.f; }
-#pragma unroll 8
-    for (int t = 0; t < C / 16; ++t) {
-      const h16x8 ah = *reinterpret_cast<const h16x8*>(px + 16 * t), al = *reinterpret_cast<const h16x8*>(px + 16 * t + 4);
-      const h16x8 bh = *reinterpret_cast<const h16x8*>(fw + 16 * t), bl = *reinterpret_cast<const h16x8*>(fw + 16 * t + 4);
-      hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, hh, 0, 0, 0);
-      xa = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, xa, 0, 0, 0);
-      xa = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, xa, 0, 0, 0);
-    }
-    const int row = 32 * pt + l31;
-    const bool live = r0 + row < n;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // (the norms' loads: nothing of mine may be in flight)
+    MB_ISSUE(0, 0)
+    MB_ISSUE(1, 1)
 #pragma unroll
-    for (int o = 0; o < 2; ++o) {
-      const int c0 = ct * 32 + 8 * (2 * o + h);
-      const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.enc_b + c0), s1 = *reinterpret_cast<const f32x4*>(a.enc_b + c0 + 4);
-      float v[8];
+    for (int c = 0; c < C / 64; ++c) {
+      if (c + 1 < C / 64) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // chunk c has landed (chunk c + 1: four DMAs per wave)
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                                       // ... everybody's; and everybody is done with chunk c - 1
+      if (c + 2 < C / 64) MB_ISSUE(c + 2, (c + 2) % 3)
+      if (wave < 4) {
+        const float* Xc = dyn + (c % 3) * MB_STG + xrow * 64;
+        const float* Wc = dyn + (c % 3) * MB_STG + 4096 + frow * 64;
+        h16x8 ah[4], al[4], bh[4], bl[4];                  // (all sixteen reads of the chunk in flight before the first MFMA)
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = hh[8 * o + k] + xa[8 * o + k] * S_LO_INV;
+        for (int s = 0; s < 4; ++s) {
+          const int g = 2 * s + h;
+          ah[s] = *reinterpret_cast<const h16x8*>(Xc + (((2 * g) ^ swz) << 2));
+          al[s] = *reinterpret_cast<const h16x8*>(Xc + (((2 * g + 1) ^ swz) << 2));
+          bh[s] = *reinterpret_cast<const h16x8*>(Wc + (((2 * g) ^ swzb) << 2));
+          bl[s] = *reinterpret_cast<const h16x8*>(Wc + (((2 * g + 1) ^ swzb) << 2));
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { v[k] += s0[k]; v[4 + k] += s1[k]; }
-      if (!live) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = 0.f;
+        for (int s = 0; s < 4; ++s) {
+          hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s], ah[s], hh, 0, 0, 0);
+          xa = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[s], ah[s], xa, 0, 0, 0);
+          xa = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s], al[s], xa, 0, 0, 0);
+        }
       }
-      const int kg = c0 >> 3;
-      *reinterpret_cast<f32x4*>(xs + row * SD + (((2 * kg) ^ (row & 15)) << 2)) = f32x4{v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<f32x4*>(xs + row * SD + (((2 * kg + 1) ^ (row & 15)) << 2)) = f32x4{v[4], v[5], v[6], v[7]};
-      ammc_u4 hi, lo;
-      ammc_s16_split8(v, hi, lo);
-      *reinterpret_cast<ammc_u4*>(xh + row * 2 * SD + ((kg ^ (row & 15)) << 3)) = hi;
-      *reinterpret_cast<ammc_u4*>(xh + row * 2 * SD + (((8 + kg) ^ (row & 15)) << 3)) = lo;
+    }
+#undef MB_ISSUE
+    // (stage 2 held chunk 5: every wave is past the barrier of chunk 7, i.e. done with chunk 6 - free to take z)
+    if (wave < 4) {
+      const bool live = r0 + xrow < n;
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        const int c0 = ct * 32 + 8 * (2 * o + h);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.enc_b + c0), s1 = *reinterpret_cast<const f32x4*>(a.enc_b + c0 + 4);
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = hh[8 * o + k] + xa[8 * o + k] * S_LO_INV;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] += s0[k]; v[4 + k] += s1[k]; }
+        if (!live) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = 0.f;
+        }
+        const int kg = c0 >> 3;
+        *reinterpret_cast<f32x4*>(xs + xrow * SD + (((2 * kg) ^ (xrow & 15)) << 2)) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(xs + xrow * SD + (((2 * kg + 1) ^ (xrow & 15)) << 2)) = f32x4{v[4], v[5], v[6], v[7]};
+        ammc_u4 hi, lo;
+        ammc_s16_split8(v, hi, lo);
+        *reinterpret_cast<ammc_u4*>(xh + xrow * 2 * SD + ((kg ^ (xrow & 15)) << 3)) = hi;
+        *reinterpret_cast<ammc_u4*>(xh + xrow * 2 * SD + (((8 + kg) ^ (xrow & 15)) << 3)) = lo;
+      }
     }
   }
   __syncthreads();
+  MB_STAMP(1)
   if (tid < SBR) {
     float s = 0.f;
     for (int sl = 0; sl < SD / 4; ++sl) {
@@ -450,6 +520,7 @@ __global__ __launch_bounds__(512, 2) void memory_block_s16_kernel(MemBlockArgs a
     xx[tid] = s;
   }
   __syncthreads();
+  MB_STAMP(2)
 
   // ---- B: distances + running top-2 (memory_topk_s16_kernel<2, true, 2>'s sweep) ---------------------------------------------
   {
@@ -530,6 +601,7 @@ __global__ __launch_bounds__(512, 2) void memory_block_s16_kernel(MemBlockArgs a
     }
 #undef F_LOAD
 #undef F_TILES
+    MB_STAMP(3)
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -540,19 +612,36 @@ __global__ __launch_bounds__(512, 2) void memory_block_s16_kernel(MemBlockArgs a
       }
   }
   __syncthreads();
-  if (tid < SBR) {
+  MB_STAMP(4)
+  {
+    // eight lanes per row, four candidates each, then three exchange rounds (the order (value, slot) is total: any merge
+    // tree returns the two smallest)
+    const int row = tid >> 3, part = tid & 7;
     float v[K];
     int ix[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) { v[j] = INFINITY; ix[j] = 0x7fffffff; }
-    for (int c = 0; c < 2 * NW * K; ++c) s_topk_insert<K>(v, ix, cand_v[tid * CROW + c], cand_i[tid * CROW + c]);
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-      best[tid * K + j] = ix[j];
-      if (r0 + tid < n) a.idx[(int64_t)(r0 + tid) * K + j] = ix[j];
+    for (int c = 0; c < 4; ++c) s_topk_insert<K>(v, ix, cand_v[row * CROW + part * 4 + c], cand_i[row * CROW + part * 4 + c]);
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      float pv[K];
+      int pi_[K];
+#pragma unroll
+      for (int j = 0; j < K; ++j) { pv[j] = __shfl_xor(v[j], o); pi_[j] = __shfl_xor(ix[j], o); }
+#pragma unroll
+      for (int j = 0; j < K; ++j) s_topk_insert<K>(v, ix, pv[j], pi_[j]);
+    }
+    if (part == 0) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        best[row * K + j] = ix[j];
+        if (r0 + row < n) a.idx[(int64_t)(r0 + row) * K + j] = ix[j];
+      }
     }
   }
   __syncthreads();
+  MB_STAMP(5)
 
   // ---- C: gather + commit distance (the map of memory_topk_s16_kernel: the same partial sums), S16 image of the rows -------------
   float part = 0.f;
@@ -595,13 +684,21 @@ __global__ __launch_bounds__(512, 2) void memory_block_s16_kernel(MemBlockArgs a
     *reinterpret_cast<ammc_u4*>(qs + row * 2 * SD + (((2 * kg) ^ (row & 31)) << 2)) = hi;
     *reinterpret_cast<ammc_u4*>(qs + row * 2 * SD + (((2 * kg + 1) ^ (row & 31)) << 2)) = lo;
   }
+  // the kernel above sums red[t] += red[t + o] for o = 128 ... 1 with a barrier per level; the same pairs here: two levels
+  // through LDS, six inside wave 0 of each half (v + shfl_down(v, o) IS red[t] + red[t + o])
   red[tid] = part;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (t8 < o) red[tid] += red[tid + o];
-    __syncthreads();
+  if (t8 < 128) red[tid] += red[tid + 128];
+  __syncthreads();
+  if (t8 < 64) {
+    float v = red[tid] + red[tid + 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if (t8 == 0 && (int)blockIdx.x * RT + half < a.nparts)
+      __hip_atomic_store(a.diff_partial + blockIdx.x * RT + half, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (t8 == 0 && (int)blockIdx.x * RT + half < a.nparts) a.diff_partial[blockIdx.x * RT + half] = red[tid];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  MB_STAMP(6)
 
   // ---- D: dec 1x1 + bias + residual, S16 out: wave = 64 output channels x 64 pixels ------------------------------------------------
   {
@@ -612,21 +709,22 @@ __global__ __launch_bounds__(512, 2) void memory_block_s16_kernel(MemBlockArgs a
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { hh[rt][c][r] = 0.f; xa[rt][c][r] = 0.f; }
-    const float* fw0 = a.dec_w + (int64_t)(wave * 64 + pl31) * (2 * SD) + 8 * h;
+    // fragment-major filters: [group g][hi | lo][C rows, MFMA order][8 halfs]: lane l31 of tile (wave, c) reads row 64 wave + 32 c + l31
+    const float* fw0 = a.dec_wf + (int64_t)(wave * 64 + l31) * 4;
 #pragma unroll
     for (int t = 0; t < (2 * SD) / 16; ++t) {
       const int g = 2 * t + h;
       h16x8 ah[RT], al[RT], bh[2], bl[2];
 #pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        bh[c] = *reinterpret_cast<const h16x8*>(fw0 + ((int64_t)(2 * g) * C + 32 * c) * 4);
+        bl[c] = *reinterpret_cast<const h16x8*>(fw0 + ((int64_t)(2 * g + 1) * C + 32 * c) * 4);
+      }
+#pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         const int row = 32 * rt + l31;
         ah[rt] = *reinterpret_cast<const h16x8*>(qs + row * 2 * SD + (((2 * g) ^ (row & 31)) << 2));
         al[rt] = *reinterpret_cast<const h16x8*>(qs + row * 2 * SD + (((2 * g + 1) ^ (row & 31)) << 2));
-      }
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        bh[c] = *reinterpret_cast<const h16x8*>(fw0 + (int64_t)c * 32 * (2 * SD) + 16 * t);
-        bl[c] = *reinterpret_cast<const h16x8*>(fw0 + (int64_t)c * 32 * (2 * SD) + 16 * t + 4);
       }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -637,44 +735,72 @@ __global__ __launch_bounds__(512, 2) void memory_block_s16_kernel(MemBlockArgs a
           xa[rt][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[c], al[rt], xa[rt][c], 0, 0, 0);
         }
     }
+    MB_STAMP(7)
+    // epilogue through a wave-private tile [32 px][64 ch] fp32 (16-B pieces XOR-swizzled by pixel): the accumulators go in
+    // with one pixel per lane, come out with eight lanes per pixel = 256 contiguous bytes of residual and of output
+    float* tile = dyn + (wave < 4 ? wave * 2048 : 2 * MB_STG + (wave - 4) * 2048);
+    const int gq = lane & 7, psub = lane >> 3;
+    const int cw = wave * 64 + gq * 8;                                      // this lane's eight output channels
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.dec_b + cw), b1 = *reinterpret_cast<const f32x4*>(a.dec_b + cw + 4);
     bool bad = false;
+    h16x8 rh[RT][4], rl[RT][4];                                            // the residual's S16 groups, a whole row tile at a time
+    int pout[RT][4];
+#define MB_RES(rt)                                                                                   \
+  _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                                 \
+    int pin_;                                                                                        \
+    pix_of(32 * (rt) + 8 * it + psub, pin_, pout[rt][it]);                                           \
+    const float* rp_ = a.x + pin_ + cw;                                                              \
+    rh[rt][it] = *reinterpret_cast<const h16x8*>(rp_);                                               \
+    rl[rt][it] = *reinterpret_cast<const h16x8*>(rp_ + 4);                                           \
+  }
+    MB_RES(0)
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      if (r0 + 32 * rt + l31 >= n) continue;
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
-          const int c0 = wave * 64 + c * 32 + 8 * (2 * o + h);
-          const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.dec_b + c0), s1 = *reinterpret_cast<const f32x4*>(a.dec_b + c0 + 4);
-          float v[8];
+          const int q = c * 8 + 2 * (2 * o + h);                            // 16-B piece of channels 32 c + 8 (2 o + h) ..
+          float* tp = tile + l31 * 64;
+          *reinterpret_cast<f32x4*>(tp + ((q ^ (l31 & 15)) << 2)) =
+              f32x4{hh[rt][c][8 * o] + xa[rt][c][8 * o] * S_LO_INV, hh[rt][c][8 * o + 1] + xa[rt][c][8 * o + 1] * S_LO_INV,
+                    hh[rt][c][8 * o + 2] + xa[rt][c][8 * o + 2] * S_LO_INV, hh[rt][c][8 * o + 3] + xa[rt][c][8 * o + 3] * S_LO_INV};
+          *reinterpret_cast<f32x4*>(tp + (((q + 1) ^ (l31 & 15)) << 2)) =
+              f32x4{hh[rt][c][8 * o + 4] + xa[rt][c][8 * o + 4] * S_LO_INV, hh[rt][c][8 * o + 5] + xa[rt][c][8 * o + 5] * S_LO_INV,
+                    hh[rt][c][8 * o + 6] + xa[rt][c][8 * o + 6] * S_LO_INV, hh[rt][c][8 * o + 7] + xa[rt][c][8 * o + 7] * S_LO_INV};
+        }
+      if (rt == 0) MB_RES(1)                                               // (the next row tile's residuals fly behind this one's stores)
 #pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = hh[rt][c][8 * o + k] + xa[rt][c][8 * o + k] * S_LO_INV;
+      for (int it = 0; it < 4; ++it) {
+        const int px = 8 * it + psub, row = 32 * rt + px;
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(tile + px * 64 + (((2 * gq) ^ (px & 15)) << 2));
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(tile + px * 64 + (((2 * gq + 1) ^ (px & 15)) << 2));
+        float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
 #pragma unroll
-          for (int k = 0; k < 4; ++k) { v[k] += s0[k]; v[4 + k] += s1[k]; }
-          const float* rp = a.x + pix_in[rt] + c0;
-          const h16x8 rh = *reinterpret_cast<const h16x8*>(rp), rl = *reinterpret_cast<const h16x8*>(rp + 4);
+        for (int k = 0; k < 4; ++k) { v[k] += b0[k]; v[4 + k] += b1[k]; }
 #pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] += (float)rh[k] + (float)rl[k] * S_LO_INV;
-          ammc_u4 hi, lo;
-          ammc_s16_split8(v, hi, lo);
+        for (int k = 0; k < 8; ++k) v[k] += (float)rh[rt][it][k] + (float)rl[rt][it][k] * S_LO_INV;
+        ammc_u4 hi, lo;
+        ammc_s16_split8(v, hi, lo);
+        if (r0 + row < n) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) bad |= !(fabsf(v[k]) <= 65504.f);
-          float* yp = a.y + pix_out[rt] + c0;
+          float* yp = a.y + pout[rt][it] + cw;
           *reinterpret_cast<ammc_u4*>(yp) = hi;
           *reinterpret_cast<ammc_u4*>(yp + 4) = lo;
         }
+      }
     }
+#undef MB_RES
     if (bad && a.overflow_flag) atomicOr(a.overflow_flag, 1);
   }
 
   // ---- E: the last workgroup sums the commit partials (sum_partials_kernel's expressions, operation for operation) -------------
-  __threadfence();                                             // release: this workgroup's partials before its arrival
-  __syncthreads();
-  if (tid == 0) is_last = atomicAdd(a.counter, 1) == (int)gridDim.x - 1;
+  MB_STAMP(8)
+  __syncthreads();                                             // (every partial store of this workgroup has completed: see C)
+  if (tid == 0) is_last = __hip_atomic_fetch_add(a.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
   __syncthreads();
   if (is_last) {
-    __threadfence();                                           // acquire
     if (tid < 256) {
       double s = 0.0;
       for (int i = tid; i < a.nparts; i += 256)
@@ -691,37 +817,72 @@ __global__ __launch_bounds__(512, 2) void memory_block_s16_kernel(MemBlockArgs a
       __hip_atomic_store(a.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  MB_STAMP(9)
+}
+
+// S16 filter rows [N][K] (ammc_pack_conv_weight_f32 + ammc_split_rows_f32) -> FRAGMENT-major [K/8][hi | lo][N][8 halfs] with
+// the rows of every 32-row tile in MFMA order (row l of a tile = filter pi(l), bits 2 and 3 of l swapped): the A operand
+// of memory_block_s16_kernel's dec phase - 32 lanes read 512 contiguous bytes
+__global__ __launch_bounds__(256) void pack_frag_rows_s16_kernel(const float* __restrict__ w, int n, int k, float* __restrict__ out) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;           // one 16-byte piece
+  const int kg = k >> 3;
+  if (gid >= (int64_t)n * kg * 2) return;
+  const int r = (int)(gid % n);
+  const int gp = (int)(gid / n);                                          // 2 g + plane
+  const int l = r & 31;
+  const int src_row = (r & ~31) | (l & 19) | ((l & 4) << 1) | ((l & 8) >> 1);
+  *reinterpret_cast<f32x4*>(out + gid * 4) = *reinterpret_cast<const f32x4*>(w + (int64_t)src_row * k + (gp >> 1) * 8 + (gp & 1) * 4);
 }
 
 }  // namespace ammc_impl
 using namespace ammc_impl;
 
+extern "C" int ammc_pack_frag_rows_s16(const float* w_s16, int32_t n, int32_t k, float* out, void* stream) {
+  if (!w_s16 || !out || n <= 0 || (n % 32) || k <= 0 || (k % 8) || (((uintptr_t)w_s16 | (uintptr_t)out) & 15)) return AMMC_EINVAL;
+  const int64_t pieces = (int64_t)n * (k >> 3) * 2;
+  hipLaunchKernelGGL(pack_frag_rows_s16_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_s16, n, k,
+                     out);
+  return ammc_launch_status();
+}
+
+// (profiling only, not part of the ABI header) the s_memtime stamps of the last launch made with AMMC_MB_STAMPS=1
+extern "C" int ammc_dbg_memory_block_stamps(unsigned long long* out32) {
+  return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_mb_stamps), sizeof(unsigned long long) * 32);
+}
+
 extern "C" int ammc_memory_block_s16(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, float* y, int64_t y_bs, int64_t y_rs,
                                      int64_t y_ps, int32_t batch, int32_t h, int32_t w, int32_t c, const float* enc_w,
                                      const float* enc_b, const void* e_s16, const float* embed_md, const float* enorm, int32_t d,
-                                     int32_t m, int32_t k, const float* dec_w, const float* dec_b, int32_t* idx_topk,
+                                     int32_t m, int32_t k, const float* dec_wf, const float* dec_b, int32_t* idx_topk,
                                      float* q_topk, float* q_one, float* diff_partial, float* diff, int32_t* counter,
                                      int32_t* overflow_flag, void* stream) {
-  if (!x || !y || !enc_w || !enc_b || !e_s16 || !embed_md || !enorm || !dec_w || !dec_b || !idx_topk || !diff_partial || !diff ||
+  if (!x || !y || !enc_w || !enc_b || !e_s16 || !embed_md || !enorm || !dec_wf || !dec_b || !idx_topk || !diff_partial || !diff ||
       !counter)
     return AMMC_EINVAL;
   if (batch <= 0 || h <= 0 || w <= 0 || m <= 0 || k <= 0 || k > m) return AMMC_EINVAL;
   if ((x_bs | x_rs | x_ps | y_bs | y_rs | y_ps) & 7) return AMMC_EINVAL;
-  if ((((uintptr_t)x | (uintptr_t)y) & 31) || (((uintptr_t)enc_w | (uintptr_t)dec_w | (uintptr_t)enc_b | (uintptr_t)dec_b) & 15))
+  if ((((uintptr_t)x | (uintptr_t)y) & 31) || (((uintptr_t)enc_w | (uintptr_t)dec_wf | (uintptr_t)enc_b | (uintptr_t)dec_b) & 15))
     return AMMC_EINVAL;
   if (d != SD || k != 2 || c != 512 || m > 2048) return AMMC_EUNSUP;       // the shipped block's shape; else the five-launch chain
   const int64_t n64 = (int64_t)batch * h * w;
   if (n64 >= (1LL << 31)) return AMMC_EUNSUP;
+  if ((int64_t)batch * x_bs >= (1LL << 31) || (int64_t)batch * y_bs >= (1LL << 31)) return AMMC_EUNSUP;      // 32-bit pixel offsets
   MemBlockArgs a;
   a.x = x; a.x_bs = x_bs; a.x_rs = x_rs; a.x_ps = x_ps;
   a.y = y; a.y_bs = y_bs; a.y_rs = y_rs; a.y_ps = y_ps;
-  a.enc_w = enc_w; a.enc_b = enc_b; a.dec_w = dec_w; a.dec_b = dec_b;
+  a.enc_w = enc_w; a.enc_b = enc_b; a.dec_wf = dec_wf; a.dec_b = dec_b;
   a.e_s16 = reinterpret_cast<const h16x8*>(e_s16); a.e_md = embed_md; a.enorm = enorm;
   a.n = (int)n64; a.hw = h * w; a.w = w; a.m = m; a.mpad = (m + 31) / 32 * 32; a.nparts = (a.n + 31) / 32;
   a.idx = idx_topk; a.q_topk = q_topk; a.q_one = q_one;
   a.diff_partial = diff_partial; a.diff = diff; a.counter = counter; a.inv_count = 1.f / ((float)a.n * (float)SD);
   a.overflow_flag = overflow_flag;
-  hipLaunchKernelGGL(memory_block_s16_kernel<512>, dim3((a.n + 63) / 64), dim3(512), 0, (hipStream_t)stream, a);
+  static const int stamps = getenv("AMMC_MB_STAMPS") ? atoi(getenv("AMMC_MB_STAMPS")) : 0;
+  a.stamps = stamps;
+  constexpr int lds = MB_DYN_FLOATS * (int)sizeof(float);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(memory_block_s16_kernel<512>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (attr != hipSuccess) return (int)attr;
+  hipLaunchKernelGGL(memory_block_s16_kernel<512>, dim3((a.n + 63) / 64), dim3(512), lds, (hipStream_t)stream, a);
   return ammc_launch_status();
 }
 

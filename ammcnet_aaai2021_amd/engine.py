@@ -532,10 +532,14 @@ class StreamGraph:
             # distances, the gathered rows and their S16 re-encoding never leave the CU; bit-identical to the chain below
             self.x4q = bld.act(B, h, w, 512)
             counter = torch.zeros(1, device=bld.device, dtype=torch.int32)      # the last workgroup leaves it at zero
-            bld.plan.keep.extend([v["e_s16"], v["enc_w"], v["enc_b"], v["dec_w"], v["dec_b"], counter])
+            if v.get("dec_wf") is None:                  # dec's filters in fragment order (once per parameter version)
+                v["dec_wf"] = torch.empty_like(v["dec_w"])
+                _lib.check(lib.ammc_pack_frag_rows_s16(_ptr(v["dec_w"]), 512, k * d, _ptr(v["dec_wf"]),
+                                                       torch.cuda.current_stream(bld.device).cuda_stream), "pack_frag_rows")
+            bld.plan.keep.extend([v["e_s16"], v["enc_w"], v["enc_b"], v["dec_wf"], v["dec_b"], counter])
             bld.plan.add(lib.ammc_memory_block_s16, self.x4.pix0(), *self.x4.strides, self.x4q.pix0(), *self.x4q.strides,
                          B, h, w, 512, _ptr(v["enc_w"]), _ptr(v["enc_b"]), v["e_s16"].data_ptr(), _ptr(v["e_md"]),
-                         _ptr(v["enorm"]), d, m, k, _ptr(v["dec_w"]), _ptr(v["dec_b"]), self.idx.data_ptr(), None,
+                         _ptr(v["enorm"]), d, m, k, _ptr(v["dec_wf"]), _ptr(v["dec_b"]), self.idx.data_ptr(), None,
                          _ptr(self.q_one), _ptr(self.diff_part), _ptr(self.diff), counter.data_ptr(),
                          bld.overflow.data_ptr(), name="vq.block",
                          flops=2.0 * n * (512 * d + d * m + k * d * 512), nbytes=4.0 * n * (512 + 512 + 512 + k + d),

@@ -200,12 +200,17 @@ int ammc_memory_topk_fwd_s16(const float* x, const void* e_s16, const float* emb
  * distance (the LAST workgroup sums diff_partial[ammc_memory_topk_blocks(n)] in ammc_sum_partials_f32's order; *counter
  * is a device int32 the caller zeroes ONCE - the kernel leaves it at zero), *overflow_flag raised like the S16 epilogues
  * and ammc_split_rows_guarded_f32 do.  Bit-identical to the five-launch chain it replaces (same k order and expressions).
+ * dec_wf is dec_w in FRAGMENT-major order (ammc_pack_frag_rows_s16 below).
  * Shapes: d = 64, k = 2, c = 512, m <= 2048 (the shipped block; otherwise AMMC_EUNSUP: use the chain). */
 int ammc_memory_block_s16(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_ps, float* y, int64_t y_bs, int64_t y_rs,
                           int64_t y_ps, int32_t batch, int32_t h, int32_t w, int32_t c, const float* enc_w, const float* enc_b,
                           const void* e_s16, const float* embed_md, const float* enorm, int32_t d, int32_t m, int32_t k,
-                          const float* dec_w, const float* dec_b, int32_t* idx_topk, float* q_topk, float* q_one,
+                          const float* dec_wf, const float* dec_b, int32_t* idx_topk, float* q_topk, float* q_one,
                           float* diff_partial, float* diff, int32_t* counter, int32_t* overflow_flag, void* stream);
+/* S16 filter rows [n][k] (ammc_pack_conv_weight_f32 + ammc_split_rows_f32; n % 32 == 0, k % 8 == 0) -> fragment-major
+ * [k/8][hi | lo][n][8 halfs], the rows of every 32-row tile in MFMA order: what a lane of ammc_memory_block_s16's dec
+ * phase reads is then 16 bytes of a 512-byte run shared with its 31 neighbours.  Same size in bytes. */
+int ammc_pack_frag_rows_s16(const float* w_s16, int32_t n, int32_t k, float* out, void* stream);
 
 /* diff = sum(partials) / count, fixed order (deterministic) */
 int ammc_sum_partials_f32(const float* partial, int32_t nparts, float inv_count, float* out, void* stream);

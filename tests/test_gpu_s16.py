@@ -313,10 +313,11 @@ def _memory_s16(embed, x, k):
     lead = x.shape[:-1]
     x2 = x.to(DEV).float().contiguous().view(-1, d)
     n = x2.shape[0]
-    pk = _Packer(torch.device(DEV))
+    pk = _Packer(torch.device(DEV), s16=True)
     e = embed.to(DEV).contiguous()
     e_md, enorm = pk.codebook(e)
-    e16 = pk.codebook_s16(e)
+    e16, flag = pk.codebook_s16(e)
+    assert pk.flags.tolist()[flag] == 0                      # (inside the half range: no verdict)
     idx = torch.empty((n, k), device=DEV, dtype=torch.int32)
     qk = torch.empty((n, k * d), device=DEV)
     q1 = torch.empty((n, d), device=DEV)
