@@ -70,8 +70,17 @@ __device__ __forceinline__ void r_dma16_ptr(const void* src, unsigned lds_byte) 
 }
 // 16 bytes per lane to global memory, hidden from the compiler like the DMAs (its vmcnt bookkeeping must not see one kind
 // of vector-memory operation and miss the other); `base` wave-uniform
+// AMMC_F16R_NT (compile time, A/B builds): 1 = the stores carry the non-temporal hint - 1.6 GB of gathered rows / q_one per
+// 262144-row launch that nothing on the device reads again should not push the codebook out of the L2 / Infinity Cache
+#ifndef AMMC_F16R_NT
+#define AMMC_F16R_NT 0
+#endif
 __device__ __forceinline__ void r_store16(void* base, unsigned off, f32x4 v) {
+#if AMMC_F16R_NT
+  asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base) : "memory");
+#else
   asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base) : "memory");
+#endif
 }
 #define R_VMCNT(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory")
 
@@ -168,8 +177,8 @@ __device__ __forceinline__ void r_update(const f32x16& acc, float (&bv)[K], int 
 }
 
 // ---- branch-free running top-2 on PACKED keys (the pipelined form, K = 2) ----------------------------------------------
-// A candidate's key x.E - |E|^2 / 2 carries its own accumulator register in its four lowest mantissa bits (15 - r, so
-// that of two keys equal in the upper 28 bits the lower slot is the larger float for positive keys), and the running
+// A candidate's key x.E - |E|^2 / 2 carries its own accumulator register in its four lowest mantissa bits (15 - r for a
+// positive key, r for a negative one, so that of two keys equal in the upper 28 bits the lower slot is the larger float), and the running
 // (best, second) of a row is updated by TWO operations per candidate, no compare, no branch:
 //     second = med3(key, best, second);  best = max(key, best)
 // - 3 VALU operations per candidate with the packing, 16 candidates per tile and row tile, spread one candidate per
@@ -177,8 +186,16 @@ __device__ __forceinline__ void r_update(const f32x16& acc, float (&bv)[K], int 
 // of the sweep: ~100 scalar / vector instructions per tile that the in-order wave issues instead of MFMAs).  The slot
 // tile of the two survivors is tracked once per tile (6 operations).  What changes against the exact compare: candidates closer than 2^-19 of their
 // magnitude - far inside the noise of the fp32 accumulation order, let alone of the fp16 operands - rank by register.
+// Round 6 (advisor): the tag depends on the key's SIGN.  Keys x.E - |E|^2 / 2 are negative for any feature that is not
+// close to a slot (config 5's random features: -207 +- 16), and among negative floats the larger mantissa is the SMALLER
+// value: with 15 - r for every key, two candidates equal in the upper 28 bits - duplicated codebook rows - came back as
+// (higher slot, lower slot), against the contract (ties to the lower slot, as torch.topk and memory_topk_f16 do).  Tag =
+// 15 - r for positive keys, r for negative ones: (15 - r) ^ (sign extended over the four bits); three operations
+// (v_ashrrev, v_xor, v_bfi) where the unsigned form took one.
 __device__ __forceinline__ float r_pack_key(float v, int r) {
-  return __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, v) & 0xFFFFFFF0u) | (unsigned)(15 - r));
+  const unsigned bits = __builtin_bit_cast(unsigned, v);
+  const unsigned tag = (unsigned)(15 - r) ^ (unsigned)((int)bits >> 31);       // low four bits: 15 - r | r
+  return __builtin_bit_cast(float, (bits & 0xFFFFFFF0u) | (tag & 15u));
 }
 __device__ __forceinline__ void r_top2_step(float key, float& b0, float& b1) {
   // (asm: from __builtin_fmaxf / fmed3f hipcc first canonicalises the bit-built key - v_max_f32 k, k, k - a quarter more
@@ -568,8 +585,10 @@ __device__ __forceinline__ void r_sweep(const F16rArgs& a, unsigned char* smem, 
             for (int r = 0; r < 16; ++r) r_top2_step(r_pack_key(odd ? acc[0][rt][r] : acc[1][rt][r], r), pb0[rt], pb1[rt]);
             r_top2_track(pb0[rt], pb1[rt], o0, o1, pt0[rt], pt1[rt], a.ntile - 1);
           }
-          // the survivors as (key, slot): register 15 - (key & 15) of tile pt, slot = 32 pt + (r & 3) + 8 (r >> 2) + 4 h
-          const int r0_ = 15 - (int)(__builtin_bit_cast(unsigned, pb0[rt]) & 15u), r1_ = 15 - (int)(__builtin_bit_cast(unsigned, pb1[rt]) & 15u);
+          // the survivors as (key, slot): the tag is 15 - r for a positive key, r for a negative one (r_pack_key);
+          // register r of tile pt is slot 32 pt + (r & 3) + 8 (r >> 2) + 4 h
+          const unsigned k0_ = __builtin_bit_cast(unsigned, pb0[rt]), k1_ = __builtin_bit_cast(unsigned, pb1[rt]);
+          const int r0_ = (int)((15u ^ k0_ ^ (unsigned)((int)k0_ >> 31)) & 15u), r1_ = (int)((15u ^ k1_ ^ (unsigned)((int)k1_ >> 31)) & 15u);
           bv[rt][0] = pb0[rt];
           bv[rt][K > 1 ? 1 : 0] = pb1[rt];
           bi[rt][0] = pt0[rt] < 0 ? 0x7fffffff : (pt0[rt] << 5) + (r0_ & 3) + 8 * (r0_ >> 2) + 4 * h;

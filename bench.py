@@ -1017,6 +1017,10 @@ def run_eval_e2e(args, dev, model_only_fps=None, n_videos=12, frames=180, h=240,
         "value": round(n_pred / el, 1), "unit": "frames/s", "predicted_frames": n_pred, "seconds": round(el, 4),
         "passes_s": [round(t, 4) for t in times],
         "fraction_of_model_only": round(n_pred / el / model_only_fps, 4) if model_only_fps else None,
+        "excludes": "JPEG decoding and file / LMDB reads: the clock starts with DECODED uint8 frames and flow payloads in pinned "
+                    "host memory.  The reference's published 17.6-22 fps (README.md:52-56, test_helper.py:392, 485-486) include "
+                    "decode and disk, so the two numbers are NOT comparable; what this leg shows is that upload, resize, forward, "
+                    "scoring and fusion together run at the model-only rate",
         "config": {"workload": f"{n_videos} sub-videos x {frames} frames of {h}x{w} uint8 RGB + {frames - 1} flows (.flo payload, "
                                f"fp32) -> {args.size}x{args.size}, batches of 16 clips per sub-video, {args.n_embed} slots",
                    "reference": "run_helper/test_helper.py:408-488, dataset/two_stream_dataset.py:72-99,491-539"},

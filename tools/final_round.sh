@@ -16,5 +16,11 @@ for mode in infer stress train train_gan; do
   # the raw counter CSVs stay on the box (only the summaries are judged): keep the merge small
   rm -rf gpurun_out/prof_${TAG}_$short/pmc_sq gpurun_out/prof_${TAG}_$short/pmc_lds gpurun_out/prof_${TAG}_$short/pmc_fetch gpurun_out/prof_${TAG}_$short/pmc_write gpurun_out/prof_${TAG}_$short/trace
 done
+# the exact-fp32 kernels (the S16 guard's fallback; bench.py's `fp32_exact` leg quotes rNN_fp32_pmc_traffic.json)
+bash tools/profile_round.sh ${TAG}_fp32 infer --precision fp32 > gpurun_out/final_${TAG}_prof_fp32.log 2>&1
+for f in kernel_stats.csv pmc_summary.txt pmc_busy.json pmc_traffic.json bench_line.json; do
+  cp gpurun_out/prof_${TAG}_fp32/$f profiles/${TAG}_fp32_$f
+done
+rm -rf gpurun_out/prof_${TAG}_fp32/pmc_sq gpurun_out/prof_${TAG}_fp32/pmc_lds gpurun_out/prof_${TAG}_fp32/pmc_fetch gpurun_out/prof_${TAG}_fp32/pmc_write gpurun_out/prof_${TAG}_fp32/trace
 python bench.py > gpurun_out/${TAG}_final_bench_line.json 2> gpurun_out/final_${TAG}_bench.err
 tail -c 600 gpurun_out/${TAG}_final_bench_line.json
