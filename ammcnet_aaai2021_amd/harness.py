@@ -16,6 +16,8 @@ loop makes one device->host copy per BATCH (the reference syncs once per frame, 
 """
 from __future__ import annotations
 
+import contextlib
+import os
 from typing import Callable, Dict, List, Optional, Sequence
 
 import numpy as np
@@ -391,6 +393,7 @@ def train_step_gan(generator: torch.nn.Module, discriminator: torch.nn.Module, o
     rgb_t, op_t = rgb[:, -1], op[:, -1]
     out = generator(rgb_in, op_in)
     flow_pred = flow_gt = None
+    flow_mods = [m for m in (getattr(flow_fn, "__self__", None), getattr(flow_fn, "net", None)) if m is not None]
     if flow_fn is not None:
         with torch.no_grad():
             # the reference pairs BOTH frames with `rgb_input_last = rgb[:, -1]`, i.e. with the target frame itself
@@ -408,23 +411,55 @@ def train_step_gan(generator: torch.nn.Module, discriminator: torch.nn.Module, o
         for p in d_params:
             p.requires_grad_(True)
     g_loss = generator_loss_full(out, rgb_t, op_t, d_gen, flow_pred, flow_gt, **lams)
-    # D(real) and D(fake.detach()) (train_helper.py:326-327) as one call on 2 b frames: the discriminator has no
-    # batch-coupled layer, the patch maps and every gradient are those of the two calls
-    d_both = discriminator(torch.cat([rgb_t, out[0].detach()]))
-    d_loss = discriminate_loss(d_both[:b], d_both[b:])
     vote, group = _watch_group(generator, discriminator)
+    # Round 6 (`AMMC_GAN_OVERLAP`, default on): the D update is independent of the G backward - it reads the prediction
+    # detached, and the gradient that reaches G through D uses the filter packs of the `d_gen` forward, not the live
+    # parameters - so its forward, backward and Adam step run on a SECOND HIP stream beside the generator's backward, whose
+    # BatchNorm passes leave the matrix pipe idle (the two-stream argument of DESIGN.md section 4).  Same kernels, same
+    # order on each stream: every number is what the serial form computes.  Off with a gradient reducer / synchronised
+    # statistics attached (their collectives are ordered on the caller's stream) and on the CPU.
+    overlap = GAN_OVERLAP and out[0].is_cuda and not vote and getattr(discriminator, "_grad_reducer", None) is None
+    main = torch.cuda.current_stream(out[0].device) if overlap else None
+    lane = _gan_side_stream(out[0].device) if overlap else None
+    if overlap:
+        lane.wait_stream(main)
+    with (torch.cuda.stream(lane) if overlap else contextlib.nullcontext()):
+        # D(real) and D(fake.detach()) (train_helper.py:326-327) as one call on 2 b frames: the discriminator has no
+        # batch-coupled layer, the patch maps and every gradient are those of the two calls
+        d_both = discriminator(torch.cat([rgb_t, out[0].detach()]))
+        d_loss = discriminate_loss(d_both[:b], d_both[b:])
+        d_flag = getattr(discriminator, "last_overflow", None)
+    if overlap:
+        main.wait_stream(lane)                     # (the verdict below reads d_loss on the caller's stream)
+        for t in (d_both, d_loss) + ((d_flag,) if d_flag is not None else ()):
+            t.record_stream(main)
     # (the S16 range flags of the discriminator and - where `flow_fn` is a bound method / has `.net` - of the frozen flow
     # estimator join the verdict: `s16_guard = "defer"` on those modules leaves them on the device instead of syncing)
-    side = [discriminator, getattr(flow_fn, "__self__", None), getattr(flow_fn, "net", None)]
     watch = _FiniteWatch(d_loss, g_loss, group=group, vote=vote,
-                         flags=[getattr(m, "last_overflow", None) for m in side if m is not None])
-    optimizer_D.zero_grad(set_to_none=True)
-    d_loss.backward()
-    watch.step(optimizer_D)
+                         flags=[d_flag] + [getattr(m, "last_overflow", None) for m in flow_mods])
+    with (torch.cuda.stream(lane) if overlap else contextlib.nullcontext()):
+        optimizer_D.zero_grad(set_to_none=True)
+        d_loss.backward()                          # (autograd runs it on the stream of its forward: the lane)
+        watch.step(optimizer_D)
     optimizer_G.zero_grad(set_to_none=True)
     g_loss.backward()
     optimizer_G.step()
+    if overlap:
+        main.wait_stream(lane)                     # successors on the caller's stream see both updates
     return g_loss.detach(), d_loss.detach()
+
+
+# (the two FlowNet2-SD forwards on a third stream, their no-gradient term joined to the loss value at the end, were built and
+# measured as well: 80.2 / 80.4 ms against 80.2 / 79.3 - nothing; removed)
+GAN_OVERLAP = os.environ.get("AMMC_GAN_OVERLAP", "1") != "0"
+_GAN_LANES: Dict = {}
+
+
+def _gan_side_stream(device, which: int = 0) -> "torch.cuda.Stream":
+    key = (device.type, device.index, which)
+    if key not in _GAN_LANES:
+        _GAN_LANES[key] = torch.cuda.Stream(device=device)
+    return _GAN_LANES[key]
 
 
 # ---- score fusion and frame-level AUC (the step after the records) ------------------------------
