@@ -1492,7 +1492,7 @@ class MemoryBlockFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, engine: MemoryBlockEngine, x, *params):
-        outs = engine.forward(x)
+        outs = tuple(o.detach() for o in engine.forward(x))
         ctx.engine, ctx.generation, ctx.params = engine, engine.generation, params
         ctx.set_materialize_grads(False)
         if engine.kind == "quantize":
@@ -1513,7 +1513,7 @@ class BlockFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, engine: BlockEngine, n_inputs: int, *tensors):
-        outs = engine.forward(*tensors[:n_inputs])
+        outs = tuple(o.detach() for o in engine.forward(*tensors[:n_inputs]))
         ctx.engine, ctx.generation, ctx.params, ctx.n_inputs = engine, engine.generation, tensors[n_inputs:], n_inputs
         return outs if len(outs) > 1 else outs[0]
 
@@ -1532,7 +1532,11 @@ class HipPathFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, engine: TrainEngine, n_inputs: int, *tensors):
         inputs, params = tensors[:n_inputs], tensors[n_inputs:]
-        outs = engine.forward(*inputs)
+        # (fresh tensor objects for autograd to hang its node on: the engine keeps the ones it made - `stream.out`, `mem_out` -
+        # and a node on THOSE objects would close a cycle engine -> tensor -> grad_fn -> ctx -> engine through the C++ autograd
+        # graph, which Python's collector cannot see: every training forward's ~60-GB workspace then outlived its model
+        # (round 6: the GPU suite's live set reached 284 GB))
+        outs = tuple(o.detach() for o in engine.forward(*inputs))
         ctx.engine, ctx.generation, ctx.params, ctx.n_inputs = engine, engine.generation, params, n_inputs
         ctx.set_materialize_grads(False)
         return outs

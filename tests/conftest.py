@@ -29,10 +29,11 @@ def rel_err(a, b):
 
 @pytest.fixture(autouse=True)
 def _release_device_memory(request):
-    """A model and its engine reference each other (module -> engine -> module), so a test's 60-GB training workspace is
-    only freed by the cycle collector - which counts Python allocations, not device bytes: by the end of the -m gpu suite
-    the live set had grown to 284 of 288 GB and the batch-32 fp64 truth ran out of memory (round 6).  Collect after every
-    GPU test and hand the cache back."""
+    """Collect garbage and hand the allocator's cache back after every GPU test (a model and its engine reference each other,
+    so a test's workspaces go with the cycle collector, which counts Python allocations, not device bytes).  Round 6 found
+    the real leak behind the suite's growing live set - the training Functions hung autograd's node on tensors the
+    engine keeps, a cycle through the C++ graph no collector sees (fixed in train.py: they return aliases) - with
+    AMMC_TEST_MEMLOG=<file>: live device bytes after every test."""
     yield
     if request.node.get_closest_marker("gpu") is not None:
         import gc
@@ -40,3 +41,6 @@ def _release_device_memory(request):
         gc.collect()
         if torch.cuda.is_available():
             torch.cuda.empty_cache()
+            if os.environ.get("AMMC_TEST_MEMLOG"):            # (diagnostics: live device bytes after every GPU test)
+                with open(os.environ["AMMC_TEST_MEMLOG"], "a") as fp:
+                    fp.write(f"{torch.cuda.memory_allocated() / 2**30:8.2f} GiB live  {torch.cuda.memory_reserved() / 2**30:8.2f} reserved  {request.node.nodeid}\n")

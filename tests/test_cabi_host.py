@@ -80,6 +80,31 @@ def test_round5_entry_points_reject_bad_arguments_without_a_gpu():
     assert "memory_topk_f16r.hip" in digests and "ammc_common.h" in digests
 
 
+def test_round6_entry_points_reject_bad_arguments_without_a_gpu():
+    """`ammc_memory_block_s16`, `ammc_pack_frag_rows_s16` and the guarded packs: argument errors are status codes decided
+    before anything touches the device"""
+    lib = _lib.load()
+    ok = dict(x=64, xs=(34 * 34 * 512, 34 * 512, 512), y=128, ys=(34 * 34 * 512, 34 * 512, 512), b=2, h=32, w=32, c=512,
+              enc_w=256, enc_b=512, e16=1024, emd=2048, en=4096, d=64, m=2000, k=2, dec_w=8192, dec_b=16384, idx=64, qk=None,
+              q1=None, part=64, diff=64, cnt=64, flag=None)
+
+    def call(**kw):
+        a = dict(ok, **kw)
+        return lib.ammc_memory_block_s16(a["x"], *a["xs"], a["y"], *a["ys"], a["b"], a["h"], a["w"], a["c"], a["enc_w"], a["enc_b"],
+                                         a["e16"], a["emd"], a["en"], a["d"], a["m"], a["k"], a["dec_w"], a["dec_b"], a["idx"],
+                                         a["qk"], a["q1"], a["part"], a["diff"], a["cnt"], a["flag"], None)
+    assert call(x=None) == -1 and call(cnt=None) == -1 and call(b=0) == -1
+    assert call(xs=(34 * 34 * 512, 34 * 512, 510)) == -1          # strides: whole S16 groups
+    assert call(x=72) == -1                                       # activations 32-byte aligned
+    for kw in (dict(c=256), dict(d=128), dict(k=1), dict(m=4096)):
+        assert call(**kw) == -2, kw                               # not the shipped block's shape: the five-launch chain
+    assert lib.ammc_pack_frag_rows_s16(None, 512, 128, 64, None) == -1
+    assert lib.ammc_pack_frag_rows_s16(64, 500, 128, 128, None) == -1 and lib.ammc_pack_frag_rows_s16(64, 512, 100, 128, None) == -1
+    assert lib.ammc_split_rows_guarded_f32(None, 64, 64, None, None) == -1 and lib.ammc_split_rows_guarded_f32(64, 60, 128, None, None) == -1
+    assert lib.ammc_pack_codebook_s16_guarded(None, 64, 256, 64, None, None) == -1
+    assert lib.ammc_pack_codebook_s16_guarded(64, 60, 256, 64, None, None) == -1
+
+
 def test_state_dict_schema_matches_reference():
     with open(os.path.join(GOLDEN, "param_counts.json")) as fp:
         pc = json.load(fp)
