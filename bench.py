@@ -1127,7 +1127,7 @@ def _norm_kernel(name: str) -> str:
         if len(a) == 7 and a[6] == "0":
             a = a[:6]
         name = f"{m.group(1)}<{', '.join(a)}>"
-    return re.sub(r"<[^>]*>$", "", name) if name.startswith("memory_topk") else name
+    return re.sub(r"<[^>]*>$", "", name) if name.startswith(("memory_topk", "memory_block")) else name
 
 
 def _profiles(suffixes):
