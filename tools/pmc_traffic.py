@@ -45,6 +45,8 @@ def label(name):
         return "conv_first_s16"
     if "conv_outc_s16_kernel" in name:
         return "conv_outc_s16"
+    if "memory_block_s16_kernel" in name:               # round 6: the whole memory block as one launch
+        return "memory_block_s16"
     if "memory_topk_s16_kernel" in name:                # (rocprofv3 leaves this one mangled)
         return "memory_topk_s16"
     if re.search(r"memory_topk_kernel", name):
