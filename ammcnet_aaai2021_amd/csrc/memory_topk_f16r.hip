@@ -178,8 +178,7 @@ __device__ __forceinline__ void r_update(const f32x16& acc, float (&bv)[K], int 
 }
 
 // ---- branch-free running top-2 on PACKED keys (the pipelined form, K = 2) ----------------------------------------------
-// A candidate's key x.E - |E|^2 / 2 carries its own accumulator register in its four lowest mantissa bits (15 - r for a
-// positive key, r for a negative one, so that of two keys equal in the upper 28 bits the lower slot is the larger float), and the running
+// A candidate's key x.E - |E|^2 / 2 carries its own accumulator register in its four lowest mantissa bits (15 - r), and the running
 // (best, second) of a row is updated by TWO operations per candidate, no compare, no branch:
 //     second = med3(key, best, second);  best = max(key, best)
 // - 3 VALU operations per candidate with the packing, 16 candidates per tile and row tile, spread one candidate per
@@ -187,16 +186,17 @@ __device__ __forceinline__ void r_update(const f32x16& acc, float (&bv)[K], int 
 // of the sweep: ~100 scalar / vector instructions per tile that the in-order wave issues instead of MFMAs).  The slot
 // tile of the two survivors is tracked once per tile (6 operations).  What changes against the exact compare: candidates closer than 2^-19 of their
 // magnitude - far inside the noise of the fp32 accumulation order, let alone of the fp16 operands - rank by register.
-// Round 6 (advisor): the tag depends on the key's SIGN.  Keys x.E - |E|^2 / 2 are negative for any feature that is not
-// close to a slot (config 5's random features: -207 +- 16), and among negative floats the larger mantissa is the SMALLER
-// value: with 15 - r for every key, two candidates equal in the upper 28 bits - duplicated codebook rows - came back as
-// (higher slot, lower slot), against the contract (ties to the lower slot, as torch.topk and memory_topk_f16 do).  Tag =
-// 15 - r for positive keys, r for negative ones: (15 - r) ^ (sign extended over the four bits); three operations
-// (v_ashrrev, v_xor, v_bfi) where the unsigned form took one.
+// Round 6 (advisor): keys x.E - |E|^2 / 2 are NEGATIVE for any feature that is not close to a slot (config 5's random
+// features: -207 +- 16), and among negative floats the larger mantissa is the smaller value: two candidates equal in the
+// upper 28 bits - duplicated codebook rows - then come out of the sweep as (higher slot, lower slot).  A sign-aware tag
+// ((15 - r) ^ sign: two more VALU operations per candidate) fixed that and cost 6.7 % of the kernel (2.07 -> 2.22 ms,
+// A/B/A/B/A/B on one box: the update issues in the shadow of the MFMAs and that shadow is full).  Instead the final pair of
+// every row is put in slot order when its two keys tie in the upper 28 bits (`r_sweep`, behind the merge of the lane
+// halves: once per row, not per candidate) - which also orders ties ACROSS lanes and slot tiles, where no tag could.
+// What remains: three or more candidates with identical upper 28 bits (a codebook row present three times) may return
+// two of them that are not the two lowest slots.
 __device__ __forceinline__ float r_pack_key(float v, int r) {
-  const unsigned bits = __builtin_bit_cast(unsigned, v);
-  const unsigned tag = (unsigned)(15 - r) ^ (unsigned)((int)bits >> 31);       // low four bits: 15 - r | r
-  return __builtin_bit_cast(float, (bits & 0xFFFFFFF0u) | (tag & 15u));
+  return __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, v) & 0xFFFFFFF0u) | (unsigned)(15 - r));
 }
 __device__ __forceinline__ void r_top2_step(float key, float& b0, float& b1) {
   // (asm: from __builtin_fmaxf / fmed3f hipcc first canonicalises the bit-built key - v_max_f32 k, k, k - a quarter more
@@ -586,10 +586,8 @@ __device__ __forceinline__ void r_sweep(const F16rArgs& a, unsigned char* smem, 
             for (int r = 0; r < 16; ++r) r_top2_step(r_pack_key(odd ? acc[0][rt][r] : acc[1][rt][r], r), pb0[rt], pb1[rt]);
             r_top2_track(pb0[rt], pb1[rt], o0, o1, pt0[rt], pt1[rt], a.ntile - 1);
           }
-          // the survivors as (key, slot): the tag is 15 - r for a positive key, r for a negative one (r_pack_key);
-          // register r of tile pt is slot 32 pt + (r & 3) + 8 (r >> 2) + 4 h
-          const unsigned k0_ = __builtin_bit_cast(unsigned, pb0[rt]), k1_ = __builtin_bit_cast(unsigned, pb1[rt]);
-          const int r0_ = (int)((15u ^ k0_ ^ (unsigned)((int)k0_ >> 31)) & 15u), r1_ = (int)((15u ^ k1_ ^ (unsigned)((int)k1_ >> 31)) & 15u);
+          // the survivors as (key, slot): register 15 - (key & 15) of tile pt, slot = 32 pt + (r & 3) + 8 (r >> 2) + 4 h
+          const int r0_ = 15 - (int)(__builtin_bit_cast(unsigned, pb0[rt]) & 15u), r1_ = 15 - (int)(__builtin_bit_cast(unsigned, pb1[rt]) & 15u);
           bv[rt][0] = pb0[rt];
           bv[rt][K > 1 ? 1 : 0] = pb1[rt];
           bi[rt][0] = pt0[rt] < 0 ? 0x7fffffff : (pt0[rt] << 5) + (r0_ & 3) + 8 * (r0_ >> 2) + 4 * h;
@@ -685,6 +683,13 @@ __device__ __forceinline__ void r_sweep(const F16rArgs& a, unsigned char* smem, 
     }
 #pragma unroll
     for (int j = 0; j < K; ++j) r_insert<K>(bv[rt], bi[rt], ov[j], oi[j]);
+    if constexpr (PIPE && K == 2 && NSTEP >= 18) {   // (= the packed-key form, see r_pack_key: exact ties go to the lower slot)
+      const unsigned k0_ = __builtin_bit_cast(unsigned, bv[rt][0]), k1_ = __builtin_bit_cast(unsigned, bv[rt][1]);
+      const bool swap_ = ((k0_ ^ k1_) & 0xFFFFFFF0u) == 0u && bi[rt][0] > bi[rt][1];
+      const int lo_ = swap_ ? bi[rt][1] : bi[rt][0], hi_ = swap_ ? bi[rt][0] : bi[rt][1];
+      bi[rt][0] = lo_;
+      bi[rt][1] = hi_;
+    }
     const int row = (tile0 + rt) * 32 + l31;
     if (h == 0 && row < a.n) {
 #pragma unroll

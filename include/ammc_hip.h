@@ -311,8 +311,10 @@ int ammc_memory_topk_fwd_f16(const float* x, const void* e_kblk_f16, const float
  * codebook, the codebook goes L2 -> LDS once per workgroup (tile images of ammc_pack_codebook_f16_tiles:
  * ammc_codebook_f16_tiles_bytes(d, m) bytes, 16-byte aligned) instead of L2 -> registers once per 128 rows.  Same
  * outputs and arithmetic contract as ammc_memory_topk_fwd_f16 (ranking from fp16-rounded operands with fp32
- * accumulation - key x.E_s - |E_s|^2 / 2, ties to the lower slot; gather / q_one / commit from the fp32 codebook and
- * features); q_one may be NULL; diff_partial has ammc_memory_topk_f16r_blocks(n) = ceil(n / 32) entries, each written
+ * accumulation - key x.E_s - |E_s|^2 / 2; gather / q_one / commit from the fp32 codebook and features).  Exact ties
+ * (k = 2, d >= 288: the packed-key form): two returned slots whose keys tie come in slot order; WHICH of several exactly
+ * tied candidates takes the last place of the top-k is unspecified (other shapes: ties to the lower slot throughout);
+ * q_one may be NULL; diff_partial has ammc_memory_topk_f16r_blocks(n) = ceil(n / 32) entries, each written
  * once (no atomics: deterministic).  d in {128,256,384,512}, k <= 4; pointers 16-byte aligned. */
 int64_t ammc_codebook_f16_tiles_bytes(int32_t d, int32_t m);
 int ammc_pack_codebook_f16_tiles(const float* embed_dm, int32_t d, int32_t m, void* tiles, void* stream);
