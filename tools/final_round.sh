@@ -22,5 +22,6 @@ for f in kernel_stats.csv pmc_summary.txt pmc_busy.json pmc_traffic.json bench_l
   cp gpurun_out/prof_${TAG}_fp32/$f profiles/${TAG}_fp32_$f
 done
 rm -rf gpurun_out/prof_${TAG}_fp32/pmc_sq gpurun_out/prof_${TAG}_fp32/pmc_lds gpurun_out/prof_${TAG}_fp32/pmc_fetch gpurun_out/prof_${TAG}_fp32/pmc_write gpurun_out/prof_${TAG}_fp32/trace
+# (the box's profiles/ does not travel back: tools/install_profiles.sh <tag> copies the summaries from gpurun_out/ at home)
 python bench.py > gpurun_out/${TAG}_final_bench_line.json 2> gpurun_out/final_${TAG}_bench.err
 tail -c 600 gpurun_out/${TAG}_final_bench_line.json
