@@ -382,6 +382,9 @@ __device__ __forceinline__ void mb_dma16(const float* src, unsigned lds_byte) {
                : "=&s"(keep) : "v"(src), "s"(lds_byte) : "memory");
 }
 
+#ifndef AMMC_MB_STAGGER
+#define AMMC_MB_STAGGER 0
+#endif
 constexpr int MB_STG = 8192;                       // floats per stage of phase A: x chunk [64 px][64 ch] | filter chunk [64][64]
 constexpr int MB_DYN_FLOATS = 3 * MB_STG;          // 96 KB of dynamic LDS
 
@@ -587,6 +590,12 @@ __global__ __launch_bounds__(512, 2) void memory_block_s16_kernel(MemBlockArgs a
       h16x8 ah0[4], al0[4], ah1[4], al1[4];
       int tile = wave;
       F_LOAD(ah0, al0, tile)
+#if AMMC_MB_STAGGER
+      // the two waves of a SIMD (w and w + 4) run the same program in step: both contract (the matrix pipe serves both, 2 x
+      // 768 cycles), then both insert (the VALU serves both, 2 x 1400) - the phases add up.  The second wave starts the
+      // sweep half a period late, so that its insertions meet the first wave's MFMAs.
+      if (wave >= 4) __builtin_amdgcn_s_sleep(AMMC_MB_STAGGER);
+#endif
       while (tile < ntile) {
         F_LOAD(ah1, al1, tile + 8)
         __builtin_amdgcn_sched_barrier(0);
