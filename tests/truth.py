@@ -75,10 +75,17 @@ def hip_lookups(net) -> dict:
     out = {p: st["streams"][si].idx.reshape(-1, 2).long().clone() for si, p in enumerate(("rgb", "op"))}
     pools = {}
     for si, p in enumerate(("rgb", "op")):
-        pi = getattr(st["streams"][si], "pool_idx", None)
+        stream = st["streams"][si]
+        pi = getattr(stream, "pool_idx", None)
         if pi:
             for lvl, t in enumerate(pi):
                 pools[f"{p}.down{lvl + 1}"] = t.permute(0, 3, 1, 2).long().contiguous()       # [B, h, w, C] bytes -> [B, C, h, w]
+        elif not getattr(stream, "twins", True):
+            # exact-fp32 training path: no recorded routes, but the fp32 skip tensors the pooling read are still in the
+            # workspace - their first maxima (row-major, what `ammc_maxpool2x2_bwd_f32` routes to) are the routes taken
+            for lvl in range(3):
+                sk = stream.skip[lvl]
+                pools[f"{p}.down{lvl + 1}"] = O.maxpool2x2_routes(sk.interior().permute(0, 3, 1, 2).float())[1]
     if pools:
         out["pool"] = pools
     return out
