@@ -392,6 +392,28 @@ def train_step_gan(generator: torch.nn.Module, discriminator: torch.nn.Module, o
     op_in = op[:, :-1].reshape(b, -1, *op.shape[-2:])
     rgb_t, op_t = rgb[:, -1], op[:, -1]
     out = generator(rgb_in, op_in)
+    vote, group = _watch_group(generator, discriminator)
+    # Round 6 (`AMMC_GAN_OVERLAP`, default on): the D update is independent of everything the generator still has to do - it
+    # reads the prediction detached, and the gradient that reaches G through D uses the filter packs of the `d_gen`
+    # forward, not the live parameters - so its forward (beside FlowNet2-SD and the `d_gen` forward), its backward and its
+    # Adam step (beside the generator's backward, whose BatchNorm passes leave the matrix pipe idle: the two-stream argument
+    # of DESIGN.md section 4) run on a SECOND HIP stream.  Same kernels, same order on each stream: every number is what
+    # the serial form computes.  Off with a gradient reducer / synchronised statistics attached (their collectives are
+    # ordered on the caller's stream) and on the CPU.
+    overlap = GAN_OVERLAP and out[0].is_cuda and not vote and getattr(discriminator, "_grad_reducer", None) is None
+    main = torch.cuda.current_stream(out[0].device) if overlap else None
+    lane = _gan_side_stream(out[0].device) if overlap else None
+
+    def d_forward():
+        # D(real) and D(fake.detach()) (train_helper.py:326-327) as one call on 2 b frames: the discriminator has no
+        # batch-coupled layer, the patch maps and every gradient are those of the two calls
+        d_both_ = discriminator(torch.cat([rgb_t, out[0].detach()]))
+        return d_both_, discriminate_loss(d_both_[:b], d_both_[b:]), getattr(discriminator, "last_overflow", None)
+    early = overlap and GAN_OVERLAP_EARLY
+    if early:
+        lane.wait_stream(main)
+        with torch.cuda.stream(lane):
+            d_both, d_loss, d_flag = d_forward()
     flow_pred = flow_gt = None
     flow_mods = [m for m in (getattr(flow_fn, "__self__", None), getattr(flow_fn, "net", None)) if m is not None]
     if flow_fn is not None:
@@ -411,24 +433,11 @@ def train_step_gan(generator: torch.nn.Module, discriminator: torch.nn.Module, o
         for p in d_params:
             p.requires_grad_(True)
     g_loss = generator_loss_full(out, rgb_t, op_t, d_gen, flow_pred, flow_gt, **lams)
-    vote, group = _watch_group(generator, discriminator)
-    # Round 6 (`AMMC_GAN_OVERLAP`, default on): the D update is independent of the G backward - it reads the prediction
-    # detached, and the gradient that reaches G through D uses the filter packs of the `d_gen` forward, not the live
-    # parameters - so its forward, backward and Adam step run on a SECOND HIP stream beside the generator's backward, whose
-    # BatchNorm passes leave the matrix pipe idle (the two-stream argument of DESIGN.md section 4).  Same kernels, same
-    # order on each stream: every number is what the serial form computes.  Off with a gradient reducer / synchronised
-    # statistics attached (their collectives are ordered on the caller's stream) and on the CPU.
-    overlap = GAN_OVERLAP and out[0].is_cuda and not vote and getattr(discriminator, "_grad_reducer", None) is None
-    main = torch.cuda.current_stream(out[0].device) if overlap else None
-    lane = _gan_side_stream(out[0].device) if overlap else None
-    if overlap:
-        lane.wait_stream(main)
-    with (torch.cuda.stream(lane) if overlap else contextlib.nullcontext()):
-        # D(real) and D(fake.detach()) (train_helper.py:326-327) as one call on 2 b frames: the discriminator has no
-        # batch-coupled layer, the patch maps and every gradient are those of the two calls
-        d_both = discriminator(torch.cat([rgb_t, out[0].detach()]))
-        d_loss = discriminate_loss(d_both[:b], d_both[b:])
-        d_flag = getattr(discriminator, "last_overflow", None)
+    if not early:
+        if overlap:
+            lane.wait_stream(main)
+        with (torch.cuda.stream(lane) if overlap else contextlib.nullcontext()):
+            d_both, d_loss, d_flag = d_forward()
     if overlap:
         main.wait_stream(lane)                     # (the verdict below reads d_loss on the caller's stream)
         for t in (d_both, d_loss) + ((d_flag,) if d_flag is not None else ()):
@@ -451,7 +460,11 @@ def train_step_gan(generator: torch.nn.Module, discriminator: torch.nn.Module, o
 
 # (the two FlowNet2-SD forwards on a third stream, their no-gradient term joined to the loss value at the end, were built and
 # measured as well: 80.2 / 80.4 ms against 80.2 / 79.3 - nothing; removed)
-GAN_OVERLAP = os.environ.get("AMMC_GAN_OVERLAP", "1") != "0"
+# AMMC_GAN_OVERLAP: 2 (default) = the D lane starts right behind the generator's forward (its own forward beside FlowNet2-SD and
+# the d_gen forward: 79.84 / 80.20 / 79.85 -> 79.04 / 78.82 / 78.88 ms against 1), 1 = it starts behind g_loss (the first form:
+# 81.69 / 81.59 -> 78.94 / 79.19 against 0), 0 = serial
+GAN_OVERLAP = os.environ.get("AMMC_GAN_OVERLAP", "2") != "0"
+GAN_OVERLAP_EARLY = os.environ.get("AMMC_GAN_OVERLAP", "2") == "2"
 _GAN_LANES: Dict = {}
 
 
